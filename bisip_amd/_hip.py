@@ -1,0 +1,221 @@
+"""ctypes binding of ``libbisip_hip.so`` (C ABI in ``include/bisip_hip.h``).
+
+This is the only compute backend of the package.  There is no CPU fallback: if the
+shared library is missing or no MI355X is visible, calls raise ``RuntimeError``.
+"""
+
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libbisip_hip.so')
+
+MODEL_POLYDECOMP, MODEL_COLECOLE, MODEL_DIAS2000, MODEL_SHIN2015 = 0, 1, 2, 3
+VARIANT_AUTO, VARIANT_FAITHFUL, VARIANT_COLLAPSED, VARIANT_REDUCED = 0, 1, 2, 3
+VARIANTS = {'auto': VARIANT_AUTO, 'faithful': VARIANT_FAITHFUL,
+            'collapsed': VARIANT_COLLAPSED, 'reduced': VARIANT_REDUCED}
+
+_dp = ctypes.POINTER(ctypes.c_double)
+
+
+class ModelDesc(ctypes.Structure):
+    """``bisip_model_desc`` of include/bisip_hip.h."""
+    _fields_ = [('n_modes', ctypes.c_int), ('poly_deg', ctypes.c_int), ('n_taus', ctypes.c_int),
+                ('c_exp', ctypes.c_double), ('taus', _dp), ('log_taus', _dp)]
+
+
+# name -> (restype, argtypes); every symbol include/bisip_hip.h declares
+SYMBOLS = {
+    'bisip_ctx_create': (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int,
+                                        ctypes.c_int, _dp, _dp, _dp, ctypes.c_int, _dp, _dp,
+                                        ctypes.POINTER(ModelDesc)]),
+    'bisip_ctx_destroy': (None, [ctypes.c_void_p]),
+    'bisip_ctx_set_bounds': (ctypes.c_int, [ctypes.c_void_p, _dp, _dp]),
+    'bisip_ctx_set_variant': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    'bisip_ctx_get_variant': (ctypes.c_int, [ctypes.c_void_p]),
+    'bisip_logprob': (ctypes.c_int, [ctypes.c_void_p, _dp, ctypes.c_int64, _dp]),
+    'bisip_logprob_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                         ctypes.c_void_p, ctypes.c_void_p]),
+    'bisip_forward': (ctypes.c_int, [ctypes.c_void_p, _dp, ctypes.c_int64, _dp]),
+    'bisip_forward_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                         ctypes.c_void_p, ctypes.c_void_p]),
+    'bisip_ctx_ndim': (ctypes.c_int, [ctypes.c_void_p]),
+    'bisip_ctx_nfreq': (ctypes.c_int, [ctypes.c_void_p]),
+    'bisip_ctx_device': (ctypes.c_int, [ctypes.c_void_p]),
+    'bisip_ctx_loglike_const': (ctypes.c_double, [ctypes.c_void_p]),
+    'bisip_ctx_kernel_name': (ctypes.c_char_p, [ctypes.c_void_p]),
+    'bisip_polydecomp_operands': (ctypes.c_int, [ctypes.c_int, _dp, _dp, _dp, ctypes.POINTER(ModelDesc),
+                                                 _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
+    'bisip_abi_version': (ctypes.c_int, []),
+    'bisip_device_count': (ctypes.c_int, []),
+    'bisip_last_error': (ctypes.c_char_p, []),
+}
+
+_lib = None
+
+
+def load_library():
+    """Load the HIP library; raise loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f'{LIB_PATH} is missing: build it with `make -C bisip_amd/csrc` '
+                '(or __graft_entry__.build()).  bisip_amd has no CPU fallback.')
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)  # AttributeError if the ABI and the header drift apart
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        msg = load_library().bisip_last_error().decode('utf-8', 'replace')
+        if rc == -1:
+            raise ValueError(f'bisip_hip: {msg}')
+        raise RuntimeError(f'bisip_hip (status {rc}): {msg}')
+
+
+def _c(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp)
+
+
+def polydecomp_operands(w, zn, zn_err, taus, log_taus, c_exp):
+    """Host-side precompute of the PolynomialDecomposition operands (no GPU needed)."""
+    lib = load_library()
+    w, zn, zn_err = _c(w).ravel(), _c(zn).reshape(2, -1), _c(zn_err).reshape(2, -1)
+    taus = _c(taus).ravel()
+    log_taus = _c(log_taus).reshape(-1, taus.size)
+    N, D = w.size, log_taus.shape[0]
+    n = D + 1
+    desc = ModelDesc(0, D - 1, taus.size, float(c_exp), _p(taus), _p(log_taus))
+    out = dict(G_re=np.empty((N, D)), G_im=np.empty((N, D)), R=np.empty((n, n)),
+               bhat=np.empty(n), e=np.empty(n), rest=np.empty(1), lconst=np.empty(1))
+    _check(lib.bisip_polydecomp_operands(N, _p(w), _p(zn), _p(zn_err), ctypes.byref(desc),
+                                         *[_p(out[k]) for k in
+                                           ('G_re', 'G_im', 'R', 'bhat', 'e', 'rest', 'lconst')]))
+    out['rest'] = float(out['rest'][0])
+    out['lconst'] = float(out['lconst'][0])
+    return out
+
+
+def device_count():
+    return int(load_library().bisip_device_count())
+
+
+class HipContext:
+    """One inversion problem resident on one GPU (``bisip_ctx``)."""
+
+    def __init__(self, model_id, w, zn, zn_err, bounds, device=0, n_modes=0, poly_deg=0,
+                 c_exp=1.0, taus=None, log_taus=None, variant='auto'):
+        lib = load_library()
+        if lib.bisip_device_count() < 1:
+            raise RuntimeError('bisip_amd needs a visible AMD GPU (hipGetDeviceCount() == 0); '
+                               'there is no CPU fallback')
+        w = _c(w).ravel()
+        zn = _c(zn).reshape(2, -1)
+        zn_err = _c(zn_err).reshape(2, -1)
+        b = _c(bounds).reshape(2, -1)
+        lo, hi = _c(b[0]), _c(b[1])
+        if zn.shape[1] != w.size or zn_err.shape[1] != w.size:
+            raise ValueError('zn and zn_err must have shape (2, N) with N = len(w)')
+        desc = ModelDesc()
+        desc.n_modes = int(n_modes)
+        desc.poly_deg = int(poly_deg)
+        desc.c_exp = float(c_exp)
+        keep = []
+        if taus is not None:
+            taus = _c(taus).ravel()
+            log_taus = _c(log_taus).reshape(int(poly_deg) + 1, taus.size)
+            desc.n_taus = taus.size
+            desc.taus = _p(taus)
+            desc.log_taus = _p(log_taus)
+            keep = [taus, log_taus]
+        handle = ctypes.c_void_p()
+        _check(lib.bisip_ctx_create(ctypes.byref(handle), int(device), int(model_id), w.size,
+                                    _p(w), _p(zn), _p(zn_err), lo.size, _p(lo), _p(hi),
+                                    ctypes.byref(desc)))
+        del keep
+        self._lib = lib
+        self._h = handle
+        self.ndim = lo.size
+        self.N = w.size
+        self.device = int(device)
+        if variant != 'auto':
+            self.set_variant(variant)
+
+    # -- lifetime ---------------------------------------------------------------------
+    def close(self):
+        if getattr(self, '_h', None):
+            self._lib.bisip_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- configuration ----------------------------------------------------------------
+    def set_bounds(self, bounds):
+        b = _c(bounds).reshape(2, -1)
+        if b.shape[1] != self.ndim:
+            raise ValueError(f'bounds must have shape (2, {self.ndim})')
+        lo, hi = _c(b[0]), _c(b[1])
+        _check(self._lib.bisip_ctx_set_bounds(self._h, _p(lo), _p(hi)))
+
+    def set_variant(self, variant):
+        v = VARIANTS[variant] if isinstance(variant, str) else int(variant)
+        _check(self._lib.bisip_ctx_set_variant(self._h, v))
+
+    @property
+    def variant(self):
+        v = self._lib.bisip_ctx_get_variant(self._h)
+        return {num: name for name, num in VARIANTS.items()}[v]
+
+    @property
+    def kernel_name(self):
+        return self._lib.bisip_ctx_kernel_name(self._h).decode()
+
+    @property
+    def loglike_const(self):
+        return float(self._lib.bisip_ctx_loglike_const(self._h))
+
+    # -- compute ----------------------------------------------------------------------
+    def _theta2d(self, theta):
+        theta = np.asarray(theta)
+        if theta.ndim != 2 or theta.shape[1] != self.ndim:
+            raise ValueError(f'theta must have shape (W, {self.ndim}), got {theta.shape}')
+        return _c(theta)
+
+    def logprob(self, theta):
+        """theta (W, ndim) host -> logp (W,) host."""
+        theta = self._theta2d(theta)
+        out = np.empty(theta.shape[0], dtype=np.float64)
+        _check(self._lib.bisip_logprob(self._h, _p(theta), theta.shape[0], _p(out)))
+        return out
+
+    def forward(self, theta):
+        """theta (W, ndim) host -> Z (W, 2, N) host."""
+        theta = self._theta2d(theta)
+        out = np.empty((theta.shape[0], 2, self.N), dtype=np.float64)
+        _check(self._lib.bisip_forward(self._h, _p(theta), theta.shape[0], _p(out)))
+        return out
+
+    def logprob_dev(self, d_theta_ptr, W, d_out_ptr, stream=0):
+        """Device pointers (ints), asynchronous on ``stream`` (a hipStream_t as int)."""
+        _check(self._lib.bisip_logprob_dev(self._h, ctypes.c_void_p(d_theta_ptr), int(W),
+                                           ctypes.c_void_p(d_out_ptr), ctypes.c_void_p(stream)))
+
+    def forward_dev(self, d_theta_ptr, W, d_Z_ptr, stream=0):
+        _check(self._lib.bisip_forward_dev(self._h, ctypes.c_void_p(d_theta_ptr), int(W),
+                                           ctypes.c_void_p(d_Z_ptr), ctypes.c_void_p(stream)))

@@ -1,0 +1,500 @@
+// bisip_hip.hip -- C ABI (include/bisip_hip.h) over the kernels in kernels.h.
+// Host side: context = device copies of the walker-independent operands + the prior
+// box; every call is one kernel launch on the caller's stream.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/bisip_hip.h"
+#include "host_precompute.h"
+#include "kernels.h"
+
+using namespace bisip;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                  \
+    do {                                                                               \
+        hipError_t e_ = (expr);                                                        \
+        if (e_ != hipSuccess)                                                          \
+            return fail(BISIP_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                           \
+    } while (0)
+
+constexpr int BLK_SMALL = 64;    // few walkers: spread them over more CUs
+constexpr int BLK_LARGE = 256;
+constexpr long long SMALL_W = 256LL * 256 * 2;  // below this, 64-lane workgroups
+
+}  // namespace
+
+struct bisip_ctx {
+    int device = 0, model_id = 0, N = 0, ndim = 0, variant = BISIP_VARIANT_AUTO;
+    int P = 0, D = 0, S = 0, SPAD = 0;
+    double c_exp = 1.0, lconst = 0.0;
+    Bounds bounds{};
+    double *d_cb = nullptr;        // records for k_logprob / k_forward
+    double *d_cb_faithful = nullptr;
+    std::vector<double> Rpacked, bhat, evec;
+    double rest = 0.0;
+    // workspace of the host-pointer entry points
+    double *d_ws = nullptr;
+    size_t ws_bytes = 0;
+    hipStream_t stream = nullptr;
+    const char *kernel_name = "";
+};
+
+namespace {
+
+int upload(double **dst, const std::vector<double> &src)
+{
+    HIP_TRY(hipMalloc((void **)dst, src.size() * sizeof(double)));
+    HIP_TRY(hipMemcpy(*dst, src.data(), src.size() * sizeof(double), hipMemcpyHostToDevice));
+    return BISIP_OK;
+}
+
+int effective_variant(const bisip_ctx *c)
+{
+    if (c->model_id != BISIP_MODEL_POLYDECOMP) return BISIP_VARIANT_COLLAPSED;
+    return c->variant == BISIP_VARIANT_AUTO ? BISIP_VARIANT_REDUCED : c->variant;
+}
+
+LaunchArgs make_args(const bisip_ctx *c, const double *theta, double *out, int64_t W,
+                     const double *cb)
+{
+    LaunchArgs a;
+    a.theta = theta;
+    a.out = out;
+    a.W = W;
+    a.cb = cb;
+    a.N = c->N;
+    a.lconst = c->lconst;
+    a.b = c->bounds;
+    return a;
+}
+
+template <class M>
+int launch_logprob(const bisip_ctx *c, const double *theta, int64_t W, double *out, hipStream_t st)
+{
+    const LaunchArgs a = make_args(c, theta, out, W, c->d_cb);
+    const bool vec = ((uintptr_t)theta % 16) == 0;
+    if (W < SMALL_W) {
+        const unsigned grid = (unsigned)((W + BLK_SMALL - 1) / BLK_SMALL);
+        if (vec) hipLaunchKernelGGL((k_logprob<M, BLK_SMALL, true>), dim3(grid), dim3(BLK_SMALL), 0, st, a);
+        else hipLaunchKernelGGL((k_logprob<M, BLK_SMALL, false>), dim3(grid), dim3(BLK_SMALL), 0, st, a);
+    } else {
+        const unsigned grid = (unsigned)((W + BLK_LARGE - 1) / BLK_LARGE);
+        if (vec) hipLaunchKernelGGL((k_logprob<M, BLK_LARGE, true>), dim3(grid), dim3(BLK_LARGE), 0, st, a);
+        else hipLaunchKernelGGL((k_logprob<M, BLK_LARGE, false>), dim3(grid), dim3(BLK_LARGE), 0, st, a);
+    }
+    HIP_TRY(hipGetLastError());
+    return BISIP_OK;
+}
+
+template <int P>
+int launch_reduced(const bisip_ctx *c, const double *theta, int64_t W, double *out, hipStream_t st)
+{
+    const LaunchArgs a = make_args(c, theta, out, W, nullptr);
+    ReducedArgs<P> r;
+    std::memcpy(r.R, c->Rpacked.data(), sizeof(r.R));
+    std::memcpy(r.bhat, c->bhat.data(), sizeof(r.bhat));
+    std::memcpy(r.e, c->evec.data(), sizeof(r.e));
+    r.rest = c->rest;
+    const bool vec = ((uintptr_t)theta % 16) == 0;
+    if (W < SMALL_W) {
+        const unsigned grid = (unsigned)((W + BLK_SMALL - 1) / BLK_SMALL);
+        if (vec) hipLaunchKernelGGL((k_logprob_pd_reduced<P, BLK_SMALL, true>), dim3(grid), dim3(BLK_SMALL), 0, st, a, r);
+        else hipLaunchKernelGGL((k_logprob_pd_reduced<P, BLK_SMALL, false>), dim3(grid), dim3(BLK_SMALL), 0, st, a, r);
+    } else {
+        const unsigned grid = (unsigned)((W + BLK_LARGE - 1) / BLK_LARGE);
+        if (vec) hipLaunchKernelGGL((k_logprob_pd_reduced<P, BLK_LARGE, true>), dim3(grid), dim3(BLK_LARGE), 0, st, a, r);
+        else hipLaunchKernelGGL((k_logprob_pd_reduced<P, BLK_LARGE, false>), dim3(grid), dim3(BLK_LARGE), 0, st, a, r);
+    }
+    HIP_TRY(hipGetLastError());
+    return BISIP_OK;
+}
+
+template <int P, int SPAD>
+int launch_faithful(const bisip_ctx *c, const double *theta, int64_t W, double *out, hipStream_t st)
+{
+    const LaunchArgs a = make_args(c, theta, out, W, c->d_cb_faithful);
+    const bool vec = ((uintptr_t)theta % 16) == 0;
+    const unsigned grid = (unsigned)((W + BLK_SMALL - 1) / BLK_SMALL);
+    if (vec) hipLaunchKernelGGL((k_logprob_pd_faithful<P, SPAD, BLK_SMALL, true>), dim3(grid), dim3(BLK_SMALL), 0, st, a);
+    else hipLaunchKernelGGL((k_logprob_pd_faithful<P, SPAD, BLK_SMALL, false>), dim3(grid), dim3(BLK_SMALL), 0, st, a);
+    HIP_TRY(hipGetLastError());
+    return BISIP_OK;
+}
+
+template <class M>
+int launch_forward(const bisip_ctx *c, const double *theta, int64_t W, double *Z, hipStream_t st)
+{
+    const LaunchArgs a = make_args(c, theta, Z, W, c->d_cb);
+    const long long total = (long long)W * c->N;
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    hipLaunchKernelGGL((k_forward<M>), dim3(grid), dim3(256), 0, st, a);
+    HIP_TRY(hipGetLastError());
+    return BISIP_OK;
+}
+
+#define PD_CASES(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10)
+#define CC_CASES(X) X(1) X(2) X(3) X(4) X(5)
+
+int dispatch_logprob(const bisip_ctx *c, const double *theta, int64_t W, double *out, hipStream_t st)
+{
+    if (W == 0) return BISIP_OK;
+    if ((W + BLK_SMALL - 1) / BLK_SMALL > 0x7fffffffLL)
+        return fail(BISIP_EINVAL, "W=%lld exceeds the launch grid limit", (long long)W);
+    switch (c->model_id) {
+    case BISIP_MODEL_POLYDECOMP: {
+        const int v = effective_variant(c);
+        if (v == BISIP_VARIANT_REDUCED) {
+            switch (c->P) {
+#define X(p) case p: return launch_reduced<p>(c, theta, W, out, st);
+                PD_CASES(X)
+#undef X
+            }
+        } else if (v == BISIP_VARIANT_COLLAPSED) {
+            switch (c->P) {
+#define X(p) case p: return launch_logprob<PDCollapsed<p>>(c, theta, W, out, st);
+                PD_CASES(X)
+#undef X
+            }
+        } else if (v == BISIP_VARIANT_FAITHFUL) {
+            if (!c->d_cb_faithful)
+                return fail(BISIP_EUNSUPPORTED, "faithful variant needs poly_deg in 3..5 and n_taus <= 128");
+#define X(p, s) if (c->P == p && c->SPAD == s) return launch_faithful<p, s>(c, theta, W, out, st);
+            X(3, 64) X(3, 128) X(4, 64) X(4, 128) X(5, 64) X(5, 128)
+#undef X
+        }
+        return fail(BISIP_EUNSUPPORTED, "no kernel for poly_deg=%d variant=%d", c->P, v);
+    }
+    case BISIP_MODEL_COLECOLE:
+        switch (c->D) {
+#define X(d) case d: return launch_logprob<ColeCole<d>>(c, theta, W, out, st);
+            CC_CASES(X)
+#undef X
+        }
+        return fail(BISIP_EUNSUPPORTED, "no kernel for n_modes=%d", c->D);
+    case BISIP_MODEL_DIAS2000: return launch_logprob<Dias>(c, theta, W, out, st);
+    case BISIP_MODEL_SHIN2015: return launch_logprob<Shin>(c, theta, W, out, st);
+    }
+    return fail(BISIP_EINVAL, "bad model_id %d", c->model_id);
+}
+
+int dispatch_forward(const bisip_ctx *c, const double *theta, int64_t W, double *Z, hipStream_t st)
+{
+    if (W == 0) return BISIP_OK;
+    if (((long long)W * c->N + 255) / 256 > 0x7fffffffLL)
+        return fail(BISIP_EINVAL, "W=%lld exceeds the launch grid limit", (long long)W);
+    switch (c->model_id) {
+    case BISIP_MODEL_POLYDECOMP:
+        switch (c->P) {
+#define X(p) case p: return launch_forward<PDCollapsed<p>>(c, theta, W, Z, st);
+            PD_CASES(X)
+#undef X
+        }
+        break;
+    case BISIP_MODEL_COLECOLE:
+        switch (c->D) {
+#define X(d) case d: return launch_forward<ColeCole<d>>(c, theta, W, Z, st);
+            CC_CASES(X)
+#undef X
+        }
+        break;
+    case BISIP_MODEL_DIAS2000: return launch_forward<Dias>(c, theta, W, Z, st);
+    case BISIP_MODEL_SHIN2015: return launch_forward<Shin>(c, theta, W, Z, st);
+    }
+    return fail(BISIP_EUNSUPPORTED, "no forward kernel for this model shape");
+}
+
+int ensure_ws(bisip_ctx *c, size_t bytes)
+{
+    if (c->ws_bytes >= bytes) return BISIP_OK;
+    if (c->d_ws) { (void)hipFree(c->d_ws); c->d_ws = nullptr; c->ws_bytes = 0; }
+    hipError_t e = hipMalloc((void **)&c->d_ws, bytes);
+    if (e != hipSuccess) return fail(BISIP_ENOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    c->ws_bytes = bytes;
+    return BISIP_OK;
+}
+
+const char *name_for(const bisip_ctx *c)
+{
+    switch (c->model_id) {
+    case BISIP_MODEL_POLYDECOMP:
+        switch (effective_variant(c)) {
+        case BISIP_VARIANT_REDUCED: return "k_logprob_pd_reduced";
+        case BISIP_VARIANT_FAITHFUL: return "k_logprob_pd_faithful";
+        default: return "k_logprob<PDCollapsed>";
+        }
+    case BISIP_MODEL_COLECOLE: return "k_logprob<ColeCole>";
+    case BISIP_MODEL_DIAS2000: return "k_logprob<Dias>";
+    default: return "k_logprob<Shin>";
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int bisip_abi_version(void) { return BISIP_ABI_VERSION; }
+
+const char *bisip_last_error(void) { return g_err; }
+
+int bisip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int bisip_polydecomp_operands(int N, const double *w, const double *zn, const double *zn_err,
+                              const bisip_model_desc *desc, double *G_re, double *G_im,
+                              double *R, double *bhat, double *e, double *rest, double *lconst)
+{
+    if (!w || !zn || !zn_err || !desc || !desc->taus || !desc->log_taus || !G_re || !G_im || !R ||
+        !bhat || !e || !rest || !lconst)
+        return fail(BISIP_EINVAL, "null argument");
+    if (N < 1 || desc->poly_deg < 0 || desc->poly_deg > BISIP_MAX_POLY_DEG || desc->n_taus < 1)
+        return fail(BISIP_EINVAL, "bad shape");
+    PolyDecompOperands o;
+    const int D = desc->poly_deg + 1, n = D + 1;
+    polydecomp_operands(N, w, desc->n_taus, desc->taus, D, desc->log_taus, desc->c_exp, zn, zn_err, o);
+    std::memcpy(G_re, o.G_re.data(), sizeof(double) * (size_t)N * D);
+    std::memcpy(G_im, o.G_im.data(), sizeof(double) * (size_t)N * D);
+    std::memcpy(R, o.R.data(), sizeof(double) * (size_t)n * n);
+    std::memcpy(bhat, o.bhat.data(), sizeof(double) * n);
+    std::memcpy(e, o.e.data(), sizeof(double) * n);
+    *rest = o.rest;
+    *lconst = loglike_const(2 * N, zn_err);
+    return BISIP_OK;
+}
+
+int bisip_ctx_create(bisip_ctx **out, int device, int model_id, int N, const double *w,
+                     const double *zn, const double *zn_err, int ndim, const double *lo,
+                     const double *hi, const bisip_model_desc *desc)
+{
+    if (!out || !w || !zn || !zn_err || !lo || !hi) return fail(BISIP_EINVAL, "null argument");
+    *out = nullptr;
+    if (N < 1 || N > 4096) return fail(BISIP_EINVAL, "N=%d out of range [1,4096]", N);
+    if (ndim < 1 || ndim > BISIP_MAX_NDIM) return fail(BISIP_EINVAL, "ndim=%d out of range", ndim);
+    for (int i = 0; i < 2 * N; ++i)
+        if (!(zn_err[i] > 0.0) || !std::isfinite(zn_err[i]) || !std::isfinite(zn[i]))
+            return fail(BISIP_EINVAL, "zn/zn_err[%d] must be finite and zn_err > 0", i);
+    for (int j = 0; j < N; ++j)
+        if (!(w[j] > 0.0) || !std::isfinite(w[j])) return fail(BISIP_EINVAL, "w[%d] must be finite and > 0", j);
+
+    int P = 0, D = 0, S = 0;
+    switch (model_id) {
+    case BISIP_MODEL_POLYDECOMP:
+        if (!desc || !desc->taus || !desc->log_taus) return fail(BISIP_EINVAL, "PolynomialDecomposition needs taus/log_taus");
+        P = desc->poly_deg; S = desc->n_taus;
+        if (P < 0 || P > BISIP_MAX_POLY_DEG) return fail(BISIP_EUNSUPPORTED, "poly_deg=%d not in [0,%d]", P, BISIP_MAX_POLY_DEG);
+        if (S < 1 || S > 8192) return fail(BISIP_EINVAL, "n_taus=%d out of range", S);
+        if (ndim != P + 2) return fail(BISIP_EINVAL, "ndim=%d but poly_deg+2=%d", ndim, P + 2);
+        break;
+    case BISIP_MODEL_COLECOLE:
+        if (!desc) return fail(BISIP_EINVAL, "PeltonColeCole needs n_modes");
+        D = desc->n_modes;
+        if (D < 1 || D > BISIP_MAX_MODES) return fail(BISIP_EUNSUPPORTED, "n_modes=%d not in [1,%d]", D, BISIP_MAX_MODES);
+        if (ndim != 1 + 3 * D) return fail(BISIP_EINVAL, "ndim=%d but 1+3*n_modes=%d", ndim, 1 + 3 * D);
+        break;
+    case BISIP_MODEL_DIAS2000:
+        if (ndim != 5) return fail(BISIP_EINVAL, "Dias2000 has ndim 5, got %d", ndim);
+        break;
+    case BISIP_MODEL_SHIN2015:
+        if (ndim != 6) return fail(BISIP_EINVAL, "Shin2015 has ndim 6, got %d", ndim);
+        break;
+    default: return fail(BISIP_EINVAL, "bad model_id %d", model_id);
+    }
+
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(BISIP_EINVAL, "device %d not in [0,%d)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+
+    bisip_ctx *c = new (std::nothrow) bisip_ctx;
+    if (!c) return fail(BISIP_ENOMEM, "out of host memory");
+    c->device = device; c->model_id = model_id; c->N = N; c->ndim = ndim;
+    c->P = P; c->D = D; c->S = S;
+    c->lconst = loglike_const(2 * N, zn_err);
+    for (int q = 0; q < MAXD; ++q) { c->bounds.lo[q] = 0.0; c->bounds.hi[q] = 0.0; }
+    for (int q = 0; q < ndim; ++q) { c->bounds.lo[q] = lo[q]; c->bounds.hi[q] = hi[q]; }
+
+    std::vector<double> lnw, iv;
+    common_operands(N, w, zn_err, lnw, iv);
+    int rc = BISIP_OK;
+    if (model_id == BISIP_MODEL_POLYDECOMP) {
+        c->c_exp = desc->c_exp;
+        PolyDecompOperands o;
+        polydecomp_operands(N, w, S, desc->taus, P + 1, desc->log_taus, desc->c_exp, zn, zn_err, o);
+        const int rec = 4 + 2 * (P + 1);
+        std::vector<double> cb((size_t)N * rec);
+        for (int j = 0; j < N; ++j) {
+            double *r = &cb[(size_t)j * rec];
+            r[0] = zn[j]; r[1] = zn[N + j]; r[2] = iv[j]; r[3] = iv[N + j];
+            for (int p = 0; p <= P; ++p) {
+                r[4 + p] = o.G_re[(size_t)j * (P + 1) + p];
+                r[4 + P + 1 + p] = o.G_im[(size_t)j * (P + 1) + p];
+            }
+        }
+        rc = upload(&c->d_cb, cb);
+        const int n = P + 2;
+        c->Rpacked.clear();
+        for (int i = 0; i < n; ++i)
+            for (int j = i; j < n; ++j) c->Rpacked.push_back(o.R[(size_t)i * n + j]);
+        c->bhat = o.bhat; c->evec = o.e; c->rest = o.rest;
+        if (rc == BISIP_OK && P >= 3 && P <= 5 && S <= 128) {
+            const int SPAD = S <= 64 ? 64 : 128;
+            c->SPAD = SPAD;
+            std::vector<double> fb((size_t)(P + 1) * SPAD + (size_t)N * (4 + 2 * SPAD), 0.0);
+            for (int p = 0; p <= P; ++p)
+                for (int k = 0; k < S; ++k) fb[(size_t)p * SPAD + k] = desc->log_taus[(size_t)p * S + k];
+            double *base = &fb[(size_t)(P + 1) * SPAD];
+            for (int j = 0; j < N; ++j) {
+                double *r = base + (size_t)j * (4 + 2 * SPAD);
+                r[0] = zn[j]; r[1] = zn[N + j]; r[2] = iv[j]; r[3] = iv[N + j];
+                for (int k = 0; k < S; ++k) {
+                    r[4 + k] = o.K_re[(size_t)j * S + k];
+                    r[4 + SPAD + k] = o.K_im[(size_t)j * S + k];
+                }
+            }
+            rc = upload(&c->d_cb_faithful, fb);
+        }
+    } else {
+        std::vector<double> cb((size_t)N * 8, 0.0);
+        for (int j = 0; j < N; ++j) {
+            double *r = &cb[(size_t)j * 8];
+            r[0] = zn[j]; r[1] = zn[N + j]; r[2] = iv[j]; r[3] = iv[N + j];
+            r[4] = w[j]; r[5] = lnw[j];
+        }
+        rc = upload(&c->d_cb, cb);
+    }
+    if (rc == BISIP_OK) {
+        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) rc = fail(BISIP_EHIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
+    }
+    if (rc != BISIP_OK) { bisip_ctx_destroy(c); return rc; }
+    c->kernel_name = name_for(c);
+    *out = c;
+    return BISIP_OK;
+}
+
+void bisip_ctx_destroy(bisip_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->d_cb) (void)hipFree(c->d_cb);
+    if (c->d_cb_faithful) (void)hipFree(c->d_cb_faithful);
+    if (c->d_ws) (void)hipFree(c->d_ws);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int bisip_ctx_set_bounds(bisip_ctx *c, const double *lo, const double *hi)
+{
+    if (!c || !lo || !hi) return fail(BISIP_EINVAL, "null argument");
+    for (int q = 0; q < c->ndim; ++q) { c->bounds.lo[q] = lo[q]; c->bounds.hi[q] = hi[q]; }
+    return BISIP_OK;
+}
+
+int bisip_ctx_set_variant(bisip_ctx *c, int variant)
+{
+    if (!c) return fail(BISIP_EINVAL, "null context");
+    if (variant < BISIP_VARIANT_AUTO || variant > BISIP_VARIANT_REDUCED)
+        return fail(BISIP_EINVAL, "bad variant %d", variant);
+    if (c->model_id != BISIP_MODEL_POLYDECOMP && variant != BISIP_VARIANT_AUTO &&
+        variant != BISIP_VARIANT_COLLAPSED)
+        return fail(BISIP_EUNSUPPORTED, "this model has a single formulation");
+    if (variant == BISIP_VARIANT_FAITHFUL && !c->d_cb_faithful)
+        return fail(BISIP_EUNSUPPORTED, "faithful variant needs poly_deg in 3..5 and n_taus <= 128");
+    c->variant = variant;
+    c->kernel_name = name_for(c);
+    return BISIP_OK;
+}
+
+int bisip_ctx_get_variant(const bisip_ctx *c) { return c ? effective_variant(c) : BISIP_EINVAL; }
+int bisip_ctx_ndim(const bisip_ctx *c) { return c ? c->ndim : BISIP_EINVAL; }
+int bisip_ctx_nfreq(const bisip_ctx *c) { return c ? c->N : BISIP_EINVAL; }
+int bisip_ctx_device(const bisip_ctx *c) { return c ? c->device : BISIP_EINVAL; }
+double bisip_ctx_loglike_const(const bisip_ctx *c) { return c ? c->lconst : NAN; }
+const char *bisip_ctx_kernel_name(const bisip_ctx *c) { return c ? c->kernel_name : ""; }
+
+int bisip_logprob_dev(bisip_ctx *c, const double *d_theta, int64_t W, double *d_logp, void *stream)
+{
+    if (!c) return fail(BISIP_EINVAL, "null context");
+    if (W < 0) return fail(BISIP_EINVAL, "W=%lld < 0", (long long)W);
+    if (W > 0 && (!d_theta || !d_logp)) return fail(BISIP_EINVAL, "null buffer");
+    if (((uintptr_t)d_theta % 8) || ((uintptr_t)d_logp % 8)) return fail(BISIP_EINVAL, "buffers must be 8-byte aligned");
+    HIP_TRY(hipSetDevice(c->device));
+    return dispatch_logprob(c, d_theta, W, d_logp, (hipStream_t)stream);
+}
+
+int bisip_forward_dev(bisip_ctx *c, const double *d_theta, int64_t W, double *d_Z, void *stream)
+{
+    if (!c) return fail(BISIP_EINVAL, "null context");
+    if (W < 0) return fail(BISIP_EINVAL, "W=%lld < 0", (long long)W);
+    if (W > 0 && (!d_theta || !d_Z)) return fail(BISIP_EINVAL, "null buffer");
+    HIP_TRY(hipSetDevice(c->device));
+    return dispatch_forward(c, d_theta, W, d_Z, (hipStream_t)stream);
+}
+
+int bisip_logprob(bisip_ctx *c, const double *theta, int64_t W, double *logp)
+{
+    if (!c) return fail(BISIP_EINVAL, "null context");
+    if (W < 0) return fail(BISIP_EINVAL, "W=%lld < 0", (long long)W);
+    if (W == 0) return BISIP_OK;
+    if (!theta || !logp) return fail(BISIP_EINVAL, "null buffer");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t tb = (size_t)W * c->ndim * sizeof(double), ob = (size_t)W * sizeof(double);
+    const size_t tb_al = (tb + 255) & ~(size_t)255;
+    int rc = ensure_ws(c, tb_al + ob);
+    if (rc != BISIP_OK) return rc;
+    double *d_theta = c->d_ws;
+    double *d_out = (double *)((char *)c->d_ws + tb_al);
+    HIP_TRY(hipMemcpyAsync(d_theta, theta, tb, hipMemcpyHostToDevice, c->stream));
+    rc = dispatch_logprob(c, d_theta, W, d_out, c->stream);
+    if (rc != BISIP_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(logp, d_out, ob, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return BISIP_OK;
+}
+
+int bisip_forward(bisip_ctx *c, const double *theta, int64_t W, double *Z)
+{
+    if (!c) return fail(BISIP_EINVAL, "null context");
+    if (W < 0) return fail(BISIP_EINVAL, "W=%lld < 0", (long long)W);
+    if (W == 0) return BISIP_OK;
+    if (!theta || !Z) return fail(BISIP_EINVAL, "null buffer");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t tb = (size_t)W * c->ndim * sizeof(double), zb = (size_t)W * 2 * c->N * sizeof(double);
+    const size_t tb_al = (tb + 255) & ~(size_t)255;
+    int rc = ensure_ws(c, tb_al + zb);
+    if (rc != BISIP_OK) return rc;
+    double *d_theta = c->d_ws;
+    double *d_Z = (double *)((char *)c->d_ws + tb_al);
+    HIP_TRY(hipMemcpyAsync(d_theta, theta, tb, hipMemcpyHostToDevice, c->stream));
+    rc = dispatch_forward(c, d_theta, W, d_Z, c->stream);
+    if (rc != BISIP_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(Z, d_Z, zb, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return BISIP_OK;
+}
+
+}  // extern "C"

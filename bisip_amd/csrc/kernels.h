@@ -1,0 +1,404 @@
+// kernels.h -- CDNA4 (gfx950) device code of the log-probability hot path.
+//
+// Mapping: ONE LANE PER WALKER.  A workgroup takes a contiguous block
+// of BLK walkers; their theta rows (row-major (W,ndim), the layout emcee hands over)
+// are fetched with fully coalesced 16-byte loads into LDS and read back one row per
+// lane (a transposition, not a reuse buffer).  Everything that does not depend on
+// the walker -- the frequency array, the measured spectrum, 1/sigma^2, the
+// pre-reduced model operands -- is wave-uniform, so it is read through the scalar
+// cache into SGPRs (s_load) and costs no vector registers, no LDS bandwidth and no
+// cross-lane traffic.  With one walker per lane there is no cross-lane reduction
+// at all: the sum over frequencies is a sequential in-register accumulation, so a
+// walker's result does not depend on where it sits in the batch.
+//
+// All arithmetic is IEEE binary64; no fast-math, no MFMA (elementwise complex
+// arithmetic).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/bisip_hip.h"
+
+namespace bisip {
+
+constexpr int MAXD = BISIP_MAX_NDIM;
+
+typedef double dbl2 __attribute__((ext_vector_type(2)));
+
+struct Bounds {
+    double lo[MAXD];
+    double hi[MAXD];
+};
+
+struct LaunchArgs {
+    const double *__restrict__ theta;  // (W, NDIM) row-major
+    double *__restrict__ out;          // (W,) log-probabilities   | (W,2,N) forward
+    long long W;
+    const double *__restrict__ cb;     // per-frequency records (wave-uniform reads)
+    int N;
+    double lconst;                     // -sum ln sigma^2
+    Bounds b;
+};
+
+// ---------------------------------------------------------------------------------
+// theta staging: BLK rows, coalesced global -> LDS, then one row per lane.
+// ---------------------------------------------------------------------------------
+template <int NDIM, int BLK, bool VEC>
+__device__ __forceinline__ void stage_theta(const double *__restrict__ theta, long long W,
+                                            long long row0, double *lds)
+{
+    constexpr int CHUNK = BLK * NDIM;  // doubles per block
+    const int t = threadIdx.x;
+    const long long base = row0 * NDIM;
+    const long long avail = (W - row0) * (long long)NDIM;  // doubles left from row0
+    if constexpr (VEC && (CHUNK % 2 == 0)) {
+        const dbl2 *__restrict__ src = reinterpret_cast<const dbl2 *>(theta + base);
+        dbl2 *dst = reinterpret_cast<dbl2 *>(lds);
+        constexpr int N2 = CHUNK / 2;
+        constexpr int ROUNDS = (N2 + BLK - 1) / BLK;
+        if (avail >= CHUNK) {
+#pragma unroll
+            for (int r = 0; r < ROUNDS; ++r) {
+                const int i = r * BLK + t;
+                if ((r + 1) * BLK <= N2 || i < N2) dst[i] = __builtin_nontemporal_load(src + i);
+            }
+        } else {
+            for (int i = t; i < N2; i += BLK) {
+                if (2LL * i + 1 < avail) dst[i] = src[i];
+                else if (2LL * i < avail) lds[2 * i] = theta[base + 2 * i];
+            }
+        }
+    } else {
+        if (avail >= CHUNK) {
+#pragma unroll
+            for (int r = 0; r < NDIM; ++r)
+                lds[r * BLK + t] = __builtin_nontemporal_load(theta + base + r * BLK + t);
+        } else {
+            for (int i = t; i < CHUNK; i += BLK)
+                if (i < avail) lds[i] = theta[base + i];
+        }
+    }
+}
+
+// strict open box, NaN -> false   (reference src/bisip/models.py:64-69)
+template <int NDIM>
+__device__ __forceinline__ bool in_prior(const double (&th)[NDIM], const Bounds &b)
+{
+    bool ok = true;
+#pragma unroll
+    for (int q = 0; q < NDIM; ++q) ok = ok && (b.lo[q] < th[q]) && (th[q] < b.hi[q]);
+    return ok;
+}
+
+// ---------------------------------------------------------------------------------
+// Forward models.  Each exposes
+//   NDIM, REC (doubles per frequency record; rec[0..3] = y_re, y_im, 1/s2_re, 1/s2_im)
+//   Setup / setup(theta row)           per-walker quantities, computed once per lane
+//   eval(setup, rec+4, zr, zi)         complex impedance at one frequency
+// ---------------------------------------------------------------------------------
+
+// PolynomialDecomposition, collapsed: Z_j = R0*(1 - sum_p a_p G[j,p]).
+// G[j,p] = sum_k log_taus[p,k]*K[j,k] is walker-independent because c_exp and the tau
+// grid are fixed per model (reference src/bisip/models.py:195-209, cython_funcs.pyx:84-93).
+template <int P>
+struct PDCollapsed {
+    static constexpr int NDIM = P + 2;
+    static constexpr int REC = 4 + 2 * (P + 1);
+    struct Setup {
+        double r0;
+        double a[P + 1];
+    };
+    __device__ static __forceinline__ Setup setup(const double (&th)[NDIM])
+    {
+        Setup s;
+        s.r0 = th[0];
+#pragma unroll
+        for (int p = 0; p <= P; ++p) s.a[p] = th[1 + p];  // ascending a0..aP
+        return s;
+    }
+    __device__ static __forceinline__ void eval(const Setup &s, const double *__restrict__ m,
+                                                double &zr, double &zi)
+    {
+        double gr = 0.0, gi = 0.0;
+#pragma unroll
+        for (int p = 0; p <= P; ++p) {
+            gr = fma(s.a[p], m[p], gr);
+            gi = fma(s.a[p], m[P + 1 + p], gi);
+        }
+        zr = s.r0 * (1.0 - gr);
+        zi = s.r0 * (0.0 - gi);
+    }
+};
+
+// PeltonColeCole with D modes (reference src/bisip/cython_funcs.pyx:33-34, 49-62):
+// (i w e^lt)^c = exp(c (ln w + lt)) * (cos(c pi/2) + i sin(c pi/2)).
+template <int D>
+struct ColeCole {
+    static constexpr int NDIM = 1 + 3 * D;
+    static constexpr int REC = 8;  // y_re y_im iv_re iv_im | w lnw pad pad
+    struct Setup {
+        double r0;
+        double m[D], lt[D], c[D], cs[D], sn[D];
+    };
+    __device__ static __forceinline__ Setup setup(const double (&th)[NDIM])
+    {
+        Setup s;
+        s.r0 = th[0];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            s.m[i] = th[1 + i];
+            s.lt[i] = th[1 + D + i];
+            s.c[i] = th[1 + 2 * D + i];
+            sincospi(0.5 * s.c[i], &s.sn[i], &s.cs[i]);
+        }
+        return s;
+    }
+    __device__ static __forceinline__ void eval(const Setup &s, const double *__restrict__ m,
+                                                double &zr, double &zi)
+    {
+        const double lnw = m[1];
+        double sr = 0.0, si = 0.0;
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            const double e = exp(s.c[i] * (lnw + s.lt[i]));
+            const double dr = fma(e, s.cs[i], 1.0);  // 1 + x
+            const double di = e * s.sn[i];
+            const double inv = 1.0 / fma(dr, dr, di * di);
+            sr = fma(s.m[i], 1.0 - dr * inv, sr);  // m*(1 - 1/(1+x))
+            si = fma(s.m[i], di * inv, si);
+        }
+        zr = s.r0 * (1.0 - sr);
+        zi = s.r0 * (0.0 - si);
+    }
+};
+
+// Dias2000 (reference src/bisip/cython_funcs.pyx:36-40, 64-73)
+struct Dias {
+    static constexpr int NDIM = 5;
+    static constexpr int REC = 8;
+    struct Setup {
+        double r0, m, tau, taup, taupp;
+    };
+    __device__ static __forceinline__ Setup setup(const double (&th)[NDIM])
+    {
+        Setup s;
+        s.r0 = th[0];
+        s.m = th[1];
+        s.tau = exp(th[2]);
+        s.taup = s.tau * (1.0 / th[4] - 1.0) / (1.0 - s.m);
+        s.taupp = (s.tau * s.tau) * (th[3] * th[3]);
+        return s;
+    }
+    __device__ static __forceinline__ void eval(const Setup &s, const double *__restrict__ m,
+                                                double &zr, double &zi)
+    {
+        const double w = m[0];
+        // (i w tau'')^0.5 = sqrt(w tau'') (cos(pi/4) + i sin(pi/4))
+        const double sq = sqrt(w * s.taupp) * 0.70710678118654752440;
+        const double mur = sq, mui = fma(w, s.tau, sq);
+        const double inv = 1.0 / fma(mur, mur, mui * mui);
+        const double tr = fma(mur, inv, 1.0), ti = -(mui * inv);  // 1 + 1/mu
+        const double a = w * s.taup;
+        const double dr = fma(-a, ti, 1.0), di = a * tr;          // 1 + i a (tr + i ti)
+        const double inv2 = 1.0 / fma(dr, dr, di * di);
+        const double fr = 1.0 - dr * inv2, fi = di * inv2;        // 1 - 1/den
+        zr = s.r0 * (1.0 - s.m * fr);
+        zi = s.r0 * (0.0 - s.m * fi);
+    }
+};
+
+// Shin2015 (reference src/bisip/cython_funcs.pyx:42-44, 96-108): two CPE||R elements.
+struct Shin {
+    static constexpr int NDIM = 6;
+    static constexpr int REC = 8;
+    struct Setup {
+        double invR[2], Q[2], n[2], cs[2], sn[2];
+    };
+    __device__ static __forceinline__ Setup setup(const double (&th)[NDIM])
+    {
+        Setup s;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            s.invR[i] = 1.0 / th[i];
+            s.Q[i] = exp(th[2 + i]);
+            s.n[i] = th[4 + i];
+            sincospi(0.5 * s.n[i], &s.sn[i], &s.cs[i]);
+        }
+        return s;
+    }
+    __device__ static __forceinline__ void eval(const Setup &s, const double *__restrict__ m,
+                                                double &zr, double &zi)
+    {
+        const double lnw = m[1];
+        zr = 0.0;
+        zi = 0.0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const double p = s.Q[i] * exp(s.n[i] * lnw);  // Q (iw)^n = p (cs + i sn)
+            const double yr = fma(p, s.cs[i], s.invR[i]), yi = p * s.sn[i];
+            const double inv = 1.0 / fma(yr, yr, yi * yi);
+            zr = fma(yr, inv, zr);
+            zi = fma(-yi, inv, zi);
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------
+// log-probability, one lane per walker, any model above.
+// ---------------------------------------------------------------------------------
+template <class M, int BLK, bool VEC>
+__global__ __launch_bounds__(BLK) void k_logprob(const LaunchArgs a)
+{
+    constexpr int NDIM = M::NDIM;
+    __shared__ __attribute__((aligned(16))) double lds[BLK * NDIM];
+    const long long row0 = (long long)blockIdx.x * BLK;
+    stage_theta<NDIM, BLK, VEC>(a.theta, a.W, row0, lds);
+    __syncthreads();
+    const long long row = row0 + threadIdx.x;
+    if (row >= a.W) return;
+    double th[NDIM];
+#pragma unroll
+    for (int q = 0; q < NDIM; ++q) th[q] = lds[threadIdx.x * NDIM + q];
+
+    double lp = -__builtin_inf();
+    if (in_prior<NDIM>(th, a.b)) {  // out-of-prior rows never touch the forward model
+        const typename M::Setup s = M::setup(th);
+        double acc0 = 0.0, acc1 = 0.0;
+        const double *__restrict__ rec = a.cb;
+        for (int j = 0; j < a.N; ++j, rec += M::REC) {
+            double zr, zi;
+            M::eval(s, rec + 4, zr, zi);
+            const double rr = rec[0] - zr, ri = rec[1] - zi;
+            acc0 = fma(rr * rr, rec[2], acc0);
+            acc1 = fma(ri * ri, rec[3], acc1);
+        }
+        lp = fma(-0.5, acc0 + acc1, a.lconst);
+    }
+    a.out[row] = lp;
+}
+
+// ---------------------------------------------------------------------------------
+// PolynomialDecomposition, QR-reduced (BISIP_VARIANT_REDUCED).
+// The forward model is linear in b = R0*(1, a_0..a_P), so with the weighted design
+// matrix A (2N x n, n = P+2) factored once on the host, A = Q [R;0]:
+//   chi^2(b) = |y/s - A b|^2 = rest + | e + R (bhat - b) |^2     (exact for ANY bhat,
+//   e = Q^T(y/s)[:n] - R bhat carried explicitly).
+// Per walker: n products, n subtractions, n(n+1)/2 FMAs, n squares -- the kernel is
+// then bound by streaming theta in and logp out (8*(ndim+1) B/eval).
+// ---------------------------------------------------------------------------------
+template <int P>
+struct ReducedArgs {
+    static constexpr int n = P + 2;
+    double R[n * (n + 1) / 2];  // packed upper triangle, row-major
+    double bhat[n];
+    double e[n];
+    double rest;
+};
+
+template <int P, int BLK, bool VEC>
+__global__ __launch_bounds__(BLK) void k_logprob_pd_reduced(const LaunchArgs a,
+                                                            const ReducedArgs<P> r)
+{
+    constexpr int NDIM = P + 2;
+    constexpr int n = NDIM;
+    __shared__ __attribute__((aligned(16))) double lds[BLK * NDIM];
+    const long long row0 = (long long)blockIdx.x * BLK;
+    stage_theta<NDIM, BLK, VEC>(a.theta, a.W, row0, lds);
+    __syncthreads();
+    const long long row = row0 + threadIdx.x;
+    if (row >= a.W) return;
+    double th[NDIM];
+#pragma unroll
+    for (int q = 0; q < NDIM; ++q) th[q] = lds[threadIdx.x * NDIM + q];
+
+    double d[n];
+    d[0] = r.bhat[0] - th[0];
+#pragma unroll
+    for (int q = 1; q < n; ++q) d[q] = r.bhat[q] - th[0] * th[q];
+    double chi2 = r.rest;
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < n; ++i) {
+        double u = r.e[i];
+#pragma unroll
+        for (int j = i; j < n; ++j, ++k) u = fma(r.R[k], d[j], u);
+        chi2 = fma(u, u, chi2);
+    }
+    const double lp = fma(-0.5, chi2, a.lconst);
+    a.out[row] = in_prior<NDIM>(th, a.b) ? lp : -__builtin_inf();
+}
+
+// ---------------------------------------------------------------------------------
+// PolynomialDecomposition, loop-faithful (BISIP_VARIANT_FAITHFUL): the reference's own
+// structure  M_k = sum_p a_p L[p,k];  z_j = sum_k M_k K[j,k]  (cython_funcs.pyx:84-90)
+// in the reference's summation order, with only the walker-independent K[j,k] hoisted.
+// The tau axis is zero-padded to SPAD so the k loops unroll into straight FMA chains
+// fed by scalar loads (a padded term contributes an exact +0).
+// cb layout: L (P+1, SPAD) | per j: y_re y_im iv_re iv_im | K_re[j,0:SPAD] | K_im[j,0:SPAD].
+// ---------------------------------------------------------------------------------
+template <int P, int SPAD, int BLK, bool VEC>
+__global__ __launch_bounds__(BLK) void k_logprob_pd_faithful(const LaunchArgs a)
+{
+    constexpr int NDIM = P + 2;
+    __shared__ __attribute__((aligned(16))) double lds[BLK * NDIM];
+    const long long row0 = (long long)blockIdx.x * BLK;
+    stage_theta<NDIM, BLK, VEC>(a.theta, a.W, row0, lds);
+    __syncthreads();
+    const long long row = row0 + threadIdx.x;
+    if (row >= a.W) return;
+    double th[NDIM];
+#pragma unroll
+    for (int q = 0; q < NDIM; ++q) th[q] = lds[threadIdx.x * NDIM + q];
+    double lp = -__builtin_inf();
+    if (in_prior<NDIM>(th, a.b)) {
+        double M[SPAD];
+        const double *__restrict__ L = a.cb;
+#pragma unroll
+        for (int k = 0; k < SPAD; ++k) M[k] = 0.0;
+#pragma unroll
+        for (int p = 0; p <= P; ++p)  // i outer, k inner, as cython_funcs.pyx:84-86
+#pragma unroll
+            for (int k = 0; k < SPAD; ++k) M[k] = fma(th[1 + p], L[p * SPAD + k], M[k]);
+        const double *__restrict__ rec = a.cb + (P + 1) * SPAD;
+        constexpr int STRIDE = 4 + 2 * SPAD;
+        double acc0 = 0.0, acc1 = 0.0;
+        for (int j = 0; j < a.N; ++j, rec += STRIDE) {
+            double sr = 0.0, si = 0.0;
+#pragma unroll
+            for (int k = 0; k < SPAD; ++k) {
+                sr = fma(M[k], rec[4 + k], sr);
+                si = fma(M[k], rec[4 + SPAD + k], si);
+            }
+            const double zr = th[0] * (1.0 - sr), zi = th[0] * (0.0 - si);
+            const double rr = rec[0] - zr, ri = rec[1] - zi;
+            acc0 = fma(rr * rr, rec[2], acc0);
+            acc1 = fma(ri * ri, rec[3], acc1);
+        }
+        lp = fma(-0.5, acc0 + acc1, a.lconst);
+    }
+    a.out[row] = lp;
+}
+
+// ---------------------------------------------------------------------------------
+// Batched forward(): one thread per (walker, frequency); Z is (W,2,N).
+// Per-walker setup is recomputed per thread; this kernel is bound by writing Z.
+// ---------------------------------------------------------------------------------
+template <class M>
+__global__ __launch_bounds__(256) void k_forward(const LaunchArgs a)
+{
+    constexpr int NDIM = M::NDIM;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = a.W * (long long)a.N;
+    if (idx >= total) return;
+    const long long wk = idx / a.N;
+    const int j = (int)(idx - wk * a.N);
+    double th[NDIM];
+#pragma unroll
+    for (int q = 0; q < NDIM; ++q) th[q] = a.theta[wk * NDIM + q];
+    const typename M::Setup s = M::setup(th);
+    double zr, zi;
+    M::eval(s, a.cb + (long long)j * M::REC + 4, zr, zi);
+    a.out[wk * 2 * a.N + j] = zr;
+    a.out[wk * 2 * a.N + a.N + j] = zi;
+}
+
+}  // namespace bisip

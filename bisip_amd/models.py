@@ -1,0 +1,322 @@
+"""Model classes: the reference's ``bisip.models`` surface over the HIP kernels.
+
+Same class names, constructor arguments, parameter dictionaries, ``forward`` /
+``_log_prior`` / ``_log_likelihood`` / ``_log_probability`` signatures and ``fit()``
+workflow as the reference (src/bisip/models.py), so user code only changes its
+import.  What differs is where the arithmetic runs: every log-probability and
+forward evaluation is a launch of a gfx950 kernel through ``libbisip_hip.so``, and
+all of them accept a whole ensemble ``theta (n, ndim)`` at once (the emcee
+``vectorize=True`` contract) besides the reference's single ``theta (ndim,)``.
+
+There is no CPU fallback: without the HIP library or without a GPU these methods
+raise ``RuntimeError``.
+"""
+
+import numpy as np
+
+from . import _hip
+from . import utils as _utils
+from .sampler import EnsembleSampler
+
+
+class Inversion(_utils.utils):
+    """Base class for the SIP inversion models (reference: src/bisip/models.py:21-179).
+
+    Args:
+        filepath (str): path of the 5-column data file.
+        nwalkers (int): number of walkers. Defaults to 32.
+        nsteps (int): number of MCMC steps. Defaults to 5000.
+        headers (int): number of header lines to skip. Defaults to 1.
+        ph_units (str): 'mrad', 'rad' or 'deg'. Defaults to 'mrad'.
+        device (int): GPU ordinal the model's operands live on (new; default 0).
+    """
+
+    _model_id = None
+
+    def __init__(self, filepath, nwalkers=32, nsteps=5000, headers=1, ph_units='mrad',
+                 device=0):
+        self.filepath = filepath
+        self.nwalkers = nwalkers
+        self.nsteps = nsteps
+        self.headers = headers
+        self.ph_units = ph_units
+        self.device = device
+
+        self._p0 = None
+        self._params = {}
+        self.__fitted = False
+        self._ctx_cache = {}
+        self._sampler = None
+
+        self._data = self.load_data(self.filepath, self.headers, self.ph_units)
+
+    # -- device contexts ----------------------------------------------------------------
+    def _desc(self):
+        """Model-specific kwargs of HipContext; overridden by subclasses."""
+        return {}
+
+    def _context(self, x=None, y=None, yerr=None):
+        """The HIP context holding (x, y, yerr) = (w, zn, zn_err).  Contexts are cached
+        by operand bytes, so the usual call pattern (always the loaded data) builds
+        exactly one."""
+        d = self._data
+        x = d['w'] if x is None else np.ascontiguousarray(x, dtype=np.float64)
+        y = d['zn'] if y is None else np.ascontiguousarray(y, dtype=np.float64)
+        yerr = d['zn_err'] if yerr is None else np.ascontiguousarray(yerr, dtype=np.float64)
+        desc = self._desc()
+        key = (x.tobytes(), y.tobytes(), yerr.tobytes(),
+               tuple(sorted((k, np.asarray(v).tobytes()) for k, v in desc.items())))
+        ctx = self._ctx_cache.get(key)
+        if ctx is None:
+            ctx = _hip.HipContext(self._model_id, x, y, yerr, self.param_bounds,
+                                  device=self.device, **desc)
+            if len(self._ctx_cache) >= 8:
+                self._ctx_cache.pop(next(iter(self._ctx_cache))).close()
+            self._ctx_cache[key] = ctx
+        return ctx
+
+    def _check_model(self, f):
+        if f is not None and f != self.forward:
+            raise ValueError('the fused GPU log-likelihood evaluates this model\'s own '
+                             'forward(); pass model.forward (or None)')
+
+    @staticmethod
+    def _as_rows(theta):
+        theta = np.asarray(theta, dtype=np.float64)
+        if theta.ndim == 1:
+            return theta[None, :], True
+        if theta.ndim != 2:
+            raise ValueError(f'theta must be (ndim,) or (n, ndim), got shape {theta.shape}')
+        return theta, False
+
+    # -- the log-probability trio (reference: src/bisip/models.py:59-76) ------------------
+    def _log_likelihood(self, theta, f, x, y, yerr):
+        """Gaussian log-likelihood  -0.5*sum((y - f(theta,x))**2/yerr**2 + 2*log(yerr**2)).
+
+        ``theta`` may be one vector or an (n, ndim) ensemble."""
+        self._check_model(f)
+        rows, single = self._as_rows(theta)
+        ctx = self._context(x, y, yerr)
+        open_box = np.array([np.full(rows.shape[1], -np.inf), np.full(rows.shape[1], np.inf)])
+        ctx.set_bounds(open_box)
+        try:
+            out = ctx.logprob(rows)
+        finally:
+            ctx.set_bounds(self.param_bounds)
+        return float(out[0]) if single else out
+
+    def _log_prior(self, theta, bounds):
+        """Uniform prior on the OPEN box: 0 inside, -inf on or outside a bound."""
+        rows, single = self._as_rows(theta)
+        bounds = np.asarray(bounds, dtype=np.float64)
+        inside = np.logical_and(bounds[0] < rows, rows < bounds[1]).all(axis=1)
+        out = np.where(inside, 0.0, -np.inf)
+        return float(out[0]) if single else out
+
+    def _log_probability(self, theta, model=None, bounds=None, x=None, y=None, yerr=None):
+        """Bayes numerator: prior + likelihood, fused in one kernel launch.  Rows outside
+        the prior return -inf without evaluating the forward model."""
+        self._check_model(model)
+        rows, single = self._as_rows(theta)
+        ctx = self._context(x, y, yerr)
+        ctx.set_bounds(self.param_bounds if bounds is None else bounds)
+        out = ctx.logprob(rows)
+        return float(out[0]) if single else out
+
+    # public aliases named by the north star
+    log_likelihood = _log_likelihood
+    log_prior = _log_prior
+    log_probability = _log_probability
+    log_prob = _log_probability
+
+    def _forward_rows(self, theta, w):
+        rows, single = self._as_rows(theta)
+        d = self._data
+        w = d['w'] if w is None else np.ascontiguousarray(w, dtype=np.float64)
+        if w.shape == d['w'].shape and np.array_equal(w, d['w']):
+            ctx = self._context()
+        else:  # forward on another frequency grid: operands y/yerr are irrelevant
+            ones = np.ones((2, w.size))
+            ctx = self._context(w, ones, ones)
+        Z = ctx.forward(rows)
+        return Z[0] if single else Z
+
+    # -- sampling (reference: src/bisip/models.py:78-137) ----------------------------------
+    def _check_if_fitted(self):
+        if not self.fitted:
+            raise AssertionError('Model is not fitted! Fit the model to a '
+                                 'dataset before attempting to plot results.')
+
+    def fit(self, p0=None, pool=None, moves=None):
+        """Sample the posterior with the stretch-move ensemble sampler.
+
+        Args:
+            p0 (ndarray): starting positions (nwalkers, ndim); drawn uniformly from the
+                prior box with the global NumPy RNG when None.
+            pool: accepted for signature compatibility and ignored -- the whole
+                half-ensemble is evaluated by one kernel launch.
+            moves: an emcee ``moves`` object; requires emcee (the native sampler
+                implements the default StretchMove only).
+        """
+        self._p0 = p0
+        self.ndim = self.param_bounds.shape[1]
+        if self._p0 is None:
+            self._p0 = np.random.uniform(*self.param_bounds, (self.nwalkers, self.ndim))
+
+        ctx = self._context()
+        ctx.set_bounds(self.param_bounds)  # bounds are read at fit() time, not at construction
+        log_prob_fn = ctx.logprob
+        if moves is not None:
+            import emcee  # optional: non-default moves
+            self._sampler = emcee.EnsembleSampler(self.nwalkers, self.ndim, log_prob_fn,
+                                                  moves=moves, vectorize=True)
+        else:
+            self._sampler = EnsembleSampler(self.nwalkers, self.ndim, log_prob_fn)
+        self._sampler.run_mcmc(self._p0, self.nsteps, progress=True)
+        self.__fitted = True
+
+    def get_chain(self, **kwargs):
+        """MCMC chain; kwargs ``discard``, ``thin``, ``flat`` as in emcee."""
+        self._check_if_fitted()
+        return self._sampler.get_chain(**kwargs)
+
+    # -- properties (reference: src/bisip/models.py:139-179) --------------------------------
+    @property
+    def p0(self):
+        return self._p0
+
+    @property
+    def params(self):
+        return self._params
+
+    @params.setter
+    def params(self, var):
+        self._params = var
+
+    @property
+    def sampler(self):
+        self._check_if_fitted()
+        return self._sampler
+
+    @property
+    def data(self):
+        return self._data
+
+    @property
+    def fitted(self):
+        return self.__fitted
+
+    @property
+    def param_names(self):
+        return list(self.params.keys())
+
+    @property
+    def param_bounds(self):
+        return np.array(list(self.params.values()), dtype=np.float64).T
+
+
+class PolynomialDecomposition(Inversion):
+    """Debye / Warburg polynomial decomposition (reference: src/bisip/models.py:182-229).
+
+    Args:
+        poly_deg (int): polynomial degree. Defaults to 5.
+        c_exp (float): fixed Cole-Cole exponent, 1.0 Debye, 0.5 Warburg. Defaults to 1.0.
+        variant (str): kernel formulation, 'auto' | 'reduced' | 'collapsed' | 'faithful'.
+    """
+
+    _model_id = _hip.MODEL_POLYDECOMP
+
+    def __init__(self, *args, poly_deg=5, c_exp=1.0, variant='auto', **kwargs):
+        super().__init__(*args, **kwargs)
+        self.c_exp = c_exp
+        self.poly_deg = poly_deg
+        self.variant = variant
+
+        # relaxation-time grid: one decade beyond the period range, 2N points
+        period = np.log10(1. / self._data['w'])
+        min_tau = np.floor(min(period) - 1)
+        max_tau = np.floor(max(period) + 1)
+        n_tau = 2 * self._data['N']
+        self.log_tau = np.linspace(min_tau, max_tau, n_tau)
+        deg_range = list(range(self.poly_deg + 1))
+        self.log_taus = np.array([self.log_tau ** i for i in deg_range])
+        self.taus = 10 ** self.log_tau
+
+        self.params.update({'r0': [0.9, 1.1]})
+        self.params.update({f'a{x}': [-1, 1] for x in deg_range})
+
+    def _desc(self):
+        return dict(poly_deg=self.poly_deg, c_exp=float(self.c_exp), taus=self.taus,
+                    log_taus=self.log_taus, variant=self.variant)
+
+    def forward(self, theta, w=None):
+        """Impedance for theta = (R0, a_0, ..., a_P) [ascending]; (2,N) or (n,2,N)."""
+        return self._forward_rows(theta, w)
+
+
+class PeltonColeCole(Inversion):
+    """Generalised (multi-mode) Pelton Cole-Cole model
+    (reference: src/bisip/models.py:232-271).
+
+    Args:
+        n_modes (int): number of Cole-Cole modes. Defaults to 1.
+    """
+
+    _model_id = _hip.MODEL_COLECOLE
+
+    def __init__(self, *args, n_modes=1, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.n_modes = n_modes
+        modes = list(range(self.n_modes))
+        self.params.update({'r0': [0.9, 1.1]})
+        self.params.update({f'm{i+1}': [0.0, 1.0] for i in modes})
+        self.params.update({f'log_tau{i+1}': [-15, 5] for i in modes})
+        self.params.update({f'c{i+1}': [0.0, 1.0] for i in modes})
+
+    def _desc(self):
+        return dict(n_modes=self.n_modes)
+
+    def forward(self, theta, w=None):
+        """theta = (R0, m_1..m_D, log_tau_1..D [natural log], c_1..D)."""
+        return self._forward_rows(theta, w)
+
+
+ColeCole = PeltonColeCole  # the name BASELINE.json's north star uses
+
+
+class Dias2000(Inversion):
+    """Dias (2000) model (reference: src/bisip/models.py:274-305)."""
+
+    _model_id = _hip.MODEL_DIAS2000
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.params.update({'r0': [0.9, 1.1],
+                            'm': [0, 1],
+                            'log_tau': [-20, 0],
+                            'eta': [0, 150],
+                            'delta': [0, 1]})
+
+    def forward(self, theta, w=None):
+        """theta = (R0, m, log_tau, eta, delta)."""
+        return self._forward_rows(theta, w)
+
+
+class Shin2015(Inversion):
+    """Shin (2015) model (reference: src/bisip/models.py:308-349; flagged by its
+    authors as yielding unexpected results, reproduced as written)."""
+
+    _model_id = _hip.MODEL_SHIN2015
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.params.update({'R1': [0.0, 1.0],
+                            'R2': [0.0, 1.0],
+                            'log_Q1': [-15, -13],
+                            'log_Q2': [-7, -5],
+                            'n1': [0, 1],
+                            'n2': [0, 1]})
+
+    def forward(self, theta, w=None):
+        """theta = (R1, R2, log_Q1, log_Q2, n1, n2)."""
+        return self._forward_rows(theta, w)

@@ -1,0 +1,112 @@
+"""Data ingest and chain statistics (host side of the drop-in surface).
+
+``load_data`` defines the constant operands of the hot path -- ``w (N,)``,
+``zn (2,N)``, ``zn_err (2,N)`` -- and follows the arithmetic of the reference's
+``utils.load_data`` (src/bisip/utils.py:108-146) step for step so that the
+operands are bit-identical (pinned by tests/golden/load_data.npz).  The chain
+statistics mirror src/bisip/utils.py:17-106; the model-space percentiles run the
+batched forward kernel instead of a Python loop over the chain.
+"""
+
+import warnings
+
+import numpy as np
+
+_COLUMNS = ('freq', 'amp', 'pha', 'amp_err', 'pha_err')
+
+
+def columns_to_data(table, ph_units='mrad'):
+    """(N,5) table [freq, amp, pha, amp_err, pha_err] -> the reference's data dict.
+
+    reference: src/bisip/utils.py:121-144
+    """
+    table = np.asarray(table, dtype=np.float64)
+    if table.ndim != 2 or table.shape[1] < 5:
+        raise ValueError('expected 5 comma-separated columns: freq, amp, pha, amp_err, pha_err')
+    data = {name: table[:, i] for i, name in enumerate(_COLUMNS)}
+    if ph_units == 'mrad':
+        data['pha'] = data['pha'] / 1000
+        data['pha_err'] = data['pha_err'] / 1000
+    if ph_units == 'deg':
+        data['pha'] = np.radians(data['pha'])
+        data['pha_err'] = np.radians(data['pha_err'])
+    amp, pha = data['amp'], data['pha']
+    cos_p, sin_p = np.cos(pha), np.sin(pha)
+    data['Z'] = amp * (cos_p + 1j * sin_p)
+    # first-order propagation of (amp_err, pha_err) to the real/imaginary parts
+    err_im = np.sqrt((amp * cos_p * data['pha_err']) ** 2 + (sin_p * data['amp_err']) ** 2)
+    err_re = np.sqrt((amp * sin_p * data['pha_err']) ** 2 + (cos_p * data['amp_err']) ** 2)
+    data['Z_err'] = err_re + 1j * err_im
+    data['norm_factor'] = max(abs(data['Z']))
+    zn = data['Z'] / data['norm_factor']
+    zn_err = data['Z_err'] / data['norm_factor']
+    data['zn'] = np.array([zn.real, zn.imag])
+    data['zn_err'] = np.array([zn_err.real, zn_err.imag])
+    data['N'] = len(data['freq'])
+    data['w'] = 2 * np.pi * data['freq']
+    return data
+
+
+def load_data(filename, headers=1, ph_units='mrad'):
+    """Read one 5-column spectrum file (reference: src/bisip/utils.py:108-146,
+    format: docs/user/data_format.rst:7-28)."""
+    table = np.loadtxt(f'{filename}', skiprows=headers, delimiter=',')
+    return columns_to_data(np.atleast_2d(table), ph_units)
+
+
+def load_data_batch(filenames, headers=1, ph_units='mrad'):
+    """Load many spectra that share one frequency count -> stacked operands
+    ``w (B,N)``, ``zn (B,2,N)``, ``zn_err (B,2,N)``, ``norm_factor (B,)``."""
+    items = [load_data(f, headers, ph_units) for f in filenames]
+    n = {d['N'] for d in items}
+    if len(n) != 1:
+        raise ValueError(f'spectra have different frequency counts: {sorted(n)}')
+    return {'w': np.stack([d['w'] for d in items]),
+            'zn': np.stack([d['zn'] for d in items]),
+            'zn_err': np.stack([d['zn_err'] for d in items]),
+            'norm_factor': np.array([d['norm_factor'] for d in items]),
+            'N': items[0]['N']}
+
+
+class utils(object):
+    """Mixin with the reference's utility methods (src/bisip/utils.py:15)."""
+
+    def load_data(self, filename, headers=1, ph_units='mrad'):
+        return load_data(filename, headers, ph_units)
+
+    def parse_chain(self, chain, **kwargs):
+        """reference: src/bisip/utils.py:87-106"""
+        if chain is None:
+            kwargs['flat'] = True
+            chain = self.get_chain(**kwargs)
+            if 'discard' not in kwargs and 'thin' not in kwargs:
+                warnings.warn('No samples were discarded from the chain.\n'
+                              'Pass discard and thin keywords to remove '
+                              'burn-in samples and reduce autocorrelation.', UserWarning)
+            return chain
+        if chain.ndim > 2:
+            raise ValueError('Flatten chain by passing flat=True.')
+        if 'discard' in kwargs or 'thin' in kwargs:
+            raise ValueError('Please pass either a chain obtained with the get_chain() '
+                             'method or pass discard and thin keywords to parse the full '
+                             'chain. Do not pass both.')
+        return chain
+
+    def get_model_percentile(self, p=[2.5, 50, 97.5], chain=None, **kwargs):
+        """Percentiles of the model response over a chain (src/bisip/utils.py:17-35);
+        the forward pass over the whole chain is one batched kernel launch."""
+        chain = self.parse_chain(chain, **kwargs)
+        results = self.forward(np.ascontiguousarray(chain), self.data['w'])
+        return np.percentile(results, p, axis=0)
+
+    def get_param_percentile(self, p=[2.5, 50, 97.5], chain=None, **kwargs):
+        """reference: src/bisip/utils.py:37-53"""
+        return np.percentile(self.parse_chain(chain, **kwargs), p, axis=0)
+
+    def get_param_mean(self, chain=None, **kwargs):
+        """reference: src/bisip/utils.py:55-69"""
+        return np.mean(self.parse_chain(chain, **kwargs), axis=0)
+
+    def get_param_std(self, chain=None, **kwargs):
+        """reference: src/bisip/utils.py:71-85"""
+        return np.std(self.parse_chain(chain, **kwargs), axis=0)

@@ -1,0 +1,129 @@
+/*
+ * bisip_hip.h -- C ABI of libbisip_hip.so, the MI355X (gfx950) implementation of
+ * BISIP's ensemble-MCMC log-probability hot path.
+ *
+ * This is the drop-in boundary.  Every entry point replaces a
+ * piece of the reference's per-walker Python/Cython path with its batched
+ * (walker-vectorised) form; citations are relative to /root/reference:
+ *
+ *   bisip_ctx_create      the walker-independent operands the reference binds into
+ *                         emcee's `args` tuple and the model's precompute:
+ *                         src/bisip/models.py:108-109 (forward, bounds, w, zn, zn_err),
+ *                         src/bisip/models.py:200-213 (taus, log_taus, c_exp),
+ *                         src/bisip/utils.py:138-144 (zn, zn_err, w layout)
+ *   bisip_ctx_set_bounds  `model.params.update(...)` between fits; param_bounds is
+ *                         re-read at fit() time: src/bisip/models.py:176-179, 102-109
+ *   bisip_logprob[_dev]   Inversion._log_probability for W rows at once:
+ *                         src/bisip/models.py:59-76 fused with the forward models of
+ *                         src/bisip/cython_funcs.pyx:33-108
+ *   bisip_forward[_dev]   Model.forward(theta, w) for W rows at once:
+ *                         src/bisip/models.py:217-229, 256-271, 295-305, 335-349
+ *                         (the loop of src/bisip/utils.py:33-34)
+ *
+ * Conventions: plain pointers and sizes, no framework types.  All arrays are
+ * C-contiguous IEEE binary64.  theta is (W, ndim) row-major -- the layout emcee
+ * hands to log_prob_fn -- and row i of the input produces element i of the
+ * output.  Functions return 0 on success and a negative BISIP_E* code on failure;
+ * bisip_last_error() then describes the failure (thread-local string).
+ * A context is bound to one device and is not thread-safe.
+ */
+#ifndef BISIP_HIP_H
+#define BISIP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BISIP_ABI_VERSION 1
+
+/* model_id -- the four reference model classes (src/bisip/models.py:182,232,274,308) */
+#define BISIP_MODEL_POLYDECOMP 0 /* PolynomialDecomposition -> Decomp_cyth  */
+#define BISIP_MODEL_COLECOLE   1 /* PeltonColeCole          -> ColeCole_cyth */
+#define BISIP_MODEL_DIAS2000   2 /* Dias2000                -> Dias2000_cyth */
+#define BISIP_MODEL_SHIN2015   3 /* Shin2015                -> Shin2015_cyth */
+
+/* kernel formulation for PolynomialDecomposition (other models have one) */
+#define BISIP_VARIANT_AUTO      0 /* fastest formulation that holds the parity tolerance */
+#define BISIP_VARIANT_FAITHFUL  1 /* sum_k M_k*K[j,k], the reference's loop structure     */
+#define BISIP_VARIANT_COLLAPSED 2 /* Z_j = R0*(1 - sum_p a_p*G[j,p])                       */
+#define BISIP_VARIANT_REDUCED   3 /* QR-reduced chi^2: (P+2)x(P+2) triangular form         */
+
+/* status codes */
+#define BISIP_OK          0
+#define BISIP_EINVAL     -1 /* bad argument (shape, null pointer, unsupported size) */
+#define BISIP_EHIP       -2 /* a HIP runtime call failed                             */
+#define BISIP_ENOMEM     -3
+#define BISIP_EUNSUPPORTED -4
+
+#define BISIP_MAX_NDIM 16
+#define BISIP_MAX_MODES 5
+#define BISIP_MAX_POLY_DEG 10
+
+typedef struct bisip_ctx bisip_ctx;
+
+/* Model-specific description.  Unused fields are ignored. */
+typedef struct bisip_model_desc {
+    int n_modes;            /* COLECOLE: number of Cole-Cole modes D (ndim = 1+3D)        */
+    int poly_deg;           /* POLYDECOMP: P (ndim = P+2)                                 */
+    int n_taus;             /* POLYDECOMP: S, length of the relaxation-time grid           */
+    double c_exp;           /* POLYDECOMP: fixed Cole-Cole exponent (1 Debye, 0.5 Warburg) */
+    const double *taus;     /* POLYDECOMP: (S,)       = 10**log_tau                        */
+    const double *log_taus; /* POLYDECOMP: (P+1, S)   = log_tau**i, row-major              */
+} bisip_model_desc;
+
+/* Create a context on `device`.  w (N,), zn (2,N) [row 0 real, row 1 imaginary],
+ * zn_err (2,N), lo/hi (ndim,) are copied; the caller keeps ownership. */
+int bisip_ctx_create(bisip_ctx **out, int device, int model_id, int N, const double *w,
+                     const double *zn, const double *zn_err, int ndim, const double *lo,
+                     const double *hi, const bisip_model_desc *desc);
+
+void bisip_ctx_destroy(bisip_ctx *ctx);
+
+/* Replace the prior box (strict inequalities, lo < theta < hi). */
+int bisip_ctx_set_bounds(bisip_ctx *ctx, const double *lo, const double *hi);
+
+/* Choose the kernel formulation (BISIP_VARIANT_*). */
+int bisip_ctx_set_variant(bisip_ctx *ctx, int variant);
+int bisip_ctx_get_variant(const bisip_ctx *ctx);
+
+/* theta (W,ndim) host -> logp (W,) host.  Synchronous. */
+int bisip_logprob(bisip_ctx *ctx, const double *theta, int64_t W, double *logp);
+
+/* Same with device-resident buffers, asynchronous on `stream` (a hipStream_t;
+ * NULL = the default stream). */
+int bisip_logprob_dev(bisip_ctx *ctx, const double *d_theta, int64_t W, double *d_logp,
+                      void *stream);
+
+/* theta (W,ndim) -> Z (W,2,N). */
+int bisip_forward(bisip_ctx *ctx, const double *theta, int64_t W, double *Z);
+int bisip_forward_dev(bisip_ctx *ctx, const double *d_theta, int64_t W, double *d_Z,
+                      void *stream);
+
+/* Introspection */
+int bisip_ctx_ndim(const bisip_ctx *ctx);
+int bisip_ctx_nfreq(const bisip_ctx *ctx);
+int bisip_ctx_device(const bisip_ctx *ctx);
+/* Walker-independent part of the log-likelihood, -0.5*sum(2*ln(sigma^2)). */
+double bisip_ctx_loglike_const(const bisip_ctx *ctx);
+/* Name of the kernel bisip_logprob_dev launches for the current variant. */
+const char *bisip_ctx_kernel_name(const bisip_ctx *ctx);
+
+/* Host-only inspection of the walker-independent PolynomialDecomposition operands the
+ * context precomputes (no GPU needed; used by the CPU-side tests).  Outputs:
+ * G_re/G_im (N, P+1);  R (n,n) upper triangle row-major, bhat (n,), e (n,), rest (1,)
+ * with n = P+2 (see BISIP_VARIANT_REDUCED);  lconst (1,) = -0.5*sum(2 ln sigma^2). */
+int bisip_polydecomp_operands(int N, const double *w, const double *zn, const double *zn_err,
+                              const bisip_model_desc *desc, double *G_re, double *G_im,
+                              double *R, double *bhat, double *e, double *rest,
+                              double *lconst);
+
+int bisip_abi_version(void);
+int bisip_device_count(void);
+const char *bisip_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BISIP_HIP_H */
