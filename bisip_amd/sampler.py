@@ -23,6 +23,8 @@ own NumPy/oracle replay instead.
 
 import numpy as np
 
+from .dist import all_gather_rows, shard_range
+
 
 def walkers_independent(coords):
     """True when the initial ensemble spans the parameter space (no degenerate
@@ -49,10 +51,12 @@ class EnsembleSampler:
         log_prob_fn: vectorised callable ``theta (n, ndim) -> logp (n,)``.
         a: stretch scale (emcee default 2.0).
         args: extra positional arguments appended to every ``log_prob_fn`` call.
+        distributed, group: shard the evaluations over a ``torch.distributed`` group
+            (see bisip_amd/dist.py); the chain is bit-identical to a single-rank run.
     """
 
     def __init__(self, nwalkers, ndim, log_prob_fn, a=2.0, args=None, pool=None, moves=None,
-                 live_dangerously=False):
+                 live_dangerously=False, group=None, distributed=False):
         if moves is not None:
             raise NotImplementedError('only the default StretchMove is implemented natively; '
                                       'install emcee to use other moves')
@@ -62,6 +66,15 @@ class EnsembleSampler:
         self.args = tuple(args) if args is not None else ()
         self.a = float(a)
         self.live_dangerously = live_dangerously
+        # distributed=True: shard every half-step's log-prob evaluations over the ranks of
+        # `group` (all ranks must construct the sampler with the same NumPy RNG state)
+        self._group = group
+        self._world, self._rank = 1, 0
+        if distributed:
+            import torch.distributed as dist
+            if dist.is_initialized():
+                self._world = dist.get_world_size(group)
+                self._rank = dist.get_rank(group)
         self._random = np.random.mtrand.RandomState()
         self._random.set_state(np.random.get_state())
         self.reset()
@@ -106,15 +119,22 @@ class EnsembleSampler:
             factors = (ndim - 1.0) * np.log(zz)
             rint = rng.randint(Nc, size=(Ns,))
             q = c[rint] - (c[rint] - s) * zz[:, None]
-            new_lp = self.compute_log_prob(q)
-            lnpdiff = factors + new_lp - self._lp[S1]
             u = rng.rand(Ns)  # one uniform per walker, in walker order
+            # this rank's block of the active half (the whole half when not distributed)
+            lo, hi = shard_range(Ns, self._world, self._rank)
+            new_lp = self.compute_log_prob(q[lo:hi])
+            old_lp = self._lp[S1][lo:hi]
             with np.errstate(divide='ignore'):
-                acc = lnpdiff > np.log(u)
-            idx = all_inds[S1][acc]
-            self._coords[idx] = q[acc]
-            self._lp[idx] = new_lp[acc]
-            accepted[idx] = True
+                acc = factors[lo:hi] + new_lp - old_lp > np.log(u[lo:hi])
+            block = np.concatenate([np.where(acc[:, None], q[lo:hi], s[lo:hi]),
+                                    np.where(acc, new_lp, old_lp)[:, None],
+                                    acc[:, None].astype(np.float64)], axis=1)
+            if self._world > 1:  # one all-gather of the just-updated rows per half-step
+                block = all_gather_rows(block, Ns, self._group)
+            idx = all_inds[S1]
+            self._coords[idx] = block[:, :ndim]
+            self._lp[idx] = block[:, ndim]
+            accepted[idx] = block[:, ndim + 1] > 0
         self._accepted += accepted
 
     def run_mcmc(self, initial_state, nsteps, progress=False, **kwargs):

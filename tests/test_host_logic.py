@@ -1,0 +1,160 @@
+"""CPU-side checks of the product's host logic (no GPU, no compute launches):
+the C ABI loads and exports what include/bisip_hip.h declares, the host precompute
+feeds formulations that reproduce the reference, the model classes mirror the
+reference's surface, and a missing GPU fails loudly."""
+
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, assert_logp_close, assert_Z_close, case_id, golden_cases
+
+PD_CASES = [p for p in golden_cases() if 'PolynomialDecomposition' in p]
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, 'include', 'bisip_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(bisip_[a-z_]+)\s*\(', text)))
+
+
+def test_abi_exports_every_declared_symbol(hip_lib):
+    from bisip_amd import _hip
+    names = declared_functions()
+    assert len(names) >= 18
+    for name in names:
+        assert hasattr(hip_lib, name), f'{name} declared in include/bisip_hip.h but not exported'
+        assert name in _hip.SYMBOLS, f'{name} has no ctypes prototype in bisip_amd/_hip.py'
+    assert set(_hip.SYMBOLS) == set(names)
+    assert hip_lib.bisip_abi_version() == 1
+    assert isinstance(hip_lib.bisip_last_error(), bytes)
+
+
+def test_library_is_in_tree_and_built_for_gfx950():
+    from bisip_amd import _hip
+    assert os.path.dirname(_hip.LIB_PATH) == os.path.join(ROOT, 'bisip_amd')
+    blob = open(_hip.LIB_PATH, 'rb').read()
+    assert b'gfx950' in blob
+    assert b'k_logprob_pd_reduced' in blob
+
+
+@pytest.mark.parametrize('path', PD_CASES, ids=case_id)
+def test_precomputed_operands_reproduce_reference(path):
+    """NumPy emulation of the collapsed and QR-reduced kernels from the operands the
+    context precomputes (x87 long double, rounded once)."""
+    from bisip_amd import _hip
+    g = np.load(path)
+    o = _hip.polydecomp_operands(g['w'], g['zn'], g['zn_err'], g['taus'], g['log_taus'],
+                                 float(g['c_exp']))
+    th, ref = g['theta'], g['logp'].copy()
+    inside = np.isfinite(ref)
+    th = th[inside]
+    ref = ref[inside]
+    r0, a = th[:, :1], th[:, 1:]
+    iv = 1.0 / g['zn_err'] ** 2
+    Zr = r0 * (1 - a @ o['G_re'].T)
+    Zi = r0 * (0 - a @ o['G_im'].T)
+    chi2 = ((g['zn'][0] - Zr) ** 2 * iv[0]).sum(1) + ((g['zn'][1] - Zi) ** 2 * iv[1]).sum(1)
+    assert_logp_close(o['lconst'] - 0.5 * chi2, ref, 1e-12)
+    assert_Z_close(np.stack([Zr, Zi], axis=1), g['Z'][inside], 1e-13)
+    b = np.concatenate([r0, r0 * a], axis=1)
+    u = o['e'][None, :] + (o['bhat'][None, :] - b) @ o['R'].T
+    assert_logp_close(o['lconst'] - 0.5 * (o['rest'] + (u ** 2).sum(1)), ref, 1e-12)
+    assert np.allclose(np.tril(o['R'], -1), 0)
+    const = -0.5 * np.sum(2 * np.log(g['zn_err'] ** 2))
+    assert abs(o['lconst'] - const) <= 1e-13 * abs(const)
+
+
+def test_model_surface_matches_reference():
+    import bisip_amd
+    path = bisip_amd.DataFiles()['SIP-K389175']
+    g = np.load(PD_CASES[4])  # K389175, poly_deg 5
+    m = bisip_amd.PolynomialDecomposition(path, nwalkers=32, nsteps=10)
+    assert m.param_names == ['r0', 'a0', 'a1', 'a2', 'a3', 'a4', 'a5'] == list(g['param_names'])
+    assert np.array_equal(m.param_bounds, g['bounds'])
+    # a4: tau grid, log_tau**i table, taus = 10**log_tau, bit for bit
+    assert np.array_equal(m.log_tau, g['log_tau'])
+    assert np.array_equal(m.log_taus, g['log_taus'])
+    assert np.array_equal(m.taus, g['taus'])
+    assert m.log_tau[0] == -6 and m.log_tau[-1] == 2 and m.log_tau.size == 40
+    assert (m.nwalkers, m.nsteps, m.headers, m.ph_units) == (32, 10, 1, 'mrad')
+    assert bisip_amd.PolynomialDecomposition(path).nsteps == 5000
+    # bounds are re-read from the params dict on every access
+    m.params.update(a0=[-2, 2])
+    assert m.param_bounds[0, 1] == -2 and m.param_bounds[1, 1] == 2
+    assert not m.fitted
+    with pytest.raises(AssertionError):
+        m.get_chain()
+
+    cc = bisip_amd.PeltonColeCole(path, n_modes=2)
+    assert cc.param_names == ['r0', 'm1', 'm2', 'log_tau1', 'log_tau2', 'c1', 'c2']
+    assert np.array_equal(cc.param_bounds, [[0.9, 0, 0, -15, -15, 0, 0], [1.1, 1, 1, 5, 5, 1, 1]])
+    assert bisip_amd.ColeCole is bisip_amd.PeltonColeCole
+    d = bisip_amd.Dias2000(path)
+    assert d.param_names == ['r0', 'm', 'log_tau', 'eta', 'delta']
+    assert np.array_equal(d.param_bounds, [[0.9, 0, -20, 0, 0], [1.1, 1, 0, 150, 1]])
+    s = bisip_amd.Shin2015(path)
+    assert s.param_names == ['R1', 'R2', 'log_Q1', 'log_Q2', 'n1', 'n2']
+    assert np.array_equal(s.param_bounds, [[0, 0, -15, -7, 0, 0], [1, 1, -13, -5, 1, 1]])
+
+    # the standalone prior is host logic: open box, vectorised
+    b = cc.param_bounds
+    inside = 0.5 * (b[0] + b[1])
+    assert cc._log_prior(inside, b) == 0.0
+    on = inside.copy()
+    on[0] = b[0, 0]
+    assert cc._log_prior(on, b) == -np.inf
+    assert np.array_equal(cc.log_prior(np.array([inside, on]), b), [0.0, -np.inf])
+
+
+def test_no_gpu_fails_loudly():
+    """The product has no CPU fallback: without a device, compute entry points raise."""
+    from bisip_amd import _hip
+    import bisip_amd
+    if _hip.device_count() > 0:
+        pytest.skip('a GPU is visible')
+    m = bisip_amd.PeltonColeCole(bisip_amd.DataFiles()['SIP-K389175'])
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        m.log_prob(np.array([1.0, 0.3, -2.0, 0.5]))
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        m.forward(np.array([1.0, 0.3, -2.0, 0.5]))
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        m.fit()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, 'bisip_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith(('.py', '.hip', '.cpp', '.h')):
+                text = open(os.path.join(dirpath, fn)).read()
+                assert 'import oracle' not in text and 'from oracle' not in text, fn
+                assert 'libbisip_oracle' not in text, fn
+
+
+def test_context_argument_validation(hip_lib):
+    """ctx_create rejects bad shapes before touching the device."""
+    import ctypes
+    from bisip_amd import _hip
+    if _hip.device_count() == 0:
+        # shape validation happens before device selection
+        w = np.array([1.0, 2.0])
+        zn = np.ones((2, 2))
+        lo = np.zeros(5)
+        hi = np.ones(5)
+        h = ctypes.c_void_p()
+        desc = _hip.ModelDesc()
+        rc = hip_lib.bisip_ctx_create(ctypes.byref(h), 0, _hip.MODEL_DIAS2000, 2, _hip._p(w),
+                                      _hip._p(zn), _hip._p(zn), 4, _hip._p(lo), _hip._p(hi),
+                                      ctypes.byref(desc))
+        assert rc == -1 and b'ndim 5' in hip_lib.bisip_last_error()
+        rc = hip_lib.bisip_ctx_create(ctypes.byref(h), 0, 9, 2, _hip._p(w), _hip._p(zn),
+                                      _hip._p(zn), 5, _hip._p(lo), _hip._p(hi), ctypes.byref(desc))
+        assert rc == -1
+        bad = -np.ones((2, 2))
+        rc = hip_lib.bisip_ctx_create(ctypes.byref(h), 0, _hip.MODEL_DIAS2000, 2, _hip._p(w),
+                                      _hip._p(zn), _hip._p(bad), 5, _hip._p(lo), _hip._p(hi),
+                                      ctypes.byref(desc))
+        assert rc == -1 and b'zn_err' in hip_lib.bisip_last_error()

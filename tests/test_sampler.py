@@ -1,0 +1,85 @@
+"""The native ensemble sampler (host logic), driven by the CPU oracle as log_prob_fn.
+
+Sampler parity with emcee is unpinned; these tests pin this
+implementation: RNG contract / reproducibility, chain bookkeeping, and that it
+samples the right distribution.
+"""
+
+import numpy as np
+import pytest
+
+import oracle
+from bisip_amd.sampler import EnsembleSampler, walkers_independent
+from conftest import golden_cases
+
+
+def gaussian_logp(theta, mu, icov):
+    d = theta - mu
+    return -0.5 * np.einsum('ni,ij,nj->n', d, icov, d)
+
+
+def test_samples_a_correlated_gaussian():
+    np.random.seed(123)
+    mu = np.array([1.0, -2.0, 0.5])
+    cov = np.array([[1.0, 0.6, 0.0], [0.6, 2.0, -0.3], [0.0, -0.3, 0.5]])
+    s = EnsembleSampler(48, 3, gaussian_logp, args=(mu, np.linalg.inv(cov)))
+    p0 = mu + 0.1 * np.random.randn(48, 3)
+    s.run_mcmc(p0, 1500)
+    flat = s.get_chain(discard=400, flat=True)
+    assert flat.shape == (1100 * 48, 3)
+    assert np.allclose(flat.mean(0), mu, atol=0.1)
+    assert np.allclose(np.cov(flat.T), cov, atol=0.2)
+    assert 0.2 < s.acceptance_fraction.mean() < 0.9
+
+
+def test_rng_contract_and_bookkeeping():
+    def run(seed):
+        np.random.seed(seed)
+        s = EnsembleSampler(16, 2, gaussian_logp, args=(np.zeros(2), np.eye(2)))
+        p0 = np.random.uniform(-1, 1, (16, 2))
+        s.run_mcmc(p0, 40)
+        return s
+    a, b, c = run(7), run(7), run(8)
+    assert np.array_equal(a.get_chain(), b.get_chain())       # same global seed -> same chain
+    assert not np.array_equal(a.get_chain(), c.get_chain())
+    ch = a.get_chain()
+    assert ch.shape == (40, 16, 2) and a.get_log_prob().shape == (40, 16)
+    # emcee slicing: chain[discard + thin - 1 : iteration : thin]
+    assert np.array_equal(a.get_chain(discard=10, thin=3), ch[12:40:3])
+    assert a.get_chain(discard=10, thin=3, flat=True).shape == (len(ch[12:40:3]) * 16, 2)
+    # the stored log-prob is the log-prob of the stored position
+    assert np.allclose(a.get_log_prob()[-1], gaussian_logp(ch[-1], np.zeros(2), np.eye(2)))
+    # continuing from the last state appends
+    a.run_mcmc(None, 5)
+    assert a.get_chain().shape[0] == 45 and a.iteration == 45
+
+
+def test_input_validation():
+    s = EnsembleSampler(8, 3, gaussian_logp, args=(np.zeros(3), np.eye(3)))
+    with pytest.raises(ValueError):
+        s.run_mcmc(np.zeros((7, 3)), 2)
+    with pytest.raises(ValueError):                       # degenerate ensemble
+        s.run_mcmc(np.ones((8, 3)), 2)
+    with pytest.raises(RuntimeError):                     # fewer walkers than 2*ndim
+        EnsembleSampler(4, 3, gaussian_logp, args=(np.zeros(3), np.eye(3))).run_mcmc(
+            np.random.randn(4, 3), 1)
+    with pytest.raises(ValueError):                       # NaN from the log-prob
+        EnsembleSampler(8, 3, lambda t: np.full(len(t), np.nan)).run_mcmc(np.random.randn(8, 3), 1)
+    with pytest.raises(AttributeError):
+        s.get_chain()
+    assert walkers_independent(np.random.randn(10, 3))
+    assert not walkers_independent(np.zeros((10, 3)))
+
+
+def test_minus_inf_proposals_are_always_rejected():
+    """Walkers start inside the box; -inf (out-of-prior) proposals never get accepted."""
+    g = np.load([p for p in golden_cases() if 'PeltonColeCole_SIP-K389175' in p][0])
+    prob = oracle.OracleProblem.from_golden(g, 'PeltonColeCole')
+    np.random.seed(5)
+    lo, hi = g['bounds']
+    p0 = np.random.uniform(lo, hi, (16, lo.size))
+    s = EnsembleSampler(16, lo.size, lambda t: oracle.logprob(prob, t))
+    s.run_mcmc(p0, 60)
+    ch = s.get_chain(flat=True)
+    assert np.all(ch > lo) and np.all(ch < hi)
+    assert np.all(np.isfinite(s.get_log_prob()))
