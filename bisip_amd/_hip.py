@@ -5,7 +5,9 @@ shared library is missing or no MI355X is visible, calls raise ``RuntimeError``.
 """
 
 import ctypes
+import importlib.util
 import os
+import sys
 
 import numpy as np
 
@@ -56,10 +58,29 @@ SYMBOLS = {
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels bundle their own ``libamdhip64.so.7``; the system ROCm has one
+    with the same soname.  Only one HIP runtime may own the GPU in a process, so when
+    torch is installed (it supplies device memory, streams and RCCL around this library)
+    its runtime is mapped first and ``libbisip_hip.so`` binds to it by soname."""
+    if 'torch' in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec('torch')
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), 'lib', 'libamdhip64.so')
+    if os.path.exists(cand):
+        ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+
+
 def load_library():
     """Load the HIP library; raise loudly when it has not been built."""
     global _lib
     if _lib is None:
+        _share_hip_runtime_with_torch()
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 f'{LIB_PATH} is missing: build it with `make -C bisip_amd/csrc` '

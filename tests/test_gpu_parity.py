@@ -57,3 +57,213 @@ def test_forward_matches_reference_golden(path):
     got = ctx.forward(g['theta'][rows])
     assert_Z_close(got, g['Z'][rows])
     ctx.close()
+
+
+# ----------------------------------------------------------------------------------
+# fresh seeded inputs against the CPU oracle (sizes the oracle finishes in seconds)
+# ----------------------------------------------------------------------------------
+
+def _oracle_problem(g, model):
+    import oracle
+    return oracle.OracleProblem.from_golden(g, model)
+
+
+@pytest.mark.parametrize('path', golden_cases()[::2], ids=case_id)
+def test_seeded_batch_against_oracle(path):
+    import oracle
+    g = np.load(path)
+    model = case_model(path)
+    rng = np.random.RandomState(4242)
+    lo, hi = g['bounds']
+    n = 3000
+    theta = rng.uniform(lo, hi, (n, lo.size))
+    # sprinkle out-of-prior rows: they must come back as -inf in place
+    theta[::97, 0] = hi[0] + 1.0
+    theta[5::211, -1] = lo[-1]
+    want = oracle.logprob(_oracle_problem(g, model), theta, n_threads=4)
+    for variant in variants_for(g, model):
+        ctx = make_ctx(g, model, variant)
+        assert_logp_close(ctx.logprob(theta), want)
+        ctx.close()
+
+
+@pytest.mark.parametrize('W', [0, 1, 2, 63, 64, 65, 255, 256, 257, 1000, 131071, 131072, 131073])
+def test_ragged_batch_sizes(W):
+    """Empty, sub-wave, wave/workgroup boundaries and the small/large launch switch
+    (131072) -- each row's value must not depend on the batch it sits in."""
+    import oracle
+    path = [p for p in golden_cases() if 'PolynomialDecomposition_synthetic-N32-i0' in p][0]
+    g = np.load(path)
+    rng = np.random.RandomState(W)
+    lo, hi = g['bounds']
+    theta = rng.uniform(lo, hi, (W, lo.size))
+    prob = _oracle_problem(g, 'PolynomialDecomposition')
+    ref_rows = min(W, 512)
+    want = oracle.logprob(prob, theta[:ref_rows])
+    for variant in ('reduced', 'collapsed', 'faithful'):
+        ctx = make_ctx(g, 'PolynomialDecomposition', variant)
+        got = ctx.logprob(theta)
+        assert got.shape == (W,)
+        assert_logp_close(got[:ref_rows], want)
+        if W > 600:
+            # batch-composition independence, bitwise: tail rows alone == tail rows in batch
+            tail = ctx.logprob(theta[-300:])
+            assert np.array_equal(tail, got[-300:])
+        ctx.close()
+
+
+def test_unaligned_device_pointer_path():
+    """bisip_logprob_dev on a theta view that starts 8 B (not 16 B) aligned takes the
+    scalar-load staging path; results must be identical."""
+    import torch
+    path = [p for p in golden_cases() if 'PolynomialDecomposition_synthetic-N32-i0' in p][0]
+    g = np.load(path)
+    ctx = make_ctx(g, 'PolynomialDecomposition', 'reduced')
+    rng = np.random.RandomState(3)
+    lo, hi = g['bounds']
+    W = 5000
+    theta = rng.uniform(lo, hi, (W + 1, lo.size))
+    dev = torch.from_numpy(theta).cuda()
+    out_a = torch.empty(W, dtype=torch.float64, device='cuda')
+    out_b = torch.empty(W, dtype=torch.float64, device='cuda')
+    view = dev[1:]                       # offset by 7 doubles = 56 B -> 8-B aligned only
+    assert view.data_ptr() % 16 == 8
+    st = torch.cuda.current_stream().cuda_stream
+    ctx.logprob_dev(view.data_ptr(), W, out_a.data_ptr(), st)
+    aligned = view.clone()
+    assert aligned.data_ptr() % 16 == 0
+    ctx.logprob_dev(aligned.data_ptr(), W, out_b.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert torch.equal(out_a, out_b)
+    assert_logp_close(out_a.cpu().numpy(), ctx.logprob(theta[1:]))
+    ctx.close()
+
+
+def test_full_size_properties():
+    """BASELINE sizes (no oracle at this scale): permutation equivariance (walker index
+    preserved bit-exactly), agreement of the three formulations, chunk invariance,
+    -inf exactly where the prior says."""
+    path = [p for p in golden_cases() if 'PolynomialDecomposition_synthetic-N64-i0' in p][0]
+    g = np.load(path)   # cfg3 shape: N=64, S=128, P=5
+    rng = np.random.RandomState(77)
+    lo, hi = g['bounds']
+    W = 65536
+    theta = rng.uniform(lo, hi, (W, lo.size))
+    bad = rng.rand(W) < 0.1
+    theta[bad, 2] = 1.5
+    ctx = make_ctx(g, 'PolynomialDecomposition', 'reduced')
+    a = ctx.logprob(theta)
+    assert np.array_equal(np.isneginf(a), bad)
+    perm = rng.permutation(W)
+    assert np.array_equal(ctx.logprob(theta[perm]), a[perm])
+    assert np.array_equal(np.concatenate([ctx.logprob(theta[:30000]), ctx.logprob(theta[30000:])]), a)
+    for variant in ('collapsed', 'faithful'):
+        ctx.set_variant(variant)
+        assert_logp_close(ctx.logprob(theta), a, 1e-11)
+    ctx.close()
+
+
+def test_cfg2_shape_colecole_4096_walkers():
+    """BASELINE config 2: single Cole-Cole, 32 synthetic frequencies, 4096 walkers."""
+    import oracle
+    path = [p for p in golden_cases() if 'case25_PeltonColeCole_synthetic-N32-i0' in p][0]
+    g = np.load(path)
+    from bisip_amd.synthetic import synthetic_theta
+    theta = synthetic_theta(g['bounds'][0], g['bounds'][1], 4096)
+    ctx = make_ctx(g, 'PeltonColeCole')
+    want = oracle.logprob(_oracle_problem(g, 'PeltonColeCole'), theta, n_threads=4)
+    assert_logp_close(ctx.logprob(theta), want)
+    ctx.close()
+
+
+def test_bounds_update_and_error_paths():
+    from bisip_amd import _hip
+    path = [p for p in golden_cases() if 'Dias2000_SIP-K389175' in p][0]
+    g = np.load(path)
+    ctx = make_ctx(g, 'Dias2000')
+    th = g['theta'][:40].copy()
+    base = ctx.logprob(th)
+    assert np.isfinite(base).all()
+    nb = g['bounds'].copy()
+    nb[1, 3] = 25.0                                   # eta in [0, 25], as the tutorial does
+    ctx.set_bounds(nb)
+    got = ctx.logprob(th)
+    outside = th[:, 3] >= 25.0
+    assert outside.any() and (~outside).any()
+    assert np.isneginf(got[outside]).all() and np.array_equal(got[~outside], base[~outside])
+    with pytest.raises(ValueError):
+        ctx.logprob(np.zeros((3, 4)))                 # wrong ndim
+    with pytest.raises(RuntimeError):
+        ctx.set_variant('reduced')                    # single-formulation model
+    with pytest.raises(ValueError):
+        _hip.HipContext(2, g['w'], g['zn'], g['zn_err'], g['bounds'][:, :4])
+    ctx.close()
+
+
+# ----------------------------------------------------------------------------------
+# the drop-in class surface on the GPU
+# ----------------------------------------------------------------------------------
+
+def test_model_classes_drop_in():
+    import bisip_amd
+    path = bisip_amd.DataFiles()['SIP-K389175']
+    g = np.load([p for p in golden_cases() if 'case04_' in p][0])
+    m = bisip_amd.PolynomialDecomposition(path, nwalkers=32, nsteps=50)
+    d = m.data
+    args = (m.forward, m.param_bounds, d['w'], d['zn'], d['zn_err'])
+    # emcee's per-walker call:  log_prob_fn(theta, *args) -> float
+    i = int(g['n_prior'])
+    one = m._log_probability(g['theta'][i], *args)
+    assert isinstance(one, float)
+    assert abs(one - g['logp'][i]) <= 1e-10 * max(1, abs(g['logp'][i]))
+    # vectorised call: (n, ndim) -> (n,)
+    assert_logp_close(m._log_probability(g['theta'], *args), g['logp'])
+    assert_logp_close(m.log_prob(g['theta']), g['logp'])
+    # forward: (ndim,) -> (2,N), (n,ndim) -> (n,2,N)
+    rows = np.all(np.isfinite(g['theta']), axis=1)
+    assert m.forward(g['theta'][i], d['w']).shape == (2, 20)
+    assert_Z_close(m.forward(g['theta'][rows], d['w']), g['Z'][rows])
+    # likelihood alone ignores the prior box
+    outside = g['theta'][i].copy()
+    outside[0] = 1.2
+    assert np.isneginf(m._log_probability(outside, *args))
+    assert np.isfinite(m._log_likelihood(outside, m.forward, d['w'], d['zn'], d['zn_err']))
+    ll = m._log_likelihood(g['theta'][i], m.forward, d['w'], d['zn'], d['zn_err'])
+    assert abs(ll - g['logp'][i]) <= 1e-10 * max(1, abs(g['logp'][i]))
+    # forward on another frequency grid (denser, for plotting)
+    w2 = np.logspace(5, -2, 50)
+    assert m.forward(g['theta'][i], w2).shape == (2, 50)
+    with pytest.raises(ValueError):
+        m._log_probability(g['theta'][i], lambda t, w: None, m.param_bounds, d['w'], d['zn'], d['zn_err'])
+
+
+def test_fit_runs_and_matches_oracle_replay():
+    """model.fit() on the GPU reproduces, step for step, the same sampler driven by the
+    CPU oracle (accept decisions and positions identical; log-probs to tolerance)."""
+    import bisip_amd
+    import oracle
+    from bisip_amd.sampler import EnsembleSampler
+    path = bisip_amd.DataFiles()['SIP-K389175']
+    m = bisip_amd.PeltonColeCole(path, nwalkers=32, nsteps=300, n_modes=2)
+    np.random.seed(42)
+    m.fit()
+    chain = m.get_chain()
+    assert chain.shape == (300, 32, 7) and m.fitted
+    d = m.data
+    prob = oracle.OracleProblem('PeltonColeCole', d['w'], d['zn'], d['zn_err'], m.param_bounds,
+                                n_modes=2)
+    np.random.seed(42)
+    p0 = np.random.uniform(*m.param_bounds, (32, 7))
+    assert np.array_equal(p0, m.p0)
+    ref = EnsembleSampler(32, 7, lambda t: oracle.logprob(prob, t))
+    ref.run_mcmc(p0, 300)
+    assert np.array_equal(chain, ref.get_chain())
+    assert_logp_close(m.sampler.get_log_prob(), ref.get_log_prob())
+    # reference workflow after the fit
+    flat = m.get_chain(discard=100, thin=2, flat=True)
+    assert flat.shape == (100 * 32, 7)
+    assert m.get_param_mean(flat).shape == (7,) and m.get_param_std(flat).shape == (7,)
+    pct = m.get_model_percentile([2.5, 50, 97.5], flat)
+    assert pct.shape == (3, 2, 20)
+    with pytest.warns(UserWarning):
+        m.get_param_mean()
