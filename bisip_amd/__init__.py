@@ -18,7 +18,7 @@ from .models import ColeCole
 from .models import Dias2000
 from .models import Shin2015
 from .data import DataFiles
-from .sampler import EnsembleSampler
+from .sampler import DeviceEnsembleSampler, EnsembleSampler
 from .utils import load_data, load_data_batch
 
 __all__ = (
@@ -30,6 +30,7 @@ __all__ = (
     'Shin2015',
     'DataFiles',
     'EnsembleSampler',
+    'DeviceEnsembleSampler',
     'load_data',
     'load_data_batch',
 )

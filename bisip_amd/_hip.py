@@ -28,6 +28,17 @@ class ModelDesc(ctypes.Structure):
                 ('c_exp', ctypes.c_double), ('taus', _dp), ('log_taus', _dp)]
 
 
+class StretchArgs(ctypes.Structure):
+    """``bisip_stretch_args`` of include/bisip_hip.h (device pointers as integers)."""
+    _fields_ = [('coords', ctypes.c_void_p), ('logp', ctypes.c_void_p),
+                ('active', ctypes.c_void_p), ('partner', ctypes.c_void_p),
+                ('zz', ctypes.c_void_p), ('factor', ctypes.c_void_p), ('logu', ctypes.c_void_p),
+                ('n_slots', ctypes.c_int64), ('slot_lo', ctypes.c_int64), ('slot_hi', ctypes.c_int64),
+                ('block', ctypes.c_void_p), ('chain_row', ctypes.c_void_p),
+                ('logp_row', ctypes.c_void_p), ('naccept', ctypes.c_void_p),
+                ('status', ctypes.c_void_p), ('pad', ctypes.c_int64), ('world', ctypes.c_int32)]
+
+
 # name -> (restype, argtypes); every symbol include/bisip_hip.h declares
 SYMBOLS = {
     'bisip_ctx_create': (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int,
@@ -43,6 +54,9 @@ SYMBOLS = {
     'bisip_forward': (ctypes.c_int, [ctypes.c_void_p, _dp, ctypes.c_int64, _dp]),
     'bisip_forward_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                          ctypes.c_void_p, ctypes.c_void_p]),
+    'bisip_stretch_half_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(StretchArgs), ctypes.c_void_p]),
+    'bisip_stretch_eval_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(StretchArgs), ctypes.c_void_p]),
+    'bisip_stretch_apply_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(StretchArgs), ctypes.c_void_p]),
     'bisip_ctx_ndim': (ctypes.c_int, [ctypes.c_void_p]),
     'bisip_ctx_nfreq': (ctypes.c_int, [ctypes.c_void_p]),
     'bisip_ctx_device': (ctypes.c_int, [ctypes.c_void_p]),
@@ -240,3 +254,13 @@ class HipContext:
     def forward_dev(self, d_theta_ptr, W, d_Z_ptr, stream=0):
         _check(self._lib.bisip_forward_dev(self._h, ctypes.c_void_p(d_theta_ptr), int(W),
                                            ctypes.c_void_p(d_Z_ptr), ctypes.c_void_p(stream)))
+
+    # -- device-resident stretch move ---------------------------------------------------
+    def stretch_half_dev(self, args, stream=0):
+        _check(self._lib.bisip_stretch_half_dev(self._h, ctypes.byref(args), ctypes.c_void_p(stream)))
+
+    def stretch_eval_dev(self, args, stream=0):
+        _check(self._lib.bisip_stretch_eval_dev(self._h, ctypes.byref(args), ctypes.c_void_p(stream)))
+
+    def stretch_apply_dev(self, args, stream=0):
+        _check(self._lib.bisip_stretch_apply_dev(self._h, ctypes.byref(args), ctypes.c_void_p(stream)))

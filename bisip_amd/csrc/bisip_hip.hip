@@ -14,6 +14,7 @@
 #include "../../include/bisip_hip.h"
 #include "host_precompute.h"
 #include "kernels.h"
+#include "sampler_kernels.h"
 
 using namespace bisip;
 
@@ -222,6 +223,115 @@ int dispatch_forward(const bisip_ctx *c, const double *theta, int64_t W, double 
     case BISIP_MODEL_SHIN2015: return launch_forward<Shin>(c, theta, W, Z, st);
     }
     return fail(BISIP_EUNSUPPORTED, "no forward kernel for this model shape");
+}
+
+StretchArgs to_device_args(const bisip_stretch_args *u)
+{
+    StretchArgs a;
+    a.coords = u->coords; a.logp = u->logp;
+    a.active = u->active; a.partner = u->partner;
+    a.zz = u->zz; a.factor = u->factor; a.logu = u->logu;
+    a.n_slots = u->n_slots; a.slot_lo = u->slot_lo; a.slot_hi = u->slot_hi;
+    a.block = u->block; a.chain_row = u->chain_row; a.logp_row = u->logp_row;
+    a.naccept = u->naccept; a.status = u->status;
+    a.pad = u->pad;
+    const long long world = u->world > 0 ? u->world : 1;
+    a.base = u->n_slots / world;
+    a.extra = u->n_slots % world;
+    return a;
+}
+
+enum StretchKind { STRETCH_HALF, STRETCH_EVAL };
+
+template <class LP>
+int launch_stretch(const StretchArgs &a, const LP &lp, StretchKind kind, hipStream_t st)
+{
+    if (kind == STRETCH_HALF) {
+        const unsigned grid = (unsigned)((a.n_slots + 63) / 64);
+        hipLaunchKernelGGL((k_stretch_half<LP>), dim3(grid), dim3(64), 0, st, a, lp);
+    } else {
+        const unsigned grid = (unsigned)((a.slot_hi - a.slot_lo + 63) / 64);
+        hipLaunchKernelGGL((k_stretch_eval<LP>), dim3(grid), dim3(64), 0, st, a, lp);
+    }
+    HIP_TRY(hipGetLastError());
+    return BISIP_OK;
+}
+
+template <class M>
+int stretch_generic(const bisip_ctx *c, const StretchArgs &a, StretchKind kind, hipStream_t st)
+{
+    GenericLP<M> lp;
+    lp.o = ModelOperands{c->d_cb, c->N, c->lconst};
+    lp.b = c->bounds;
+    return launch_stretch(a, lp, kind, st);
+}
+
+template <int P>
+int stretch_reduced(const bisip_ctx *c, const StretchArgs &a, StretchKind kind, hipStream_t st)
+{
+    ReducedLP<P> lp;
+    std::memcpy(lp.r.R, c->Rpacked.data(), sizeof(lp.r.R));
+    std::memcpy(lp.r.bhat, c->bhat.data(), sizeof(lp.r.bhat));
+    std::memcpy(lp.r.e, c->evec.data(), sizeof(lp.r.e));
+    lp.r.rest = c->rest;
+    lp.lconst = c->lconst;
+    lp.b = c->bounds;
+    return launch_stretch(a, lp, kind, st);
+}
+
+int dispatch_stretch(const bisip_ctx *c, const StretchArgs &a, StretchKind kind, hipStream_t st)
+{
+    switch (c->model_id) {
+    case BISIP_MODEL_POLYDECOMP:
+        if (effective_variant(c) == BISIP_VARIANT_REDUCED) {
+            switch (c->P) {
+#define X(p) case p: return stretch_reduced<p>(c, a, kind, st);
+                PD_CASES(X)
+#undef X
+            }
+        } else {  // collapsed (the faithful formulation has no sampler kernel)
+            switch (c->P) {
+#define X(p) case p: return stretch_generic<PDCollapsed<p>>(c, a, kind, st);
+                PD_CASES(X)
+#undef X
+            }
+        }
+        break;
+    case BISIP_MODEL_COLECOLE:
+        switch (c->D) {
+#define X(d) case d: return stretch_generic<ColeCole<d>>(c, a, kind, st);
+            CC_CASES(X)
+#undef X
+        }
+        break;
+    case BISIP_MODEL_DIAS2000: return stretch_generic<Dias>(c, a, kind, st);
+    case BISIP_MODEL_SHIN2015: return stretch_generic<Shin>(c, a, kind, st);
+    }
+    return fail(BISIP_EUNSUPPORTED, "no stretch kernel for this model shape");
+}
+
+int dispatch_apply(const bisip_ctx *c, const StretchArgs &a, hipStream_t st)
+{
+    const unsigned grid = (unsigned)((a.n_slots + 63) / 64);
+    switch (c->ndim) {
+#define X(n) case n: hipLaunchKernelGGL((k_stretch_apply<n>), dim3(grid), dim3(64), 0, st, a); break;
+        X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
+#undef X
+    default: return fail(BISIP_EUNSUPPORTED, "ndim=%d", c->ndim);
+    }
+    HIP_TRY(hipGetLastError());
+    return BISIP_OK;
+}
+
+int check_stretch(const bisip_ctx *c, const bisip_stretch_args *u, bool need_block)
+{
+    if (!c || !u) return fail(BISIP_EINVAL, "null argument");
+    if (u->n_slots < 0) return fail(BISIP_EINVAL, "n_slots < 0");
+    if (u->n_slots == 0) return BISIP_OK;
+    if (!u->coords || !u->logp || !u->active || !u->status)
+        return fail(BISIP_EINVAL, "coords/logp/active/status must not be null");
+    if (need_block && !u->block) return fail(BISIP_EINVAL, "block must not be null");
+    return BISIP_OK;
 }
 
 int ensure_ws(bisip_ctx *c, size_t bytes)
@@ -453,6 +563,39 @@ int bisip_forward_dev(bisip_ctx *c, const double *d_theta, int64_t W, double *d_
     if (W > 0 && (!d_theta || !d_Z)) return fail(BISIP_EINVAL, "null buffer");
     HIP_TRY(hipSetDevice(c->device));
     return dispatch_forward(c, d_theta, W, d_Z, (hipStream_t)stream);
+}
+
+int bisip_stretch_half_dev(bisip_ctx *c, const bisip_stretch_args *u, void *stream)
+{
+    int rc = check_stretch(c, u, false);
+    if (rc != BISIP_OK || u->n_slots == 0) return rc;
+    if (!u->partner || !u->zz || !u->factor || !u->logu) return fail(BISIP_EINVAL, "null RNG stream");
+    HIP_TRY(hipSetDevice(c->device));
+    return dispatch_stretch(c, to_device_args(u), STRETCH_HALF, (hipStream_t)stream);
+}
+
+int bisip_stretch_eval_dev(bisip_ctx *c, const bisip_stretch_args *u, void *stream)
+{
+    int rc = check_stretch(c, u, true);
+    if (rc != BISIP_OK || u->n_slots == 0) return rc;
+    if (!u->partner || !u->zz || !u->factor || !u->logu) return fail(BISIP_EINVAL, "null RNG stream");
+    if (u->slot_lo < 0 || u->slot_hi > u->n_slots || u->slot_lo > u->slot_hi)
+        return fail(BISIP_EINVAL, "bad slot range [%lld,%lld) of %lld", (long long)u->slot_lo,
+                    (long long)u->slot_hi, (long long)u->n_slots);
+    if (u->slot_lo == u->slot_hi) return BISIP_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    return dispatch_stretch(c, to_device_args(u), STRETCH_EVAL, (hipStream_t)stream);
+}
+
+int bisip_stretch_apply_dev(bisip_ctx *c, const bisip_stretch_args *u, void *stream)
+{
+    int rc = check_stretch(c, u, true);
+    if (rc != BISIP_OK || u->n_slots == 0) return rc;
+    if (u->world < 1 || u->pad * u->world < u->n_slots)
+        return fail(BISIP_EINVAL, "gathered block too small: world=%d pad=%lld n_slots=%lld", u->world,
+                    (long long)u->pad, (long long)u->n_slots);
+    HIP_TRY(hipSetDevice(c->device));
+    return dispatch_apply(c, to_device_args(u), (hipStream_t)stream);
 }
 
 int bisip_logprob(bisip_ctx *c, const double *theta, int64_t W, double *logp)

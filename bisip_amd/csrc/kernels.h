@@ -243,6 +243,35 @@ struct Shin {
 };
 
 // ---------------------------------------------------------------------------------
+// log-probability of ONE row held in registers -- shared by the batch kernels below and
+// by the stretch-move kernels in sampler_kernels.h, so a walker's value is the same
+// bits whichever kernel evaluates it.
+// ---------------------------------------------------------------------------------
+struct ModelOperands {
+    const double *__restrict__ cb;  // per-frequency records
+    int N;
+    double lconst;
+};
+
+template <class M>
+__device__ __forceinline__ double logprob_row(const double (&th)[M::NDIM], const ModelOperands &o,
+                                              const Bounds &b)
+{
+    if (!in_prior<M::NDIM>(th, b)) return -__builtin_inf();  // never touches the forward model
+    const typename M::Setup s = M::setup(th);
+    double acc0 = 0.0, acc1 = 0.0;
+    const double *__restrict__ rec = o.cb;
+    for (int j = 0; j < o.N; ++j, rec += M::REC) {
+        double zr, zi;
+        M::eval(s, rec + 4, zr, zi);
+        const double rr = rec[0] - zr, ri = rec[1] - zi;
+        acc0 = fma(rr * rr, rec[2], acc0);
+        acc1 = fma(ri * ri, rec[3], acc1);
+    }
+    return fma(-0.5, acc0 + acc1, o.lconst);
+}
+
+// ---------------------------------------------------------------------------------
 // log-probability, one lane per walker, any model above.
 // ---------------------------------------------------------------------------------
 template <class M, int BLK, bool VEC>
@@ -258,22 +287,8 @@ __global__ __launch_bounds__(BLK) void k_logprob(const LaunchArgs a)
     double th[NDIM];
 #pragma unroll
     for (int q = 0; q < NDIM; ++q) th[q] = lds[threadIdx.x * NDIM + q];
-
-    double lp = -__builtin_inf();
-    if (in_prior<NDIM>(th, a.b)) {  // out-of-prior rows never touch the forward model
-        const typename M::Setup s = M::setup(th);
-        double acc0 = 0.0, acc1 = 0.0;
-        const double *__restrict__ rec = a.cb;
-        for (int j = 0; j < a.N; ++j, rec += M::REC) {
-            double zr, zi;
-            M::eval(s, rec + 4, zr, zi);
-            const double rr = rec[0] - zr, ri = rec[1] - zi;
-            acc0 = fma(rr * rr, rec[2], acc0);
-            acc1 = fma(ri * ri, rec[3], acc1);
-        }
-        lp = fma(-0.5, acc0 + acc1, a.lconst);
-    }
-    a.out[row] = lp;
+    const ModelOperands o{a.cb, a.N, a.lconst};
+    a.out[row] = logprob_row<M>(th, o, a.b);
 }
 
 // ---------------------------------------------------------------------------------
@@ -294,22 +309,12 @@ struct ReducedArgs {
     double rest;
 };
 
-template <int P, int BLK, bool VEC>
-__global__ __launch_bounds__(BLK) void k_logprob_pd_reduced(const LaunchArgs a,
-                                                            const ReducedArgs<P> r)
+template <int P>
+__device__ __forceinline__ double logprob_row_reduced(const double (&th)[P + 2],
+                                                      const ReducedArgs<P> &r, double lconst,
+                                                      const Bounds &b)
 {
-    constexpr int NDIM = P + 2;
-    constexpr int n = NDIM;
-    __shared__ __attribute__((aligned(16))) double lds[BLK * NDIM];
-    const long long row0 = (long long)blockIdx.x * BLK;
-    stage_theta<NDIM, BLK, VEC>(a.theta, a.W, row0, lds);
-    __syncthreads();
-    const long long row = row0 + threadIdx.x;
-    if (row >= a.W) return;
-    double th[NDIM];
-#pragma unroll
-    for (int q = 0; q < NDIM; ++q) th[q] = lds[threadIdx.x * NDIM + q];
-
+    constexpr int n = P + 2;
     double d[n];
     d[0] = r.bhat[0] - th[0];
 #pragma unroll
@@ -323,8 +328,25 @@ __global__ __launch_bounds__(BLK) void k_logprob_pd_reduced(const LaunchArgs a,
         for (int j = i; j < n; ++j, ++k) u = fma(r.R[k], d[j], u);
         chi2 = fma(u, u, chi2);
     }
-    const double lp = fma(-0.5, chi2, a.lconst);
-    a.out[row] = in_prior<NDIM>(th, a.b) ? lp : -__builtin_inf();
+    const double lp = fma(-0.5, chi2, lconst);
+    return in_prior<n>(th, b) ? lp : -__builtin_inf();
+}
+
+template <int P, int BLK, bool VEC>
+__global__ __launch_bounds__(BLK) void k_logprob_pd_reduced(const LaunchArgs a,
+                                                            const ReducedArgs<P> r)
+{
+    constexpr int NDIM = P + 2;
+    __shared__ __attribute__((aligned(16))) double lds[BLK * NDIM];
+    const long long row0 = (long long)blockIdx.x * BLK;
+    stage_theta<NDIM, BLK, VEC>(a.theta, a.W, row0, lds);
+    __syncthreads();
+    const long long row = row0 + threadIdx.x;
+    if (row >= a.W) return;
+    double th[NDIM];
+#pragma unroll
+    for (int q = 0; q < NDIM; ++q) th[q] = lds[threadIdx.x * NDIM + q];
+    a.out[row] = logprob_row_reduced<P>(th, r, a.lconst, a.b);
 }
 
 // ---------------------------------------------------------------------------------

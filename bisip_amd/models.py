@@ -16,7 +16,7 @@ import numpy as np
 
 from . import _hip
 from . import utils as _utils
-from .sampler import EnsembleSampler
+from .sampler import DeviceEnsembleSampler, EnsembleSampler
 
 
 class Inversion(_utils.utils):
@@ -147,16 +147,19 @@ class Inversion(_utils.utils):
             raise AssertionError('Model is not fitted! Fit the model to a '
                                  'dataset before attempting to plot results.')
 
-    def fit(self, p0=None, pool=None, moves=None):
+    def fit(self, p0=None, pool=None, moves=None, sampler='device'):
         """Sample the posterior with the stretch-move ensemble sampler.
 
         Args:
             p0 (ndarray): starting positions (nwalkers, ndim); drawn uniformly from the
                 prior box with the global NumPy RNG when None.
-            pool: accepted for signature compatibility and ignored -- the whole
+            pool: accepted for signature compatibility and ignored -- a whole
                 half-ensemble is evaluated by one kernel launch.
-            moves: an emcee ``moves`` object; requires emcee (the native sampler
-                implements the default StretchMove only).
+            moves: an emcee ``moves`` object; requires emcee (the native samplers
+                implement the default StretchMove only).
+            sampler (str): 'device' (default) keeps the ensemble and the chain on the GPU
+                and runs one fused kernel per half-step; 'host' runs the stretch move in
+                NumPy around the vectorised GPU log-probability.  Same chain either way.
         """
         self._p0 = p0
         self.ndim = self.param_bounds.shape[1]
@@ -165,13 +168,16 @@ class Inversion(_utils.utils):
 
         ctx = self._context()
         ctx.set_bounds(self.param_bounds)  # bounds are read at fit() time, not at construction
-        log_prob_fn = ctx.logprob
         if moves is not None:
             import emcee  # optional: non-default moves
-            self._sampler = emcee.EnsembleSampler(self.nwalkers, self.ndim, log_prob_fn,
+            self._sampler = emcee.EnsembleSampler(self.nwalkers, self.ndim, ctx.logprob,
                                                   moves=moves, vectorize=True)
+        elif sampler == 'device':
+            self._sampler = DeviceEnsembleSampler(self.nwalkers, self.ndim, ctx)
+        elif sampler == 'host':
+            self._sampler = EnsembleSampler(self.nwalkers, self.ndim, ctx.logprob)
         else:
-            self._sampler = EnsembleSampler(self.nwalkers, self.ndim, log_prob_fn)
+            raise ValueError("sampler must be 'device' or 'host'")
         self._sampler.run_mcmc(self._p0, self.nsteps, progress=True)
         self.__fitted = True
 

@@ -1,24 +1,30 @@
-"""Affine-invariant ensemble sampler driving the vectorised GPU log-probability.
+"""Affine-invariant ensemble samplers around the GPU log-probability.
 
 The reference delegates sampling to ``emcee.EnsembleSampler`` (call sites
 src/bisip/models.py:111-118, 137); emcee is third-party, unpinned
 (requirements.txt:2) and not part of the reference tree.  This module restates the
 published algorithm emcee runs by default -- Goodman & Weare's stretch move with a
-red/blue split -- around ONE difference: the log-probability
-is evaluated for a whole half-ensemble per call (``vectorize=True`` in emcee's
-terms), which is what the HIP kernels consume.
+red/blue split -- in two drivers that produce THE SAME CHAIN:
 
-RNG contract (so runs are reproducible and shardable): a private
-``numpy.random.RandomState`` seeded from the global NumPy state at construction
-(which is why ``np.random.seed(42)`` before ``fit()`` pins a run, as in the
-reference's notebooks).  Per iteration it is consumed in this order: one
-``choice`` over the move list, one ``shuffle`` of the split labels, then for each
-of the two halves ``rand(Ns)`` (stretch factors), ``randint(Nc, size=Ns)``
-(partners) and one ``rand()`` per walker of the half (accept test).
+* ``EnsembleSampler``        host loop; the log-probability of each half-ensemble is one
+                             vectorised call (emcee's ``vectorize=True`` contract).
+* ``DeviceEnsembleSampler``  ensemble, chain and the whole half-step (proposal,
+                             log-probability, accept, update) stay on the GPU: one
+                             kernel launch per half-step through the C ABI
+                             (``bisip_stretch_half_dev``), or eval + RCCL all-gather +
+                             apply when walkers are sharded over several GPUs.
+
+RNG contract (reproducible and shardable): a private ``numpy.random.RandomState``
+seeded from the global NumPy state at construction (so ``np.random.seed(42)`` before
+``fit()`` pins a run, as in the reference's notebooks).  Per iteration it is consumed
+in this order: one ``choice`` over the move list, one ``shuffle`` of the split labels,
+then for each of the two halves ``rand(Ns)`` (stretch factors), ``randint(Nc, Ns)``
+(partners) and ``rand(Ns)`` (accept uniforms, walker order).  ``draw_step`` is the
+single implementation of that order.
 
 Sampler parity with emcee itself is UNPINNED (no emcee here, and the reference's
-tests assert nothing at this boundary); tests pin this implementation against its
-own NumPy/oracle replay instead.
+tests assert nothing at this boundary); tests pin the two drivers against each other
+and against an oracle-driven replay.
 """
 
 import numpy as np
@@ -41,33 +47,43 @@ def walkers_independent(coords):
     return np.linalg.cond(c) <= 1e8
 
 
-class EnsembleSampler:
-    """Stretch-move ensemble sampler with the subset of emcee's interface that the
-    reference uses: ``run_mcmc``, ``get_chain``, ``get_log_prob``,
-    ``acceptance_fraction``.
+def draw_step(rng, nwalkers, ndim, a=2.0):
+    """Consume the RNG for ONE iteration and return the two half-steps.
 
-    Args:
-        nwalkers, ndim: ensemble shape.
-        log_prob_fn: vectorised callable ``theta (n, ndim) -> logp (n,)``.
-        a: stretch scale (emcee default 2.0).
-        args: extra positional arguments appended to every ``log_prob_fn`` call.
-        distributed, group: shard the evaluations over a ``torch.distributed`` group
-            (see bisip_amd/dist.py); the chain is bit-identical to a single-rank run.
+    Each half is a dict of arrays over its Ns slots: ``active`` (walker moved by the
+    slot), ``partner`` (walker of the complementary half it stretches from), ``zz``
+    (stretch factor), ``factor`` = (ndim-1) ln zz and ``logu`` = ln u.
     """
+    rng.choice(1)  # the draw over the (single-entry) move list
+    all_inds = np.arange(nwalkers)
+    inds = all_inds % 2
+    rng.shuffle(inds)
+    halves = []
+    for split in (0, 1):
+        S1 = inds == split
+        active = all_inds[S1]
+        comp = all_inds[~S1]
+        Ns, Nc = len(active), len(comp)
+        zz = ((a - 1.0) * rng.rand(Ns) + 1) ** 2.0 / a
+        rint = rng.randint(Nc, size=(Ns,))
+        u = rng.rand(Ns)
+        with np.errstate(divide='ignore'):
+            logu = np.log(u)
+        halves.append(dict(active=active, partner=comp[rint], zz=zz,
+                           factor=(ndim - 1.0) * np.log(zz), logu=logu))
+    return halves
 
-    def __init__(self, nwalkers, ndim, log_prob_fn, a=2.0, args=None, pool=None, moves=None,
-                 live_dangerously=False, group=None, distributed=False):
-        if moves is not None:
-            raise NotImplementedError('only the default StretchMove is implemented natively; '
-                                      'install emcee to use other moves')
+
+class _SamplerBase:
+    """Chain bookkeeping shared by the two drivers (emcee backend semantics)."""
+
+    def __init__(self, nwalkers, ndim, a, live_dangerously, group, distributed):
         self.nwalkers = int(nwalkers)
         self.ndim = int(ndim)
-        self.log_prob_fn = log_prob_fn
-        self.args = tuple(args) if args is not None else ()
         self.a = float(a)
         self.live_dangerously = live_dangerously
-        # distributed=True: shard every half-step's log-prob evaluations over the ranks of
-        # `group` (all ranks must construct the sampler with the same NumPy RNG state)
+        # distributed=True: shard every half-step's evaluations over the ranks of `group`
+        # (all ranks must construct the sampler with the same NumPy RNG state)
         self._group = group
         self._world, self._rank = 1, 0
         if distributed:
@@ -87,94 +103,31 @@ class EnsembleSampler:
         self._coords = None
         self._lp = None
 
-    # -- log-probability ----------------------------------------------------------------
-    def compute_log_prob(self, coords):
-        coords = np.ascontiguousarray(coords, dtype=np.float64)
+    def _check_initial(self, initial_state):
+        p0 = np.array(initial_state, dtype=np.float64, copy=True)
+        if p0.shape != (self.nwalkers, self.ndim):
+            raise ValueError(f'incompatible input dimensions {p0.shape}')
+        if not self.live_dangerously and self.nwalkers < 2 * self.ndim:
+            raise RuntimeError('It is unadvisable to use a red-blue move with fewer walkers '
+                               'than twice the number of dimensions.')
+        if not self.live_dangerously and not walkers_independent(p0):
+            raise ValueError('Initial state has a large condition number. Make sure that '
+                             'your walkers are linearly independent for the best performance')
+        return p0
+
+    @staticmethod
+    def _check_coords(coords):
         if np.any(np.isinf(coords)):
             raise ValueError('At least one parameter value was infinite')
         if np.any(np.isnan(coords)):
             raise ValueError('At least one parameter value was NaN')
-        lp = np.asarray(self.log_prob_fn(coords, *self.args), dtype=np.float64)
-        if lp.shape != (coords.shape[0],):
-            raise ValueError(f'log_prob_fn returned shape {lp.shape}, expected ({coords.shape[0]},)')
-        if np.any(np.isnan(lp)):
-            raise ValueError('Probability function returned NaN')
-        return lp
 
-    # -- one iteration ------------------------------------------------------------------
-    def _stretch_iteration(self):
-        rng = self._random
-        W, ndim = self.nwalkers, self.ndim
-        rng.choice(1)  # the draw over the (single-entry) move list
-        all_inds = np.arange(W)
-        inds = all_inds % 2
-        rng.shuffle(inds)
-        accepted = np.zeros(W, dtype=bool)
-        for split in (0, 1):
-            S1 = inds == split
-            s = self._coords[S1]
-            c = self._coords[~S1]  # read after the other half's update
-            Ns, Nc = len(s), len(c)
-            zz = ((self.a - 1.0) * rng.rand(Ns) + 1) ** 2.0 / self.a
-            factors = (ndim - 1.0) * np.log(zz)
-            rint = rng.randint(Nc, size=(Ns,))
-            q = c[rint] - (c[rint] - s) * zz[:, None]
-            u = rng.rand(Ns)  # one uniform per walker, in walker order
-            # this rank's block of the active half (the whole half when not distributed)
-            lo, hi = shard_range(Ns, self._world, self._rank)
-            new_lp = self.compute_log_prob(q[lo:hi])
-            old_lp = self._lp[S1][lo:hi]
-            with np.errstate(divide='ignore'):
-                acc = factors[lo:hi] + new_lp - old_lp > np.log(u[lo:hi])
-            block = np.concatenate([np.where(acc[:, None], q[lo:hi], s[lo:hi]),
-                                    np.where(acc, new_lp, old_lp)[:, None],
-                                    acc[:, None].astype(np.float64)], axis=1)
-            if self._world > 1:  # one all-gather of the just-updated rows per half-step
-                block = all_gather_rows(block, Ns, self._group)
-            idx = all_inds[S1]
-            self._coords[idx] = block[:, :ndim]
-            self._lp[idx] = block[:, ndim]
-            accepted[idx] = block[:, ndim + 1] > 0
-        self._accepted += accepted
-
-    def run_mcmc(self, initial_state, nsteps, progress=False, **kwargs):
-        """Advance the ensemble ``nsteps`` iterations from ``initial_state`` (W, ndim);
-        pass ``None`` to continue from the last position."""
-        if initial_state is None:
-            if self._coords is None:
-                raise ValueError('Cannot have `initial_state=None` if run_mcmc has never been called.')
-        else:
-            p0 = np.array(initial_state, dtype=np.float64, copy=True)
-            if p0.shape != (self.nwalkers, self.ndim):
-                raise ValueError(f'incompatible input dimensions {p0.shape}')
-            if not self.live_dangerously and self.nwalkers < 2 * self.ndim:
-                raise RuntimeError('It is unadvisable to use a red-blue move with fewer walkers '
-                                   'than twice the number of dimensions.')
-            if not self.live_dangerously and not walkers_independent(p0):
-                raise ValueError('Initial state has a large condition number. Make sure that '
-                                 'your walkers are linearly independent for the best performance')
-            self._coords = p0
-            self._lp = self.compute_log_prob(p0)
-        nsteps = int(nsteps)
-        chain = np.empty((nsteps, self.nwalkers, self.ndim))
-        logp = np.empty((nsteps, self.nwalkers))
-        it = range(nsteps)
-        if progress:
-            try:
-                from tqdm import tqdm
-                it = tqdm(it, total=nsteps)
-            except ImportError:
-                pass
-        for i in it:
-            self._stretch_iteration()
-            chain[i] = self._coords
-            logp[i] = self._lp
+    def _append(self, chain, logp):
         self._chain = np.concatenate([self._chain, chain], axis=0)
         self._log_prob = np.concatenate([self._log_prob, logp], axis=0)
-        self.iteration += nsteps
-        return self._coords.copy(), self._lp.copy()
+        self.iteration += chain.shape[0]
 
-    # -- chain access (emcee backend semantics: chain[discard+thin-1 : iteration : thin]) ----
+    # chain access: chain[discard + thin - 1 : iteration : thin]
     def _get_value(self, arr, discard=0, thin=1, flat=False):
         if self.iteration <= 0:
             raise AttributeError('you must run the sampler before accessing the results')
@@ -196,3 +149,250 @@ class EnsembleSampler:
     @property
     def random_state(self):
         return self._random.get_state()
+
+
+class EnsembleSampler(_SamplerBase):
+    """Host-loop stretch-move sampler with the subset of emcee's interface that the
+    reference uses: ``run_mcmc``, ``get_chain``, ``get_log_prob``,
+    ``acceptance_fraction``.
+
+    Args:
+        nwalkers, ndim: ensemble shape.
+        log_prob_fn: vectorised callable ``theta (n, ndim) -> logp (n,)``.
+        a: stretch scale (emcee default 2.0).
+        args: extra positional arguments appended to every ``log_prob_fn`` call.
+        distributed, group: shard the evaluations over a ``torch.distributed`` group
+            (see bisip_amd/dist.py); the chain is bit-identical to a single-rank run.
+    """
+
+    def __init__(self, nwalkers, ndim, log_prob_fn, a=2.0, args=None, pool=None, moves=None,
+                 live_dangerously=False, group=None, distributed=False):
+        if moves is not None:
+            raise NotImplementedError('only the default StretchMove is implemented natively; '
+                                      'install emcee to use other moves')
+        self.log_prob_fn = log_prob_fn
+        self.args = tuple(args) if args is not None else ()
+        super().__init__(nwalkers, ndim, a, live_dangerously, group, distributed)
+
+    def compute_log_prob(self, coords):
+        coords = np.ascontiguousarray(coords, dtype=np.float64)
+        self._check_coords(coords)
+        lp = np.asarray(self.log_prob_fn(coords, *self.args), dtype=np.float64)
+        if lp.shape != (coords.shape[0],):
+            raise ValueError(f'log_prob_fn returned shape {lp.shape}, expected ({coords.shape[0]},)')
+        if np.any(np.isnan(lp)):
+            raise ValueError('Probability function returned NaN')
+        return lp
+
+    def _stretch_iteration(self):
+        ndim = self.ndim
+        accepted = np.zeros(self.nwalkers, dtype=bool)
+        for h in draw_step(self._random, self.nwalkers, ndim, self.a):
+            idx = h['active']
+            Ns = len(idx)
+            s = self._coords[idx]
+            c = self._coords[h['partner']]  # the other half, read after its update
+            q = c - (c - s) * h['zz'][:, None]
+            # this rank's block of the active half (the whole half when not distributed)
+            lo, hi = shard_range(Ns, self._world, self._rank)
+            new_lp = self.compute_log_prob(q[lo:hi])
+            old_lp = self._lp[idx][lo:hi]
+            acc = h['factor'][lo:hi] + new_lp - old_lp > h['logu'][lo:hi]
+            block = np.concatenate([np.where(acc[:, None], q[lo:hi], s[lo:hi]),
+                                    np.where(acc, new_lp, old_lp)[:, None],
+                                    acc[:, None].astype(np.float64)], axis=1)
+            if self._world > 1:  # one all-gather of the just-updated rows per half-step
+                block = all_gather_rows(block, Ns, self._group)
+            self._coords[idx] = block[:, :ndim]
+            self._lp[idx] = block[:, ndim]
+            accepted[idx] = block[:, ndim + 1] > 0
+        self._accepted += accepted
+
+    def run_mcmc(self, initial_state, nsteps, progress=False, **kwargs):
+        """Advance the ensemble ``nsteps`` iterations from ``initial_state`` (W, ndim);
+        pass ``None`` to continue from the last position."""
+        if initial_state is None:
+            if self._coords is None:
+                raise ValueError('Cannot have `initial_state=None` if run_mcmc has never been called.')
+        else:
+            self._coords = self._check_initial(initial_state)
+            self._lp = self.compute_log_prob(self._coords)
+        nsteps = int(nsteps)
+        chain = np.empty((nsteps, self.nwalkers, self.ndim))
+        logp = np.empty((nsteps, self.nwalkers))
+        it = range(nsteps)
+        if progress:
+            try:
+                from tqdm import tqdm
+                it = tqdm(it, total=nsteps)
+            except ImportError:
+                pass
+        for i in it:
+            self._stretch_iteration()
+            chain[i] = self._coords
+            logp[i] = self._lp
+        self._append(chain, logp)
+        return self._coords.copy(), self._lp.copy()
+
+
+class HipStretchBackend:
+    """Device side of ``DeviceEnsembleSampler``: buffers are torch CUDA tensors (device
+    memory + stream plumbing), the arithmetic is the HIP library's."""
+
+    def __init__(self, ctx):
+        import torch
+        self.torch = torch
+        self.ctx = ctx
+        self.device = torch.device('cuda', ctx.device)
+
+    def tensor(self, array, dtype=None):
+        t = self.torch.as_tensor(np.ascontiguousarray(array), dtype=dtype)
+        return t.to(self.device)
+
+    def empty(self, shape, dtype):
+        return self.torch.empty(shape, dtype=dtype, device=self.device)
+
+    def zeros(self, shape, dtype):
+        return self.torch.zeros(shape, dtype=dtype, device=self.device)
+
+    def stream(self):
+        return self.torch.cuda.current_stream(self.device).cuda_stream
+
+    def logprob(self, coords_t, out_t):
+        self.ctx.logprob_dev(coords_t.data_ptr(), coords_t.shape[0], out_t.data_ptr(), self.stream())
+
+    def _args(self, st, k, h, n_slots):
+        from ._hip import StretchArgs
+        a = StretchArgs()
+        a.coords = st['coords'].data_ptr()
+        a.logp = st['logp'].data_ptr()
+        off = (k * 2 + h) * st['nh']
+        a.active = st['active'].data_ptr() + 4 * off
+        a.partner = st['partner'].data_ptr() + 4 * off
+        a.zz = st['zz'].data_ptr() + 8 * off
+        a.factor = st['factor'].data_ptr() + 8 * off
+        a.logu = st['logu'].data_ptr() + 8 * off
+        a.n_slots = n_slots
+        W, ndim = st['coords'].shape
+        a.chain_row = st['chain'].data_ptr() + 8 * k * W * ndim
+        a.logp_row = st['logp_chain'].data_ptr() + 8 * k * W
+        a.naccept = st['naccept'].data_ptr()
+        a.status = st['status'].data_ptr()
+        return a
+
+    def half(self, st, k, h, n_slots):
+        self.ctx.stretch_half_dev(self._args(st, k, h, n_slots), self.stream())
+
+    def eval(self, st, k, h, n_slots, lo, hi, block_t):
+        a = self._args(st, k, h, n_slots)
+        a.slot_lo, a.slot_hi = lo, hi
+        a.block = block_t.data_ptr()
+        self.ctx.stretch_eval_dev(a, self.stream())
+
+    def apply(self, st, k, h, n_slots, gathered_t, pad, world):
+        a = self._args(st, k, h, n_slots)
+        a.block = gathered_t.data_ptr()
+        a.pad, a.world = pad, world
+        self.ctx.stretch_apply_dev(a, self.stream())
+
+    def synchronize(self):
+        self.torch.cuda.synchronize(self.device)
+
+
+class DeviceEnsembleSampler(_SamplerBase):
+    """Stretch-move sampler whose ensemble, chain and half-step arithmetic live on the GPU.
+
+    Same interface, RNG contract and chain as ``EnsembleSampler``.  ``ctx`` is a
+    ``bisip_amd._hip.HipContext``; ``backend`` is injectable so the multi-rank driver
+    logic can be exercised on CPU (tests/test_dist.py).
+    ``chunk`` bounds the number of steps whose RNG stream / chain slab are resident at once.
+    """
+
+    def __init__(self, nwalkers, ndim, ctx=None, a=2.0, live_dangerously=False, group=None,
+                 distributed=False, backend=None, chunk=None):
+        self.backend = backend if backend is not None else HipStretchBackend(ctx)
+        self.chunk = chunk
+        super().__init__(nwalkers, ndim, a, live_dangerously, group, distributed)
+        self._dev = None
+
+    def _upload_state(self, coords, lp=None):
+        import torch
+        be = self.backend
+        W = self.nwalkers
+        dev = dict(coords=be.tensor(coords, torch.float64),
+                   naccept=be.zeros((W,), torch.int32), status=be.zeros((1,), torch.int32))
+        if lp is None:
+            dev['logp'] = be.empty((W,), torch.float64)
+            be.logprob(dev['coords'], dev['logp'])
+            be.synchronize()
+            lp0 = dev['logp'].cpu().numpy()
+            if np.any(np.isnan(lp0)):
+                raise ValueError('Probability function returned NaN')
+        else:
+            dev['logp'] = be.tensor(lp, torch.float64)
+        self._dev = dev
+
+    def _chunk_steps(self, nsteps):
+        if self.chunk:
+            return max(1, int(self.chunk))
+        per_step = self.nwalkers * (8 * self.ndim + 8 + 3 * 8 + 2 * 4)
+        return max(1, min(nsteps, (256 << 20) // per_step))
+
+    def run_mcmc(self, initial_state, nsteps, progress=False, **kwargs):
+        import torch
+        be = self.backend
+        W, ndim = self.nwalkers, self.ndim
+        if initial_state is None:
+            if self._dev is None:
+                raise ValueError('Cannot have `initial_state=None` if run_mcmc has never been called.')
+        else:
+            p0 = self._check_initial(initial_state)
+            self._check_coords(p0)
+            self._upload_state(p0)
+        nsteps = int(nsteps)
+        nh = (W + 1) // 2                       # slots per half (the first half gets the odd one)
+        chains, logps = [], []
+        done = 0
+        while done < nsteps:
+            n = min(self._chunk_steps(nsteps), nsteps - done)
+            # RNG stream for n steps, drawn on the host in the documented order
+            host = dict(active=np.zeros((n, 2, nh), np.int32), partner=np.zeros((n, 2, nh), np.int32),
+                        zz=np.ones((n, 2, nh)), factor=np.zeros((n, 2, nh)), logu=np.zeros((n, 2, nh)))
+            counts = np.zeros((n, 2), np.int64)
+            for k in range(n):
+                for h, half in enumerate(draw_step(self._random, W, ndim, self.a)):
+                    ns = len(half['active'])
+                    counts[k, h] = ns
+                    for name in host:
+                        host[name][k, h, :ns] = half[name]
+            st = dict(self._dev)
+            st['nh'] = nh
+            for name, arr in host.items():
+                st[name] = be.tensor(arr)
+            st['chain'] = be.empty((n, W, ndim), torch.float64)
+            st['logp_chain'] = be.empty((n, W), torch.float64)
+            for k in range(n):
+                for h in (0, 1):
+                    ns = int(counts[k, h])
+                    if self._world == 1:
+                        be.half(st, k, h, ns)
+                    else:
+                        lo, hi = shard_range(ns, self._world, self._rank)
+                        pad = -(-ns // self._world)
+                        block = be.zeros((pad, ndim + 2), torch.float64)
+                        be.eval(st, k, h, ns, lo, hi, block)
+                        gathered = be.empty((self._world * pad, ndim + 2), torch.float64)
+                        import torch.distributed as dist
+                        dist.all_gather_into_tensor(gathered, block, group=self._group)
+                        be.apply(st, k, h, ns, gathered, pad, self._world)
+            be.synchronize()
+            if int(st['status'].cpu()[0]) & 1:
+                raise ValueError('Probability function returned NaN')
+            chains.append(st['chain'].cpu().numpy())
+            logps.append(st['logp_chain'].cpu().numpy())
+            done += n
+        self._append(np.concatenate(chains, axis=0), np.concatenate(logps, axis=0))
+        self._accepted = self._dev['naccept'].cpu().numpy().astype(np.float64)
+        self._coords = self._dev['coords'].cpu().numpy()
+        self._lp = self._dev['logp'].cpu().numpy()
+        return self._coords.copy(), self._lp.copy()

@@ -101,6 +101,46 @@ int bisip_forward(bisip_ctx *ctx, const double *theta, int64_t W, double *Z);
 int bisip_forward_dev(bisip_ctx *ctx, const double *d_theta, int64_t W, double *d_Z,
                       void *stream);
 
+/* ---- device-resident stretch move (the emcee inner loop the reference runs around the
+ * log-probability: src/bisip/models.py:111-118; algorithm: emcee StretchMove with a
+ * red/blue split, a = stretch scale) -------------------------------------------------
+ * One half-step moves the walkers of the active half.  Slot t moves walker active[t]
+ * along the line through walker partner[t] (a member of the complementary half):
+ *     q = c - (c - s)*zz[t];   accept iff factor[t] + logp(q) - logp(s) > logu[t]
+ * where the caller supplies factor = (ndim-1)*ln(zz) and logu = ln(u) from its RNG
+ * stream (bisip_amd/sampler.py documents the stream order).  All pointers are device
+ * pointers; coords (W,ndim) and logp (W,) are updated in place; optional chain_row
+ * (W,ndim) / logp_row (W,) receive the post-move state of the moved walkers and
+ * naccept (W,) counts acceptances; status gets bit 0 set if a proposal's
+ * log-probability is NaN. */
+typedef struct bisip_stretch_args {
+    double *coords;
+    double *logp;
+    const int32_t *active;
+    const int32_t *partner;
+    const double *zz;
+    const double *factor;
+    const double *logu;
+    int64_t n_slots;   /* slots in this half-step                                    */
+    int64_t slot_lo;   /* eval: first slot evaluated by this rank                    */
+    int64_t slot_hi;   /* eval: one past the last slot evaluated by this rank        */
+    double *block;     /* eval: out (slot_hi-slot_lo, ndim+2) = row, logp, accepted  */
+                       /* apply: in, the all-gathered (world*pad, ndim+2) buffer     */
+    double *chain_row; /* may be NULL */
+    double *logp_row;  /* may be NULL */
+    int32_t *naccept;  /* may be NULL */
+    int32_t *status;   /* required */
+    int64_t pad;       /* apply: rows per rank slab in `block`                       */
+    int32_t world;     /* apply: number of ranks that produced `block`               */
+} bisip_stretch_args;
+
+/* Single-rank half-step: evaluate all n_slots slots and update the state (one launch). */
+int bisip_stretch_half_dev(bisip_ctx *ctx, const bisip_stretch_args *args, void *stream);
+/* Sharded half-step: evaluate slots [slot_lo, slot_hi) into args->block ... */
+int bisip_stretch_eval_dev(bisip_ctx *ctx, const bisip_stretch_args *args, void *stream);
+/* ... and, after the caller's all-gather of the blocks, apply all n_slots slots. */
+int bisip_stretch_apply_dev(bisip_ctx *ctx, const bisip_stretch_args *args, void *stream);
+
 /* Introspection */
 int bisip_ctx_ndim(const bisip_ctx *ctx);
 int bisip_ctx_nfreq(const bisip_ctx *ctx);

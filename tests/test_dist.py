@@ -96,3 +96,54 @@ def test_two_rank_gloo(tmp_path):
         assert np.array_equal(r[i]['chain'], s.get_chain())
         assert np.array_equal(r[i]['logp'], s.get_log_prob())
         assert np.array_equal(r[i]['acc'], s.acceptance_fraction)
+
+
+def _device_driver_worker(rank, world, port, case, outdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import oracle
+    from bisip_amd.sampler import DeviceEnsembleSampler
+    from numpy_stretch_backend import NumpyStretchBackend
+    g = np.load(case)
+    prob = oracle.OracleProblem.from_golden(g, 'PeltonColeCole')
+    fn = lambda t: oracle.logprob(prob, t)  # noqa: E731
+    lo, hi = g['bounds']
+    np.random.seed(11)
+    p0 = np.random.uniform(lo, hi, (19, lo.size))   # odd ensemble: uneven halves and shards
+    np.random.seed(12)
+    s = DeviceEnsembleSampler(19, lo.size, backend=NumpyStretchBackend(fn), distributed=True, chunk=6)
+    s.run_mcmc(p0, 20)
+    np.savez(os.path.join(outdir, f'dev_rank{rank}.npz'), chain=s.get_chain(), logp=s.get_log_prob(),
+             acc=s.acceptance_fraction)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_device_driver_two_rank_gloo(tmp_path):
+    """DeviceEnsembleSampler's multi-rank path (eval -> all_gather_into_tensor -> apply)
+    over gloo with a NumPy stand-in for the kernels: every rank ends with the chain of
+    the single-rank host sampler."""
+    import torch.multiprocessing as mp
+    import oracle
+    from bisip_amd.sampler import EnsembleSampler
+    case = [p for p in golden_cases() if 'PeltonColeCole_SIP-K389175' in p][0]
+    world = 2
+    mp.spawn(_device_driver_worker, args=(world, _free_port(), case, str(tmp_path)), nprocs=world,
+             join=True)
+    g = np.load(case)
+    prob = oracle.OracleProblem.from_golden(g, 'PeltonColeCole')
+    lo, hi = g['bounds']
+    np.random.seed(11)
+    p0 = np.random.uniform(lo, hi, (19, lo.size))
+    np.random.seed(12)
+    s = EnsembleSampler(19, lo.size, lambda t: oracle.logprob(prob, t))
+    s.run_mcmc(p0, 20)
+    for i in range(world):
+        r = np.load(tmp_path / f'dev_rank{i}.npz')
+        assert np.array_equal(r['chain'], s.get_chain())
+        assert np.array_equal(r['logp'], s.get_log_prob())
+        assert np.array_equal(r['acc'], s.acceptance_fraction)

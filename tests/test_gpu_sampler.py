@@ -1,0 +1,137 @@
+"""Device-resident stretch move (bisip_stretch_*_dev) against the host-loop sampler.
+
+Both drivers consume the same RNG stream; the device path must reproduce the host
+path's chain BIT FOR BIT (positions, log-probs, acceptance counts), for every model
+and formulation, including odd ensemble sizes, chunked runs and the eval+apply
+(sharded) kernels driven single-rank."""
+
+import numpy as np
+import pytest
+
+from conftest import assert_logp_close, case_id, golden_cases
+from test_gpu_parity import make_ctx
+
+pytestmark = pytest.mark.gpu
+
+CASES = [('case04_', 'PolynomialDecomposition', 'reduced'),
+         ('case04_', 'PolynomialDecomposition', 'collapsed'),
+         ('case13_', 'PolynomialDecomposition', 'reduced'),
+         ('case15_', 'PeltonColeCole', 'auto'),
+         ('case16_', 'PeltonColeCole', 'auto'),
+         ('case17_', 'PeltonColeCole', 'auto'),
+         ('case18_', 'Dias2000', 'auto'),
+         ('case19_', 'Shin2015', 'auto')]
+
+
+def _case(prefix):
+    return [p for p in golden_cases() if prefix in p][0]
+
+
+def _start(g, W, seed):
+    rng = np.random.RandomState(seed)
+    i0 = int(g['n_prior'])
+    centre = g['theta'][i0]
+    lo, hi = g['bounds']
+    p0 = centre + 1e-3 * (hi - lo) * rng.randn(W, lo.size)
+    return np.clip(p0, lo + 1e-6 * (hi - lo), hi - 1e-6 * (hi - lo))
+
+
+@pytest.mark.parametrize('prefix,model,variant', CASES)
+def test_device_sampler_equals_host_sampler(prefix, model, variant):
+    from bisip_amd.sampler import DeviceEnsembleSampler, EnsembleSampler
+    g = np.load(_case(prefix))
+    ctx = make_ctx(g, model, variant)
+    ndim = g['bounds'].shape[1]
+    for W, nsteps, chunk in [(32, 60, None), (33, 25, 7), (256, 12, 5)]:
+        if W < 2 * ndim:
+            continue
+        p0 = _start(g, W, 100 + W)
+        np.random.seed(99)
+        host = EnsembleSampler(W, ndim, ctx.logprob)
+        host.run_mcmc(p0, nsteps)
+        np.random.seed(99)
+        dev = DeviceEnsembleSampler(W, ndim, ctx, chunk=chunk)
+        dev.run_mcmc(p0, nsteps)
+        assert np.array_equal(dev.get_chain(), host.get_chain())
+        assert np.array_equal(dev.get_log_prob(), host.get_log_prob())
+        assert np.array_equal(dev.acceptance_fraction, host.acceptance_fraction)
+        assert 0.05 < dev.acceptance_fraction.mean() < 0.95
+        # continuing a run appends and keeps the streams aligned
+        host.run_mcmc(None, 5)
+        dev.run_mcmc(None, 5)
+        assert np.array_equal(dev.get_chain(), host.get_chain())
+    ctx.close()
+
+
+def test_eval_apply_path_single_rank():
+    """The sharded kernels (eval -> [all-gather] -> apply) driven with world=1 give the
+    same state as the fused half-step kernel."""
+    import torch
+    from bisip_amd.sampler import DeviceEnsembleSampler, HipStretchBackend
+
+    class SplitBackend(HipStretchBackend):
+        def half(self, st, k, h, n_slots):
+            # two "ranks" worth of blocks evaluated one after the other, then applied
+            world = 3
+            pad = -(-n_slots // world)
+            gathered = self.zeros((world * pad, st['coords'].shape[1] + 2), torch.float64)
+            base, extra = divmod(n_slots, world)
+            lo = 0
+            for r in range(world):
+                hi = lo + base + (1 if r < extra else 0)
+                self.eval(st, k, h, n_slots, lo, hi, gathered[r * pad:(r + 1) * pad])
+                lo = hi
+            self.apply(st, k, h, n_slots, gathered, pad, world)
+
+    g = np.load(_case('case16_'))
+    ctx = make_ctx(g, 'PeltonColeCole')
+    W, ndim = 40, 7
+    p0 = _start(g, W, 5)
+    np.random.seed(3)
+    a = DeviceEnsembleSampler(W, ndim, ctx)
+    a.run_mcmc(p0, 30)
+    np.random.seed(3)
+    b = DeviceEnsembleSampler(W, ndim, backend=SplitBackend(ctx))
+    b.run_mcmc(p0, 30)
+    assert np.array_equal(a.get_chain(), b.get_chain())
+    assert np.array_equal(a.get_log_prob(), b.get_log_prob())
+    assert np.array_equal(a.acceptance_fraction, b.acceptance_fraction)
+    ctx.close()
+
+
+def test_device_sampler_against_oracle_replay():
+    import oracle
+    from bisip_amd.sampler import DeviceEnsembleSampler, EnsembleSampler
+    g = np.load(_case('case10_'))   # PolynomialDecomposition, synthetic N=32 (metric shape)
+    ctx = make_ctx(g, 'PolynomialDecomposition')
+    prob = oracle.OracleProblem.from_golden(g, 'PolynomialDecomposition')
+    W, ndim = 64, 7
+    p0 = _start(g, W, 8)
+    np.random.seed(21)
+    dev = DeviceEnsembleSampler(W, ndim, ctx)
+    dev.run_mcmc(p0, 200)
+    np.random.seed(21)
+    ref = EnsembleSampler(W, ndim, lambda t: oracle.logprob(prob, t))
+    ref.run_mcmc(p0, 200)
+    assert np.array_equal(dev.get_chain(), ref.get_chain())
+    assert_logp_close(dev.get_log_prob(), ref.get_log_prob())
+
+
+def test_out_of_prior_start_and_nan_detection():
+    from bisip_amd.sampler import DeviceEnsembleSampler
+    g = np.load(_case('case15_'))
+    ctx = make_ctx(g, 'PeltonColeCole')
+    lo, hi = g['bounds']
+    p0 = _start(g, 32, 1)
+    p0[0, 0] = hi[0] + 0.01       # one walker starts outside: logp -inf, must move in or stay
+    np.random.seed(4)
+    s = DeviceEnsembleSampler(32, 4, ctx)
+    s.run_mcmc(p0, 50)
+    lp = s.get_log_prob()
+    assert np.isneginf(lp[0, 0]) or np.isfinite(lp[0, 0])
+    assert np.isfinite(lp[-1, 1:]).all()
+    with pytest.raises(ValueError):
+        bad = p0.copy()
+        bad[1, 1] = np.nan
+        s.run_mcmc(bad, 2)
+    ctx.close()
