@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""End-to-end fit() throughput (MCMC iterations/s) -- BASELINE config 1 (README quickstart)
+and larger ensembles -- for the device-resident and host-loop samplers.  1 GPU."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import bisip_amd
+    path = bisip_amd.DataFiles()['SIP-K389175']
+    cases = [
+        ('cfg1 PolynomialDecomposition K389175 32x1000 (reference README: 558.64 it/s)',
+         bisip_amd.PolynomialDecomposition, {}, 32, 1000),
+        ('PeltonColeCole n_modes=2 K389175 64x1000 (reference tutorial: 356-435 it/s)',
+         bisip_amd.PeltonColeCole, dict(n_modes=2), 64, 1000),
+        ('Dias2000 K389175 32x1000 (reference tutorial: 511-533 it/s)', bisip_amd.Dias2000, {}, 32, 1000),
+        ('PolynomialDecomposition 4096 walkers x 200', bisip_amd.PolynomialDecomposition, {}, 4096, 200),
+        ('PeltonColeCole n_modes=2 4096 walkers x 200', bisip_amd.PeltonColeCole, dict(n_modes=2), 4096, 200),
+        ('PolynomialDecomposition 32768 walkers x 50', bisip_amd.PolynomialDecomposition, {}, 32768, 50),
+    ]
+    for name, cls, kw, W, nsteps in cases:
+        for sampler in ('device-philox', 'device', 'host'):
+            m = cls(path, nwalkers=W, nsteps=nsteps, **kw)
+            lo, hi = m.param_bounds
+            np.random.seed(42)
+            p0 = np.random.uniform(lo, hi, (W, lo.size))
+            if sampler == 'device-philox':
+                from bisip_amd.sampler import DeviceEnsembleSampler
+                ctx = m._context()
+                ctx.set_bounds(m.param_bounds)
+                DeviceEnsembleSampler(W, lo.size, ctx, rng='philox', seed=1).run_mcmc(p0, 5)
+                smp = DeviceEnsembleSampler(W, lo.size, ctx, rng='philox', seed=1)
+                t0 = time.perf_counter()
+                smp.run_mcmc(p0, nsteps)
+                dt = time.perf_counter() - t0
+                m._sampler = smp
+                m._Inversion__fitted = True
+            else:
+                m.nsteps = 5
+                m.fit(p0=p0, sampler=sampler)        # warm-up (context, kernels, allocator)
+                m.nsteps = nsteps
+                t0 = time.perf_counter()
+                m.fit(p0=p0, sampler=sampler)
+                dt = time.perf_counter() - t0
+            print(json.dumps({'case': name, 'sampler': sampler, 'walkers': W, 'nsteps': nsteps,
+                              'seconds': round(dt, 4), 'it_per_s': round(nsteps / dt, 1),
+                              'walker_steps_per_s': float('%.4g' % (nsteps * W / dt)),
+                              'acceptance': round(float(m.sampler.acceptance_fraction.mean()), 3)}),
+                  flush=True)
+
+
+if __name__ == '__main__':
+    main()

@@ -57,6 +57,12 @@ SYMBOLS = {
     'bisip_stretch_half_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(StretchArgs), ctypes.c_void_p]),
     'bisip_stretch_eval_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(StretchArgs), ctypes.c_void_p]),
     'bisip_stretch_apply_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(StretchArgs), ctypes.c_void_p]),
+    'bisip_stretch_run_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(StretchArgs), ctypes.c_int64,
+                                             ctypes.c_int64, ctypes.c_void_p]),
+    'bisip_stretch_draw_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_double,
+                                              ctypes.c_uint64, ctypes.c_int64, ctypes.c_int64] +
+                               [ctypes.c_void_p] * 7),
+    'bisip_philox4x32': (None, [ctypes.POINTER(ctypes.c_uint32)] * 3),
     'bisip_ctx_ndim': (ctypes.c_int, [ctypes.c_void_p]),
     'bisip_ctx_nfreq': (ctypes.c_int, [ctypes.c_void_p]),
     'bisip_ctx_device': (ctypes.c_int, [ctypes.c_void_p]),
@@ -264,3 +270,24 @@ class HipContext:
 
     def stretch_apply_dev(self, args, stream=0):
         _check(self._lib.bisip_stretch_apply_dev(self._h, ctypes.byref(args), ctypes.c_void_p(stream)))
+
+    def stretch_run_dev(self, first_args, W, n_steps, stream=0):
+        _check(self._lib.bisip_stretch_run_dev(self._h, ctypes.byref(first_args), int(W),
+                                               int(n_steps), ctypes.c_void_p(stream)))
+
+    def stretch_draw_dev(self, W, a, seed, step0, n_steps, perm, active, partner, zz, factor, logu,
+                         stream=0):
+        _check(self._lib.bisip_stretch_draw_dev(self._h, int(W), float(a), int(seed), int(step0),
+                                                int(n_steps), *[ctypes.c_void_p(p) for p in
+                                                                (perm, active, partner, zz, factor, logu)],
+                                                ctypes.c_void_p(stream)))
+
+
+def philox4x32(counter, key):
+    """One Philox4x32-10 block on the host (same inline code as the device stream)."""
+    lib = load_library()
+    c = (ctypes.c_uint32 * 4)(*[int(x) & 0xffffffff for x in counter])
+    k = (ctypes.c_uint32 * 2)(*[int(x) & 0xffffffff for x in key])
+    out = (ctypes.c_uint32 * 4)()
+    lib.bisip_philox4x32(c, k, out)
+    return [int(x) for x in out]

@@ -598,6 +598,62 @@ int bisip_stretch_apply_dev(bisip_ctx *c, const bisip_stretch_args *u, void *str
     return dispatch_apply(c, to_device_args(u), (hipStream_t)stream);
 }
 
+int bisip_stretch_run_dev(bisip_ctx *c, const bisip_stretch_args *first, int64_t W, int64_t n_steps,
+                          void *stream)
+{
+    if (!c || !first) return fail(BISIP_EINVAL, "null argument");
+    if (W < 2 || n_steps < 0) return fail(BISIP_EINVAL, "bad W=%lld or n_steps=%lld", (long long)W, (long long)n_steps);
+    if (!first->coords || !first->logp || !first->active || !first->partner || !first->zz ||
+        !first->factor || !first->logu || !first->status)
+        return fail(BISIP_EINVAL, "null buffer");
+    HIP_TRY(hipSetDevice(c->device));
+    const int64_t nh = (W + 1) / 2;
+    bisip_stretch_args u = *first;
+    for (int64_t k = 0; k < n_steps; ++k) {
+        for (int h = 0; h < 2; ++h) {
+            const int64_t off = (k * 2 + h) * nh;
+            u.active = first->active + off; u.partner = first->partner + off;
+            u.zz = first->zz + off; u.factor = first->factor + off; u.logu = first->logu + off;
+            u.n_slots = h ? W / 2 : nh;
+            u.chain_row = first->chain_row ? first->chain_row + k * W * c->ndim : nullptr;
+            u.logp_row = first->logp_row ? first->logp_row + k * W : nullptr;
+            int rc = dispatch_stretch(c, to_device_args(&u), STRETCH_HALF, (hipStream_t)stream);
+            if (rc != BISIP_OK) return rc;
+        }
+    }
+    return BISIP_OK;
+}
+
+int bisip_stretch_draw_dev(bisip_ctx *c, int64_t W, double a, uint64_t seed, int64_t step0,
+                           int64_t n_steps, const int32_t *d_perm, int32_t *d_active,
+                           int32_t *d_partner, double *d_zz, double *d_factor, double *d_logu,
+                           void *stream)
+{
+    if (!c || !d_perm || !d_active || !d_partner || !d_zz || !d_factor || !d_logu)
+        return fail(BISIP_EINVAL, "null argument");
+    if (W < 2 || W > 0x7fffffffLL || n_steps < 0 || step0 < 0 || step0 + n_steps > 0xffffffffLL)
+        return fail(BISIP_EINVAL, "bad W/step range");
+    if (n_steps == 0) return BISIP_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    DrawArgs d;
+    d.W = W; d.nh = (W + 1) / 2; d.n_steps = n_steps; d.step0 = step0;
+    d.a = a; d.ndim_m1 = (double)(c->ndim - 1);
+    d.seed_lo = (unsigned int)(seed & 0xffffffffu); d.seed_hi = (unsigned int)(seed >> 32);
+    d.perm = d_perm; d.active = d_active; d.partner = d_partner;
+    d.zz = d_zz; d.factor = d_factor; d.logu = d_logu;
+    const long long total = n_steps * 2 * d.nh;
+    hipLaunchKernelGGL(k_stretch_draw, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, d);
+    HIP_TRY(hipGetLastError());
+    return BISIP_OK;
+}
+
+void bisip_philox4x32(const uint32_t *counter, const uint32_t *key, uint32_t *out)
+{
+    const Philox4 r = philox4x32_10(counter[0], counter[1], counter[2], counter[3], key[0], key[1]);
+    for (int i = 0; i < 4; ++i) out[i] = r.v[i];
+}
+
 int bisip_logprob(bisip_ctx *c, const double *theta, int64_t W, double *logp)
 {
     if (!c) return fail(BISIP_EINVAL, "null context");

@@ -16,6 +16,7 @@
 // kernels (kernels.h: logprob_row / logprob_row_reduced) -- identical bits.
 #pragma once
 #include "kernels.h"
+#include "philox.h"
 
 namespace bisip {
 
@@ -151,6 +152,63 @@ __global__ __launch_bounds__(64) void k_stretch_apply(const StretchArgs a)
 #pragma unroll
     for (int k = 0; k < NDIM; ++k) row[k] = in[k];
     commit_row<NDIM>(a, a.active[t], row, in[NDIM], in[NDIM + 1] > 0.0);
+}
+
+// ---------------------------------------------------------------------------------
+// Device-side generation of the stretch-move random stream (rng='philox').
+// Counter-based, so every (step, half, slot) is independent of launch shape and every
+// rank of a sharded run derives the same numbers with no communication.
+//   key     = (seed_lo, seed_hi)
+//   counter = (slot t, step k, half h, purpose)   purpose 0: (z, partner), 1: accept
+//   split   : per-step affine bijection pi(i) = (A*i + B) mod W (host-drawn, gcd(A,W)=1);
+//             walker i is in half pi(i)&1 at slot pi(i)>>1, so slot t of half h holds
+//             walker Ainv*((2t+h-B) mod W) mod W.
+//   z       = ((a-1)*u53(x0,x1) + 1)^2 / a;  partner slot r = (x2*Nc)>>32 in the other half
+// Outputs are the same (n_steps, 2, nh) arrays the host-stream mode uploads.
+// ---------------------------------------------------------------------------------
+struct DrawArgs {
+    long long W, nh, n_steps, step0;
+    double a, ndim_m1;
+    unsigned int seed_lo, seed_hi;
+    const int *perm;  // (n_steps, 3): A, Ainv, B
+    int *active, *partner;
+    double *zz, *factor, *logu;
+};
+
+__device__ __forceinline__ int perm_inverse(long long y, long long W, long long Ainv, long long B)
+{
+    long long v = (y - B) % W;
+    if (v < 0) v += W;
+    return (int)((Ainv * v) % W);
+}
+
+__global__ __launch_bounds__(256) void k_stretch_draw(const DrawArgs d)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = d.n_steps * 2 * d.nh;
+    if (idx >= total) return;
+    const long long k = idx / (2 * d.nh);
+    const int h = (int)((idx / d.nh) & 1);
+    const long long t = idx % d.nh;
+    const long long n0 = (d.W + 1) / 2, n1 = d.W / 2;
+    const long long Ns = h ? n1 : n0, Nc = h ? n0 : n1;
+    if (t >= Ns) {  // padding slot of the smaller half
+        d.active[idx] = 0; d.partner[idx] = 0; d.zz[idx] = 1.0; d.factor[idx] = 0.0; d.logu[idx] = 0.0;
+        return;
+    }
+    const long long A_inv = d.perm[3 * k + 1], B = d.perm[3 * k + 2];
+    const unsigned int step = (unsigned int)(d.step0 + k);
+    const Philox4 r0 = philox4x32_10((unsigned int)t, step, (unsigned int)h, 0u, d.seed_lo, d.seed_hi);
+    const Philox4 r1 = philox4x32_10((unsigned int)t, step, (unsigned int)h, 1u, d.seed_lo, d.seed_hi);
+    const double uz = u53(r0.v[0], r0.v[1]);
+    const long long r = (long long)(((unsigned long long)r0.v[2] * (unsigned long long)Nc) >> 32);
+    const double v = (d.a - 1.0) * uz + 1.0;
+    const double z = (v * v) / d.a;
+    d.active[idx] = perm_inverse(2 * t + h, d.W, A_inv, B);
+    d.partner[idx] = perm_inverse(2 * r + (1 - h), d.W, A_inv, B);
+    d.zz[idx] = z;
+    d.factor[idx] = d.ndim_m1 * log(z);
+    d.logu[idx] = log(u53(r1.v[0], r1.v[1]));
 }
 
 }  // namespace bisip

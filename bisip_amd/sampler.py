@@ -22,6 +22,12 @@ then for each of the two halves ``rand(Ns)`` (stretch factors), ``randint(Nc, Ns
 (partners) and ``rand(Ns)`` (accept uniforms, walker order).  ``draw_step`` is the
 single implementation of that order.
 
+``rng='philox'`` (DeviceEnsembleSampler only) removes the host from the loop: the same
+per-slot quantities come from a counter-based Philox4x32-10 stream generated on the
+device (contract in bisip_amd/csrc/sampler_kernels.h: key = seed, counter = (slot,
+step, half, purpose)); only the per-step split -- an affine bijection (A, B) of the
+walker indices drawn by ``affine_splits`` -- is drawn on the host.
+
 Sampler parity with emcee itself is UNPINNED (no emcee here, and the reference's
 tests assert nothing at this boundary); tests pin the two drivers against each other
 and against an oracle-driven replay.
@@ -72,6 +78,21 @@ def draw_step(rng, nwalkers, ndim, a=2.0):
         halves.append(dict(active=active, partner=comp[rint], zz=zz,
                            factor=(ndim - 1.0) * np.log(zz), logu=logu))
     return halves
+
+
+def affine_splits(rng, nwalkers, nsteps):
+    """Per-step random balanced split for rng='philox': pi(i) = (A*i + B) mod W with
+    gcd(A, W) = 1; walker i belongs to half pi(i) & 1.  Returns int32 (nsteps, 3) rows
+    (A, A^-1 mod W, B)."""
+    import math
+    W = int(nwalkers)
+    out = np.empty((nsteps, 3), dtype=np.int32)
+    for k in range(nsteps):
+        A = int(rng.randint(1, W))
+        while math.gcd(A, W) != 1:
+            A = int(rng.randint(1, W))
+        out[k] = (A, pow(A, -1, W), int(rng.randint(W)))
+    return out
 
 
 class _SamplerBase:
@@ -295,6 +316,18 @@ class HipStretchBackend:
         a.pad, a.world = pad, world
         self.ctx.stretch_apply_dev(a, self.stream())
 
+    def run(self, st, n_steps):
+        """All n_steps iterations of a chunk in one C call (2 launches per step, no host
+        round trip)."""
+        W = st['coords'].shape[0]
+        self.ctx.stretch_run_dev(self._args(st, 0, 0, (W + 1) // 2), W, n_steps, self.stream())
+
+    def draw(self, st, W, a, seed, step0, n_steps):
+        self.ctx.stretch_draw_dev(W, a, seed, step0, n_steps, st['perm'].data_ptr(),
+                                  st['active'].data_ptr(), st['partner'].data_ptr(),
+                                  st['zz'].data_ptr(), st['factor'].data_ptr(),
+                                  st['logu'].data_ptr(), self.stream())
+
     def synchronize(self):
         self.torch.cuda.synchronize(self.device)
 
@@ -309,10 +342,18 @@ class DeviceEnsembleSampler(_SamplerBase):
     """
 
     def __init__(self, nwalkers, ndim, ctx=None, a=2.0, live_dangerously=False, group=None,
-                 distributed=False, backend=None, chunk=None):
+                 distributed=False, backend=None, chunk=None, rng='numpy', seed=None):
+        if rng not in ('numpy', 'philox'):
+            raise ValueError("rng must be 'numpy' or 'philox'")
         self.backend = backend if backend is not None else HipStretchBackend(ctx)
         self.chunk = chunk
+        self.rng = rng
         super().__init__(nwalkers, ndim, a, live_dangerously, group, distributed)
+        # philox key: explicit seed, else drawn from the (seeded) private RandomState
+        # (never in 'numpy' mode: that stream must stay aligned with EnsembleSampler's)
+        self.seed = None
+        if rng == 'philox':
+            self.seed = int(seed) if seed is not None else int(self._random.randint(0, 2 ** 31 - 1))
         self._dev = None
 
     def _upload_state(self, coords, lp=None):
@@ -355,34 +396,44 @@ class DeviceEnsembleSampler(_SamplerBase):
         done = 0
         while done < nsteps:
             n = min(self._chunk_steps(nsteps), nsteps - done)
-            # RNG stream for n steps, drawn on the host in the documented order
-            host = dict(active=np.zeros((n, 2, nh), np.int32), partner=np.zeros((n, 2, nh), np.int32),
-                        zz=np.ones((n, 2, nh)), factor=np.zeros((n, 2, nh)), logu=np.zeros((n, 2, nh)))
-            counts = np.zeros((n, 2), np.int64)
-            for k in range(n):
-                for h, half in enumerate(draw_step(self._random, W, ndim, self.a)):
-                    ns = len(half['active'])
-                    counts[k, h] = ns
-                    for name in host:
-                        host[name][k, h, :ns] = half[name]
             st = dict(self._dev)
             st['nh'] = nh
-            for name, arr in host.items():
-                st[name] = be.tensor(arr)
+            counts = np.empty((n, 2), np.int64)
+            counts[:, 0], counts[:, 1] = nh, W // 2
+            if self.rng == 'numpy':
+                # RNG stream for n steps, drawn on the host in the documented order
+                host = dict(active=np.zeros((n, 2, nh), np.int32), partner=np.zeros((n, 2, nh), np.int32),
+                            zz=np.ones((n, 2, nh)), factor=np.zeros((n, 2, nh)), logu=np.zeros((n, 2, nh)))
+                for k in range(n):
+                    for h, half in enumerate(draw_step(self._random, W, ndim, self.a)):
+                        ns = len(half['active'])
+                        for name in host:
+                            host[name][k, h, :ns] = half[name]
+                for name, arr in host.items():
+                    st[name] = be.tensor(arr)
+            else:
+                # only the per-step split is drawn on the host; the stream is generated on
+                # the device from (seed, step, half, slot) counters
+                st['perm'] = be.tensor(affine_splits(self._random, W, n))
+                for name, dt in (('active', torch.int32), ('partner', torch.int32),
+                                 ('zz', torch.float64), ('factor', torch.float64),
+                                 ('logu', torch.float64)):
+                    st[name] = be.empty((n, 2, nh), dt)
+                be.draw(st, W, self.a, self.seed, self.iteration + done, n)
             st['chain'] = be.empty((n, W, ndim), torch.float64)
             st['logp_chain'] = be.empty((n, W), torch.float64)
-            for k in range(n):
-                for h in (0, 1):
-                    ns = int(counts[k, h])
-                    if self._world == 1:
-                        be.half(st, k, h, ns)
-                    else:
+            if self._world == 1:
+                be.run(st, n)
+            else:
+                import torch.distributed as dist
+                for k in range(n):
+                    for h in (0, 1):
+                        ns = int(counts[k, h])
                         lo, hi = shard_range(ns, self._world, self._rank)
                         pad = -(-ns // self._world)
                         block = be.zeros((pad, ndim + 2), torch.float64)
                         be.eval(st, k, h, ns, lo, hi, block)
                         gathered = be.empty((self._world * pad, ndim + 2), torch.float64)
-                        import torch.distributed as dist
                         dist.all_gather_into_tensor(gathered, block, group=self._group)
                         be.apply(st, k, h, ns, gathered, pad, self._world)
             be.synchronize()

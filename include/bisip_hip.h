@@ -141,6 +141,24 @@ int bisip_stretch_eval_dev(bisip_ctx *ctx, const bisip_stretch_args *args, void 
 /* ... and, after the caller's all-gather of the blocks, apply all n_slots slots. */
 int bisip_stretch_apply_dev(bisip_ctx *ctx, const bisip_stretch_args *args, void *stream);
 
+/* Run n_steps whole iterations (2 half-steps each) back to back on `stream` with no host
+ * round trip.  `first` holds the pointers of step 0 / half 0; the random-stream arrays are
+ * laid out (n_steps, 2, nh) with nh = (W+1)/2 (half 0 has ceil(W/2) slots, half 1
+ * floor(W/2)); chain_row / logp_row advance by W*ndim / W per step. */
+int bisip_stretch_run_dev(bisip_ctx *ctx, const bisip_stretch_args *first, int64_t W,
+                          int64_t n_steps, void *stream);
+
+/* Fill the random-stream arrays on the device (counter-based Philox4x32-10; the contract
+ * is documented in bisip_amd/csrc/sampler_kernels.h and bisip_amd/sampler.py).
+ * d_perm (n_steps,3) = per-step affine split (A, A^-1 mod W, B). */
+int bisip_stretch_draw_dev(bisip_ctx *ctx, int64_t W, double a, uint64_t seed, int64_t step0,
+                           int64_t n_steps, const int32_t *d_perm, int32_t *d_active,
+                           int32_t *d_partner, double *d_zz, double *d_factor, double *d_logu,
+                           void *stream);
+
+/* Host: one Philox4x32-10 block (counter[4], key[2]) -> out[4]; for known-answer tests. */
+void bisip_philox4x32(const uint32_t *counter, const uint32_t *key, uint32_t *out);
+
 /* Introspection */
 int bisip_ctx_ndim(const bisip_ctx *ctx);
 int bisip_ctx_nfreq(const bisip_ctx *ctx);

@@ -7,6 +7,56 @@ import numpy as np
 import torch
 
 
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Vectorised Philox4x32-10 on uint64 arrays holding 32-bit values (independent of
+    the C implementation in bisip_amd/csrc/philox.h)."""
+    M0, M1, W0, W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
+    mask = np.uint64(0xffffffff)
+    c0, c1, c2, c3 = [np.asarray(x, dtype=np.uint64) & mask for x in np.broadcast_arrays(c0, c1, c2, c3)]
+    k0, k1 = np.uint64(k0), np.uint64(k1)
+    for _ in range(10):
+        p0 = np.uint64(M0) * c0
+        p1 = np.uint64(M1) * c2
+        c0, c1, c2, c3 = ((p1 >> np.uint64(32)) ^ c1 ^ k0) & mask, p1 & mask, \
+                         ((p0 >> np.uint64(32)) ^ c3 ^ k1) & mask, p0 & mask
+        k0 = (k0 + np.uint64(W0)) & mask
+        k1 = (k1 + np.uint64(W1)) & mask
+    return c0, c1, c2, c3
+
+
+def u53(a, b):
+    return (((a >> np.uint64(5)) << np.uint64(26)) | (b >> np.uint64(6))).astype(np.float64) / 9007199254740992.0
+
+
+def philox_stream(W, ndim, a, seed, step0, perm):
+    """NumPy statement of the rng='philox' contract (bisip_amd/csrc/sampler_kernels.h):
+    returns active, partner, zz, factor, logu of shape (n, 2, nh)."""
+    n = perm.shape[0]
+    nh = (W + 1) // 2
+    out = dict(active=np.zeros((n, 2, nh), np.int32), partner=np.zeros((n, 2, nh), np.int32),
+               zz=np.ones((n, 2, nh)), factor=np.zeros((n, 2, nh)), logu=np.zeros((n, 2, nh)))
+    k0, k1 = seed & 0xffffffff, seed >> 32
+    for k in range(n):
+        A, Ainv, B = [int(x) for x in perm[k]]
+        for h in (0, 1):
+            Ns = nh if h == 0 else W // 2
+            Nc = W // 2 if h == 0 else nh
+            t = np.arange(Ns, dtype=np.uint64)
+            x0, x1, x2, _ = philox4x32_10(t, step0 + k, h, 0, k0, k1)
+            y0, y1, _, _ = philox4x32_10(t, step0 + k, h, 1, k0, k1)
+            r = ((x2 * np.uint64(Nc)) >> np.uint64(32)).astype(np.int64)
+            v = (a - 1.0) * u53(x0, x1) + 1.0
+            z = (v * v) / a
+            ti = t.astype(np.int64)
+            out['active'][k, h, :Ns] = (Ainv * ((2 * ti + h - B) % W)) % W
+            out['partner'][k, h, :Ns] = (Ainv * ((2 * r + (1 - h) - B) % W)) % W
+            out['zz'][k, h, :Ns] = z
+            out['factor'][k, h, :Ns] = (ndim - 1.0) * np.log(z)
+            with np.errstate(divide='ignore'):
+                out['logu'][k, h, :Ns] = np.log(u53(y0, y1))
+    return out
+
+
 class NumpyStretchBackend:
     def __init__(self, logprob_fn):
         self.logprob_fn = logprob_fn
@@ -51,6 +101,18 @@ class NumpyStretchBackend:
 
     def half(self, st, k, h, n_slots):
         self._commit(st, k, *self._slot(st, k, h, n_slots, 0, n_slots))
+
+    def run(self, st, n_steps):
+        W = st['coords'].shape[0]
+        for k in range(n_steps):
+            self.half(st, k, 0, (W + 1) // 2)
+            self.half(st, k, 1, W // 2)
+
+    def draw(self, st, W, a, seed, step0, n_steps):
+        ndim = st['coords'].shape[1]
+        arrs = philox_stream(W, ndim, a, seed, step0, st['perm'].numpy())
+        for name, arr in arrs.items():
+            st[name][:] = torch.from_numpy(arr)
 
     def eval(self, st, k, h, n_slots, lo, hi, block_t):
         idx, rows, lps, acc = self._slot(st, k, h, n_slots, lo, hi)

@@ -135,3 +135,80 @@ def test_out_of_prior_start_and_nan_detection():
         bad[1, 1] = np.nan
         s.run_mcmc(bad, 2)
     ctx.close()
+
+
+def test_philox_draw_kernel_matches_contract():
+    """bisip_stretch_draw_dev against the NumPy statement of the philox contract."""
+    import torch
+    from bisip_amd.sampler import affine_splits
+    from numpy_stretch_backend import philox_stream
+    g = np.load(_case('case16_'))
+    ctx = make_ctx(g, 'PeltonColeCole')
+    for W, n, step0, seed in [(32, 9, 0, 1), (33, 5, 1000, 0xdeadbeefcafe), (4096, 3, 7, 42)]:
+        perm = affine_splits(np.random.RandomState(W), W, n)
+        nh = (W + 1) // 2
+        dperm = torch.from_numpy(perm).cuda()
+        bufs = {k: torch.empty((n, 2, nh), dtype=dt, device='cuda')
+                for k, dt in (('active', torch.int32), ('partner', torch.int32), ('zz', torch.float64),
+                              ('factor', torch.float64), ('logu', torch.float64))}
+        ctx.stretch_draw_dev(W, 2.0, seed, step0, n, dperm.data_ptr(), bufs['active'].data_ptr(),
+                             bufs['partner'].data_ptr(), bufs['zz'].data_ptr(),
+                             bufs['factor'].data_ptr(), bufs['logu'].data_ptr(),
+                             torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        want = philox_stream(W, 7, 2.0, seed, step0, perm)
+        assert np.array_equal(bufs['active'].cpu().numpy(), want['active'])
+        assert np.array_equal(bufs['partner'].cpu().numpy(), want['partner'])
+        assert np.array_equal(bufs['zz'].cpu().numpy(), want['zz'])           # pure arithmetic
+        np.testing.assert_allclose(bufs['factor'].cpu().numpy(), want['factor'], rtol=1e-15, atol=1e-15)
+        np.testing.assert_allclose(bufs['logu'].cpu().numpy(), want['logu'], rtol=1e-15, atol=1e-15)
+        # every step is a balanced partition and partners come from the other half
+        act = want['active']
+        for k in range(n):
+            halves = [set(act[k, 0, :nh]), set(act[k, 1, :W // 2])]
+            assert halves[0] | halves[1] == set(range(W)) and not (halves[0] & halves[1])
+            assert set(want['partner'][k, 0, :nh]) <= halves[1]
+            assert set(want['partner'][k, 1, :W // 2]) <= halves[0]
+        z = want['zz'][:, 0, :]
+        assert z.min() >= 0.5 and z.max() <= 2.0
+    ctx.close()
+
+
+def test_philox_mode_chain_replay_and_posterior():
+    from bisip_amd.sampler import DeviceEnsembleSampler
+    from numpy_stretch_backend import NumpyStretchBackend
+    g = np.load(_case('case16_'))
+    ctx = make_ctx(g, 'PeltonColeCole')
+    W, ndim = 64, 7
+    p0 = _start(g, W, 2)
+    np.random.seed(5)
+    dev = DeviceEnsembleSampler(W, ndim, ctx, rng='philox', seed=2024, chunk=64)
+    dev.run_mcmc(p0, 150)
+    # (a) replay: same contract evaluated in NumPy around the GPU log-probability
+    np.random.seed(5)
+    rep = DeviceEnsembleSampler(W, ndim, backend=NumpyStretchBackend(ctx.logprob), rng='philox',
+                                seed=2024, chunk=50)
+    rep.run_mcmc(p0, 150)
+    assert np.array_equal(dev.get_chain(), rep.get_chain())
+    assert np.array_equal(dev.acceptance_fraction, rep.acceptance_fraction)
+    # (b) chunking and seeds: counter-based stream does not depend on the chunk size
+    np.random.seed(5)
+    dev2 = DeviceEnsembleSampler(W, ndim, ctx, rng='philox', seed=2024, chunk=17)
+    dev2.run_mcmc(p0, 150)
+    assert np.array_equal(dev.get_chain(), dev2.get_chain())
+    np.random.seed(5)
+    dev3 = DeviceEnsembleSampler(W, ndim, ctx, rng='philox', seed=2025)
+    dev3.run_mcmc(p0, 150)
+    assert not np.array_equal(dev.get_chain(), dev3.get_chain())
+    # (c) posterior agreement between the two RNG modes (long runs, same target)
+    np.random.seed(6)
+    a = DeviceEnsembleSampler(W, ndim, ctx, rng='philox', seed=1)
+    a.run_mcmc(p0, 3000)
+    np.random.seed(7)
+    b = DeviceEnsembleSampler(W, ndim, ctx, rng='numpy')
+    b.run_mcmc(p0, 3000)
+    fa, fb = a.get_chain(discard=1000, flat=True), b.get_chain(discard=1000, flat=True)
+    sd = fb.std(axis=0)
+    assert np.all(np.abs(fa.mean(0) - fb.mean(0)) < 0.25 * sd)
+    assert np.all(np.abs(fa.std(0) / sd - 1) < 0.25)
+    ctx.close()

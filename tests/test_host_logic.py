@@ -17,7 +17,7 @@ PD_CASES = [p for p in golden_cases() if 'PolynomialDecomposition' in p]
 def declared_functions():
     text = open(os.path.join(ROOT, 'include', 'bisip_hip.h')).read()
     text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
-    return sorted(set(re.findall(r'\b(bisip_[a-z_]+)\s*\(', text)))
+    return sorted(set(re.findall(r'\b(bisip_[a-z0-9_]+)\s*\(', text)))
 
 
 def test_abi_exports_every_declared_symbol(hip_lib):
@@ -158,3 +158,35 @@ def test_context_argument_validation(hip_lib):
                                       _hip._p(zn), _hip._p(bad), 5, _hip._p(lo), _hip._p(hi),
                                       ctypes.byref(desc))
         assert rc == -1 and b'zn_err' in hip_lib.bisip_last_error()
+
+
+def test_philox_known_answers():
+    """Philox4x32-10 of bisip_amd/csrc/philox.h against the Random123 known-answer
+    vectors, and against the independent NumPy implementation used by the tests."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from bisip_amd import _hip
+    from numpy_stretch_backend import philox4x32_10
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        assert tuple(_hip.philox4x32(ctr, key)) == want
+        assert tuple(int(x) for x in philox4x32_10(*ctr, *key)) == want
+    rng = np.random.RandomState(0)
+    for _ in range(50):
+        ctr = rng.randint(0, 2 ** 32, 4, dtype=np.uint64)
+        key = rng.randint(0, 2 ** 32, 2, dtype=np.uint64)
+        assert tuple(_hip.philox4x32(ctr, key)) == tuple(int(x) for x in philox4x32_10(*ctr, *key))
+
+
+def test_affine_splits_are_bijections():
+    from bisip_amd.sampler import affine_splits
+    for W in (14, 15, 32, 33, 256, 1000):
+        perm = affine_splits(np.random.RandomState(W), W, 20)
+        for A, Ainv, B in perm:
+            assert (int(A) * int(Ainv)) % W == 1 and 0 <= B < W
+            pi = (int(A) * np.arange(W) + int(B)) % W
+            assert sorted(pi) == list(range(W))
+            assert abs(int((pi % 2 == 0).sum()) - (W + 1) // 2) == 0
