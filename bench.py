@@ -121,15 +121,15 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     dist = None
-    if world > 1:
+    torch.cuda.set_device(local_rank)
+    if 'RANK' in os.environ:   # launched by torch.distributed.run: one rank per GPU over RCCL
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
-    if args.gpus != world and rank == 0 and world > 1:
+        dist.init_process_group('nccl', rank=rank, world_size=world,
+                                device_id=torch.device('cuda', local_rank))
+    if args.gpus != world and rank == 0:
         print(f'warning: --gpus {args.gpus} but WORLD_SIZE {world}', file=sys.stderr)
 
     from bisip_amd import _hip

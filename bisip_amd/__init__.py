@@ -20,6 +20,7 @@ from .models import Shin2015
 from .data import DataFiles
 from .sampler import DeviceEnsembleSampler, EnsembleSampler
 from .utils import load_data, load_data_batch
+from .batch import SpectraBatch
 
 __all__ = (
     'Inversion',
@@ -33,4 +34,5 @@ __all__ = (
     'DeviceEnsembleSampler',
     'load_data',
     'load_data_batch',
+    'SpectraBatch',
 )

@@ -36,7 +36,8 @@ class StretchArgs(ctypes.Structure):
                 ('n_slots', ctypes.c_int64), ('slot_lo', ctypes.c_int64), ('slot_hi', ctypes.c_int64),
                 ('block', ctypes.c_void_p), ('chain_row', ctypes.c_void_p),
                 ('logp_row', ctypes.c_void_p), ('naccept', ctypes.c_void_p),
-                ('status', ctypes.c_void_p), ('pad', ctypes.c_int64), ('world', ctypes.c_int32)]
+                ('status', ctypes.c_void_p), ('pad', ctypes.c_int64), ('world', ctypes.c_int32),
+                ('walkers_per_spectrum', ctypes.c_int64)]
 
 
 # name -> (restype, argtypes); every symbol include/bisip_hip.h declares
@@ -44,6 +45,10 @@ SYMBOLS = {
     'bisip_ctx_create': (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int,
                                         ctypes.c_int, _dp, _dp, _dp, ctypes.c_int, _dp, _dp,
                                         ctypes.POINTER(ModelDesc)]),
+    'bisip_batch_create': (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_int, ctypes.c_int, _dp, _dp, _dp, ctypes.c_int, _dp, _dp,
+                                          ctypes.POINTER(ModelDesc)]),
+    'bisip_ctx_nspectra': (ctypes.c_int, [ctypes.c_void_p]),
     'bisip_ctx_destroy': (None, [ctypes.c_void_p]),
     'bisip_ctx_set_bounds': (ctypes.c_int, [ctypes.c_void_p, _dp, _dp]),
     'bisip_ctx_set_variant': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
@@ -162,13 +167,17 @@ class HipContext:
         if lib.bisip_device_count() < 1:
             raise RuntimeError('bisip_amd needs a visible AMD GPU (hipGetDeviceCount() == 0); '
                                'there is no CPU fallback')
-        w = _c(w).ravel()
-        zn = _c(zn).reshape(2, -1)
-        zn_err = _c(zn_err).reshape(2, -1)
+        w = _c(w)
+        batch = w.ndim == 2          # (E, N): batch of spectra
+        E = w.shape[0] if batch else 1
+        N = w.shape[-1]
+        w = w.reshape(E, N)
+        zn = _c(zn).reshape(E, 2, -1)
+        zn_err = _c(zn_err).reshape(E, 2, -1)
         b = _c(bounds).reshape(2, -1)
         lo, hi = _c(b[0]), _c(b[1])
-        if zn.shape[1] != w.size or zn_err.shape[1] != w.size:
-            raise ValueError('zn and zn_err must have shape (2, N) with N = len(w)')
+        if zn.shape[2] != N or zn_err.shape[2] != N:
+            raise ValueError('zn and zn_err must have shape (2, N) [or (E, 2, N)] with N = len(w)')
         desc = ModelDesc()
         desc.n_modes = int(n_modes)
         desc.poly_deg = int(poly_deg)
@@ -182,14 +191,20 @@ class HipContext:
             desc.log_taus = _p(log_taus)
             keep = [taus, log_taus]
         handle = ctypes.c_void_p()
-        _check(lib.bisip_ctx_create(ctypes.byref(handle), int(device), int(model_id), w.size,
-                                    _p(w), _p(zn), _p(zn_err), lo.size, _p(lo), _p(hi),
-                                    ctypes.byref(desc)))
+        if batch:
+            _check(lib.bisip_batch_create(ctypes.byref(handle), int(device), int(model_id), E, N,
+                                          _p(w), _p(zn), _p(zn_err), lo.size, _p(lo), _p(hi),
+                                          ctypes.byref(desc)))
+        else:
+            _check(lib.bisip_ctx_create(ctypes.byref(handle), int(device), int(model_id), N,
+                                        _p(w), _p(zn), _p(zn_err), lo.size, _p(lo), _p(hi),
+                                        ctypes.byref(desc)))
         del keep
         self._lib = lib
         self._h = handle
         self.ndim = lo.size
-        self.N = w.size
+        self.N = N
+        self.n_spectra = E
         self.device = int(device)
         if variant != 'auto':
             self.set_variant(variant)

@@ -1,0 +1,151 @@
+"""Batch of independent spectra (BASELINE config 5): E spectra x Wp walkers each.
+
+The reference inverts one data file per ``Inversion`` object (src/bisip/models.py:41-57)
+and a survey of many spectra is a Python loop over objects; here the E spectra share one
+device context (``bisip_batch_create``) so one launch evaluates all E*Wp walkers and one
+launch per half-step advances all E ensembles.  Ensembles are independent: across GPUs
+they shard as whole replicas (spectra [start, stop) per rank, no collective).
+"""
+
+import numpy as np
+
+from . import _hip
+from .dist import shard_range
+from .sampler import DeviceEnsembleSampler
+from .utils import columns_to_data, load_data
+
+_MODELS = {
+    'PolynomialDecomposition': _hip.MODEL_POLYDECOMP,
+    'PeltonColeCole': _hip.MODEL_COLECOLE,
+    'ColeCole': _hip.MODEL_COLECOLE,
+    'Dias2000': _hip.MODEL_DIAS2000,
+    'Shin2015': _hip.MODEL_SHIN2015,
+}
+
+
+def default_params(model, n_modes=1, poly_deg=5):
+    """Parameter names and prior box of a model class (same as the reference's
+    __init__ dictionaries, src/bisip/models.py:211-213, 247-252, 287-291, 325-331)."""
+    if model == 'PolynomialDecomposition':
+        p = {'r0': [0.9, 1.1]}
+        p.update({f'a{x}': [-1, 1] for x in range(poly_deg + 1)})
+    elif model in ('PeltonColeCole', 'ColeCole'):
+        p = {'r0': [0.9, 1.1]}
+        p.update({f'm{i+1}': [0.0, 1.0] for i in range(n_modes)})
+        p.update({f'log_tau{i+1}': [-15, 5] for i in range(n_modes)})
+        p.update({f'c{i+1}': [0.0, 1.0] for i in range(n_modes)})
+    elif model == 'Dias2000':
+        p = {'r0': [0.9, 1.1], 'm': [0, 1], 'log_tau': [-20, 0], 'eta': [0, 150], 'delta': [0, 1]}
+    elif model == 'Shin2015':
+        p = {'R1': [0.0, 1.0], 'R2': [0.0, 1.0], 'log_Q1': [-15, -13], 'log_Q2': [-7, -5],
+             'n1': [0, 1], 'n2': [0, 1]}
+    else:
+        raise ValueError(f'unknown model {model!r}')
+    return p
+
+
+class SpectraBatch:
+    """E spectra inverted together with the same model class.
+
+    Args:
+        model (str): 'PolynomialDecomposition', 'PeltonColeCole', 'Dias2000' or 'Shin2015'.
+        spectra: list of file paths or of raw (N,5) tables [freq, amp, pha, amp_err, pha_err];
+            all must have the same number of frequencies.
+        nwalkers (int): walkers per spectrum (even). nsteps (int): MCMC steps.
+        n_modes / poly_deg / c_exp: model options as in the reference classes.
+        rank, world: keep only this rank's block of spectra (whole-replica sharding).
+    """
+
+    def __init__(self, model, spectra, nwalkers=256, nsteps=1000, headers=1, ph_units='mrad',
+                 n_modes=1, poly_deg=5, c_exp=1.0, device=0, rank=0, world=1):
+        if model not in _MODELS:
+            raise ValueError(f'unknown model {model!r}')
+        self.model = 'PeltonColeCole' if model == 'ColeCole' else model
+        lo, hi = shard_range(len(spectra), world, rank)
+        self.spectrum_range = (lo, hi)
+        items = []
+        for sp in spectra[lo:hi]:
+            items.append(load_data(sp, headers, ph_units) if isinstance(sp, str)
+                         else columns_to_data(sp, ph_units))
+        if not items:
+            raise ValueError('no spectra for this rank')
+        if len({d['N'] for d in items}) != 1:
+            raise ValueError('all spectra of a batch must have the same number of frequencies')
+        self.n_spectra = len(items)
+        self.N = items[0]['N']
+        self.w = np.stack([d['w'] for d in items])
+        self.zn = np.stack([d['zn'] for d in items])
+        self.zn_err = np.stack([d['zn_err'] for d in items])
+        self.norm_factor = np.array([d['norm_factor'] for d in items])
+        self.nwalkers, self.nsteps = int(nwalkers), int(nsteps)
+        self.n_modes, self.poly_deg, self.c_exp = n_modes, poly_deg, c_exp
+        self.params = default_params(self.model, n_modes, poly_deg)
+        kw = {}
+        if self.model == 'PolynomialDecomposition':
+            # one tau grid for the whole batch, from the union of the frequency ranges
+            # (identical to the reference's per-file grid when the spectra share w)
+            period = np.log10(1. / self.w)
+            self.log_tau = np.linspace(np.floor(period.min() - 1), np.floor(period.max() + 1), 2 * self.N)
+            self.log_taus = np.array([self.log_tau ** i for i in range(poly_deg + 1)])
+            self.taus = 10 ** self.log_tau
+            kw = dict(poly_deg=poly_deg, c_exp=float(c_exp), taus=self.taus, log_taus=self.log_taus)
+        elif self.model == 'PeltonColeCole':
+            kw = dict(n_modes=n_modes)
+        self.ctx = _hip.HipContext(_MODELS[self.model], self.w, self.zn, self.zn_err,
+                                   self.param_bounds, device=device, **kw)
+        self._sampler = None
+
+    @property
+    def param_names(self):
+        return list(self.params.keys())
+
+    @property
+    def param_bounds(self):
+        return np.array(list(self.params.values()), dtype=np.float64).T
+
+    @property
+    def ndim(self):
+        return self.param_bounds.shape[1]
+
+    def log_prob(self, theta):
+        """theta (E, n, ndim) -> logp (E, n): n walkers of every spectrum in one launch."""
+        theta = np.ascontiguousarray(theta, dtype=np.float64)
+        if theta.ndim != 3 or theta.shape[0] != self.n_spectra or theta.shape[2] != self.ndim:
+            raise ValueError(f'theta must have shape ({self.n_spectra}, n, {self.ndim})')
+        self.ctx.set_bounds(self.param_bounds)
+        return self.ctx.logprob(theta.reshape(-1, self.ndim)).reshape(theta.shape[:2])
+
+    def forward(self, theta):
+        """theta (E, n, ndim) -> Z (E, n, 2, N)."""
+        theta = np.ascontiguousarray(theta, dtype=np.float64)
+        Z = self.ctx.forward(theta.reshape(-1, self.ndim))
+        return Z.reshape(theta.shape[0], theta.shape[1], 2, self.N)
+
+    def fit(self, p0=None, seed=None):
+        """Run E independent stretch-move ensembles on the device (rng='philox')."""
+        E, Wp, ndim = self.n_spectra, self.nwalkers, self.ndim
+        if p0 is None:
+            p0 = np.random.uniform(*self.param_bounds, (E, Wp, ndim))
+        self.ctx.set_bounds(self.param_bounds)
+        self._sampler = DeviceEnsembleSampler(Wp, ndim, self.ctx, rng='philox', seed=seed,
+                                              n_ensembles=E)
+        self._sampler.run_mcmc(np.asarray(p0).reshape(E * Wp, ndim), self.nsteps)
+        return self
+
+    def get_chain(self, discard=0, thin=1, flat=False):
+        """(nsteps', E, Wp, ndim); flat=True -> (E, nsteps'*Wp, ndim)."""
+        if self._sampler is None:
+            raise AssertionError('Model is not fitted!')
+        ch = self._sampler.get_chain(discard=discard, thin=thin)
+        ch = ch.reshape(ch.shape[0], self.n_spectra, self.nwalkers, self.ndim)
+        if flat:
+            ch = ch.transpose(1, 0, 2, 3).reshape(self.n_spectra, -1, self.ndim)
+        return ch
+
+    def get_log_prob(self, discard=0, thin=1):
+        lp = self._sampler.get_log_prob(discard=discard, thin=thin)
+        return lp.reshape(lp.shape[0], self.n_spectra, self.nwalkers)
+
+    @property
+    def acceptance_fraction(self):
+        return self._sampler.acceptance_fraction.reshape(self.n_spectra, self.nwalkers)

@@ -50,8 +50,12 @@ struct bisip_ctx {
     int P = 0, D = 0, S = 0, SPAD = 0;
     double c_exp = 1.0, lconst = 0.0;
     Bounds bounds{};
-    double *d_cb = nullptr;        // records for k_logprob / k_forward
+    int E = 1;                      // spectra in the context (batch of spectra: E > 1)
+    double *d_cb = nullptr;        // records for k_logprob / k_forward: (E, N, REC)
     double *d_cb_faithful = nullptr;
+    double *d_lconst = nullptr;    // (E,)  batch only
+    void *d_red = nullptr;         // (E,) ReducedArgs<P>  batch only
+    long long cb_stride = 0;
     std::vector<double> Rpacked, bhat, evec;
     double rest = 0.0;
     // workspace of the host-pointer entry points
@@ -154,6 +158,101 @@ int launch_forward(const bisip_ctx *c, const double *theta, int64_t W, double *Z
     return BISIP_OK;
 }
 
+BatchArgs make_batch_args(const bisip_ctx *c, const double *theta, double *out, int64_t W)
+{
+    BatchArgs a;
+    a.theta = theta; a.out = out; a.W = W; a.Wp = W / c->E;
+    a.cb = c->d_cb; a.cb_stride = c->cb_stride; a.lconst = c->d_lconst; a.red = c->d_red;
+    a.N = c->N; a.b = c->bounds;
+    return a;
+}
+
+template <class M>
+int launch_logprob_batch(const bisip_ctx *c, const double *theta, int64_t W, double *out, hipStream_t st)
+{
+    const BatchArgs a = make_batch_args(c, theta, out, W);
+    const unsigned grid = (unsigned)((W + 63) / 64);
+    if (a.Wp % 64 == 0) hipLaunchKernelGGL((k_logprob_batch<M, true>), dim3(grid), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL((k_logprob_batch<M, false>), dim3(grid), dim3(64), 0, st, a);
+    HIP_TRY(hipGetLastError());
+    return BISIP_OK;
+}
+
+template <int P>
+int launch_reduced_batch(const bisip_ctx *c, const double *theta, int64_t W, double *out, hipStream_t st)
+{
+    const BatchArgs a = make_batch_args(c, theta, out, W);
+    const unsigned grid = (unsigned)((W + 63) / 64);
+    if (a.Wp % 64 == 0) hipLaunchKernelGGL((k_logprob_batch_reduced<P, true>), dim3(grid), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL((k_logprob_batch_reduced<P, false>), dim3(grid), dim3(64), 0, st, a);
+    HIP_TRY(hipGetLastError());
+    return BISIP_OK;
+}
+
+template <class M>
+int launch_forward_batch(const bisip_ctx *c, const double *theta, int64_t W, double *Z, hipStream_t st)
+{
+    const BatchArgs a = make_batch_args(c, theta, Z, W);
+    const long long total = (long long)W * c->N;
+    hipLaunchKernelGGL((k_forward_batch<M>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
+    HIP_TRY(hipGetLastError());
+    return BISIP_OK;
+}
+
+int dispatch_logprob_batch(const bisip_ctx *c, const double *theta, int64_t W, double *out, hipStream_t st)
+{
+    switch (c->model_id) {
+    case BISIP_MODEL_POLYDECOMP:
+        if (effective_variant(c) == BISIP_VARIANT_REDUCED) {
+            switch (c->P) {
+#define X(p) case p: return launch_reduced_batch<p>(c, theta, W, out, st);
+                X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10)
+#undef X
+            }
+        } else {
+            switch (c->P) {
+#define X(p) case p: return launch_logprob_batch<PDCollapsed<p>>(c, theta, W, out, st);
+                X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10)
+#undef X
+            }
+        }
+        break;
+    case BISIP_MODEL_COLECOLE:
+        switch (c->D) {
+#define X(d) case d: return launch_logprob_batch<ColeCole<d>>(c, theta, W, out, st);
+            X(1) X(2) X(3) X(4) X(5)
+#undef X
+        }
+        break;
+    case BISIP_MODEL_DIAS2000: return launch_logprob_batch<Dias>(c, theta, W, out, st);
+    case BISIP_MODEL_SHIN2015: return launch_logprob_batch<Shin>(c, theta, W, out, st);
+    }
+    return fail(BISIP_EUNSUPPORTED, "no batch kernel for this model shape");
+}
+
+int dispatch_forward_batch(const bisip_ctx *c, const double *theta, int64_t W, double *Z, hipStream_t st)
+{
+    switch (c->model_id) {
+    case BISIP_MODEL_POLYDECOMP:
+        switch (c->P) {
+#define X(p) case p: return launch_forward_batch<PDCollapsed<p>>(c, theta, W, Z, st);
+            X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10)
+#undef X
+        }
+        break;
+    case BISIP_MODEL_COLECOLE:
+        switch (c->D) {
+#define X(d) case d: return launch_forward_batch<ColeCole<d>>(c, theta, W, Z, st);
+            X(1) X(2) X(3) X(4) X(5)
+#undef X
+        }
+        break;
+    case BISIP_MODEL_DIAS2000: return launch_forward_batch<Dias>(c, theta, W, Z, st);
+    case BISIP_MODEL_SHIN2015: return launch_forward_batch<Shin>(c, theta, W, Z, st);
+    }
+    return fail(BISIP_EUNSUPPORTED, "no batch forward kernel for this model shape");
+}
+
 #define PD_CASES(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10)
 #define CC_CASES(X) X(1) X(2) X(3) X(4) X(5)
 
@@ -162,6 +261,10 @@ int dispatch_logprob(const bisip_ctx *c, const double *theta, int64_t W, double 
     if (W == 0) return BISIP_OK;
     if ((W + BLK_SMALL - 1) / BLK_SMALL > 0x7fffffffLL)
         return fail(BISIP_EINVAL, "W=%lld exceeds the launch grid limit", (long long)W);
+    if (c->E > 1) {
+        if (W % c->E) return fail(BISIP_EINVAL, "W=%lld is not a multiple of n_spectra=%d", (long long)W, c->E);
+        return dispatch_logprob_batch(c, theta, W, out, st);
+    }
     switch (c->model_id) {
     case BISIP_MODEL_POLYDECOMP: {
         const int v = effective_variant(c);
@@ -204,6 +307,10 @@ int dispatch_forward(const bisip_ctx *c, const double *theta, int64_t W, double 
     if (W == 0) return BISIP_OK;
     if (((long long)W * c->N + 255) / 256 > 0x7fffffffLL)
         return fail(BISIP_EINVAL, "W=%lld exceeds the launch grid limit", (long long)W);
+    if (c->E > 1) {
+        if (W % c->E) return fail(BISIP_EINVAL, "W=%lld is not a multiple of n_spectra=%d", (long long)W, c->E);
+        return dispatch_forward_batch(c, theta, W, Z, st);
+    }
     switch (c->model_id) {
     case BISIP_MODEL_POLYDECOMP:
         switch (c->P) {
@@ -279,8 +386,68 @@ int stretch_reduced(const bisip_ctx *c, const StretchArgs &a, StretchKind kind, 
     return launch_stretch(a, lp, kind, st);
 }
 
-int dispatch_stretch(const bisip_ctx *c, const StretchArgs &a, StretchKind kind, hipStream_t st)
+template <class M, bool U>
+int stretch_generic_batch(const bisip_ctx *c, const StretchArgs &a, long long Wp, StretchKind kind, hipStream_t st)
 {
+    BatchGenericLP<M, U> lp;
+    lp.cb = c->d_cb; lp.cb_stride = c->cb_stride; lp.Wp = Wp; lp.lconst = c->d_lconst; lp.N = c->N;
+    lp.b = c->bounds;
+    return launch_stretch(a, lp, kind, st);
+}
+
+template <int P, bool U>
+int stretch_reduced_batch(const bisip_ctx *c, const StretchArgs &a, long long Wp, StretchKind kind, hipStream_t st)
+{
+    BatchReducedLP<P, U> lp;
+    lp.red = reinterpret_cast<const ReducedArgs<P> *>(c->d_red); lp.Wp = Wp; lp.lconst = c->d_lconst;
+    lp.b = c->bounds;
+    return launch_stretch(a, lp, kind, st);
+}
+
+// batch of spectra: Wp walkers per spectrum; a wave of 64 slots stays inside one spectrum
+// iff (Wp/2) % 64 == 0
+int dispatch_stretch_batch(const bisip_ctx *c, const StretchArgs &a, long long Wp, StretchKind kind, hipStream_t st)
+{
+    const bool u = (Wp % 128) == 0;
+#define GEN(M) return u ? stretch_generic_batch<M, true>(c, a, Wp, kind, st) : stretch_generic_batch<M, false>(c, a, Wp, kind, st);
+#define RED(p) return u ? stretch_reduced_batch<p, true>(c, a, Wp, kind, st) : stretch_reduced_batch<p, false>(c, a, Wp, kind, st);
+    switch (c->model_id) {
+    case BISIP_MODEL_POLYDECOMP:
+        if (effective_variant(c) == BISIP_VARIANT_REDUCED) {
+            switch (c->P) {
+#define X(p) case p: RED(p)
+                X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10)
+#undef X
+            }
+        } else {
+            switch (c->P) {
+#define X(p) case p: GEN(PDCollapsed<p>)
+                X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10)
+#undef X
+            }
+        }
+        break;
+    case BISIP_MODEL_COLECOLE:
+        switch (c->D) {
+#define X(d) case d: GEN(ColeCole<d>)
+            X(1) X(2) X(3) X(4) X(5)
+#undef X
+        }
+        break;
+    case BISIP_MODEL_DIAS2000: GEN(Dias)
+    case BISIP_MODEL_SHIN2015: GEN(Shin)
+    }
+#undef GEN
+#undef RED
+    return fail(BISIP_EUNSUPPORTED, "no batch stretch kernel for this model shape");
+}
+
+int dispatch_stretch(const bisip_ctx *c, const StretchArgs &a, long long Wp, StretchKind kind, hipStream_t st)
+{
+    if (c->E > 1) {
+        if (Wp < 2 || (Wp & 1)) return fail(BISIP_EINVAL, "batch context: walkers_per_spectrum must be even and >= 2, got %lld", Wp);
+        return dispatch_stretch_batch(c, a, Wp, kind, st);
+    }
     switch (c->model_id) {
     case BISIP_MODEL_POLYDECOMP:
         if (effective_variant(c) == BISIP_VARIANT_REDUCED) {
@@ -396,19 +563,20 @@ int bisip_polydecomp_operands(int N, const double *w, const double *zn, const do
     return BISIP_OK;
 }
 
-int bisip_ctx_create(bisip_ctx **out, int device, int model_id, int N, const double *w,
-                     const double *zn, const double *zn_err, int ndim, const double *lo,
-                     const double *hi, const bisip_model_desc *desc)
+static int build_context(bisip_ctx **out, int device, int model_id, int E, int N, const double *w,
+                         const double *zn, const double *zn_err, int ndim, const double *lo,
+                         const double *hi, const bisip_model_desc *desc)
 {
     if (!out || !w || !zn || !zn_err || !lo || !hi) return fail(BISIP_EINVAL, "null argument");
     *out = nullptr;
+    if (E < 1 || E > (1 << 24)) return fail(BISIP_EINVAL, "n_spectra=%d out of range", E);
     if (N < 1 || N > 4096) return fail(BISIP_EINVAL, "N=%d out of range [1,4096]", N);
     if (ndim < 1 || ndim > BISIP_MAX_NDIM) return fail(BISIP_EINVAL, "ndim=%d out of range", ndim);
-    for (int i = 0; i < 2 * N; ++i)
+    for (long long i = 0; i < 2LL * N * E; ++i)
         if (!(zn_err[i] > 0.0) || !std::isfinite(zn_err[i]) || !std::isfinite(zn[i]))
-            return fail(BISIP_EINVAL, "zn/zn_err[%d] must be finite and zn_err > 0", i);
-    for (int j = 0; j < N; ++j)
-        if (!(w[j] > 0.0) || !std::isfinite(w[j])) return fail(BISIP_EINVAL, "w[%d] must be finite and > 0", j);
+            return fail(BISIP_EINVAL, "zn/zn_err[%lld] must be finite and zn_err > 0", i);
+    for (long long j = 0; j < (long long)N * E; ++j)
+        if (!(w[j] > 0.0) || !std::isfinite(w[j])) return fail(BISIP_EINVAL, "w[%lld] must be finite and > 0", j);
 
     int P = 0, D = 0, S = 0;
     switch (model_id) {
@@ -441,60 +609,77 @@ int bisip_ctx_create(bisip_ctx **out, int device, int model_id, int N, const dou
 
     bisip_ctx *c = new (std::nothrow) bisip_ctx;
     if (!c) return fail(BISIP_ENOMEM, "out of host memory");
-    c->device = device; c->model_id = model_id; c->N = N; c->ndim = ndim;
+    c->device = device; c->model_id = model_id; c->N = N; c->ndim = ndim; c->E = E;
     c->P = P; c->D = D; c->S = S;
-    c->lconst = loglike_const(2 * N, zn_err);
     for (int q = 0; q < MAXD; ++q) { c->bounds.lo[q] = 0.0; c->bounds.hi[q] = 0.0; }
     for (int q = 0; q < ndim; ++q) { c->bounds.lo[q] = lo[q]; c->bounds.hi[q] = hi[q]; }
 
-    std::vector<double> lnw, iv;
-    common_operands(N, w, zn_err, lnw, iv);
+    const int rec = model_id == BISIP_MODEL_POLYDECOMP ? 4 + 2 * (P + 1) : 8;
+    c->cb_stride = (long long)N * rec;
+    std::vector<double> cb((size_t)E * N * rec, 0.0), lconsts(E);
+    const int n = P + 2;
+    const size_t red_doubles = (size_t)n * (n + 1) / 2 + 2 * (size_t)n + 1;  // == sizeof(ReducedArgs<P>)/8
+    std::vector<double> red;
     int rc = BISIP_OK;
-    if (model_id == BISIP_MODEL_POLYDECOMP) {
-        c->c_exp = desc->c_exp;
-        PolyDecompOperands o;
-        polydecomp_operands(N, w, S, desc->taus, P + 1, desc->log_taus, desc->c_exp, zn, zn_err, o);
-        const int rec = 4 + 2 * (P + 1);
-        std::vector<double> cb((size_t)N * rec);
+    for (int e = 0; e < E; ++e) {
+        const double *we = w + (size_t)e * N, *zne = zn + (size_t)e * 2 * N, *erre = zn_err + (size_t)e * 2 * N;
+        lconsts[e] = loglike_const(2 * N, erre);
+        std::vector<double> lnw, iv;
+        common_operands(N, we, erre, lnw, iv);
+        double *base = &cb[(size_t)e * N * rec];
         for (int j = 0; j < N; ++j) {
-            double *r = &cb[(size_t)j * rec];
-            r[0] = zn[j]; r[1] = zn[N + j]; r[2] = iv[j]; r[3] = iv[N + j];
-            for (int p = 0; p <= P; ++p) {
-                r[4 + p] = o.G_re[(size_t)j * (P + 1) + p];
-                r[4 + P + 1 + p] = o.G_im[(size_t)j * (P + 1) + p];
-            }
+            double *r = base + (size_t)j * rec;
+            r[0] = zne[j]; r[1] = zne[N + j]; r[2] = iv[j]; r[3] = iv[N + j];
+            if (model_id != BISIP_MODEL_POLYDECOMP) { r[4] = we[j]; r[5] = lnw[j]; }
         }
-        rc = upload(&c->d_cb, cb);
-        const int n = P + 2;
-        c->Rpacked.clear();
-        for (int i = 0; i < n; ++i)
-            for (int j = i; j < n; ++j) c->Rpacked.push_back(o.R[(size_t)i * n + j]);
-        c->bhat = o.bhat; c->evec = o.e; c->rest = o.rest;
-        if (rc == BISIP_OK && P >= 3 && P <= 5 && S <= 128) {
-            const int SPAD = S <= 64 ? 64 : 128;
-            c->SPAD = SPAD;
-            std::vector<double> fb((size_t)(P + 1) * SPAD + (size_t)N * (4 + 2 * SPAD), 0.0);
-            for (int p = 0; p <= P; ++p)
-                for (int k = 0; k < S; ++k) fb[(size_t)p * SPAD + k] = desc->log_taus[(size_t)p * S + k];
-            double *base = &fb[(size_t)(P + 1) * SPAD];
+        if (model_id == BISIP_MODEL_POLYDECOMP) {
+            c->c_exp = desc->c_exp;
+            PolyDecompOperands o;
+            polydecomp_operands(N, we, S, desc->taus, P + 1, desc->log_taus, desc->c_exp, zne, erre, o);
             for (int j = 0; j < N; ++j) {
-                double *r = base + (size_t)j * (4 + 2 * SPAD);
-                r[0] = zn[j]; r[1] = zn[N + j]; r[2] = iv[j]; r[3] = iv[N + j];
-                for (int k = 0; k < S; ++k) {
-                    r[4 + k] = o.K_re[(size_t)j * S + k];
-                    r[4 + SPAD + k] = o.K_im[(size_t)j * S + k];
+                double *r = base + (size_t)j * rec;
+                for (int p = 0; p <= P; ++p) {
+                    r[4 + p] = o.G_re[(size_t)j * (P + 1) + p];
+                    r[4 + P + 1 + p] = o.G_im[(size_t)j * (P + 1) + p];
                 }
             }
-            rc = upload(&c->d_cb_faithful, fb);
+            std::vector<double> Rp;
+            for (int i = 0; i < n; ++i)
+                for (int j = i; j < n; ++j) Rp.push_back(o.R[(size_t)i * n + j]);
+            if (e == 0) { c->Rpacked = Rp; c->bhat = o.bhat; c->evec = o.e; c->rest = o.rest; }
+            if (E > 1) {  // ReducedArgs<P> image: R | bhat | e | rest
+                red.insert(red.end(), Rp.begin(), Rp.end());
+                red.insert(red.end(), o.bhat.begin(), o.bhat.end());
+                red.insert(red.end(), o.e.begin(), o.e.end());
+                red.push_back(o.rest);
+            }
+            if (E == 1 && P >= 3 && P <= 5 && S <= 128) {
+                const int SPAD = S <= 64 ? 64 : 128;
+                c->SPAD = SPAD;
+                std::vector<double> fb((size_t)(P + 1) * SPAD + (size_t)N * (4 + 2 * SPAD), 0.0);
+                for (int p = 0; p <= P; ++p)
+                    for (int k = 0; k < S; ++k) fb[(size_t)p * SPAD + k] = desc->log_taus[(size_t)p * S + k];
+                double *fbase = &fb[(size_t)(P + 1) * SPAD];
+                for (int j = 0; j < N; ++j) {
+                    double *r = fbase + (size_t)j * (4 + 2 * SPAD);
+                    r[0] = zne[j]; r[1] = zne[N + j]; r[2] = iv[j]; r[3] = iv[N + j];
+                    for (int k = 0; k < S; ++k) {
+                        r[4 + k] = o.K_re[(size_t)j * S + k];
+                        r[4 + SPAD + k] = o.K_im[(size_t)j * S + k];
+                    }
+                }
+                rc = upload(&c->d_cb_faithful, fb);
+            }
         }
-    } else {
-        std::vector<double> cb((size_t)N * 8, 0.0);
-        for (int j = 0; j < N; ++j) {
-            double *r = &cb[(size_t)j * 8];
-            r[0] = zn[j]; r[1] = zn[N + j]; r[2] = iv[j]; r[3] = iv[N + j];
-            r[4] = w[j]; r[5] = lnw[j];
+    }
+    c->lconst = lconsts[0];
+    if (rc == BISIP_OK) rc = upload(&c->d_cb, cb);
+    if (rc == BISIP_OK && E > 1) {
+        rc = upload(&c->d_lconst, lconsts);
+        if (rc == BISIP_OK && !red.empty()) {
+            if (red.size() != red_doubles * (size_t)E) rc = fail(BISIP_EHIP, "internal: reduced operand size mismatch");
+            else rc = upload((double **)&c->d_red, red);
         }
-        rc = upload(&c->d_cb, cb);
     }
     if (rc == BISIP_OK) {
         hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -506,12 +691,30 @@ int bisip_ctx_create(bisip_ctx **out, int device, int model_id, int N, const dou
     return BISIP_OK;
 }
 
+int bisip_ctx_create(bisip_ctx **out, int device, int model_id, int N, const double *w,
+                     const double *zn, const double *zn_err, int ndim, const double *lo,
+                     const double *hi, const bisip_model_desc *desc)
+{
+    return build_context(out, device, model_id, 1, N, w, zn, zn_err, ndim, lo, hi, desc);
+}
+
+int bisip_batch_create(bisip_ctx **out, int device, int model_id, int n_spectra, int N,
+                       const double *w, const double *zn, const double *zn_err, int ndim,
+                       const double *lo, const double *hi, const bisip_model_desc *desc)
+{
+    return build_context(out, device, model_id, n_spectra, N, w, zn, zn_err, ndim, lo, hi, desc);
+}
+
+int bisip_ctx_nspectra(const bisip_ctx *c) { return c ? c->E : BISIP_EINVAL; }
+
 void bisip_ctx_destroy(bisip_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->d_cb) (void)hipFree(c->d_cb);
     if (c->d_cb_faithful) (void)hipFree(c->d_cb_faithful);
+    if (c->d_lconst) (void)hipFree(c->d_lconst);
+    if (c->d_red) (void)hipFree(c->d_red);
     if (c->d_ws) (void)hipFree(c->d_ws);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -532,6 +735,8 @@ int bisip_ctx_set_variant(bisip_ctx *c, int variant)
     if (c->model_id != BISIP_MODEL_POLYDECOMP && variant != BISIP_VARIANT_AUTO &&
         variant != BISIP_VARIANT_COLLAPSED)
         return fail(BISIP_EUNSUPPORTED, "this model has a single formulation");
+    if (variant == BISIP_VARIANT_FAITHFUL && c->E > 1)
+        return fail(BISIP_EUNSUPPORTED, "the faithful formulation has no batch-of-spectra kernel");
     if (variant == BISIP_VARIANT_FAITHFUL && !c->d_cb_faithful)
         return fail(BISIP_EUNSUPPORTED, "faithful variant needs poly_deg in 3..5 and n_taus <= 128");
     c->variant = variant;
@@ -571,7 +776,7 @@ int bisip_stretch_half_dev(bisip_ctx *c, const bisip_stretch_args *u, void *stre
     if (rc != BISIP_OK || u->n_slots == 0) return rc;
     if (!u->partner || !u->zz || !u->factor || !u->logu) return fail(BISIP_EINVAL, "null RNG stream");
     HIP_TRY(hipSetDevice(c->device));
-    return dispatch_stretch(c, to_device_args(u), STRETCH_HALF, (hipStream_t)stream);
+    return dispatch_stretch(c, to_device_args(u), u->walkers_per_spectrum, STRETCH_HALF, (hipStream_t)stream);
 }
 
 int bisip_stretch_eval_dev(bisip_ctx *c, const bisip_stretch_args *u, void *stream)
@@ -584,7 +789,7 @@ int bisip_stretch_eval_dev(bisip_ctx *c, const bisip_stretch_args *u, void *stre
                     (long long)u->slot_hi, (long long)u->n_slots);
     if (u->slot_lo == u->slot_hi) return BISIP_OK;
     HIP_TRY(hipSetDevice(c->device));
-    return dispatch_stretch(c, to_device_args(u), STRETCH_EVAL, (hipStream_t)stream);
+    return dispatch_stretch(c, to_device_args(u), u->walkers_per_spectrum, STRETCH_EVAL, (hipStream_t)stream);
 }
 
 int bisip_stretch_apply_dev(bisip_ctx *c, const bisip_stretch_args *u, void *stream)
@@ -617,7 +822,7 @@ int bisip_stretch_run_dev(bisip_ctx *c, const bisip_stretch_args *first, int64_t
             u.n_slots = h ? W / 2 : nh;
             u.chain_row = first->chain_row ? first->chain_row + k * W * c->ndim : nullptr;
             u.logp_row = first->logp_row ? first->logp_row + k * W : nullptr;
-            int rc = dispatch_stretch(c, to_device_args(&u), STRETCH_HALF, (hipStream_t)stream);
+            int rc = dispatch_stretch(c, to_device_args(&u), u.walkers_per_spectrum, STRETCH_HALF, (hipStream_t)stream);
             if (rc != BISIP_OK) return rc;
         }
     }
@@ -636,12 +841,13 @@ int bisip_stretch_draw_dev(bisip_ctx *c, int64_t W, double a, uint64_t seed, int
     if (n_steps == 0) return BISIP_OK;
     HIP_TRY(hipSetDevice(c->device));
     DrawArgs d;
-    d.W = W; d.nh = (W + 1) / 2; d.n_steps = n_steps; d.step0 = step0;
+    d.W = W; d.nh = (W + 1) / 2; d.n_steps = n_steps; d.step0 = step0; d.E = c->E;
+    if (c->E > 1 && (W & 1)) return fail(BISIP_EINVAL, "batch context: walkers per spectrum must be even");
     d.a = a; d.ndim_m1 = (double)(c->ndim - 1);
     d.seed_lo = (unsigned int)(seed & 0xffffffffu); d.seed_hi = (unsigned int)(seed >> 32);
     d.perm = d_perm; d.active = d_active; d.partner = d_partner;
     d.zz = d_zz; d.factor = d_factor; d.logu = d_logu;
-    const long long total = n_steps * 2 * d.nh;
+    const long long total = n_steps * 2 * d.E * d.nh;
     hipLaunchKernelGGL(k_stretch_draw, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, d);
     HIP_TRY(hipGetLastError());

@@ -401,6 +401,80 @@ __global__ __launch_bounds__(BLK) void k_logprob_pd_faithful(const LaunchArgs a)
 }
 
 // ---------------------------------------------------------------------------------
+// Batch of independent spectra (BASELINE config 5): E spectra share the model shape and
+// the prior box; rows [e*Wp, (e+1)*Wp) of theta belong to spectrum e, whose operands sit
+// at cb + e*cb_stride.  When a wave never straddles two spectra (UNIFORM: Wp % 64 == 0)
+// the spectrum index is made scalar with readfirstlane, so operands still arrive through
+// the scalar cache; otherwise they are ordinary per-lane loads.
+// ---------------------------------------------------------------------------------
+struct BatchArgs {
+    const double *__restrict__ theta;
+    double *__restrict__ out;
+    long long W;              // total rows = E * Wp
+    long long Wp;             // rows per spectrum
+    const double *__restrict__ cb;
+    long long cb_stride;      // doubles between two spectra's records
+    const double *__restrict__ lconst;  // (E,)
+    const void *__restrict__ red;       // (E,) ReducedArgs<P> (reduced variant only)
+    int N;
+    Bounds b;
+};
+
+template <bool UNIFORM>
+__device__ __forceinline__ long long spectrum_of(long long row, long long Wp)
+{
+    const int e = (int)(row / Wp);
+    return UNIFORM ? (long long)__builtin_amdgcn_readfirstlane(e) : (long long)e;
+}
+
+template <class M, bool UNIFORM>
+__global__ __launch_bounds__(64) void k_logprob_batch(const BatchArgs a)
+{
+    constexpr int NDIM = M::NDIM;
+    const long long row = (long long)blockIdx.x * 64 + threadIdx.x;
+    if (row >= a.W) return;
+    double th[NDIM];
+#pragma unroll
+    for (int q = 0; q < NDIM; ++q) th[q] = a.theta[row * NDIM + q];
+    const long long e = spectrum_of<UNIFORM>(row, a.Wp);
+    const ModelOperands o{a.cb + e * a.cb_stride, a.N, a.lconst[e]};
+    a.out[row] = logprob_row<M>(th, o, a.b);
+}
+
+template <int P, bool UNIFORM>
+__global__ __launch_bounds__(64) void k_logprob_batch_reduced(const BatchArgs a)
+{
+    constexpr int NDIM = P + 2;
+    const long long row = (long long)blockIdx.x * 64 + threadIdx.x;
+    if (row >= a.W) return;
+    double th[NDIM];
+#pragma unroll
+    for (int q = 0; q < NDIM; ++q) th[q] = a.theta[row * NDIM + q];
+    const long long e = spectrum_of<UNIFORM>(row, a.Wp);
+    const ReducedArgs<P> *__restrict__ r = reinterpret_cast<const ReducedArgs<P> *>(a.red) + e;
+    a.out[row] = logprob_row_reduced<P>(th, *r, a.lconst[e], a.b);
+}
+
+template <class M>
+__global__ __launch_bounds__(256) void k_forward_batch(const BatchArgs a)
+{
+    constexpr int NDIM = M::NDIM;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = a.W * (long long)a.N;
+    if (idx >= total) return;
+    const long long wk = idx / a.N;
+    const int j = (int)(idx - wk * a.N);
+    double th[NDIM];
+#pragma unroll
+    for (int q = 0; q < NDIM; ++q) th[q] = a.theta[wk * NDIM + q];
+    const typename M::Setup s = M::setup(th);
+    double zr, zi;
+    M::eval(s, a.cb + (wk / a.Wp) * a.cb_stride + (long long)j * M::REC + 4, zr, zi);
+    a.out[wk * 2 * a.N + j] = zr;
+    a.out[wk * 2 * a.N + a.N + j] = zi;
+}
+
+// ---------------------------------------------------------------------------------
 // Batched forward(): one thread per (walker, frequency); Z is (W,2,N).
 // Per-walker setup is recomputed per thread; this kernel is bound by writing Z.
 // ---------------------------------------------------------------------------------

@@ -45,7 +45,7 @@ struct GenericLP {
     static constexpr int NDIM = M::NDIM;
     ModelOperands o;
     Bounds b;
-    __device__ __forceinline__ double operator()(const double (&th)[NDIM]) const
+    __device__ __forceinline__ double operator()(const double (&th)[NDIM], int) const
     {
         return logprob_row<M>(th, o, b);
     }
@@ -57,9 +57,40 @@ struct ReducedLP {
     ReducedArgs<P> r;
     double lconst;
     Bounds b;
-    __device__ __forceinline__ double operator()(const double (&th)[NDIM]) const
+    __device__ __forceinline__ double operator()(const double (&th)[NDIM], int) const
     {
         return logprob_row_reduced<P>(th, r, lconst, b);
+    }
+};
+
+// batch of spectra: operands of the spectrum that owns walker i (i / Wp)
+template <class M, bool UNIFORM>
+struct BatchGenericLP {
+    static constexpr int NDIM = M::NDIM;
+    const double *cb;
+    long long cb_stride, Wp;
+    const double *lconst;
+    int N;
+    Bounds b;
+    __device__ __forceinline__ double operator()(const double (&th)[NDIM], int walker) const
+    {
+        const long long e = spectrum_of<UNIFORM>(walker, Wp);
+        const ModelOperands o{cb + e * cb_stride, N, lconst[e]};
+        return logprob_row<M>(th, o, b);
+    }
+};
+
+template <int P, bool UNIFORM>
+struct BatchReducedLP {
+    static constexpr int NDIM = P + 2;
+    const ReducedArgs<P> *red;
+    long long Wp;
+    const double *lconst;
+    Bounds b;
+    __device__ __forceinline__ double operator()(const double (&th)[NDIM], int walker) const
+    {
+        const long long e = spectrum_of<UNIFORM>(walker, Wp);
+        return logprob_row_reduced<P>(th, red[e], lconst[e], b);
     }
 };
 
@@ -80,7 +111,7 @@ __device__ __forceinline__ bool stretch_slot(const StretchArgs &a, const LP &lp,
         q[k] = c - d * z;
     }
     const double old_lp = a.logp[i];
-    const double new_lp = lp(q);
+    const double new_lp = lp(q, i);
     if (new_lp != new_lp) atomicOr(a.status, 1);
     const bool acc = (a.factor[t] + new_lp) - old_lp > a.logu[t];
 #pragma unroll
@@ -165,9 +196,13 @@ __global__ __launch_bounds__(64) void k_stretch_apply(const StretchArgs a)
 //             walker Ainv*((2t+h-B) mod W) mod W.
 //   z       = ((a-1)*u53(x0,x1) + 1)^2 / a;  partner slot r = (x2*Nc)>>32 in the other half
 // Outputs are the same (n_steps, 2, nh) arrays the host-stream mode uploads.
+// With E ensembles (batch of spectra) the arrays are (n_steps, 2, E, nh), walker indices
+// are global (e*W + i), the counter's third word is h | (e << 1) and all ensembles share
+// the step's split.
 // ---------------------------------------------------------------------------------
 struct DrawArgs {
-    long long W, nh, n_steps, step0;
+    long long W, nh, n_steps, step0;  // W = walkers per ensemble
+    long long E;                      // ensembles (E > 1 requires W even)
     double a, ndim_m1;
     unsigned int seed_lo, seed_hi;
     const int *perm;  // (n_steps, 3): A, Ainv, B
@@ -185,11 +220,12 @@ __device__ __forceinline__ int perm_inverse(long long y, long long W, long long 
 __global__ __launch_bounds__(256) void k_stretch_draw(const DrawArgs d)
 {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long total = d.n_steps * 2 * d.nh;
+    const long long total = d.n_steps * 2 * d.E * d.nh;
     if (idx >= total) return;
-    const long long k = idx / (2 * d.nh);
-    const int h = (int)((idx / d.nh) & 1);
     const long long t = idx % d.nh;
+    const long long e = (idx / d.nh) % d.E;
+    const int h = (int)((idx / (d.nh * d.E)) & 1);
+    const long long k = idx / (2 * d.E * d.nh);
     const long long n0 = (d.W + 1) / 2, n1 = d.W / 2;
     const long long Ns = h ? n1 : n0, Nc = h ? n0 : n1;
     if (t >= Ns) {  // padding slot of the smaller half
@@ -198,14 +234,15 @@ __global__ __launch_bounds__(256) void k_stretch_draw(const DrawArgs d)
     }
     const long long A_inv = d.perm[3 * k + 1], B = d.perm[3 * k + 2];
     const unsigned int step = (unsigned int)(d.step0 + k);
-    const Philox4 r0 = philox4x32_10((unsigned int)t, step, (unsigned int)h, 0u, d.seed_lo, d.seed_hi);
-    const Philox4 r1 = philox4x32_10((unsigned int)t, step, (unsigned int)h, 1u, d.seed_lo, d.seed_hi);
+    const unsigned int c2 = (unsigned int)h | ((unsigned int)e << 1);
+    const Philox4 r0 = philox4x32_10((unsigned int)t, step, c2, 0u, d.seed_lo, d.seed_hi);
+    const Philox4 r1 = philox4x32_10((unsigned int)t, step, c2, 1u, d.seed_lo, d.seed_hi);
     const double uz = u53(r0.v[0], r0.v[1]);
     const long long r = (long long)(((unsigned long long)r0.v[2] * (unsigned long long)Nc) >> 32);
     const double v = (d.a - 1.0) * uz + 1.0;
     const double z = (v * v) / d.a;
-    d.active[idx] = perm_inverse(2 * t + h, d.W, A_inv, B);
-    d.partner[idx] = perm_inverse(2 * r + (1 - h), d.W, A_inv, B);
+    d.active[idx] = (int)(e * d.W) + perm_inverse(2 * t + h, d.W, A_inv, B);
+    d.partner[idx] = (int)(e * d.W) + perm_inverse(2 * r + (1 - h), d.W, A_inv, B);
     d.zz[idx] = z;
     d.factor[idx] = d.ndim_m1 * log(z);
     d.logu[idx] = log(u53(r1.v[0], r1.v[1]));

@@ -285,6 +285,7 @@ class HipStretchBackend:
     def _args(self, st, k, h, n_slots):
         from ._hip import StretchArgs
         a = StretchArgs()
+        a.walkers_per_spectrum = st.get('wp', 0)
         a.coords = st['coords'].data_ptr()
         a.logp = st['logp'].data_ptr()
         off = (k * 2 + h) * st['nh']
@@ -342,13 +343,25 @@ class DeviceEnsembleSampler(_SamplerBase):
     """
 
     def __init__(self, nwalkers, ndim, ctx=None, a=2.0, live_dangerously=False, group=None,
-                 distributed=False, backend=None, chunk=None, rng='numpy', seed=None):
+                 distributed=False, backend=None, chunk=None, rng='numpy', seed=None,
+                 n_ensembles=1):
         if rng not in ('numpy', 'philox'):
             raise ValueError("rng must be 'numpy' or 'philox'")
+        # n_ensembles > 1: independent ensembles of `nwalkers` walkers each (batch of spectra),
+        # stacked as rows [e*nwalkers, (e+1)*nwalkers); the chain is (nsteps, E*nwalkers, ndim)
+        self.n_ensembles = int(n_ensembles)
+        self.walkers_per_ensemble = int(nwalkers)
+        if self.n_ensembles > 1:
+            if rng != 'philox':
+                raise ValueError("n_ensembles > 1 needs rng='philox'")
+            if nwalkers % 2:
+                raise ValueError('n_ensembles > 1 needs an even number of walkers per ensemble')
+            if distributed:
+                raise ValueError('independent ensembles shard as whole replicas; run one sampler per rank')
         self.backend = backend if backend is not None else HipStretchBackend(ctx)
         self.chunk = chunk
         self.rng = rng
-        super().__init__(nwalkers, ndim, a, live_dangerously, group, distributed)
+        super().__init__(int(nwalkers) * self.n_ensembles, ndim, a, live_dangerously, group, distributed)
         # philox key: explicit seed, else drawn from the (seeded) private RandomState
         # (never in 'numpy' mode: that stream must stay aligned with EnsembleSampler's)
         self.seed = None
@@ -387,7 +400,18 @@ class DeviceEnsembleSampler(_SamplerBase):
             if self._dev is None:
                 raise ValueError('Cannot have `initial_state=None` if run_mcmc has never been called.')
         else:
-            p0 = self._check_initial(initial_state)
+            if self.n_ensembles == 1:
+                p0 = self._check_initial(initial_state)
+            else:
+                p0 = np.array(initial_state, dtype=np.float64, copy=True).reshape(W, ndim)
+                Wp = self.walkers_per_ensemble
+                if not self.live_dangerously:
+                    if Wp < 2 * ndim:
+                        raise RuntimeError('It is unadvisable to use a red-blue move with fewer '
+                                           'walkers than twice the number of dimensions.')
+                    for e in np.unique(np.linspace(0, self.n_ensembles - 1, 32).astype(int)):
+                        if not walkers_independent(p0[e * Wp:(e + 1) * Wp]):
+                            raise ValueError(f'Initial state of ensemble {e} has a large condition number.')
             self._check_coords(p0)
             self._upload_state(p0)
         nsteps = int(nsteps)
@@ -398,6 +422,8 @@ class DeviceEnsembleSampler(_SamplerBase):
             n = min(self._chunk_steps(nsteps), nsteps - done)
             st = dict(self._dev)
             st['nh'] = nh
+            if self.n_ensembles > 1:
+                st['wp'] = self.walkers_per_ensemble
             counts = np.empty((n, 2), np.int64)
             counts[:, 0], counts[:, 1] = nh, W // 2
             if self.rng == 'numpy':
@@ -414,12 +440,12 @@ class DeviceEnsembleSampler(_SamplerBase):
             else:
                 # only the per-step split is drawn on the host; the stream is generated on
                 # the device from (seed, step, half, slot) counters
-                st['perm'] = be.tensor(affine_splits(self._random, W, n))
+                st['perm'] = be.tensor(affine_splits(self._random, self.walkers_per_ensemble, n))
                 for name, dt in (('active', torch.int32), ('partner', torch.int32),
                                  ('zz', torch.float64), ('factor', torch.float64),
                                  ('logu', torch.float64)):
                     st[name] = be.empty((n, 2, nh), dt)
-                be.draw(st, W, self.a, self.seed, self.iteration + done, n)
+                be.draw(st, self.walkers_per_ensemble, self.a, self.seed, self.iteration + done, n)
             st['chain'] = be.empty((n, W, ndim), torch.float64)
             st['logp_chain'] = be.empty((n, W), torch.float64)
             if self._world == 1:

@@ -79,6 +79,16 @@ int bisip_ctx_create(bisip_ctx **out, int device, int model_id, int N, const dou
                      const double *zn, const double *zn_err, int ndim, const double *lo,
                      const double *hi, const bisip_model_desc *desc);
 
+/* Batch of independent spectra (BASELINE config 5): n_spectra spectra that share the model
+ * shape, N and the prior box; w (E,N), zn (E,2,N), zn_err (E,2,N).  The same entry points
+ * then take theta (E*Wp, ndim) with rows [e*Wp, (e+1)*Wp) belonging to spectrum e (W must
+ * be a multiple of E).  PolynomialDecomposition: desc->taus/log_taus are shared by all
+ * spectra.  One reference Inversion object per spectrum: src/bisip/models.py:41-57. */
+int bisip_batch_create(bisip_ctx **out, int device, int model_id, int n_spectra, int N,
+                       const double *w, const double *zn, const double *zn_err, int ndim,
+                       const double *lo, const double *hi, const bisip_model_desc *desc);
+int bisip_ctx_nspectra(const bisip_ctx *ctx);
+
 void bisip_ctx_destroy(bisip_ctx *ctx);
 
 /* Replace the prior box (strict inequalities, lo < theta < hi). */
@@ -132,6 +142,8 @@ typedef struct bisip_stretch_args {
     int32_t *status;   /* required */
     int64_t pad;       /* apply: rows per rank slab in `block`                       */
     int32_t world;     /* apply: number of ranks that produced `block`               */
+    int64_t walkers_per_spectrum; /* batch contexts: Wp (even); walker i belongs to spectrum
+                                     i / Wp.  Ignored (may be 0) for single-spectrum contexts */
 } bisip_stretch_args;
 
 /* Single-rank half-step: evaluate all n_slots slots and update the state (one launch). */
@@ -144,13 +156,15 @@ int bisip_stretch_apply_dev(bisip_ctx *ctx, const bisip_stretch_args *args, void
 /* Run n_steps whole iterations (2 half-steps each) back to back on `stream` with no host
  * round trip.  `first` holds the pointers of step 0 / half 0; the random-stream arrays are
  * laid out (n_steps, 2, nh) with nh = (W+1)/2 (half 0 has ceil(W/2) slots, half 1
- * floor(W/2)); chain_row / logp_row advance by W*ndim / W per step. */
+ * floor(W/2)); chain_row / logp_row advance by W*ndim / W per step.  For a batch context W
+ * is the TOTAL number of walkers E*Wp and the arrays are (n_steps, 2, E, Wp/2). */
 int bisip_stretch_run_dev(bisip_ctx *ctx, const bisip_stretch_args *first, int64_t W,
                           int64_t n_steps, void *stream);
 
 /* Fill the random-stream arrays on the device (counter-based Philox4x32-10; the contract
  * is documented in bisip_amd/csrc/sampler_kernels.h and bisip_amd/sampler.py).
- * d_perm (n_steps,3) = per-step affine split (A, A^-1 mod W, B). */
+ * d_perm (n_steps,3) = per-step affine split (A, A^-1 mod W, B).  W = walkers per ensemble;
+ * a batch context draws for all its spectra: arrays (n_steps, 2, E, W/2), global walker ids. */
 int bisip_stretch_draw_dev(bisip_ctx *ctx, int64_t W, double a, uint64_t seed, int64_t step0,
                            int64_t n_steps, const int32_t *d_perm, int32_t *d_active,
                            int32_t *d_partner, double *d_zz, double *d_factor, double *d_logu,

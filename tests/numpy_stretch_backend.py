@@ -28,13 +28,14 @@ def u53(a, b):
     return (((a >> np.uint64(5)) << np.uint64(26)) | (b >> np.uint64(6))).astype(np.float64) / 9007199254740992.0
 
 
-def philox_stream(W, ndim, a, seed, step0, perm):
+def philox_stream(W, ndim, a, seed, step0, perm, E=1):
     """NumPy statement of the rng='philox' contract (bisip_amd/csrc/sampler_kernels.h):
-    returns active, partner, zz, factor, logu of shape (n, 2, nh)."""
+    returns active, partner, zz, factor, logu of shape (n, 2, E*nh); W = walkers per
+    ensemble, walker ids are global (e*W + i)."""
     n = perm.shape[0]
     nh = (W + 1) // 2
-    out = dict(active=np.zeros((n, 2, nh), np.int32), partner=np.zeros((n, 2, nh), np.int32),
-               zz=np.ones((n, 2, nh)), factor=np.zeros((n, 2, nh)), logu=np.zeros((n, 2, nh)))
+    out = dict(active=np.zeros((n, 2, E, nh), np.int32), partner=np.zeros((n, 2, E, nh), np.int32),
+               zz=np.ones((n, 2, E, nh)), factor=np.zeros((n, 2, E, nh)), logu=np.zeros((n, 2, E, nh)))
     k0, k1 = seed & 0xffffffff, seed >> 32
     for k in range(n):
         A, Ainv, B = [int(x) for x in perm[k]]
@@ -42,24 +43,27 @@ def philox_stream(W, ndim, a, seed, step0, perm):
             Ns = nh if h == 0 else W // 2
             Nc = W // 2 if h == 0 else nh
             t = np.arange(Ns, dtype=np.uint64)
-            x0, x1, x2, _ = philox4x32_10(t, step0 + k, h, 0, k0, k1)
-            y0, y1, _, _ = philox4x32_10(t, step0 + k, h, 1, k0, k1)
-            r = ((x2 * np.uint64(Nc)) >> np.uint64(32)).astype(np.int64)
-            v = (a - 1.0) * u53(x0, x1) + 1.0
-            z = (v * v) / a
             ti = t.astype(np.int64)
-            out['active'][k, h, :Ns] = (Ainv * ((2 * ti + h - B) % W)) % W
-            out['partner'][k, h, :Ns] = (Ainv * ((2 * r + (1 - h) - B) % W)) % W
-            out['zz'][k, h, :Ns] = z
-            out['factor'][k, h, :Ns] = (ndim - 1.0) * np.log(z)
-            with np.errstate(divide='ignore'):
-                out['logu'][k, h, :Ns] = np.log(u53(y0, y1))
-    return out
+            for e in range(E):
+                c2 = h | (e << 1)
+                x0, x1, x2, _ = philox4x32_10(t, step0 + k, c2, 0, k0, k1)
+                y0, y1, _, _ = philox4x32_10(t, step0 + k, c2, 1, k0, k1)
+                r = ((x2 * np.uint64(Nc)) >> np.uint64(32)).astype(np.int64)
+                v = (a - 1.0) * u53(x0, x1) + 1.0
+                z = (v * v) / a
+                out['active'][k, h, e, :Ns] = e * W + (Ainv * ((2 * ti + h - B) % W)) % W
+                out['partner'][k, h, e, :Ns] = e * W + (Ainv * ((2 * r + (1 - h) - B) % W)) % W
+                out['zz'][k, h, e, :Ns] = z
+                out['factor'][k, h, e, :Ns] = (ndim - 1.0) * np.log(z)
+                with np.errstate(divide='ignore'):
+                    out['logu'][k, h, e, :Ns] = np.log(u53(y0, y1))
+    return {name: arr.reshape(n, 2, E * nh) for name, arr in out.items()}
 
 
 class NumpyStretchBackend:
-    def __init__(self, logprob_fn):
+    def __init__(self, logprob_fn, n_ensembles=1):
         self.logprob_fn = logprob_fn
+        self.n_ensembles = n_ensembles
 
     def tensor(self, array, dtype=None):
         return torch.as_tensor(np.ascontiguousarray(array), dtype=dtype).clone()
@@ -110,7 +114,7 @@ class NumpyStretchBackend:
 
     def draw(self, st, W, a, seed, step0, n_steps):
         ndim = st['coords'].shape[1]
-        arrs = philox_stream(W, ndim, a, seed, step0, st['perm'].numpy())
+        arrs = philox_stream(W, ndim, a, seed, step0, st['perm'].numpy(), self.n_ensembles)
         for name, arr in arrs.items():
             st[name][:] = torch.from_numpy(arr)
 

@@ -147,3 +147,12 @@ def test_sharded_device_driver_two_rank_gloo(tmp_path):
         assert np.array_equal(r['chain'], s.get_chain())
         assert np.array_equal(r['logp'], s.get_log_prob())
         assert np.array_equal(r['acc'], s.acceptance_fraction)
+
+
+def test_batch_replica_sharding():
+    """Batch of spectra shards as whole replicas: the rank blocks tile the spectrum list."""
+    from bisip_amd.dist import shard_range
+    n = 4096
+    blocks = [shard_range(n, 8, r) for r in range(8)]
+    assert blocks[0] == (0, 512) and blocks[-1] == (3584, 4096)
+    assert all(b - a == 512 for a, b in blocks)

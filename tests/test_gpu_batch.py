@@ -1,0 +1,123 @@
+"""Batch of independent spectra (BASELINE config 5: E spectra x Wp walkers, double
+Cole-Cole) -- log-prob / forward against the oracle per spectrum, and the E-ensemble
+device sampler against a NumPy replay of the same contract."""
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import assert_logp_close, assert_Z_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _tables(E, n_freq=32):
+    from bisip_amd.synthetic import synthetic_columns
+    return [synthetic_columns(n_freq, i) for i in range(E)]
+
+
+def _oracle_logp(batch, theta):
+    out = np.empty(theta.shape[:2])
+    kw = {}
+    if batch.model == 'PolynomialDecomposition':
+        kw = dict(taus=batch.taus, log_taus=batch.log_taus, c_exp=batch.c_exp)
+    if batch.model == 'PeltonColeCole':
+        kw = dict(n_modes=batch.n_modes)
+    for e in range(batch.n_spectra):
+        prob = oracle.OracleProblem(batch.model, batch.w[e], batch.zn[e], batch.zn_err[e],
+                                    batch.param_bounds, **kw)
+        out[e] = oracle.logprob(prob, theta[e])
+    return out
+
+
+@pytest.mark.parametrize('model,kw,E,Wp', [
+    ('PeltonColeCole', dict(n_modes=2), 12, 256),      # cfg5 shape per spectrum, uniform waves
+    ('PeltonColeCole', dict(n_modes=2), 5, 50),        # waves straddle spectra
+    ('PolynomialDecomposition', dict(poly_deg=5), 9, 128),
+    ('PolynomialDecomposition', dict(poly_deg=4, c_exp=0.5), 3, 30),
+    ('Dias2000', {}, 4, 64),
+    ('Shin2015', {}, 4, 20),
+])
+def test_batch_logprob_and_forward(model, kw, E, Wp):
+    import bisip_amd
+    batch = bisip_amd.SpectraBatch(model, _tables(E), nwalkers=Wp, **kw)
+    rng = np.random.RandomState(E * 1000 + Wp)
+    lo, hi = batch.param_bounds
+    theta = rng.uniform(lo, hi, (E, Wp, lo.size))
+    theta[0, 1, 0] = hi[0]                        # on-bound row -> -inf
+    got = batch.log_prob(theta)
+    assert got.shape == (E, Wp)
+    assert_logp_close(got, _oracle_logp(batch, theta))
+    if model == 'PolynomialDecomposition':
+        batch.ctx.set_variant('collapsed')
+        assert_logp_close(batch.log_prob(theta), _oracle_logp(batch, theta))
+        with pytest.raises(RuntimeError):
+            batch.ctx.set_variant('faithful')
+        batch.ctx.set_variant('auto')
+    Z = batch.forward(theta[:, :5])
+    assert Z.shape == (E, 5, 2, 32)
+    # spectrum e of the batch == a single-spectrum context on the same data
+    from bisip_amd import _hip
+    okw = dict(kw)
+    if model == 'PolynomialDecomposition':
+        okw = dict(poly_deg=batch.poly_deg, c_exp=batch.c_exp, taus=batch.taus, log_taus=batch.log_taus)
+    e = E - 1
+    single = _hip.HipContext(batch.ctx._lib and {'PolynomialDecomposition': 0, 'PeltonColeCole': 1,
+                                                 'Dias2000': 2, 'Shin2015': 3}[model],
+                             batch.w[e], batch.zn[e], batch.zn_err[e], batch.param_bounds, **okw)
+    rows = theta[e].copy()
+    rows[:, :] = np.where(np.isfinite(rows), rows, 0)
+    assert np.array_equal(single.logprob(theta[e]), got[e])
+    assert_Z_close(Z[e], single.forward(theta[e, :5]), 1e-15)
+    with pytest.raises(ValueError):
+        batch.ctx.logprob(theta.reshape(-1, lo.size)[:E * Wp - 1])   # not a multiple of E
+
+
+def test_batch_sampler_replay_and_independence():
+    """E ensembles advanced by one launch per half-step == NumPy replay of the philox
+    contract with the GPU log-prob; and each ensemble's chain does not depend on its
+    neighbours (same seed, same spectrum position -> same chain)."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import bisip_amd
+    from bisip_amd.sampler import DeviceEnsembleSampler
+    from numpy_stretch_backend import NumpyStretchBackend
+    for E, Wp in [(6, 128), (5, 30)]:
+        batch = bisip_amd.SpectraBatch('PeltonColeCole', _tables(E), nwalkers=Wp, nsteps=40, n_modes=2)
+        rng = np.random.RandomState(E)
+        centre = np.array([1.0, 0.15, 0.5, -1.5, -12.0, 0.45, 0.6])
+        p0 = centre + 1e-3 * rng.randn(E, Wp, 7)
+        np.random.seed(1)
+        batch.fit(p0=p0, seed=77)
+        chain = batch.get_chain()
+        assert chain.shape == (40, E, Wp, 7)
+        np.random.seed(1)
+        rep = DeviceEnsembleSampler(Wp, 7, backend=NumpyStretchBackend(batch.ctx.logprob, E),
+                                    rng='philox', seed=77, n_ensembles=E)
+        rep.run_mcmc(p0.reshape(E * Wp, 7), 40)
+        assert np.array_equal(chain.reshape(40, E * Wp, 7), rep.get_chain())
+        assert 0.05 < batch.acceptance_fraction.mean() < 0.9
+        # walkers never leave their own ensemble's posterior: compare with a smaller batch
+        sub = bisip_amd.SpectraBatch('PeltonColeCole', _tables(E)[:2], nwalkers=Wp, nsteps=40, n_modes=2)
+        np.random.seed(1)
+        sub.fit(p0=p0[:2], seed=77)
+        assert np.array_equal(sub.get_chain(), chain[:, :2])
+        assert batch.get_chain(discard=10, flat=True).shape == (E, 30 * Wp, 7)
+
+
+def test_cfg5_scaled_shape_runs():
+    """A slice of BASELINE config 5 (512 spectra per GPU at full scale): 64 spectra x 256
+    walkers of double Cole-Cole, a few steps; finite log-probs, in-prior positions."""
+    import bisip_amd
+    E, Wp = 64, 256
+    batch = bisip_amd.SpectraBatch('PeltonColeCole', _tables(E), nwalkers=Wp, nsteps=20, n_modes=2)
+    rng = np.random.RandomState(0)
+    centre = np.array([1.0, 0.15, 0.5, -1.5, -12.0, 0.45, 0.6])
+    p0 = centre + 1e-3 * rng.randn(E, Wp, 7)
+    batch.fit(p0=p0, seed=5)
+    lp = batch.get_log_prob()
+    assert lp.shape == (20, E, Wp) and np.isfinite(lp).all()
+    lo, hi = batch.param_bounds
+    ch = batch.get_chain()
+    assert np.all(ch > lo) and np.all(ch < hi)
+    assert lp[-1].mean() > lp[0].mean() - 50
