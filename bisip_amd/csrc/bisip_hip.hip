@@ -630,7 +630,7 @@ static int build_context(bisip_ctx **out, int device, int model_id, int E, int N
         for (int j = 0; j < N; ++j) {
             double *r = base + (size_t)j * rec;
             r[0] = zne[j]; r[1] = zne[N + j]; r[2] = iv[j]; r[3] = iv[N + j];
-            if (model_id != BISIP_MODEL_POLYDECOMP) { r[4] = we[j]; r[5] = lnw[j]; }
+            if (model_id != BISIP_MODEL_POLYDECOMP) { r[4] = we[j]; r[5] = lnw[j]; r[6] = (double)sqrtl((long double)we[j]); }
         }
         if (model_id == BISIP_MODEL_POLYDECOMP) {
             c->c_exp = desc->c_exp;

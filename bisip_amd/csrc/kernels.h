@@ -90,10 +90,81 @@ __device__ __forceinline__ bool in_prior(const double (&th)[NDIM], const Bounds 
 }
 
 // ---------------------------------------------------------------------------------
+// fp64 building blocks for the transcendental-bound models.  On gfx950 every fp64 VALU
+// op issues in ~4 cycles per wave except v_rcp/v_rsq/v_sqrt (~16; measured with
+// benchmarks/micro/valu_rates.hip), so the cost of a kernel is its instruction count.
+// ---------------------------------------------------------------------------------
+
+// exp(x) for finite x: Cody-Waite reduction by ln2 (hi/lo split), degree-11 polynomial
+// (coefficients: Chebyshev fit of (e^r-1-r)/r^2 on |r| <= ln2/2, max error 0.83 ulp
+// against a 50-digit reference), scaling by v_ldexp (saturates to +inf / 0 by itself).
+// Same structure as the device library's exp minus its overflow/underflow selects,
+// which the callers' argument ranges make dead code.
+__device__ __forceinline__ double exp_finite(double x)
+{
+    const double t = rint(x * 0x1.71547652b82fep+0);
+    double r = fma(t, -0x1.62e42fefa39efp-1, x);
+    r = fma(t, -0x1.abc9e3b39803fp-56, r);
+    double p = 0x1.af38a9b0ec855p-26;
+    p = fma(p, r, 0x1.289185613a3d6p-22);
+    p = fma(p, r, 0x1.71de0dae63bb3p-19);
+    p = fma(p, r, 0x1.a019b90d2ae7ap-16);
+    p = fma(p, r, 0x1.a01a01a7c41d5p-13);
+    p = fma(p, r, 0x1.6c16c1788bd9p-10);
+    p = fma(p, r, 0x1.11111111109b3p-7);
+    p = fma(p, r, 0x1.5555555553d63p-5);
+    p = fma(p, r, 0x1.5555555555556p-3);
+    p = fma(p, r, 0x1.0000000000001p-1);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)t);
+}
+
+// 2^y for finite y: t = rint(y), f = y - t is exact, degree-11 polynomial in f (Chebyshev
+// fit of (2^f - 1 - f ln2)/f^2 on |f| <= 1/2, max error 0.89 ulp).  The per-frequency
+// kernels fold log2(e) into per-walker constants so that exp(c*(ln w + lt)) is
+// exp2_finite(fma(c*log2e, ln w, c*log2e*lt)): no range-reduction multiplies at all.
+__device__ __forceinline__ double exp2_finite(double y)
+{
+    const double t = rint(y);
+    const double f = y - t;
+    double p = 0x1.e9bbe9e45e5a6p-32;
+    p = fma(p, f, 0x1.e5ea03c5ae3ccp-28);
+    p = fma(p, f, 0x1.b525087314718p-24);
+    p = fma(p, f, 0x1.62bfe45ac08ccp-20);
+    p = fma(p, f, 0x1.ffcbfc61f8673p-17);
+    p = fma(p, f, 0x1.4309130379f8bp-13);
+    p = fma(p, f, 0x1.5d87fe78a5dc3p-10);
+    p = fma(p, f, 0x1.3b2ab6fba385bp-7);
+    p = fma(p, f, 0x1.c6b08d704a0c0p-5);
+    p = fma(p, f, 0x1.ebfbdff82c590p-3);
+    p = fma(p, f, 0x1.62e42fefa39efp-1);
+    p = fma(p, f, 1.0);
+    return ldexp(p, (int)t);
+}
+
+constexpr double LOG2E = 0x1.71547652b82fep+0;
+
+// 1/x for normal x with a normal reciprocal: hardware estimate + two Newton steps
+// (5 instructions instead of the 10 of an IEEE division; <= 1 ulp).  Every caller's
+// argument is |1 + z|^2-like and bounded away from 0 (see the model comments).
+__device__ __forceinline__ double rcp_nr(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-x, r, 1.0);
+    return fma(r, e, r);
+}
+
+// ---------------------------------------------------------------------------------
 // Forward models.  Each exposes
 //   NDIM, REC (doubles per frequency record; rec[0..3] = y_re, y_im, 1/s2_re, 1/s2_im)
 //   Setup / setup(theta row)           per-walker quantities, computed once per lane
-//   eval(setup, rec+4, zr, zi)         complex impedance at one frequency
+//   eval(setup, rec+4, zr, zi)         complex impedance at one frequency (forward())
+//   residual(setup, rec, rr, ri)       y - Z at one frequency for the log-likelihood, with
+//                                      the walker-constant part of Z folded into per-walker
+//                                      constants (fewer instructions than y - eval())
 // ---------------------------------------------------------------------------------
 
 // PolynomialDecomposition, collapsed: Z_j = R0*(1 - sum_p a_p G[j,p]).
@@ -106,14 +177,30 @@ struct PDCollapsed {
     struct Setup {
         double r0;
         double a[P + 1];
+        double b[P + 1];  // r0 * a_p
     };
     __device__ static __forceinline__ Setup setup(const double (&th)[NDIM])
     {
         Setup s;
         s.r0 = th[0];
 #pragma unroll
-        for (int p = 0; p <= P; ++p) s.a[p] = th[1 + p];  // ascending a0..aP
+        for (int p = 0; p <= P; ++p) {
+            s.a[p] = th[1 + p];  // ascending a0..aP
+            s.b[p] = th[0] * th[1 + p];
+        }
         return s;
+    }
+    // y - Z with Z = r0 - sum_p b_p G_p
+    __device__ static __forceinline__ void residual(const Setup &s, const double *__restrict__ rec,
+                                                    double &rr, double &ri)
+    {
+        rr = rec[0] - s.r0;
+        ri = rec[1];
+#pragma unroll
+        for (int p = 0; p <= P; ++p) {
+            rr = fma(s.b[p], rec[4 + p], rr);
+            ri = fma(s.b[p], rec[4 + P + 1 + p], ri);
+        }
     }
     __device__ static __forceinline__ void eval(const Setup &s, const double *__restrict__ m,
                                                 double &zr, double &zi)
@@ -134,23 +221,46 @@ struct PDCollapsed {
 template <int D>
 struct ColeCole {
     static constexpr int NDIM = 1 + 3 * D;
-    static constexpr int REC = 8;  // y_re y_im iv_re iv_im | w lnw pad pad
+    static constexpr int REC = 8;  // y_re y_im iv_re iv_im | w lnw sqrt(w) pad
     struct Setup {
         double r0;
         double m[D], lt[D], c[D], cs[D], sn[D];
+        double A[D], c2[D], clt2[D], C;  // residual(): m r0, c log2e, c log2e lt, r0 - sum A
     };
     __device__ static __forceinline__ Setup setup(const double (&th)[NDIM])
     {
         Setup s;
         s.r0 = th[0];
+        s.C = th[0];
 #pragma unroll
         for (int i = 0; i < D; ++i) {
             s.m[i] = th[1 + i];
             s.lt[i] = th[1 + D + i];
             s.c[i] = th[1 + 2 * D + i];
             sincospi(0.5 * s.c[i], &s.sn[i], &s.cs[i]);
+            s.A[i] = s.m[i] * th[0];
+            s.c2[i] = s.c[i] * LOG2E;
+            s.clt2[i] = s.c2[i] * s.lt[i];
+            s.C -= s.A[i];
         }
         return s;
+    }
+    // Z = (r0 - sum A_i) + sum A_i (1+x_i)^-1  =>  y - Z accumulates -A_i conj(1+x_i)/|1+x_i|^2
+    __device__ static __forceinline__ void residual(const Setup &s, const double *__restrict__ rec,
+                                                    double &rr, double &ri)
+    {
+        const double lnw = rec[5];
+        rr = rec[0] - s.C;
+        ri = rec[1];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            const double e = exp2_finite(fma(s.c2[i], lnw, s.clt2[i]));
+            const double dr = fma(e, s.cs[i], 1.0);  // >= 1
+            const double di = e * s.sn[i];
+            const double t = s.A[i] * rcp_nr(fma(dr, dr, di * di));
+            rr = fma(-t, dr, rr);
+            ri = fma(t, di, ri);
+        }
     }
     __device__ static __forceinline__ void eval(const Setup &s, const double *__restrict__ m,
                                                 double &zr, double &zi)
@@ -159,10 +269,10 @@ struct ColeCole {
         double sr = 0.0, si = 0.0;
 #pragma unroll
         for (int i = 0; i < D; ++i) {
-            const double e = exp(s.c[i] * (lnw + s.lt[i]));
-            const double dr = fma(e, s.cs[i], 1.0);  // 1 + x
+            const double e = exp_finite(s.c[i] * (lnw + s.lt[i]));
+            const double dr = fma(e, s.cs[i], 1.0);  // 1 + x, >= 1 because cos(c pi/2) >= 0
             const double di = e * s.sn[i];
-            const double inv = 1.0 / fma(dr, dr, di * di);
+            const double inv = rcp_nr(fma(dr, dr, di * di));
             sr = fma(s.m[i], 1.0 - dr * inv, sr);  // m*(1 - 1/(1+x))
             si = fma(s.m[i], di * inv, si);
         }
@@ -177,16 +287,35 @@ struct Dias {
     static constexpr int REC = 8;
     struct Setup {
         double r0, m, tau, taup, taupp;
+        double A, C, teh;  // residual(): r0 m, r0 - A, tau |eta| / sqrt(2)
     };
     __device__ static __forceinline__ Setup setup(const double (&th)[NDIM])
     {
         Setup s;
         s.r0 = th[0];
         s.m = th[1];
-        s.tau = exp(th[2]);
+        s.tau = exp_finite(th[2]);
         s.taup = s.tau * (1.0 / th[4] - 1.0) / (1.0 - s.m);
         s.taupp = (s.tau * s.tau) * (th[3] * th[3]);
+        s.A = th[0] * th[1];
+        s.C = th[0] - s.A;
+        s.teh = s.tau * fabs(th[3]) * 0.70710678118654752440;
         return s;
+    }
+    // Z = r0 (1-m) + r0 m / den;  (i w tau'')^0.5 = sqrt(w) tau |eta| (1+i)/sqrt(2) with sqrt(w_j)
+    // precomputed per frequency, so no square root per (walker, frequency).
+    __device__ static __forceinline__ void residual(const Setup &s, const double *__restrict__ rec,
+                                                    double &rr, double &ri)
+    {
+        const double w = rec[4];
+        const double mur = rec[6] * s.teh, mui = fma(w, s.tau, mur);
+        const double inv = rcp_nr(fma(mur, mur, mui * mui));       // |mu| >= w tau > 0
+        const double tr = fma(mur, inv, 1.0), nti = mui * inv;     // 1 + 1/mu = tr - i nti
+        const double a = w * s.taup;
+        const double dr = fma(a, nti, 1.0), di = a * tr;           // den = 1 + i a (1 + 1/mu), Re >= 1
+        const double t = s.A * rcp_nr(fma(dr, dr, di * di));
+        rr = fma(-t, dr, rec[0] - s.C);
+        ri = fma(t, di, rec[1]);
     }
     __device__ static __forceinline__ void eval(const Setup &s, const double *__restrict__ m,
                                                 double &zr, double &zi)
@@ -195,11 +324,11 @@ struct Dias {
         // (i w tau'')^0.5 = sqrt(w tau'') (cos(pi/4) + i sin(pi/4))
         const double sq = sqrt(w * s.taupp) * 0.70710678118654752440;
         const double mur = sq, mui = fma(w, s.tau, sq);
-        const double inv = 1.0 / fma(mur, mur, mui * mui);
+        const double inv = rcp_nr(fma(mur, mur, mui * mui));       // |mu| >= w tau > 0
         const double tr = fma(mur, inv, 1.0), ti = -(mui * inv);  // 1 + 1/mu
         const double a = w * s.taup;
         const double dr = fma(-a, ti, 1.0), di = a * tr;          // 1 + i a (tr + i ti)
-        const double inv2 = 1.0 / fma(dr, dr, di * di);
+        const double inv2 = rcp_nr(fma(dr, dr, di * di));         // Re(den) >= 1
         const double fr = 1.0 - dr * inv2, fi = di * inv2;        // 1 - 1/den
         zr = s.r0 * (1.0 - s.m * fr);
         zi = s.r0 * (0.0 - s.m * fi);
@@ -212,6 +341,7 @@ struct Shin {
     static constexpr int REC = 8;
     struct Setup {
         double invR[2], Q[2], n[2], cs[2], sn[2];
+        double n2[2], lq2[2];  // residual(): n log2e, log_Q log2e
     };
     __device__ static __forceinline__ Setup setup(const double (&th)[NDIM])
     {
@@ -219,11 +349,29 @@ struct Shin {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             s.invR[i] = 1.0 / th[i];
-            s.Q[i] = exp(th[2 + i]);
+            s.Q[i] = exp_finite(th[2 + i]);
             s.n[i] = th[4 + i];
             sincospi(0.5 * s.n[i], &s.sn[i], &s.cs[i]);
+            s.n2[i] = s.n[i] * LOG2E;
+            s.lq2[i] = th[2 + i] * LOG2E;
         }
         return s;
+    }
+    // Q (iw)^n = 2^(n log2e ln w + log_Q log2e) (cs + i sn);  Z = sum_i conj(y_i)/|y_i|^2
+    __device__ static __forceinline__ void residual(const Setup &s, const double *__restrict__ rec,
+                                                    double &rr, double &ri)
+    {
+        const double lnw = rec[5];
+        rr = rec[0];
+        ri = rec[1];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const double p = exp2_finite(fma(s.n2[i], lnw, s.lq2[i]));
+            const double yr = fma(p, s.cs[i], s.invR[i]), yi = p * s.sn[i];  // yr >= 1/R > 1
+            const double inv = rcp_nr(fma(yr, yr, yi * yi));
+            rr = fma(-yr, inv, rr);
+            ri = fma(yi, inv, ri);
+        }
     }
     __device__ static __forceinline__ void eval(const Setup &s, const double *__restrict__ m,
                                                 double &zr, double &zi)
@@ -233,9 +381,9 @@ struct Shin {
         zi = 0.0;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const double p = s.Q[i] * exp(s.n[i] * lnw);  // Q (iw)^n = p (cs + i sn)
-            const double yr = fma(p, s.cs[i], s.invR[i]), yi = p * s.sn[i];
-            const double inv = 1.0 / fma(yr, yr, yi * yi);
+            const double p = s.Q[i] * exp_finite(s.n[i] * lnw);  // Q (iw)^n = p (cs + i sn)
+            const double yr = fma(p, s.cs[i], s.invR[i]), yi = p * s.sn[i];  // yr >= 1/R > 1
+            const double inv = rcp_nr(fma(yr, yr, yi * yi));
             zr = fma(yr, inv, zr);
             zi = fma(-yi, inv, zi);
         }
@@ -262,9 +410,8 @@ __device__ __forceinline__ double logprob_row(const double (&th)[M::NDIM], const
     double acc0 = 0.0, acc1 = 0.0;
     const double *__restrict__ rec = o.cb;
     for (int j = 0; j < o.N; ++j, rec += M::REC) {
-        double zr, zi;
-        M::eval(s, rec + 4, zr, zi);
-        const double rr = rec[0] - zr, ri = rec[1] - zi;
+        double rr, ri;
+        M::residual(s, rec, rr, ri);
         acc0 = fma(rr * rr, rec[2], acc0);
         acc1 = fma(ri * ri, rec[3], acc1);
     }
