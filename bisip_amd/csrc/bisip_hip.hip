@@ -47,7 +47,7 @@ constexpr long long SMALL_W = 256LL * 256 * 2;  // below this, 64-lane workgroup
 
 struct bisip_ctx {
     int device = 0, model_id = 0, N = 0, ndim = 0, variant = BISIP_VARIANT_AUTO;
-    int P = 0, D = 0, S = 0, SPAD = 0;
+    int P = 0, D = 0, S = 0;
     double c_exp = 1.0, lconst = 0.0;
     Bounds bounds{};
     int E = 1;                      // spectra in the context (batch of spectra: E > 1)
@@ -135,14 +135,14 @@ int launch_reduced(const bisip_ctx *c, const double *theta, int64_t W, double *o
     return BISIP_OK;
 }
 
-template <int P, int SPAD>
+template <int P>
 int launch_faithful(const bisip_ctx *c, const double *theta, int64_t W, double *out, hipStream_t st)
 {
     const LaunchArgs a = make_args(c, theta, out, W, c->d_cb_faithful);
     const bool vec = ((uintptr_t)theta % 16) == 0;
     const unsigned grid = (unsigned)((W + BLK_SMALL - 1) / BLK_SMALL);
-    if (vec) hipLaunchKernelGGL((k_logprob_pd_faithful<P, SPAD, BLK_SMALL, true>), dim3(grid), dim3(BLK_SMALL), 0, st, a);
-    else hipLaunchKernelGGL((k_logprob_pd_faithful<P, SPAD, BLK_SMALL, false>), dim3(grid), dim3(BLK_SMALL), 0, st, a);
+    if (vec) hipLaunchKernelGGL((k_logprob_pd_faithful<P, BLK_SMALL, true>), dim3(grid), dim3(BLK_SMALL), 0, st, a, c->S);
+    else hipLaunchKernelGGL((k_logprob_pd_faithful<P, BLK_SMALL, false>), dim3(grid), dim3(BLK_SMALL), 0, st, a, c->S);
     HIP_TRY(hipGetLastError());
     return BISIP_OK;
 }
@@ -281,11 +281,12 @@ int dispatch_logprob(const bisip_ctx *c, const double *theta, int64_t W, double 
 #undef X
             }
         } else if (v == BISIP_VARIANT_FAITHFUL) {
-            if (!c->d_cb_faithful)
-                return fail(BISIP_EUNSUPPORTED, "faithful variant needs poly_deg in 3..5 and n_taus <= 128");
-#define X(p, s) if (c->P == p && c->SPAD == s) return launch_faithful<p, s>(c, theta, W, out, st);
-            X(3, 64) X(3, 128) X(4, 64) X(4, 128) X(5, 64) X(5, 128)
+            if (!c->d_cb_faithful) return fail(BISIP_EUNSUPPORTED, "the faithful formulation is not available for this context");
+            switch (c->P) {
+#define X(p) case p: return launch_faithful<p>(c, theta, W, out, st);
+                PD_CASES(X)
 #undef X
+            }
         }
         return fail(BISIP_EUNSUPPORTED, "no kernel for poly_deg=%d variant=%d", c->P, v);
     }
@@ -653,22 +654,23 @@ static int build_context(bisip_ctx **out, int device, int model_id, int E, int N
                 red.insert(red.end(), o.e.begin(), o.e.end());
                 red.push_back(o.rest);
             }
-            if (E == 1 && P >= 3 && P <= 5 && S <= 128) {
-                const int SPAD = S <= 64 ? 64 : 128;
-                c->SPAD = SPAD;
-                std::vector<double> fb((size_t)(P + 1) * SPAD + (size_t)N * (4 + 2 * SPAD), 0.0);
-                for (int p = 0; p <= P; ++p)
-                    for (int k = 0; k < S; ++k) fb[(size_t)p * SPAD + k] = desc->log_taus[(size_t)p * S + k];
-                double *fbase = &fb[(size_t)(P + 1) * SPAD];
+            if (E == 1) {  // loop-faithful records (see k_logprob_pd_faithful)
+                const int JB = 16, nb = (N + JB - 1) / JB;
+                const size_t blk_stride = 4 * (size_t)JB + (size_t)S * 2 * JB;
+                std::vector<double> fb((size_t)S * 8 + (size_t)nb * blk_stride, 0.0);
+                for (int k = 0; k < S; ++k)
+                    for (int p = 0; p <= P && p < 8; ++p) fb[(size_t)k * 8 + p] = desc->log_taus[(size_t)p * S + k];
                 for (int j = 0; j < N; ++j) {
-                    double *r = fbase + (size_t)j * (4 + 2 * SPAD);
-                    r[0] = zne[j]; r[1] = zne[N + j]; r[2] = iv[j]; r[3] = iv[N + j];
+                    double *blk = &fb[(size_t)S * 8 + (size_t)(j / JB) * blk_stride];
+                    const int jj = j % JB;
+                    blk[jj] = zne[j]; blk[JB + jj] = zne[N + j];
+                    blk[2 * JB + jj] = iv[j]; blk[3 * JB + jj] = iv[N + j];
                     for (int k = 0; k < S; ++k) {
-                        r[4 + k] = o.K_re[(size_t)j * S + k];
-                        r[4 + SPAD + k] = o.K_im[(size_t)j * S + k];
+                        blk[4 * JB + (size_t)k * 2 * JB + jj] = o.K_re[(size_t)j * S + k];
+                        blk[4 * JB + (size_t)k * 2 * JB + JB + jj] = o.K_im[(size_t)j * S + k];
                     }
                 }
-                rc = upload(&c->d_cb_faithful, fb);
+                if (P < 8) rc = upload(&c->d_cb_faithful, fb);
             }
         }
     }
@@ -738,7 +740,7 @@ int bisip_ctx_set_variant(bisip_ctx *c, int variant)
     if (variant == BISIP_VARIANT_FAITHFUL && c->E > 1)
         return fail(BISIP_EUNSUPPORTED, "the faithful formulation has no batch-of-spectra kernel");
     if (variant == BISIP_VARIANT_FAITHFUL && !c->d_cb_faithful)
-        return fail(BISIP_EUNSUPPORTED, "faithful variant needs poly_deg in 3..5 and n_taus <= 128");
+        return fail(BISIP_EUNSUPPORTED, "faithful variant needs poly_deg <= 7");
     c->variant = variant;
     c->kernel_name = name_for(c);
     return BISIP_OK;

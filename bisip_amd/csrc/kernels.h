@@ -498,16 +498,20 @@ __global__ __launch_bounds__(BLK) void k_logprob_pd_reduced(const LaunchArgs a,
 
 // ---------------------------------------------------------------------------------
 // PolynomialDecomposition, loop-faithful (BISIP_VARIANT_FAITHFUL): the reference's own
-// structure  M_k = sum_p a_p L[p,k];  z_j = sum_k M_k K[j,k]  (cython_funcs.pyx:84-90)
-// in the reference's summation order, with only the walker-independent K[j,k] hoisted.
-// The tau axis is zero-padded to SPAD so the k loops unroll into straight FMA chains
-// fed by scalar loads (a padded term contributes an exact +0).
-// cb layout: L (P+1, SPAD) | per j: y_re y_im iv_re iv_im | K_re[j,0:SPAD] | K_im[j,0:SPAD].
+// structure  M_k = sum_p a_p L[p,k];  z_j = sum_k M_k K[j,k]  (cython_funcs.pyx:84-90),
+// each z_j summed over k in the reference's order, with only the walker-independent
+// K[j,k] hoisted.  Frequencies are processed in blocks of JB = 16 whose 32 partial sums
+// live in registers; k runs in the outer loop and M_k is rebuilt per block (6 of every 38
+// FMAs), so no per-lane M[S] array exists and S, N are plain runtime sizes.
+// cb layout (doubles):  LT (S, 8): L[0..P][k] padded to 8
+//                       then per frequency block b (N padded to a multiple of 16, padding has
+//                       weight 0):  y_re[16] y_im[16] iv_re[16] iv_im[16] | per k: K_re[16] K_im[16]
 // ---------------------------------------------------------------------------------
-template <int P, int SPAD, int BLK, bool VEC>
-__global__ __launch_bounds__(BLK) void k_logprob_pd_faithful(const LaunchArgs a)
+template <int P, int BLK, bool VEC>
+__global__ __launch_bounds__(BLK) void k_logprob_pd_faithful(const LaunchArgs a, const int S)
 {
     constexpr int NDIM = P + 2;
+    constexpr int JB = 16;
     __shared__ __attribute__((aligned(16))) double lds[BLK * NDIM];
     const long long row0 = (long long)blockIdx.x * BLK;
     stage_theta<NDIM, BLK, VEC>(a.theta, a.W, row0, lds);
@@ -519,28 +523,33 @@ __global__ __launch_bounds__(BLK) void k_logprob_pd_faithful(const LaunchArgs a)
     for (int q = 0; q < NDIM; ++q) th[q] = lds[threadIdx.x * NDIM + q];
     double lp = -__builtin_inf();
     if (in_prior<NDIM>(th, a.b)) {
-        double M[SPAD];
-        const double *__restrict__ L = a.cb;
-#pragma unroll
-        for (int k = 0; k < SPAD; ++k) M[k] = 0.0;
-#pragma unroll
-        for (int p = 0; p <= P; ++p)  // i outer, k inner, as cython_funcs.pyx:84-86
-#pragma unroll
-            for (int k = 0; k < SPAD; ++k) M[k] = fma(th[1 + p], L[p * SPAD + k], M[k]);
-        const double *__restrict__ rec = a.cb + (P + 1) * SPAD;
-        constexpr int STRIDE = 4 + 2 * SPAD;
+        const double *__restrict__ LT = a.cb;
+        const double *__restrict__ blk = a.cb + (long long)S * 8;
+        const int nblocks = (a.N + JB - 1) / JB;
+        const long long blk_stride = 4 * JB + (long long)S * 2 * JB;
         double acc0 = 0.0, acc1 = 0.0;
-        for (int j = 0; j < a.N; ++j, rec += STRIDE) {
-            double sr = 0.0, si = 0.0;
+        for (int b = 0; b < nblocks; ++b, blk += blk_stride) {
+            double sr[JB], si[JB];
 #pragma unroll
-            for (int k = 0; k < SPAD; ++k) {
-                sr = fma(M[k], rec[4 + k], sr);
-                si = fma(M[k], rec[4 + SPAD + k], si);
+            for (int jj = 0; jj < JB; ++jj) { sr[jj] = 0.0; si[jj] = 0.0; }
+            const double *__restrict__ Kk = blk + 4 * JB;
+            for (int k = 0; k < S; ++k, Kk += 2 * JB) {
+                double mk = 0.0;
+#pragma unroll
+                for (int p = 0; p <= P; ++p) mk = fma(th[1 + p], LT[k * 8 + p], mk);
+#pragma unroll
+                for (int jj = 0; jj < JB; ++jj) {
+                    sr[jj] = fma(mk, Kk[jj], sr[jj]);
+                    si[jj] = fma(mk, Kk[JB + jj], si[jj]);
+                }
             }
-            const double zr = th[0] * (1.0 - sr), zi = th[0] * (0.0 - si);
-            const double rr = rec[0] - zr, ri = rec[1] - zi;
-            acc0 = fma(rr * rr, rec[2], acc0);
-            acc1 = fma(ri * ri, rec[3], acc1);
+#pragma unroll
+            for (int jj = 0; jj < JB; ++jj) {
+                const double zr = th[0] * (1.0 - sr[jj]), zi = th[0] * (0.0 - si[jj]);
+                const double rr = blk[jj] - zr, ri = blk[JB + jj] - zi;
+                acc0 = fma(rr * rr, blk[2 * JB + jj], acc0);
+                acc1 = fma(ri * ri, blk[3 * JB + jj], acc1);
+            }
         }
         lp = fma(-0.5, acc0 + acc1, a.lconst);
     }

@@ -31,7 +31,7 @@ def variants_for(g, model):
     if model != 'PolynomialDecomposition':
         return ['auto']
     v = ['reduced', 'collapsed']
-    if 3 <= int(g['poly_deg']) <= 5 and g['taus'].size <= 128:
+    if int(g['poly_deg']) <= 7:
         v.append('faithful')
     return v
 
