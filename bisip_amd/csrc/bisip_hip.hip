@@ -41,6 +41,8 @@ int fail(int code, const char *fmt, ...)
 
 constexpr int BLK_SMALL = 64;    // few walkers: spread them over more CUs
 constexpr int BLK_LARGE = 256;
+constexpr int BLK_STREAM = 128;  // HBM-bound reduced kernel: 128-lane workgroups stream ~3 % faster
+                                 // than 256 (interleaved A/B, benchmarks/micro/reduced_variants.hip)
 constexpr long long SMALL_W = 256LL * 256 * 2;  // below this, 64-lane workgroups
 
 }  // namespace
@@ -127,9 +129,9 @@ int launch_reduced(const bisip_ctx *c, const double *theta, int64_t W, double *o
         if (vec) hipLaunchKernelGGL((k_logprob_pd_reduced<P, BLK_SMALL, true>), dim3(grid), dim3(BLK_SMALL), 0, st, a, r);
         else hipLaunchKernelGGL((k_logprob_pd_reduced<P, BLK_SMALL, false>), dim3(grid), dim3(BLK_SMALL), 0, st, a, r);
     } else {
-        const unsigned grid = (unsigned)((W + BLK_LARGE - 1) / BLK_LARGE);
-        if (vec) hipLaunchKernelGGL((k_logprob_pd_reduced<P, BLK_LARGE, true>), dim3(grid), dim3(BLK_LARGE), 0, st, a, r);
-        else hipLaunchKernelGGL((k_logprob_pd_reduced<P, BLK_LARGE, false>), dim3(grid), dim3(BLK_LARGE), 0, st, a, r);
+        const unsigned grid = (unsigned)((W + BLK_STREAM - 1) / BLK_STREAM);
+        if (vec) hipLaunchKernelGGL((k_logprob_pd_reduced<P, BLK_STREAM, true>), dim3(grid), dim3(BLK_STREAM), 0, st, a, r);
+        else hipLaunchKernelGGL((k_logprob_pd_reduced<P, BLK_STREAM, false>), dim3(grid), dim3(BLK_STREAM), 0, st, a, r);
     }
     HIP_TRY(hipGetLastError());
     return BISIP_OK;
