@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""BASELINE config 4: Debye decomposition (PolynomialDecomposition c_exp=1, 40 relaxation
+modes => the bundled 20-frequency grid, poly_deg 5), 32768 walkers sharded across the GPUs
+of one node, one RCCL all-gather of the just-updated rows per stretch half-step.
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P benchmarks/cfg4_sampler.py --steps 200
+
+With one rank it still runs the sharded path (eval -> all_gather -> apply) so the per
+half-step cost of the collective is visible on a single GPU.  Prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--walkers', type=int, default=32768)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--rng', default='philox')
+    ap.add_argument('--fused', action='store_true', help='single-rank fused path (no collective)')
+    args = ap.parse_args()
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    torch.cuda.set_device(local_rank)
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29512')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+
+    import bisip_amd
+    from bisip_amd.sampler import DeviceEnsembleSampler
+    m = bisip_amd.PolynomialDecomposition(bisip_amd.DataFiles()['SIP-K389175'], nwalkers=args.walkers,
+                                          nsteps=args.steps, device=local_rank)
+    assert m.taus.size == 40 and m.data['N'] == 20
+    ctx = m._context()
+    lo, hi = m.param_bounds
+    np.random.seed(2024)
+    centre = np.array([1.0, 0.005, -0.003, -0.001, 0.0005, 0.0002, 0.00001])
+    p0 = centre + 1e-4 * np.random.randn(args.walkers, 7)
+
+    def make():
+        np.random.seed(7)
+        return DeviceEnsembleSampler(args.walkers, 7, ctx, rng=args.rng, seed=11, distributed=True,
+                                     force_sharded_path=not args.fused)
+    make().run_mcmc(p0, 5)
+    s = make()
+    dist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    s.run_mcmc(p0, args.steps)
+    torch.cuda.synchronize(); dist.barrier()
+    dt = time.perf_counter() - t0
+    if rank == 0:
+        print(json.dumps({'config': 'cfg4 Debye decomposition S=40 N=20 P=5', 'walkers': args.walkers,
+                          'n_gpus': world, 'steps': args.steps, 'rng': args.rng,
+                          'path': 'fused (no collective)' if args.fused else 'eval -> all_gather -> apply',
+                          'seconds': round(dt, 4), 'it_per_s': round(args.steps / dt, 1),
+                          'walker_steps_per_s': float('%.4g' % (args.steps * args.walkers / dt)),
+                          'us_per_half_step': round(s.timing['steps_s'] / args.steps / 2 * 1e6, 1),
+                          'timing_s': {k: round(v, 4) for k, v in s.timing.items()},
+                          'acceptance': round(float(s.acceptance_fraction.mean()), 3)}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -118,11 +118,23 @@ class _SamplerBase:
 
     def reset(self):
         self.iteration = 0
-        self._chain = np.empty((0, self.nwalkers, self.ndim))
-        self._log_prob = np.empty((0, self.nwalkers))
+        self._chain_parts = []      # one (n, W, ndim) array per run_mcmc call
+        self._log_prob_parts = []
         self._accepted = np.zeros(self.nwalkers)
         self._coords = None
         self._lp = None
+
+    @property
+    def _chain(self):
+        if len(self._chain_parts) > 1:
+            self._chain_parts = [np.concatenate(self._chain_parts, axis=0)]
+        return self._chain_parts[0] if self._chain_parts else np.empty((0, self.nwalkers, self.ndim))
+
+    @property
+    def _log_prob(self):
+        if len(self._log_prob_parts) > 1:
+            self._log_prob_parts = [np.concatenate(self._log_prob_parts, axis=0)]
+        return self._log_prob_parts[0] if self._log_prob_parts else np.empty((0, self.nwalkers))
 
     def _check_initial(self, initial_state):
         p0 = np.array(initial_state, dtype=np.float64, copy=True)
@@ -144,8 +156,8 @@ class _SamplerBase:
             raise ValueError('At least one parameter value was NaN')
 
     def _append(self, chain, logp):
-        self._chain = np.concatenate([self._chain, chain], axis=0)
-        self._log_prob = np.concatenate([self._log_prob, logp], axis=0)
+        self._chain_parts.append(chain)
+        self._log_prob_parts.append(logp)
         self.iteration += chain.shape[0]
 
     # chain access: chain[discard + thin - 1 : iteration : thin]
@@ -344,7 +356,7 @@ class DeviceEnsembleSampler(_SamplerBase):
 
     def __init__(self, nwalkers, ndim, ctx=None, a=2.0, live_dangerously=False, group=None,
                  distributed=False, backend=None, chunk=None, rng='numpy', seed=None,
-                 n_ensembles=1):
+                 n_ensembles=1, force_sharded_path=False):
         if rng not in ('numpy', 'philox'):
             raise ValueError("rng must be 'numpy' or 'philox'")
         # n_ensembles > 1: independent ensembles of `nwalkers` walkers each (batch of spectra),
@@ -361,6 +373,8 @@ class DeviceEnsembleSampler(_SamplerBase):
         self.backend = backend if backend is not None else HipStretchBackend(ctx)
         self.chunk = chunk
         self.rng = rng
+        # run eval -> all_gather -> apply even with one rank (benchmarks the sharded path)
+        self.force_sharded_path = bool(force_sharded_path)
         super().__init__(int(nwalkers) * self.n_ensembles, ndim, a, live_dangerously, group, distributed)
         # philox key: explicit seed, else drawn from the (seeded) private RandomState
         # (never in 'numpy' mode: that stream must stay aligned with EnsembleSampler's)
@@ -416,9 +430,13 @@ class DeviceEnsembleSampler(_SamplerBase):
             self._upload_state(p0)
         nsteps = int(nsteps)
         nh = (W + 1) // 2                       # slots per half (the first half gets the odd one)
-        chains, logps = [], []
+        import time
+        chain_host = np.empty((nsteps, W, ndim))
+        logp_host = np.empty((nsteps, W))
+        self.timing = dict(stream_s=0.0, steps_s=0.0, chain_copy_s=0.0)  # where a run spends its time
         done = 0
         while done < nsteps:
+            t_a = time.perf_counter()
             n = min(self._chunk_steps(nsteps), nsteps - done)
             st = dict(self._dev)
             st['nh'] = nh
@@ -448,7 +466,9 @@ class DeviceEnsembleSampler(_SamplerBase):
                 be.draw(st, self.walkers_per_ensemble, self.a, self.seed, self.iteration + done, n)
             st['chain'] = be.empty((n, W, ndim), torch.float64)
             st['logp_chain'] = be.empty((n, W), torch.float64)
-            if self._world == 1:
+            be.synchronize()
+            t_b = time.perf_counter()
+            if self._world == 1 and not self.force_sharded_path:
                 be.run(st, n)
             else:
                 import torch.distributed as dist
@@ -463,12 +483,17 @@ class DeviceEnsembleSampler(_SamplerBase):
                         dist.all_gather_into_tensor(gathered, block, group=self._group)
                         be.apply(st, k, h, ns, gathered, pad, self._world)
             be.synchronize()
+            t_c = time.perf_counter()
             if int(st['status'].cpu()[0]) & 1:
                 raise ValueError('Probability function returned NaN')
-            chains.append(st['chain'].cpu().numpy())
-            logps.append(st['logp_chain'].cpu().numpy())
+            torch.from_numpy(chain_host[done:done + n]).copy_(st['chain'])
+            torch.from_numpy(logp_host[done:done + n]).copy_(st['logp_chain'])
             done += n
-        self._append(np.concatenate(chains, axis=0), np.concatenate(logps, axis=0))
+            t_d = time.perf_counter()
+            self.timing['stream_s'] += t_b - t_a
+            self.timing['steps_s'] += t_c - t_b
+            self.timing['chain_copy_s'] += t_d - t_c
+        self._append(chain_host, logp_host)
         self._accepted = self._dev['naccept'].cpu().numpy().astype(np.float64)
         self._coords = self._dev['coords'].cpu().numpy()
         self._lp = self._dev['logp'].cpu().numpy()

@@ -267,3 +267,77 @@ def test_fit_runs_and_matches_oracle_replay():
     assert pct.shape == (3, 2, 20)
     with pytest.warns(UserWarning):
         m.get_param_mean()
+
+
+# ----------------------------------------------------------------------------------
+# unusual shapes: frequency counts that are not multiples of anything, extreme
+# polynomial degrees / mode counts -- checked against the (golden-pinned) oracle
+# ----------------------------------------------------------------------------------
+
+def _synthetic_problem(n_freq, idx=1):
+    from bisip_amd.synthetic import synthetic_columns
+    from bisip_amd.utils import columns_to_data
+    return columns_to_data(synthetic_columns(n_freq, idx), 'mrad')
+
+
+@pytest.mark.parametrize('n_freq,poly_deg,c_exp', [(1, 0, 1.0), (3, 1, 0.5), (17, 2, 1.0), (20, 7, 0.8),
+                                                     (33, 5, 1.0), (100, 3, 0.3), (200, 5, 1.0),
+                                                     (12, 10, 1.0)])
+def test_polydecomp_unusual_shapes(n_freq, poly_deg, c_exp):
+    import oracle
+    from bisip_amd import _hip
+    d = _synthetic_problem(n_freq)
+    per = np.log10(1. / d['w'])
+    lt = np.linspace(np.floor(per.min() - 1), np.floor(per.max() + 1), max(2 * n_freq, 2))
+    taus, log_taus = 10 ** lt, np.array([lt ** i for i in range(poly_deg + 1)])
+    bounds = np.array([[0.9] + [-1.0] * (poly_deg + 1), [1.1] + [1.0] * (poly_deg + 1)])
+    prob = oracle.OracleProblem('PolynomialDecomposition', d['w'], d['zn'], d['zn_err'], bounds,
+                                taus=taus, log_taus=log_taus, c_exp=c_exp)
+    rng = np.random.RandomState(n_freq * 100 + poly_deg)
+    theta = rng.uniform(bounds[0], bounds[1], (700, poly_deg + 2))
+    theta[:350, 1:] *= 1e-3          # a cloud where the fit is decent (small |logp|)
+    want = oracle.logprob(prob, theta, n_threads=4)
+    variants = ['reduced', 'collapsed'] + (['faithful'] if poly_deg <= 7 else [])
+    for v in variants:
+        ctx = _hip.HipContext(0, d['w'], d['zn'], d['zn_err'], bounds, poly_deg=poly_deg, c_exp=c_exp,
+                              taus=taus, log_taus=log_taus, variant=v)
+        assert_logp_close(ctx.logprob(theta), want)
+        if v == 'collapsed':
+            assert_Z_close(ctx.forward(theta[:50]), oracle.forward(prob, theta[:50]))
+        ctx.close()
+
+
+@pytest.mark.parametrize('model,n_modes,n_freq', [('PeltonColeCole', 4, 7), ('PeltonColeCole', 5, 45),
+                                                   ('PeltonColeCole', 1, 1), ('Dias2000', 0, 5),
+                                                   ('Dias2000', 0, 130), ('Shin2015', 0, 3),
+                                                   ('Shin2015', 0, 77)])
+def test_other_models_unusual_shapes(model, n_modes, n_freq):
+    import oracle
+    from bisip_amd import _hip
+    from bisip_amd.batch import default_params
+    d = _synthetic_problem(n_freq, 2)
+    bounds = np.array(list(default_params(model, n_modes=n_modes).values()), float).T
+    kw = dict(n_modes=n_modes) if model == 'PeltonColeCole' else {}
+    prob = oracle.OracleProblem(model, d['w'], d['zn'], d['zn_err'], bounds, **kw)
+    rng = np.random.RandomState(n_freq)
+    theta = rng.uniform(bounds[0], bounds[1], (900, bounds.shape[1]))
+    ctx = _hip.HipContext(MODEL_IDS[model], d['w'], d['zn'], d['zn_err'], bounds, **kw)
+    assert_logp_close(ctx.logprob(theta), oracle.logprob(prob, theta, n_threads=4))
+    assert_Z_close(ctx.forward(theta[:64]), oracle.forward(prob, theta[:64]))
+    ctx.close()
+
+
+def test_unsupported_shapes_fail_loudly():
+    from bisip_amd import _hip
+    d = _synthetic_problem(8)
+    bounds6 = np.array([[0.9] + [0.0] * 18, [1.1] + [1.0] * 18])
+    with pytest.raises(ValueError, match='ndim'):
+        _hip.HipContext(1, d['w'], d['zn'], d['zn_err'], bounds6, n_modes=6)          # ndim 19 > 16
+    lt = np.linspace(-6, 2, 16)
+    with pytest.raises(RuntimeError, match='poly_deg'):                                # status -4
+        _hip.HipContext(0, d['w'], d['zn'], d['zn_err'], bounds6[:, :13], poly_deg=11, taus=10 ** lt,
+                        log_taus=np.array([lt ** i for i in range(12)]))
+    bad = d['zn_err'].copy()
+    bad[0, 0] = 0.0
+    with pytest.raises(ValueError, match='zn_err'):
+        _hip.HipContext(2, d['w'], d['zn'], bad, np.array([[0.9, 0, -20, 0, 0], [1.1, 1, 0, 150, 1.0]]))
