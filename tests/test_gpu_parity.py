@@ -341,3 +341,34 @@ def test_unsupported_shapes_fail_loudly():
     bad[0, 0] = 0.0
     with pytest.raises(ValueError, match='zn_err'):
         _hip.HipContext(2, d['w'], d['zn'], bad, np.array([[0.9, 0, -20, 0, 0], [1.1, 1, 0, 150, 1.0]]))
+
+
+def test_device_entry_points_are_graph_capturable():
+    """bisip_logprob_dev / bisip_forward_dev do no allocation and no synchronisation, so a
+    caller can capture them in a hipGraph and replay."""
+    import torch
+    path = [p for p in golden_cases() if 'case16_' in p][0]
+    g = np.load(path)
+    ctx = make_ctx(g, 'PeltonColeCole')
+    theta = torch.from_numpy(np.ascontiguousarray(g['theta'][:64])).cuda()
+    out = torch.zeros(64, dtype=torch.float64, device='cuda')
+    Z = torch.zeros((64, 2, g['w'].size), dtype=torch.float64, device='cuda')
+    side = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        ctx.logprob_dev(theta.data_ptr(), 64, out.data_ptr(), side.cuda_stream)   # warm-up outside capture
+        torch.cuda.synchronize()
+        with torch.cuda.graph(graph, stream=side):
+            ctx.logprob_dev(theta.data_ptr(), 64, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            ctx.forward_dev(theta.data_ptr(), 64, Z.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    want = ctx.logprob(g['theta'][:64])
+    for rep in range(3):
+        theta.copy_(torch.from_numpy(np.ascontiguousarray(g['theta'][:64][::-1].copy() if rep % 2 else g['theta'][:64])))
+        out.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        ref = want[::-1] if rep % 2 else want
+        assert np.array_equal(np.isfinite(got), np.isfinite(ref))
+        assert np.array_equal(got[np.isfinite(ref)], ref[np.isfinite(ref)])
+    ctx.close()
