@@ -21,7 +21,7 @@ for name, model, N, W, kw in [('PD reduced N32', 'pd', 32, 1 << 22, {}), ('CC D2
     print(json.dumps({'case': name + ' bisip_logprob (host buffers, pageable)', 'W': W,
                       'evals_per_s': float('%.4g' % (W / dt)), 'GBs_over_pcie': round(W * 8 * (bounds.shape[1] + 1) / dt / 1e9, 2)}))
     # forward kernel, device resident
-    Wf = 1 << 18
+    Wf = 1 << 21
     th = torch.from_numpy(theta[:Wf]).cuda()
     Z = torch.empty((Wf, 2, N), dtype=torch.float64, device='cuda')
     st = torch.cuda.current_stream()

@@ -153,9 +153,9 @@ template <class M>
 int launch_forward(const bisip_ctx *c, const double *theta, int64_t W, double *Z, hipStream_t st)
 {
     const LaunchArgs a = make_args(c, theta, Z, W, c->d_cb);
-    const long long total = (long long)W * c->N;
-    const unsigned grid = (unsigned)((total + 255) / 256);
-    hipLaunchKernelGGL((k_forward<M>), dim3(grid), dim3(256), 0, st, a);
+    const unsigned grid = (unsigned)((W + 63) / 64);
+    if (((uintptr_t)theta % 16) == 0) hipLaunchKernelGGL((k_forward_tiled<M, true>), dim3(grid), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL((k_forward_tiled<M, false>), dim3(grid), dim3(64), 0, st, a);
     HIP_TRY(hipGetLastError());
     return BISIP_OK;
 }
@@ -310,6 +310,7 @@ int dispatch_forward(const bisip_ctx *c, const double *theta, int64_t W, double 
     if (W == 0) return BISIP_OK;
     if (((long long)W * c->N + 255) / 256 > 0x7fffffffLL)
         return fail(BISIP_EINVAL, "W=%lld exceeds the launch grid limit", (long long)W);
+    if (((uintptr_t)theta % 8) || ((uintptr_t)Z % 8)) return fail(BISIP_EINVAL, "buffers must be 8-byte aligned");
     if (c->E > 1) {
         if (W % c->E) return fail(BISIP_EINVAL, "W=%lld is not a multiple of n_spectra=%d", (long long)W, c->E);
         return dispatch_forward_batch(c, theta, W, Z, st);

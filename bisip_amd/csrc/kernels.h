@@ -631,6 +631,73 @@ __global__ __launch_bounds__(256) void k_forward_batch(const BatchArgs a)
 }
 
 // ---------------------------------------------------------------------------------
+// Batched forward(): Z is (W,2,N).  One lane per walker (per-walker setup -- sincos, exp --
+// is computed once, as in the log-prob kernels); a wave evaluates 16 frequencies for its
+// 64 walkers into an LDS tile and streams the tile out so that every store instruction
+// writes whole 128-byte runs of Z.  Bound by writing Z (16*N B per walker).
+// ---------------------------------------------------------------------------------
+template <class M, bool VEC>
+__global__ __launch_bounds__(64) void k_forward_tiled(const LaunchArgs a)
+{
+    constexpr int NDIM = M::NDIM;
+    constexpr int JC = 16;             // frequencies per tile
+    constexpr int ROW = 2 * JC + 1;    // padded tile row (doubles): conflict-light ds_write_b64
+    __shared__ __attribute__((aligned(16))) double lds[64 * NDIM > 64 * ROW ? 64 * NDIM : 64 * ROW];
+    const long long row0 = (long long)blockIdx.x * 64;
+    stage_theta<NDIM, 64, VEC>(a.theta, a.W, row0, lds);
+    __syncthreads();
+    const int lane = threadIdx.x;
+    const long long rows_here = (a.W - row0) < 64 ? (a.W - row0) : 64;
+    double th[NDIM];
+#pragma unroll
+    for (int q = 0; q < NDIM; ++q) th[q] = lds[lane * NDIM + q];
+    __syncthreads();
+    const typename M::Setup s = M::setup(th);
+    const int N = a.N;
+    const bool wide = ((N & 1) == 0) && ((reinterpret_cast<unsigned long long>(a.out) & 15) == 0);
+    for (int j0 = 0; j0 < N; j0 += JC) {
+        const int jn = (N - j0) < JC ? (N - j0) : JC;
+        const double *__restrict__ rec = a.cb + (long long)j0 * M::REC;
+        for (int jj = 0; jj < jn; ++jj, rec += M::REC) {
+            double zr, zi;
+            M::eval(s, rec + 4, zr, zi);
+            lds[lane * ROW + jj] = zr;
+            lds[lane * ROW + JC + jj] = zi;
+        }
+        __syncthreads();
+        // stream the tile out: runs of jn doubles per (walker, part)
+        if (jn == JC && wide) {  // full tile, 16-byte stores (N even, Z 16-byte aligned)
+            const int total2 = (int)rows_here * JC;  // pairs of doubles
+#pragma unroll 4
+            for (int flat = lane; flat < total2; flat += 64) {
+                const int w = flat >> 4, c = (flat & 15) << 1;
+                dbl2 v;
+                v.x = lds[w * ROW + c];
+                v.y = lds[w * ROW + c + 1];
+                __builtin_nontemporal_store(v, reinterpret_cast<dbl2 *>(
+                    a.out + (row0 + w) * 2 * N + (long long)(c >> 4) * N + j0 + (c & 15)));
+            }
+        } else if (jn == JC) {  // full tile: index arithmetic is shifts and masks
+            const int total = (int)rows_here * 2 * JC;
+#pragma unroll 4
+            for (int flat = lane; flat < total; flat += 64) {
+                const int w = flat >> 5, c = flat & 31;
+                a.out[(row0 + w) * 2 * N + (long long)(c >> 4) * N + j0 + (c & 15)] = lds[w * ROW + c];
+            }
+        } else {
+            const int per_walker = 2 * jn;
+            const int total = (int)rows_here * per_walker;
+            for (int flat = lane; flat < total; flat += 64) {
+                const int w = flat / per_walker, c = flat - w * per_walker;
+                const int part = c / jn, jj = c - part * jn;
+                a.out[(row0 + w) * 2 * N + (long long)part * N + j0 + jj] = lds[w * ROW + part * JC + jj];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // Batched forward(): one thread per (walker, frequency); Z is (W,2,N).
 // Per-walker setup is recomputed per thread; this kernel is bound by writing Z.
 // ---------------------------------------------------------------------------------
