@@ -11,28 +11,13 @@ The arithmetic (prior + forward model + Gaussian log-likelihood for every walker
 runs in hand-written gfx950 kernels behind the C ABI of ``include/bisip_hip.h``.
 """
 
-from .models import Inversion
-from .models import PolynomialDecomposition
-from .models import PeltonColeCole
-from .models import ColeCole
-from .models import Dias2000
-from .models import Shin2015
+from .batch import SpectraBatch
 from .data import DataFiles
+from .models import (ColeCole, Dias2000, Inversion, PeltonColeCole, PolynomialDecomposition,
+                     Shin2015)
 from .sampler import DeviceEnsembleSampler, EnsembleSampler
 from .utils import load_data, load_data_batch
-from .batch import SpectraBatch
 
-__all__ = (
-    'Inversion',
-    'PolynomialDecomposition',
-    'PeltonColeCole',
-    'ColeCole',
-    'Dias2000',
-    'Shin2015',
-    'DataFiles',
-    'EnsembleSampler',
-    'DeviceEnsembleSampler',
-    'load_data',
-    'load_data_batch',
-    'SpectraBatch',
-)
+__all__ = ('Inversion', 'PolynomialDecomposition', 'PeltonColeCole', 'ColeCole', 'Dias2000',
+           'Shin2015', 'DataFiles', 'SpectraBatch', 'EnsembleSampler', 'DeviceEnsembleSampler',
+           'load_data', 'load_data_batch')

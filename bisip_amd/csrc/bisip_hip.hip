@@ -53,7 +53,8 @@ struct bisip_ctx {
     double c_exp = 1.0, lconst = 0.0;
     Bounds bounds{};
     int E = 1;                      // spectra in the context (batch of spectra: E > 1)
-    double *d_cb = nullptr;        // records for k_logprob / k_forward: (E, N, REC)
+    double *d_cb = nullptr;        // records for k_forward (and k_logprob of CC/Dias/Shin): (E, N, REC)
+    double *d_cb_lp = nullptr;     // PolynomialDecomposition: 1/sigma-weighted log-prob records (E, N, REC)
     double *d_cb_faithful = nullptr;
     double *d_lconst = nullptr;    // (E,)  batch only
     void *d_red = nullptr;         // (E,) ReducedArgs<P>  batch only
@@ -99,7 +100,7 @@ LaunchArgs make_args(const bisip_ctx *c, const double *theta, double *out, int64
 template <class M>
 int launch_logprob(const bisip_ctx *c, const double *theta, int64_t W, double *out, hipStream_t st)
 {
-    const LaunchArgs a = make_args(c, theta, out, W, c->d_cb);
+    const LaunchArgs a = make_args(c, theta, out, W, c->d_cb_lp ? c->d_cb_lp : c->d_cb);
     const bool vec = ((uintptr_t)theta % 16) == 0;
     if (W < SMALL_W) {
         const unsigned grid = (unsigned)((W + BLK_SMALL - 1) / BLK_SMALL);
@@ -172,7 +173,8 @@ BatchArgs make_batch_args(const bisip_ctx *c, const double *theta, double *out, 
 template <class M>
 int launch_logprob_batch(const bisip_ctx *c, const double *theta, int64_t W, double *out, hipStream_t st)
 {
-    const BatchArgs a = make_batch_args(c, theta, out, W);
+    BatchArgs a = make_batch_args(c, theta, out, W);
+    if (c->d_cb_lp) a.cb = c->d_cb_lp;
     const unsigned grid = (unsigned)((W + 63) / 64);
     if (a.Wp % 64 == 0) hipLaunchKernelGGL((k_logprob_batch<M, true>), dim3(grid), dim3(64), 0, st, a);
     else hipLaunchKernelGGL((k_logprob_batch<M, false>), dim3(grid), dim3(64), 0, st, a);
@@ -372,7 +374,7 @@ template <class M>
 int stretch_generic(const bisip_ctx *c, const StretchArgs &a, StretchKind kind, hipStream_t st)
 {
     GenericLP<M> lp;
-    lp.o = ModelOperands{c->d_cb, c->N, c->lconst};
+    lp.o = ModelOperands{c->d_cb_lp ? c->d_cb_lp : c->d_cb, c->N, c->lconst};
     lp.b = c->bounds;
     return launch_stretch(a, lp, kind, st);
 }
@@ -394,7 +396,7 @@ template <class M, bool U>
 int stretch_generic_batch(const bisip_ctx *c, const StretchArgs &a, long long Wp, StretchKind kind, hipStream_t st)
 {
     BatchGenericLP<M, U> lp;
-    lp.cb = c->d_cb; lp.cb_stride = c->cb_stride; lp.Wp = Wp; lp.lconst = c->d_lconst; lp.N = c->N;
+    lp.cb = c->d_cb_lp ? c->d_cb_lp : c->d_cb; lp.cb_stride = c->cb_stride; lp.Wp = Wp; lp.lconst = c->d_lconst; lp.N = c->N;
     lp.b = c->bounds;
     return launch_stretch(a, lp, kind, st);
 }
@@ -620,7 +622,8 @@ static int build_context(bisip_ctx **out, int device, int model_id, int E, int N
 
     const int rec = model_id == BISIP_MODEL_POLYDECOMP ? 4 + 2 * (P + 1) : 8;
     c->cb_stride = (long long)N * rec;
-    std::vector<double> cb((size_t)E * N * rec, 0.0), lconsts(E);
+    std::vector<double> cb((size_t)E * N * rec, 0.0), lconsts(E), cb_lp;
+    if (model_id == BISIP_MODEL_POLYDECOMP) cb_lp.assign((size_t)E * N * rec, 0.0);
     const int n = P + 2;
     const size_t red_doubles = (size_t)n * (n + 1) / 2 + 2 * (size_t)n + 1;  // == sizeof(ReducedArgs<P>)/8
     std::vector<double> red;
@@ -645,6 +648,16 @@ static int build_context(bisip_ctx **out, int device, int model_id, int E, int N
                 for (int p = 0; p <= P; ++p) {
                     r[4 + p] = o.G_re[(size_t)j * (P + 1) + p];
                     r[4 + P + 1 + p] = o.G_im[(size_t)j * (P + 1) + p];
+                }
+            }
+            for (int j = 0; j < N; ++j) {  // 1/sigma-weighted rows for the collapsed log-prob kernel
+                double *r = &cb_lp[(size_t)e * N * rec + (size_t)j * rec];
+                const long double sr = 1.0L / (long double)erre[j], si = 1.0L / (long double)erre[N + j];
+                r[0] = (double)((long double)zne[j] * sr); r[1] = (double)((long double)zne[N + j] * si);
+                r[2] = (double)(-sr); r[3] = 0.0;
+                for (int p = 0; p <= P; ++p) {
+                    r[4 + p] = (double)(sr * (long double)o.G_re[(size_t)j * (P + 1) + p]);
+                    r[4 + P + 1 + p] = (double)(si * (long double)o.G_im[(size_t)j * (P + 1) + p]);
                 }
             }
             std::vector<double> Rp;
@@ -679,6 +692,7 @@ static int build_context(bisip_ctx **out, int device, int model_id, int E, int N
     }
     c->lconst = lconsts[0];
     if (rc == BISIP_OK) rc = upload(&c->d_cb, cb);
+    if (rc == BISIP_OK && !cb_lp.empty()) rc = upload(&c->d_cb_lp, cb_lp);
     if (rc == BISIP_OK && E > 1) {
         rc = upload(&c->d_lconst, lconsts);
         if (rc == BISIP_OK && !red.empty()) {
@@ -717,6 +731,7 @@ void bisip_ctx_destroy(bisip_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->d_cb) (void)hipFree(c->d_cb);
+    if (c->d_cb_lp) (void)hipFree(c->d_cb_lp);
     if (c->d_cb_faithful) (void)hipFree(c->d_cb_faithful);
     if (c->d_lconst) (void)hipFree(c->d_lconst);
     if (c->d_red) (void)hipFree(c->d_red);

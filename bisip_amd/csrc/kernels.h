@@ -190,11 +190,15 @@ struct PDCollapsed {
         }
         return s;
     }
-    // y - Z with Z = r0 - sum_p b_p G_p
+    // Log-prob records are pre-weighted by 1/sigma (rows of the weighted design matrix):
+    //   rec = ys_re, ys_im, -s_re, pad | s_re*G_re[0..P] | s_im*G_im[0..P]
+    // so (y - Z)/sigma = ys + r0*(-s) + sum_p b_p (s G_p): 2(P+1)+1 FMAs, and the caller
+    // squares without a further multiply.
+    static constexpr bool WEIGHTED = true;
     __device__ static __forceinline__ void residual(const Setup &s, const double *__restrict__ rec,
                                                     double &rr, double &ri)
     {
-        rr = rec[0] - s.r0;
+        rr = fma(s.r0, rec[2], rec[0]);
         ri = rec[1];
 #pragma unroll
         for (int p = 0; p <= P; ++p) {
@@ -222,6 +226,7 @@ template <int D>
 struct ColeCole {
     static constexpr int NDIM = 1 + 3 * D;
     static constexpr int REC = 8;  // y_re y_im iv_re iv_im | w lnw sqrt(w) pad
+    static constexpr bool WEIGHTED = false;
     struct Setup {
         double r0;
         double m[D], lt[D], c[D], cs[D], sn[D];
@@ -285,6 +290,7 @@ struct ColeCole {
 struct Dias {
     static constexpr int NDIM = 5;
     static constexpr int REC = 8;
+    static constexpr bool WEIGHTED = false;
     struct Setup {
         double r0, m, tau, taup, taupp;
         double A, C, teh;  // residual(): r0 m, r0 - A, tau |eta| / sqrt(2)
@@ -339,6 +345,7 @@ struct Dias {
 struct Shin {
     static constexpr int NDIM = 6;
     static constexpr int REC = 8;
+    static constexpr bool WEIGHTED = false;
     struct Setup {
         double invR[2], Q[2], n[2], cs[2], sn[2];
         double n2[2], lq2[2];  // residual(): n log2e, log_Q log2e
@@ -396,7 +403,7 @@ struct Shin {
 // bits whichever kernel evaluates it.
 // ---------------------------------------------------------------------------------
 struct ModelOperands {
-    const double *__restrict__ cb;  // per-frequency records
+    const double *__restrict__ cb;  // per-frequency LOG-PROB records (weighted for PDCollapsed)
     int N;
     double lconst;
 };
@@ -409,11 +416,17 @@ __device__ __forceinline__ double logprob_row(const double (&th)[M::NDIM], const
     const typename M::Setup s = M::setup(th);
     double acc0 = 0.0, acc1 = 0.0;
     const double *__restrict__ rec = o.cb;
+#pragma unroll 2
     for (int j = 0; j < o.N; ++j, rec += M::REC) {
         double rr, ri;
         M::residual(s, rec, rr, ri);
-        acc0 = fma(rr * rr, rec[2], acc0);
-        acc1 = fma(ri * ri, rec[3], acc1);
+        if constexpr (M::WEIGHTED) {
+            acc0 = fma(rr, rr, acc0);
+            acc1 = fma(ri, ri, acc1);
+        } else {
+            acc0 = fma(rr * rr, rec[2], acc0);
+            acc1 = fma(ri * ri, rec[3], acc1);
+        }
     }
     return fma(-0.5, acc0 + acc1, o.lconst);
 }
