@@ -48,6 +48,10 @@ CASES = [
     ('metric PD P5 N32 reduced', 'pd', 32, 1 << 24, dict(variant='reduced')),
     ('metric PD P5 N32 collapsed', 'pd', 32, 1 << 24, dict(variant='collapsed')),
     ('metric PD P5 N32 faithful', 'pd', 32, 1 << 22, dict(variant='faithful')),
+    ('metric PD P5 N32 wave-per-walker (north-star mapping)', 'pd', 32, 1 << 22, dict(variant='wave')),
+    ('cfg3 PD P5 N64 W=65536 wave-per-walker', 'pd', 64, 65536, dict(variant='wave')),
+    ('PD P5 N32 W=4096 wave-per-walker', 'pd', 32, 4096, dict(variant='wave')),
+    ('PD P5 N32 W=4096 collapsed', 'pd', 32, 4096, dict(variant='collapsed')),
     ('PD P5 N32 reduced W=4096', 'pd', 32, 4096, dict(variant='reduced')),
     ('PD P5 N32 reduced W=65536', 'pd', 32, 65536, dict(variant='reduced')),
     ('PD P5 N32 reduced W=1M', 'pd', 32, 1 << 20, dict(variant='reduced')),

@@ -150,6 +150,20 @@ int launch_faithful(const bisip_ctx *c, const double *theta, int64_t W, double *
     return BISIP_OK;
 }
 
+template <int P>
+int launch_wave(const bisip_ctx *c, const double *theta, int64_t W, double *out, hipStream_t st)
+{
+    const LaunchArgs a = make_args(c, theta, out, W, c->d_cb_lp);
+    const size_t lds = (size_t)c->N * (4 + 2 * (P + 1)) * sizeof(double);
+    // persistent waves: 8 workgroups of 4 waves per CU, fewer when there are fewer walkers
+    long long blocks = (W + 3) / 4;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    if (2 * c->N <= 64) hipLaunchKernelGGL((k_logprob_pd_wave<P, 1>), dim3((unsigned)blocks), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((k_logprob_pd_wave<P, 2>), dim3((unsigned)blocks), dim3(256), lds, st, a);
+    HIP_TRY(hipGetLastError());
+    return BISIP_OK;
+}
+
 template <class M>
 int launch_forward(const bisip_ctx *c, const double *theta, int64_t W, double *Z, hipStream_t st)
 {
@@ -281,6 +295,12 @@ int dispatch_logprob(const bisip_ctx *c, const double *theta, int64_t W, double 
         } else if (v == BISIP_VARIANT_COLLAPSED) {
             switch (c->P) {
 #define X(p) case p: return launch_logprob<PDCollapsed<p>>(c, theta, W, out, st);
+                PD_CASES(X)
+#undef X
+            }
+        } else if (v == BISIP_VARIANT_WAVE) {
+            switch (c->P) {
+#define X(p) case p: return launch_wave<p>(c, theta, W, out, st);
                 PD_CASES(X)
 #undef X
             }
@@ -524,6 +544,7 @@ const char *name_for(const bisip_ctx *c)
         switch (effective_variant(c)) {
         case BISIP_VARIANT_REDUCED: return "k_logprob_pd_reduced";
         case BISIP_VARIANT_FAITHFUL: return "k_logprob_pd_faithful";
+        case BISIP_VARIANT_WAVE: return "k_logprob_pd_wave";
         default: return "k_logprob<PDCollapsed>";
         }
     case BISIP_MODEL_COLECOLE: return "k_logprob<ColeCole>";
@@ -750,8 +771,10 @@ int bisip_ctx_set_bounds(bisip_ctx *c, const double *lo, const double *hi)
 int bisip_ctx_set_variant(bisip_ctx *c, int variant)
 {
     if (!c) return fail(BISIP_EINVAL, "null context");
-    if (variant < BISIP_VARIANT_AUTO || variant > BISIP_VARIANT_REDUCED)
+    if (variant < BISIP_VARIANT_AUTO || variant > BISIP_VARIANT_WAVE)
         return fail(BISIP_EINVAL, "bad variant %d", variant);
+    if (variant == BISIP_VARIANT_WAVE && (c->model_id != BISIP_MODEL_POLYDECOMP || c->E > 1 || c->N > 64))
+        return fail(BISIP_EUNSUPPORTED, "the wave-per-walker formulation needs a single-spectrum PolynomialDecomposition with N <= 64");
     if (c->model_id != BISIP_MODEL_POLYDECOMP && variant != BISIP_VARIANT_AUTO &&
         variant != BISIP_VARIANT_COLLAPSED)
         return fail(BISIP_EUNSUPPORTED, "this model has a single formulation");

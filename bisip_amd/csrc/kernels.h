@@ -570,6 +570,68 @@ __global__ __launch_bounds__(BLK) void k_logprob_pd_faithful(const LaunchArgs a,
 }
 
 // ---------------------------------------------------------------------------------
+// PolynomialDecomposition, ONE WAVE PER WALKER (BISIP_VARIANT_WAVE) -- the mapping the
+// north star sketches, built so the design decision in DESIGN.md §3.1 rests on a measurement:
+// the 2N (frequency, part) points of the spectrum are spread over the 64 lanes, the
+// spectrum operands (weighted design rows: ys, -s, s*G[0..P]) are staged through LDS once
+// per workgroup and then held in registers, walkers stream through the wave (theta row in
+// SGPRs), every lane evaluates its own weighted residual and a wavefront butterfly
+// (6 x lane-exchange + add) reduces the 2N squares to one log-prob, written by lane 0.
+// Same operands and arithmetic per point as PDCollapsed; only the summation order over
+// points differs (tree instead of sequential).  T = ceil(2N/64) points per lane, N <= 64.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+template <int P, int T>
+__global__ __launch_bounds__(256) void k_logprob_pd_wave(const LaunchArgs a)
+{
+    constexpr int NDIM = P + 2;
+    constexpr int REC = 4 + 2 * (P + 1);
+    extern __shared__ __attribute__((aligned(16))) double lds_rec[];  // N * REC staged records
+    const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < a.N * REC; i += 256) lds_rec[i] = a.cb[i];
+    __syncthreads();
+    // this lane's points: p = lane + 64*t  ->  (part = p / N, j = p % N)
+    double ys[T], ms[T], g[T][P + 1];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int pt = lane + 64 * t;
+        const bool on = pt < 2 * a.N;
+        const int part = on ? pt / a.N : 0, j = on ? pt - part * a.N : 0;
+        const double *r = lds_rec + j * REC;
+        ys[t] = on ? r[part] : 0.0;
+        ms[t] = (on && part == 0) ? r[2] : 0.0;   // -s_re for real points, 0 for imaginary
+#pragma unroll
+        for (int p = 0; p <= P; ++p) g[t][p] = on ? r[4 + part * (P + 1) + p] : 0.0;
+    }
+    const long long wave = ((long long)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * 256) >> 6;
+    for (long long w = wave; w < a.W; w += nwaves) {
+        const long long wu = (long long)__builtin_amdgcn_readfirstlane((int)(w >> 31)) << 31 |
+                             (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(w & 0x7fffffff));
+        double th[NDIM];
+#pragma unroll
+        for (int q = 0; q < NDIM; ++q) th[q] = a.theta[wu * NDIM + q];   // wave-uniform -> scalar loads
+        double sq = 0.0;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            double r = fma(th[0], ms[t], ys[t]);
+#pragma unroll
+            for (int p = 0; p <= P; ++p) r = fma(th[0] * th[1 + p], g[t][p], r);
+            sq = fma(r, r, sq);
+        }
+        const double chi2 = wave_sum(sq);
+        if (lane == 0)
+            a.out[wu] = in_prior<NDIM>(th, a.b) ? fma(-0.5, chi2, a.lconst) : -__builtin_inf();
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // Batch of independent spectra (BASELINE config 5): E spectra share the model shape and
 // the prior box; rows [e*Wp, (e+1)*Wp) of theta belong to spectrum e, whose operands sit
 // at cb + e*cb_stride.  When a wave never straddles two spectra (UNIFORM: Wp % 64 == 0)

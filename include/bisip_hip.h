@@ -49,6 +49,8 @@ extern "C" {
 #define BISIP_VARIANT_FAITHFUL  1 /* sum_k M_k*K[j,k], the reference's loop structure     */
 #define BISIP_VARIANT_COLLAPSED 2 /* Z_j = R0*(1 - sum_p a_p*G[j,p])                       */
 #define BISIP_VARIANT_REDUCED   3 /* QR-reduced chi^2: (P+2)x(P+2) triangular form         */
+#define BISIP_VARIANT_WAVE      4 /* collapsed operands, one wave per walker, LDS-staged
+                                     spectrum, wavefront-shuffle reduction (N <= 64)        */
 
 /* status codes */
 #define BISIP_OK          0

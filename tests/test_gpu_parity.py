@@ -33,6 +33,8 @@ def variants_for(g, model):
     v = ['reduced', 'collapsed']
     if int(g['poly_deg']) <= 7:
         v.append('faithful')
+    if g['w'].size <= 64:
+        v.append('wave')
     return v
 
 
@@ -100,7 +102,7 @@ def test_ragged_batch_sizes(W):
     prob = _oracle_problem(g, 'PolynomialDecomposition')
     ref_rows = min(W, 512)
     want = oracle.logprob(prob, theta[:ref_rows])
-    for variant in ('reduced', 'collapsed', 'faithful'):
+    for variant in ('reduced', 'collapsed', 'faithful', 'wave'):
         ctx = make_ctx(g, 'PolynomialDecomposition', variant)
         got = ctx.logprob(theta)
         assert got.shape == (W,)
@@ -157,7 +159,7 @@ def test_full_size_properties():
     perm = rng.permutation(W)
     assert np.array_equal(ctx.logprob(theta[perm]), a[perm])
     assert np.array_equal(np.concatenate([ctx.logprob(theta[:30000]), ctx.logprob(theta[30000:])]), a)
-    for variant in ('collapsed', 'faithful'):
+    for variant in ('collapsed', 'faithful', 'wave'):
         ctx.set_variant(variant)
         assert_logp_close(ctx.logprob(theta), a, 1e-11)
     ctx.close()
@@ -297,7 +299,8 @@ def test_polydecomp_unusual_shapes(n_freq, poly_deg, c_exp):
     theta = rng.uniform(bounds[0], bounds[1], (700, poly_deg + 2))
     theta[:350, 1:] *= 1e-3          # a cloud where the fit is decent (small |logp|)
     want = oracle.logprob(prob, theta, n_threads=4)
-    variants = ['reduced', 'collapsed'] + (['faithful'] if poly_deg <= 7 else [])
+    variants = ['reduced', 'collapsed'] + (['faithful'] if poly_deg <= 7 else []) + \
+        (['wave'] if n_freq <= 64 else [])
     for v in variants:
         ctx = _hip.HipContext(0, d['w'], d['zn'], d['zn_err'], bounds, poly_deg=poly_deg, c_exp=c_exp,
                               taus=taus, log_taus=log_taus, variant=v)
