@@ -63,7 +63,7 @@ SYMBOLS = {
     'bisip_stretch_eval_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(StretchArgs), ctypes.c_void_p]),
     'bisip_stretch_apply_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(StretchArgs), ctypes.c_void_p]),
     'bisip_stretch_run_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(StretchArgs), ctypes.c_int64,
-                                             ctypes.c_int64, ctypes.c_void_p]),
+                                             ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]),
     'bisip_stretch_draw_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_double,
                                               ctypes.c_uint64, ctypes.c_int64, ctypes.c_int64] +
                                [ctypes.c_void_p] * 7),
@@ -286,9 +286,9 @@ class HipContext:
     def stretch_apply_dev(self, args, stream=0):
         _check(self._lib.bisip_stretch_apply_dev(self._h, ctypes.byref(args), ctypes.c_void_p(stream)))
 
-    def stretch_run_dev(self, first_args, W, n_steps, stream=0):
+    def stretch_run_dev(self, first_args, W, n_steps, thin_by=1, stream=0):
         _check(self._lib.bisip_stretch_run_dev(self._h, ctypes.byref(first_args), int(W),
-                                               int(n_steps), ctypes.c_void_p(stream)))
+                                               int(n_steps), int(thin_by), ctypes.c_void_p(stream)))
 
     def stretch_draw_dev(self, W, a, seed, step0, n_steps, perm, active, partner, zz, factor, logu,
                          stream=0):

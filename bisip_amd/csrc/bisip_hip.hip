@@ -847,9 +847,10 @@ int bisip_stretch_apply_dev(bisip_ctx *c, const bisip_stretch_args *u, void *str
 }
 
 int bisip_stretch_run_dev(bisip_ctx *c, const bisip_stretch_args *first, int64_t W, int64_t n_steps,
-                          void *stream)
+                          int64_t thin_by, void *stream)
 {
     if (!c || !first) return fail(BISIP_EINVAL, "null argument");
+    if (thin_by < 1 || n_steps % thin_by) return fail(BISIP_EINVAL, "n_steps=%lld must be a multiple of thin_by=%lld", (long long)n_steps, (long long)thin_by);
     if (W < 2 || n_steps < 0) return fail(BISIP_EINVAL, "bad W=%lld or n_steps=%lld", (long long)W, (long long)n_steps);
     if (!first->coords || !first->logp || !first->active || !first->partner || !first->zz ||
         !first->factor || !first->logu || !first->status)
@@ -863,8 +864,10 @@ int bisip_stretch_run_dev(bisip_ctx *c, const bisip_stretch_args *first, int64_t
             u.active = first->active + off; u.partner = first->partner + off;
             u.zz = first->zz + off; u.factor = first->factor + off; u.logu = first->logu + off;
             u.n_slots = h ? W / 2 : nh;
-            u.chain_row = first->chain_row ? first->chain_row + k * W * c->ndim : nullptr;
-            u.logp_row = first->logp_row ? first->logp_row + k * W : nullptr;
+            const bool store = ((k + 1) % thin_by) == 0;   // the walkers of BOTH halves of a stored step
+            const int64_t srow = k / thin_by;
+            u.chain_row = (store && first->chain_row) ? first->chain_row + srow * W * c->ndim : nullptr;
+            u.logp_row = (store && first->logp_row) ? first->logp_row + srow * W : nullptr;
             int rc = dispatch_stretch(c, to_device_args(&u), u.walkers_per_spectrum, STRETCH_HALF, (hipStream_t)stream);
             if (rc != BISIP_OK) return rc;
         }

@@ -117,7 +117,8 @@ class _SamplerBase:
         self.reset()
 
     def reset(self):
-        self.iteration = 0
+        self.iteration = 0          # stored samples
+        self._moves_done = 0        # stretch-move iterations performed (= stored * thin_by)
         self._chain_parts = []      # one (n, W, ndim) array per run_mcmc call
         self._log_prob_parts = []
         self._accepted = np.zeros(self.nwalkers)
@@ -177,7 +178,7 @@ class _SamplerBase:
 
     @property
     def acceptance_fraction(self):
-        return self._accepted / float(self.iteration)
+        return self._accepted / float(self._moves_done)
 
     @property
     def random_state(self):
@@ -241,16 +242,18 @@ class EnsembleSampler(_SamplerBase):
             accepted[idx] = block[:, ndim + 1] > 0
         self._accepted += accepted
 
-    def run_mcmc(self, initial_state, nsteps, progress=False, **kwargs):
-        """Advance the ensemble ``nsteps`` iterations from ``initial_state`` (W, ndim);
-        pass ``None`` to continue from the last position."""
+    def run_mcmc(self, initial_state, nsteps, progress=False, thin_by=1, **kwargs):
+        """Store ``nsteps`` samples, one every ``thin_by`` iterations (emcee's ``thin_by``),
+        starting from ``initial_state`` (W, ndim); pass ``None`` to continue."""
         if initial_state is None:
             if self._coords is None:
                 raise ValueError('Cannot have `initial_state=None` if run_mcmc has never been called.')
         else:
             self._coords = self._check_initial(initial_state)
             self._lp = self.compute_log_prob(self._coords)
-        nsteps = int(nsteps)
+        nsteps, thin_by = int(nsteps), int(thin_by)
+        if thin_by < 1:
+            raise ValueError('thin_by must be >= 1')
         chain = np.empty((nsteps, self.nwalkers, self.ndim))
         logp = np.empty((nsteps, self.nwalkers))
         it = range(nsteps)
@@ -261,10 +264,12 @@ class EnsembleSampler(_SamplerBase):
             except ImportError:
                 pass
         for i in it:
-            self._stretch_iteration()
+            for _ in range(thin_by):
+                self._stretch_iteration()
             chain[i] = self._coords
             logp[i] = self._lp
         self._append(chain, logp)
+        self._moves_done += nsteps * thin_by
         return self._coords.copy(), self._lp.copy()
 
 
@@ -294,7 +299,9 @@ class HipStretchBackend:
     def logprob(self, coords_t, out_t):
         self.ctx.logprob_dev(coords_t.data_ptr(), coords_t.shape[0], out_t.data_ptr(), self.stream())
 
-    def _args(self, st, k, h, n_slots):
+    def _args(self, st, k, h, n_slots, base=False):
+        """Pointers of iteration k / half h of the resident chunk.  ``base`` = the chunk's
+        first rows regardless of thinning (what bisip_stretch_run_dev wants)."""
         from ._hip import StretchArgs
         a = StretchArgs()
         a.walkers_per_spectrum = st.get('wp', 0)
@@ -308,8 +315,11 @@ class HipStretchBackend:
         a.logu = st['logu'].data_ptr() + 8 * off
         a.n_slots = n_slots
         W, ndim = st['coords'].shape
-        a.chain_row = st['chain'].data_ptr() + 8 * k * W * ndim
-        a.logp_row = st['logp_chain'].data_ptr() + 8 * k * W
+        thin = st.get('thin', 1)
+        if base or (k + 1) % thin == 0:      # only every thin-th iteration is stored
+            row = 0 if base else k // thin
+            a.chain_row = st['chain'].data_ptr() + 8 * row * W * ndim
+            a.logp_row = st['logp_chain'].data_ptr() + 8 * row * W
         a.naccept = st['naccept'].data_ptr()
         a.status = st['status'].data_ptr()
         return a
@@ -333,7 +343,27 @@ class HipStretchBackend:
         """All n_steps iterations of a chunk in one C call (2 launches per step, no host
         round trip)."""
         W = st['coords'].shape[0]
-        self.ctx.stretch_run_dev(self._args(st, 0, 0, (W + 1) // 2), W, n_steps, self.stream())
+        self.ctx.stretch_run_dev(self._args(st, 0, 0, (W + 1) // 2, base=True), W, n_steps,
+                                 st.get('thin', 1), self.stream())
+
+    def host_buffer(self, shape):
+        """Pinned host memory for big chains: slabs come back at PCIe rate (~55 GB/s vs ~13
+        pageable); small chains stay pageable (pinning costs more than it saves)."""
+        nbytes = 8 * int(np.prod(shape))
+        return self.torch.empty(shape, dtype=self.torch.float64, pin_memory=nbytes >= (32 << 20))
+
+    def copy_out(self, dst_host, src_dev):
+        """Asynchronous device->host copy on a side stream, ordered after the kernels queued
+        so far; the next chunk's kernels overlap with it."""
+        torch = self.torch
+        if not hasattr(self, '_copy_stream'):
+            self._copy_stream = torch.cuda.Stream(self.device)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self._copy_stream.wait_event(ev)
+        with torch.cuda.stream(self._copy_stream):
+            dst_host.copy_(src_dev, non_blocking=True)
+        src_dev.record_stream(self._copy_stream)
 
     def draw(self, st, W, a, seed, step0, n_steps):
         self.ctx.stretch_draw_dev(W, a, seed, step0, n_steps, st['perm'].data_ptr(),
@@ -382,6 +412,7 @@ class DeviceEnsembleSampler(_SamplerBase):
         if rng == 'philox':
             self.seed = int(seed) if seed is not None else int(self._random.randint(0, 2 ** 31 - 1))
         self._dev = None
+        self._iterations_run = 0   # philox counter: iterations done so far (stored or not)
 
     def _upload_state(self, coords, lp=None):
         import torch
@@ -406,7 +437,11 @@ class DeviceEnsembleSampler(_SamplerBase):
         per_step = self.nwalkers * (8 * self.ndim + 8 + 3 * 8 + 2 * 4)
         return max(1, min(nsteps, (256 << 20) // per_step))
 
-    def run_mcmc(self, initial_state, nsteps, progress=False, **kwargs):
+    def run_mcmc(self, initial_state, nsteps, progress=False, thin_by=1, **kwargs):
+        """Store ``nsteps`` samples, one every ``thin_by`` iterations; the ensemble, the
+        random stream and the chain slab of each chunk stay on the device, chain slabs
+        return to pinned host memory asynchronously while the next chunk runs."""
+        import time
         import torch
         be = self.backend
         W, ndim = self.nwalkers, self.ndim
@@ -428,31 +463,33 @@ class DeviceEnsembleSampler(_SamplerBase):
                             raise ValueError(f'Initial state of ensemble {e} has a large condition number.')
             self._check_coords(p0)
             self._upload_state(p0)
-        nsteps = int(nsteps)
+        nsteps, thin_by = int(nsteps), int(thin_by)
+        if thin_by < 1:
+            raise ValueError('thin_by must be >= 1')
         nh = (W + 1) // 2                       # slots per half (the first half gets the odd one)
-        import time
-        chain_host = np.empty((nsteps, W, ndim))
-        logp_host = np.empty((nsteps, W))
-        self.timing = dict(stream_s=0.0, steps_s=0.0, chain_copy_s=0.0)  # where a run spends its time
-        done = 0
+        chain_host = be.host_buffer((nsteps, W, ndim))
+        logp_host = be.host_buffer((nsteps, W))
+        self.timing = dict(stream_s=0.0, enqueue_s=0.0, drain_s=0.0)  # where a run spends its time
+        done = 0                                 # stored samples so far
+        it0 = self._iterations_run
         while done < nsteps:
             t_a = time.perf_counter()
-            n = min(self._chunk_steps(nsteps), nsteps - done)
+            ns = min(max(1, self._chunk_steps(nsteps * thin_by) // thin_by), nsteps - done)
+            n = ns * thin_by                     # iterations in this chunk
             st = dict(self._dev)
             st['nh'] = nh
+            st['thin'] = thin_by
             if self.n_ensembles > 1:
                 st['wp'] = self.walkers_per_ensemble
-            counts = np.empty((n, 2), np.int64)
-            counts[:, 0], counts[:, 1] = nh, W // 2
             if self.rng == 'numpy':
-                # RNG stream for n steps, drawn on the host in the documented order
+                # RNG stream for n iterations, drawn on the host in the documented order
                 host = dict(active=np.zeros((n, 2, nh), np.int32), partner=np.zeros((n, 2, nh), np.int32),
                             zz=np.ones((n, 2, nh)), factor=np.zeros((n, 2, nh)), logu=np.zeros((n, 2, nh)))
                 for k in range(n):
                     for h, half in enumerate(draw_step(self._random, W, ndim, self.a)):
-                        ns = len(half['active'])
+                        m = len(half['active'])
                         for name in host:
-                            host[name][k, h, :ns] = half[name]
+                            host[name][k, h, :m] = half[name]
                 for name, arr in host.items():
                     st[name] = be.tensor(arr)
             else:
@@ -463,10 +500,9 @@ class DeviceEnsembleSampler(_SamplerBase):
                                  ('zz', torch.float64), ('factor', torch.float64),
                                  ('logu', torch.float64)):
                     st[name] = be.empty((n, 2, nh), dt)
-                be.draw(st, self.walkers_per_ensemble, self.a, self.seed, self.iteration + done, n)
-            st['chain'] = be.empty((n, W, ndim), torch.float64)
-            st['logp_chain'] = be.empty((n, W), torch.float64)
-            be.synchronize()
+                be.draw(st, self.walkers_per_ensemble, self.a, self.seed, it0, n)
+            st['chain'] = be.empty((ns, W, ndim), torch.float64)
+            st['logp_chain'] = be.empty((ns, W), torch.float64)
             t_b = time.perf_counter()
             if self._world == 1 and not self.force_sharded_path:
                 be.run(st, n)
@@ -474,26 +510,29 @@ class DeviceEnsembleSampler(_SamplerBase):
                 import torch.distributed as dist
                 for k in range(n):
                     for h in (0, 1):
-                        ns = int(counts[k, h])
-                        lo, hi = shard_range(ns, self._world, self._rank)
-                        pad = -(-ns // self._world)
+                        m = nh if h == 0 else W // 2
+                        lo, hi = shard_range(m, self._world, self._rank)
+                        pad = -(-m // self._world)
                         block = be.zeros((pad, ndim + 2), torch.float64)
-                        be.eval(st, k, h, ns, lo, hi, block)
+                        be.eval(st, k, h, m, lo, hi, block)
                         gathered = be.empty((self._world * pad, ndim + 2), torch.float64)
                         dist.all_gather_into_tensor(gathered, block, group=self._group)
-                        be.apply(st, k, h, ns, gathered, pad, self._world)
-            be.synchronize()
+                        be.apply(st, k, h, m, gathered, pad, self._world)
+            be.copy_out(chain_host[done:done + ns], st['chain'])
+            be.copy_out(logp_host[done:done + ns], st['logp_chain'])
+            done += ns
+            it0 += n
             t_c = time.perf_counter()
-            if int(st['status'].cpu()[0]) & 1:
-                raise ValueError('Probability function returned NaN')
-            torch.from_numpy(chain_host[done:done + n]).copy_(st['chain'])
-            torch.from_numpy(logp_host[done:done + n]).copy_(st['logp_chain'])
-            done += n
-            t_d = time.perf_counter()
             self.timing['stream_s'] += t_b - t_a
-            self.timing['steps_s'] += t_c - t_b
-            self.timing['chain_copy_s'] += t_d - t_c
-        self._append(chain_host, logp_host)
+            self.timing['enqueue_s'] += t_c - t_b
+        t_d = time.perf_counter()
+        be.synchronize()
+        self.timing['drain_s'] = time.perf_counter() - t_d
+        self._iterations_run = it0
+        if int(self._dev['status'].cpu()[0]) & 1:
+            raise ValueError('Probability function returned NaN')
+        self._append(chain_host.numpy(), logp_host.numpy())
+        self._moves_done += nsteps * thin_by
         self._accepted = self._dev['naccept'].cpu().numpy().astype(np.float64)
         self._coords = self._dev['coords'].cpu().numpy()
         self._lp = self._dev['logp'].cpu().numpy()

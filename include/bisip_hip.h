@@ -159,9 +159,11 @@ int bisip_stretch_apply_dev(bisip_ctx *ctx, const bisip_stretch_args *args, void
  * round trip.  `first` holds the pointers of step 0 / half 0; the random-stream arrays are
  * laid out (n_steps, 2, nh) with nh = (W+1)/2 (half 0 has ceil(W/2) slots, half 1
  * floor(W/2)); chain_row / logp_row advance by W*ndim / W per step.  For a batch context W
- * is the TOTAL number of walkers E*Wp and the arrays are (n_steps, 2, E, Wp/2). */
+ * is the TOTAL number of walkers E*Wp and the arrays are (n_steps, 2, E, Wp/2).
+ * thin_by >= 1: only every thin_by-th iteration is stored (chain_row / logp_row then hold
+ * n_steps/thin_by rows; n_steps must be a multiple of thin_by). */
 int bisip_stretch_run_dev(bisip_ctx *ctx, const bisip_stretch_args *first, int64_t W,
-                          int64_t n_steps, void *stream);
+                          int64_t n_steps, int64_t thin_by, void *stream);
 
 /* Fill the random-stream arrays on the device (counter-based Philox4x32-10; the contract
  * is documented in bisip_amd/csrc/sampler_kernels.h and bisip_amd/sampler.py).

@@ -99,9 +99,17 @@ class NumpyStretchBackend:
         coords, logp = st['coords'].numpy(), st['logp'].numpy()
         coords[idx[acc]] = rows[acc]
         logp[idx[acc]] = lps[acc]
-        st['chain'].numpy()[k][idx] = rows
-        st['logp_chain'].numpy()[k][idx] = lps
+        thin = st.get('thin', 1)
+        if (k + 1) % thin == 0:
+            st['chain'].numpy()[k // thin][idx] = rows
+            st['logp_chain'].numpy()[k // thin][idx] = lps
         st['naccept'].numpy()[idx[acc]] += 1
+
+    def host_buffer(self, shape):
+        return torch.zeros(shape, dtype=torch.float64)
+
+    def copy_out(self, dst_host, src_dev):
+        dst_host.copy_(src_dev)
 
     def half(self, st, k, h, n_slots):
         self._commit(st, k, *self._slot(st, k, h, n_slots, 0, n_slots))
