@@ -196,7 +196,7 @@ def main():
             gpu_logp = out_t.cpu().numpy()
             if not args.no_variants:
                 variants = {}
-                for v in ('reduced', 'collapsed', 'faithful'):
+                for v in ('reduced', 'collapsed', 'faithful', 'wave'):
                     ctx.set_variant(v)
                     k = max(3, min(args.steps, 10))
                     _, ms = time_launches(ctx, theta_t, out_t, k, 2, torch)

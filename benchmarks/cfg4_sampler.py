@@ -67,7 +67,7 @@ def main():
                           'path': 'fused (no collective)' if args.fused else 'eval -> all_gather -> apply',
                           'seconds': round(dt, 4), 'it_per_s': round(args.steps / dt, 1),
                           'walker_steps_per_s': float('%.4g' % (args.steps * args.walkers / dt)),
-                          'us_per_half_step': round(s.timing['steps_s'] / args.steps / 2 * 1e6, 1),
+                          'us_per_half_step': round((s.timing['enqueue_s'] + s.timing['drain_s']) / args.steps / 2 * 1e6, 1),
                           'timing_s': {k: round(v, 4) for k, v in s.timing.items()},
                           'acceptance': round(float(s.acceptance_fraction.mean()), 3)}))
     dist.barrier()

@@ -772,27 +772,4 @@ __global__ __launch_bounds__(64) void k_forward_tiled(const LaunchArgs a)
     }
 }
 
-// ---------------------------------------------------------------------------------
-// Batched forward(): one thread per (walker, frequency); Z is (W,2,N).
-// Per-walker setup is recomputed per thread; this kernel is bound by writing Z.
-// ---------------------------------------------------------------------------------
-template <class M>
-__global__ __launch_bounds__(256) void k_forward(const LaunchArgs a)
-{
-    constexpr int NDIM = M::NDIM;
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long total = a.W * (long long)a.N;
-    if (idx >= total) return;
-    const long long wk = idx / a.N;
-    const int j = (int)(idx - wk * a.N);
-    double th[NDIM];
-#pragma unroll
-    for (int q = 0; q < NDIM; ++q) th[q] = a.theta[wk * NDIM + q];
-    const typename M::Setup s = M::setup(th);
-    double zr, zi;
-    M::eval(s, a.cb + (long long)j * M::REC + 4, zr, zi);
-    a.out[wk * 2 * a.N + j] = zr;
-    a.out[wk * 2 * a.N + a.N + j] = zi;
-}
-
 }  // namespace bisip

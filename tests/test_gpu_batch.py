@@ -62,11 +62,8 @@ def test_batch_logprob_and_forward(model, kw, E, Wp):
     if model == 'PolynomialDecomposition':
         okw = dict(poly_deg=batch.poly_deg, c_exp=batch.c_exp, taus=batch.taus, log_taus=batch.log_taus)
     e = E - 1
-    single = _hip.HipContext(batch.ctx._lib and {'PolynomialDecomposition': 0, 'PeltonColeCole': 1,
-                                                 'Dias2000': 2, 'Shin2015': 3}[model],
-                             batch.w[e], batch.zn[e], batch.zn_err[e], batch.param_bounds, **okw)
-    rows = theta[e].copy()
-    rows[:, :] = np.where(np.isfinite(rows), rows, 0)
+    model_id = {'PolynomialDecomposition': 0, 'PeltonColeCole': 1, 'Dias2000': 2, 'Shin2015': 3}[model]
+    single = _hip.HipContext(model_id, batch.w[e], batch.zn[e], batch.zn_err[e], batch.param_bounds, **okw)
     assert np.array_equal(single.logprob(theta[e]), got[e])
     assert_Z_close(Z[e], single.forward(theta[e, :5]), 1e-15)
     with pytest.raises(ValueError):

@@ -282,7 +282,7 @@ def _synthetic_problem(n_freq, idx=1):
     return columns_to_data(synthetic_columns(n_freq, idx), 'mrad')
 
 
-@pytest.mark.parametrize('n_freq,poly_deg,c_exp', [(1, 0, 1.0), (3, 1, 0.5), (17, 2, 1.0), (20, 7, 0.8),
+@pytest.mark.parametrize('n_freq,poly_deg,c_exp', [(1, 0, 1.0), (2, 5, 1.0), (1, 3, 0.5), (3, 1, 0.5), (17, 2, 1.0), (20, 7, 0.8),
                                                      (33, 5, 1.0), (100, 3, 0.3), (200, 5, 1.0),
                                                      (12, 10, 1.0)])
 def test_polydecomp_unusual_shapes(n_freq, poly_deg, c_exp):

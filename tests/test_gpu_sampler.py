@@ -70,7 +70,16 @@ def test_eval_apply_path_single_rank():
     from bisip_amd.sampler import DeviceEnsembleSampler, HipStretchBackend
 
     class SplitBackend(HipStretchBackend):
+        calls = 0
+
+        def run(self, st, n_steps):            # per-iteration driver instead of the fused C loop
+            W = st['coords'].shape[0]
+            for k in range(n_steps):
+                self.half(st, k, 0, (W + 1) // 2)
+                self.half(st, k, 1, W // 2)
+
         def half(self, st, k, h, n_slots):
+            SplitBackend.calls += 1
             # two "ranks" worth of blocks evaluated one after the other, then applied
             world = 3
             pad = -(-n_slots // world)
@@ -93,9 +102,20 @@ def test_eval_apply_path_single_rank():
     np.random.seed(3)
     b = DeviceEnsembleSampler(W, ndim, backend=SplitBackend(ctx))
     b.run_mcmc(p0, 30)
+    assert SplitBackend.calls == 60           # the eval/apply kernels really ran
     assert np.array_equal(a.get_chain(), b.get_chain())
     assert np.array_equal(a.get_log_prob(), b.get_log_prob())
     assert np.array_equal(a.acceptance_fraction, b.acceptance_fraction)
+    # thinning: every 3rd iteration stored, same stream
+    np.random.seed(3)
+    c = DeviceEnsembleSampler(W, ndim, ctx)
+    c.run_mcmc(p0, 10, thin_by=3)
+    assert np.array_equal(c.get_chain(), a.get_chain()[2::3])
+    assert np.array_equal(c.get_log_prob(), a.get_log_prob()[2::3])
+    np.random.seed(3)
+    d = DeviceEnsembleSampler(W, ndim, backend=SplitBackend(ctx))
+    d.run_mcmc(p0, 10, thin_by=3)
+    assert np.array_equal(d.get_chain(), c.get_chain())
     ctx.close()
 
 
