@@ -147,7 +147,7 @@ class Inversion(_utils.utils):
             raise AssertionError('Model is not fitted! Fit the model to a '
                                  'dataset before attempting to plot results.')
 
-    def fit(self, p0=None, pool=None, moves=None, sampler='device'):
+    def fit(self, p0=None, pool=None, moves=None, sampler='device', rng='numpy', thin_by=1):
         """Sample the posterior with the stretch-move ensemble sampler.
 
         Args:
@@ -160,6 +160,11 @@ class Inversion(_utils.utils):
             sampler (str): 'device' (default) keeps the ensemble and the chain on the GPU
                 and runs one fused kernel per half-step; 'host' runs the stretch move in
                 NumPy around the vectorised GPU log-probability.  Same chain either way.
+            rng (str): 'numpy' (default) draws the stretch-move random stream on the host
+                in emcee's order from NumPy's global state (``np.random.seed`` pins the
+                run); 'philox' generates it on the device (2-3x faster for small
+                ensembles, its own reproducible stream).  Device sampler only.
+            thin_by (int): store one sample every ``thin_by`` iterations.
         """
         self._p0 = p0
         self.ndim = self.param_bounds.shape[1]
@@ -173,12 +178,15 @@ class Inversion(_utils.utils):
             self._sampler = emcee.EnsembleSampler(self.nwalkers, self.ndim, ctx.logprob,
                                                   moves=moves, vectorize=True)
         elif sampler == 'device':
-            self._sampler = DeviceEnsembleSampler(self.nwalkers, self.ndim, ctx)
+            self._sampler = DeviceEnsembleSampler(self.nwalkers, self.ndim, ctx, rng=rng)
         elif sampler == 'host':
             self._sampler = EnsembleSampler(self.nwalkers, self.ndim, ctx.logprob)
         else:
             raise ValueError("sampler must be 'device' or 'host'")
-        self._sampler.run_mcmc(self._p0, self.nsteps, progress=True)
+        if moves is not None:
+            self._sampler.run_mcmc(self._p0, self.nsteps, progress=True)
+        else:
+            self._sampler.run_mcmc(self._p0, self.nsteps, progress=True, thin_by=thin_by)
         self.__fitted = True
 
     def get_chain(self, **kwargs):

@@ -375,3 +375,53 @@ def test_device_entry_points_are_graph_capturable():
         assert np.array_equal(np.isfinite(got), np.isfinite(ref))
         assert np.array_equal(got[np.isfinite(ref)], ref[np.isfinite(ref)])
     ctx.close()
+
+
+# ----------------------------------------------------------------------------------
+# corners of the prior box: parameters a hair inside their bounds (tiny delta, m -> 1,
+# c -> 0 and 1, extreme log_tau), where the forward models produce huge or tiny
+# intermediates.  The kernels must agree with the oracle there too (or be non-finite
+# together).
+# ----------------------------------------------------------------------------------
+
+@pytest.mark.parametrize('model,n_modes', [('PeltonColeCole', 1), ('PeltonColeCole', 3), ('Dias2000', 0),
+                                           ('Shin2015', 0), ('PolynomialDecomposition', 0)])
+def test_prior_box_corners(model, n_modes):
+    import itertools
+    import oracle
+    from bisip_amd import _hip
+    from bisip_amd.batch import default_params
+    d = _synthetic_problem(32, 4)
+    bounds = np.array(list(default_params(model, n_modes=n_modes, poly_deg=3).values()), float).T
+    lo, hi = bounds
+    nd = lo.size
+    kw, okw = {}, {}
+    if model == 'PeltonColeCole':
+        kw = okw = dict(n_modes=n_modes)
+    if model == 'PolynomialDecomposition':
+        per = np.log10(1. / d['w'])
+        lt = np.linspace(np.floor(per.min() - 1), np.floor(per.max() + 1), 64)
+        okw = dict(taus=10 ** lt, log_taus=np.array([lt ** i for i in range(4)]), c_exp=1.0)
+        kw = dict(poly_deg=3, **okw)
+    rows = []
+    rng = np.random.RandomState(12)
+    for eps in (1e-3, 1e-9, 1e-15):
+        for _ in range(150):
+            corner = rng.randint(0, 3, nd)            # 0: near lo, 1: near hi, 2: interior
+            t = np.where(corner == 0, eps, np.where(corner == 1, 1 - eps, rng.uniform(0.05, 0.95, nd)))
+            rows.append(lo + t * (hi - lo))
+    theta = np.array(rows)
+    theta = np.minimum(np.maximum(theta, np.nextafter(lo, hi)), np.nextafter(hi, lo))  # strictly inside
+    prob = oracle.OracleProblem(model, d['w'], d['zn'], d['zn_err'], bounds, **okw)
+    with np.errstate(all='ignore'):
+        want = oracle.logprob(prob, theta, n_threads=4)
+    ctx = _hip.HipContext(MODEL_IDS[model], d['w'], d['zn'], d['zn_err'], bounds, **kw)
+    got = ctx.logprob(theta)
+    both = np.isfinite(want) & np.isfinite(got)
+    assert both.mean() > 0.9, 'most corner rows should be finite in both'
+    # wherever the reference is finite the kernel must be finite and agree
+    assert np.isfinite(got[np.isfinite(want)]).all()
+    err = np.abs(got[both] - want[both]) / np.maximum(1.0, np.abs(want[both]))
+    assert err.max() <= 1e-10, err.max()
+    print(f'{model}: {both.sum()}/{len(want)} finite, max rel err {err.max():.2e}')
+    ctx.close()
