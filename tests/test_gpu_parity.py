@@ -425,3 +425,34 @@ def test_prior_box_corners(model, n_modes):
     assert err.max() <= 1e-10, err.max()
     print(f'{model}: {both.sum()}/{len(want)} finite, max rel err {err.max():.2e}')
     ctx.close()
+
+
+def test_plain_c_consumer(tmp_path):
+    """examples/c_abi_demo.c: the boundary is usable from plain C (no Python, no torch)."""
+    import os
+    import subprocess
+    import oracle
+    from conftest import ROOT
+    exe = str(tmp_path / 'c_abi_demo')
+    libdir = os.path.join(ROOT, 'bisip_amd')
+    subprocess.check_call(['gcc', '-std=c99', '-I', os.path.join(ROOT, 'include'),
+                           os.path.join(ROOT, 'examples', 'c_abi_demo.c'), '-L', libdir, '-lbisip_hip',
+                           f'-Wl,-rpath,{libdir}', '-Wl,-rpath,/opt/rocm/lib', '-lm', '-o', exe])
+    out = subprocess.check_output([exe], text=True)
+    vals = {line.split()[0]: float(line.split()[1]) for line in out.strip().splitlines()}
+    # same problem through the oracle
+    N = 8
+    th0 = np.array([1.0, 0.3, -2.0, 0.5])
+    w = 2 * 3.14159265358979323846 * 1000.0 / 4.0 ** np.arange(N)
+    z = th0[0] * (1 - th0[1] * (1 - 1 / (1 + (1j * w * np.exp(th0[2])) ** th0[3])))
+    zn = np.array([z.real, z.imag])
+    zn_err = np.array([np.full(N, 0.01), np.full(N, 0.002)])
+    bounds = np.array([[0.9, 0, -15, 0], [1.1, 1, 5, 1.0]])
+    prob = oracle.OracleProblem('PeltonColeCole', w, zn, zn_err, bounds, n_modes=1)
+    theta = np.array([[1.0, 0.3, -2.0, 0.5], [1.0, 0.3, -2.0, 0.6], [1.05, 0.2, -3.0, 0.4],
+                      [1.2, 0.3, -2.0, 0.5], [1.0, 1.0, -2.0, 0.5]])
+    want = oracle.logprob(prob, theta)
+    got = np.array([vals[f'logp[{i}]'] for i in range(5)])
+    assert_logp_close(got, want, 1e-9)     # the C demo builds its spectrum with its own libm calls
+    assert np.isneginf(got[3]) and np.isneginf(got[4])
+    assert abs(got[0] - vals['const']) < 1e-6
