@@ -21,22 +21,25 @@ def main():
         ('PeltonColeCole n_modes=2 K389175 64x1000 (reference tutorial: 356-435 it/s)',
          bisip_amd.PeltonColeCole, dict(n_modes=2), 64, 1000),
         ('Dias2000 K389175 32x1000 (reference tutorial: 511-533 it/s)', bisip_amd.Dias2000, {}, 32, 1000),
+        ('PolynomialDecomposition K389175 32x5000 (nsteps default)', bisip_amd.PolynomialDecomposition, {}, 32, 5000),
+        ('PeltonColeCole n_modes=2 512 walkers x 1000', bisip_amd.PeltonColeCole, dict(n_modes=2), 512, 1000),
         ('PolynomialDecomposition 4096 walkers x 200', bisip_amd.PolynomialDecomposition, {}, 4096, 200),
         ('PeltonColeCole n_modes=2 4096 walkers x 200', bisip_amd.PeltonColeCole, dict(n_modes=2), 4096, 200),
         ('PolynomialDecomposition 32768 walkers x 50', bisip_amd.PolynomialDecomposition, {}, 32768, 50),
     ]
     for name, cls, kw, W, nsteps in cases:
-        for sampler in ('device-philox', 'device', 'host'):
+        for sampler in ('device-philox-persistent', 'device-philox', 'device', 'host'):
             m = cls(path, nwalkers=W, nsteps=nsteps, **kw)
             lo, hi = m.param_bounds
             np.random.seed(42)
             p0 = np.random.uniform(lo, hi, (W, lo.size))
-            if sampler == 'device-philox':
+            if sampler.startswith('device-philox'):
+                pers = sampler.endswith('persistent')
                 from bisip_amd.sampler import DeviceEnsembleSampler
                 ctx = m._context()
                 ctx.set_bounds(m.param_bounds)
-                DeviceEnsembleSampler(W, lo.size, ctx, rng='philox', seed=1).run_mcmc(p0, 5)
-                smp = DeviceEnsembleSampler(W, lo.size, ctx, rng='philox', seed=1)
+                DeviceEnsembleSampler(W, lo.size, ctx, rng='philox', seed=1, persistent=pers).run_mcmc(p0, 5)
+                smp = DeviceEnsembleSampler(W, lo.size, ctx, rng='philox', seed=1, persistent=pers)
                 t0 = time.perf_counter()
                 smp.run_mcmc(p0, nsteps)
                 dt = time.perf_counter() - t0
@@ -52,7 +55,9 @@ def main():
             print(json.dumps({'case': name, 'sampler': sampler, 'walkers': W, 'nsteps': nsteps,
                               'seconds': round(dt, 4), 'it_per_s': round(nsteps / dt, 1),
                               'walker_steps_per_s': float('%.4g' % (nsteps * W / dt)),
-                              'acceptance': round(float(m.sampler.acceptance_fraction.mean()), 3)}),
+                              'acceptance': round(float(m.sampler.acceptance_fraction.mean()), 3),
+                              'path': getattr(m.sampler, 'last_path', None),
+                              'timing_s': {k: round(v, 4) for k, v in getattr(m.sampler, 'timing', {}).items()}}),
                   flush=True)
 
 

@@ -40,6 +40,16 @@ class StretchArgs(ctypes.Structure):
                 ('walkers_per_spectrum', ctypes.c_int64)]
 
 
+class PersistArgs(ctypes.Structure):
+    """``bisip_persist_args`` of include/bisip_hip.h."""
+    _fields_ = [('coords', ctypes.c_void_p), ('logp', ctypes.c_void_p), ('n_walkers', ctypes.c_int64),
+                ('walkers_per_ensemble', ctypes.c_int64), ('n_steps', ctypes.c_int64),
+                ('step0', ctypes.c_int64), ('thin_by', ctypes.c_int64), ('a', ctypes.c_double),
+                ('seed', ctypes.c_uint64), ('perm', ctypes.c_void_p), ('chain', ctypes.c_void_p),
+                ('logp_chain', ctypes.c_void_p), ('naccept', ctypes.c_void_p),
+                ('status', ctypes.c_void_p)]
+
+
 # name -> (restype, argtypes); every symbol include/bisip_hip.h declares
 SYMBOLS = {
     'bisip_ctx_create': (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int,
@@ -67,6 +77,7 @@ SYMBOLS = {
     'bisip_stretch_draw_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_double,
                                               ctypes.c_uint64, ctypes.c_int64, ctypes.c_int64] +
                                [ctypes.c_void_p] * 7),
+    'bisip_stretch_persistent_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(PersistArgs), ctypes.c_void_p]),
     'bisip_philox4x32': (None, [ctypes.POINTER(ctypes.c_uint32)] * 3),
     'bisip_ctx_ndim': (ctypes.c_int, [ctypes.c_void_p]),
     'bisip_ctx_nfreq': (ctypes.c_int, [ctypes.c_void_p]),
@@ -296,6 +307,18 @@ class HipContext:
                                                 int(n_steps), *[ctypes.c_void_p(p) for p in
                                                                 (perm, active, partner, zz, factor, logu)],
                                                 ctypes.c_void_p(stream)))
+
+
+def _persist_method(self, args, stream=0):
+    """Returns False when the ensemble does not fit one workgroup (status -4)."""
+    rc = self._lib.bisip_stretch_persistent_dev(self._h, ctypes.byref(args), ctypes.c_void_p(stream))
+    if rc == -4:
+        return False
+    _check(rc)
+    return True
+
+
+HipContext.stretch_persistent_dev = _persist_method
 
 
 def philox4x32(counter, key):

@@ -374,11 +374,23 @@ StretchArgs to_device_args(const bisip_stretch_args *u)
     return a;
 }
 
-enum StretchKind { STRETCH_HALF, STRETCH_EVAL };
+enum StretchKind { STRETCH_HALF, STRETCH_EVAL, STRETCH_PERSIST };
+
+// persistent launch parameters travel beside the (unused) StretchArgs through the dispatch
+thread_local const PersistArgs *g_persist = nullptr;
 
 template <class LP>
 int launch_stretch(const StretchArgs &a, const LP &lp, StretchKind kind, hipStream_t st)
 {
+    if (kind == STRETCH_PERSIST) {
+        const PersistArgs &p = *g_persist;
+        const long long nh = (p.W + 1) / 2;
+        const unsigned threads = (unsigned)(((nh + 63) / 64) * 64);
+        const size_t lds = (size_t)p.W * (LP::NDIM + 1) * sizeof(double);
+        hipLaunchKernelGGL((k_stretch_persistent<LP>), dim3((unsigned)p.E), dim3(threads), lds, st, p, lp);
+        HIP_TRY(hipGetLastError());
+        return BISIP_OK;
+    }
     if (kind == STRETCH_HALF) {
         const unsigned grid = (unsigned)((a.n_slots + 63) / 64);
         hipLaunchKernelGGL((k_stretch_half<LP>), dim3(grid), dim3(64), 0, st, a, lp);
@@ -434,7 +446,8 @@ int stretch_reduced_batch(const bisip_ctx *c, const StretchArgs &a, long long Wp
 // iff (Wp/2) % 64 == 0
 int dispatch_stretch_batch(const bisip_ctx *c, const StretchArgs &a, long long Wp, StretchKind kind, hipStream_t st)
 {
-    const bool u = (Wp % 128) == 0;
+    // in the persistent kernel a workgroup IS one ensemble, so the spectrum is always uniform
+    const bool u = (Wp % 128) == 0 || kind == STRETCH_PERSIST;
 #define GEN(M) return u ? stretch_generic_batch<M, true>(c, a, Wp, kind, st) : stretch_generic_batch<M, false>(c, a, Wp, kind, st);
 #define RED(p) return u ? stretch_reduced_batch<p, true>(c, a, Wp, kind, st) : stretch_reduced_batch<p, false>(c, a, Wp, kind, st);
     switch (c->model_id) {
@@ -898,6 +911,34 @@ int bisip_stretch_draw_dev(bisip_ctx *c, int64_t W, double a, uint64_t seed, int
                        (hipStream_t)stream, d);
     HIP_TRY(hipGetLastError());
     return BISIP_OK;
+}
+
+int bisip_stretch_persistent_dev(bisip_ctx *c, const bisip_persist_args *u, void *stream)
+{
+    if (!c || !u) return fail(BISIP_EINVAL, "null argument");
+    if (!u->coords || !u->logp || !u->perm || !u->status) return fail(BISIP_EINVAL, "null buffer");
+    const int64_t Wp = u->walkers_per_ensemble;
+    if (Wp < 2 || u->n_walkers < Wp || u->n_walkers % Wp) return fail(BISIP_EINVAL, "bad walker counts");
+    const int64_t E = u->n_walkers / Wp;
+    if (E != c->E) return fail(BISIP_EINVAL, "n_walkers/walkers_per_ensemble=%lld but the context holds %d spectra", (long long)E, c->E);
+    if (c->E > 1 && (Wp & 1)) return fail(BISIP_EINVAL, "batch context: walkers per spectrum must be even");
+    if (u->thin_by < 1 || u->n_steps < 0 || u->n_steps % u->thin_by) return fail(BISIP_EINVAL, "n_steps must be a multiple of thin_by");
+    if (u->step0 < 0 || u->step0 + u->n_steps > 0xffffffffLL) return fail(BISIP_EINVAL, "step counter out of range");
+    if ((size_t)Wp * (c->ndim + 1) * sizeof(double) > 65536 || (Wp + 1) / 2 > 1024)
+        return fail(BISIP_EUNSUPPORTED, "ensemble of %lld walkers does not fit one workgroup", (long long)Wp);
+    if (u->n_steps == 0) return BISIP_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    PersistArgs p;
+    p.coords = u->coords; p.logp = u->logp; p.W = Wp; p.n_steps = u->n_steps; p.step0 = u->step0;
+    p.thin_by = u->thin_by; p.a = u->a; p.ndim_m1 = (double)(c->ndim - 1);
+    p.seed_lo = (unsigned int)(u->seed & 0xffffffffu); p.seed_hi = (unsigned int)(u->seed >> 32);
+    p.perm = u->perm; p.chain = u->chain; p.logp_chain = u->logp_chain; p.naccept = u->naccept;
+    p.status = u->status; p.E = E;
+    g_persist = &p;
+    StretchArgs dummy{};
+    const int rc = dispatch_stretch(c, dummy, Wp, STRETCH_PERSIST, (hipStream_t)stream);
+    g_persist = nullptr;
+    return rc;
 }
 
 void bisip_philox4x32(const uint32_t *counter, const uint32_t *key, uint32_t *out)

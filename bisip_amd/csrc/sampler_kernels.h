@@ -94,31 +94,43 @@ struct BatchReducedLP {
     }
 };
 
-// proposal + log-prob + accept for slot t; returns the walker's row/log-prob AFTER the move
+// One stretch move: walker i (state row s, log-prob old_lp) along the line through row c.
+// `walker` is the global walker id handed to the log-prob functor (batch contexts pick
+// the spectrum from it).  Returns the row / log-prob AFTER the move.
+template <class LP>
+__device__ __forceinline__ bool stretch_move(const double *s_row, const double *c_row, double old_lp,
+                                             double z, double factor, double logu, const LP &lp,
+                                             int walker, int *status, double (&row)[LP::NDIM],
+                                             double &lp_row)
+{
+    constexpr int NDIM = LP::NDIM;
+    double s[NDIM], q[NDIM];
+#pragma unroll
+    for (int k = 0; k < NDIM; ++k) {
+        const double c = c_row[k];
+        s[k] = s_row[k];
+        const double d = c - s[k];
+        q[k] = c - d * z;
+    }
+    const double new_lp = lp(q, walker);
+    if (new_lp != new_lp) atomicOr(status, 1);
+    const bool acc = (factor + new_lp) - old_lp > logu;
+#pragma unroll
+    for (int k = 0; k < NDIM; ++k) row[k] = acc ? q[k] : s[k];
+    lp_row = acc ? new_lp : old_lp;
+    return acc;
+}
+
+// proposal + log-prob + accept for slot t of a launch-per-half-step kernel
 template <class LP>
 __device__ __forceinline__ bool stretch_slot(const StretchArgs &a, const LP &lp, long long t,
                                              int &walker, double (&row)[LP::NDIM], double &lp_row)
 {
     constexpr int NDIM = LP::NDIM;
     const int i = a.active[t], p = a.partner[t];
-    const double z = a.zz[t];
-    double s[NDIM], q[NDIM];
-#pragma unroll
-    for (int k = 0; k < NDIM; ++k) {
-        const double c = a.coords[(long long)p * NDIM + k];
-        s[k] = a.coords[(long long)i * NDIM + k];
-        const double d = c - s[k];
-        q[k] = c - d * z;
-    }
-    const double old_lp = a.logp[i];
-    const double new_lp = lp(q, i);
-    if (new_lp != new_lp) atomicOr(a.status, 1);
-    const bool acc = (a.factor[t] + new_lp) - old_lp > a.logu[t];
-#pragma unroll
-    for (int k = 0; k < NDIM; ++k) row[k] = acc ? q[k] : s[k];
-    lp_row = acc ? new_lp : old_lp;
     walker = i;
-    return acc;
+    return stretch_move(a.coords + (long long)i * NDIM, a.coords + (long long)p * NDIM, a.logp[i],
+                        a.zz[t], a.factor[t], a.logu[t], lp, i, a.status, row, lp_row);
 }
 
 template <int NDIM>
@@ -217,6 +229,53 @@ __device__ __forceinline__ int perm_inverse(long long y, long long W, long long 
     return (int)((Ainv * v) % W);
 }
 
+// same value as perm_inverse for W <= 2048 (all products < 2^22): 32-bit integers and one
+// fp32 reciprocal multiply instead of two 64-bit software divisions -- the persistent
+// kernel is latency-bound on a single wave, and the divisions were a third of its path
+__device__ __forceinline__ int perm_inverse_small(int y, int W, int Ainv, int B, float invW)
+{
+    int v = y - B;
+    v += (v < 0) ? W : 0;
+    const int x = Ainv * v;
+    int r = x - (int)((float)x * invW) * W;
+    r += (r < 0) ? W : 0;
+    r -= (r >= W) ? W : 0;
+    return r;
+}
+
+// the per-slot draw of the philox contract (shared by k_stretch_draw and the persistent kernel)
+struct SlotDraw {
+    int active, partner;  // walker indices inside the ensemble
+    double z, factor, logu;
+};
+
+template <bool SMALL = false>
+__device__ __forceinline__ SlotDraw draw_slot(long long W, double a, double ndim_m1, unsigned seed_lo,
+                                              unsigned seed_hi, unsigned step, int h, unsigned e,
+                                              long long t, long long A_inv, long long B)
+{
+    const long long Nc = h ? (W + 1) / 2 : W / 2;
+    const unsigned c2 = (unsigned)h | (e << 1);
+    const Philox4 r0 = philox4x32_10((unsigned)t, step, c2, 0u, seed_lo, seed_hi);
+    const Philox4 r1 = philox4x32_10((unsigned)t, step, c2, 1u, seed_lo, seed_hi);
+    const double uz = u53(r0.v[0], r0.v[1]);
+    const long long r = (long long)(((unsigned long long)r0.v[2] * (unsigned long long)Nc) >> 32);
+    const double v = (a - 1.0) * uz + 1.0;
+    SlotDraw d;
+    d.z = (v * v) / a;
+    if constexpr (SMALL) {
+        const float invW = 1.0f / (float)W;
+        d.active = perm_inverse_small((int)(2 * t + h), (int)W, (int)A_inv, (int)B, invW);
+        d.partner = perm_inverse_small((int)(2 * r + (1 - h)), (int)W, (int)A_inv, (int)B, invW);
+    } else {
+        d.active = perm_inverse(2 * t + h, W, A_inv, B);
+        d.partner = perm_inverse(2 * r + (1 - h), W, A_inv, B);
+    }
+    d.factor = ndim_m1 * log(d.z);
+    d.logu = log(u53(r1.v[0], r1.v[1]));
+    return d;
+}
+
 __global__ __launch_bounds__(256) void k_stretch_draw(const DrawArgs d)
 {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -226,26 +285,88 @@ __global__ __launch_bounds__(256) void k_stretch_draw(const DrawArgs d)
     const long long e = (idx / d.nh) % d.E;
     const int h = (int)((idx / (d.nh * d.E)) & 1);
     const long long k = idx / (2 * d.E * d.nh);
-    const long long n0 = (d.W + 1) / 2, n1 = d.W / 2;
-    const long long Ns = h ? n1 : n0, Nc = h ? n0 : n1;
+    const long long Ns = h ? d.W / 2 : (d.W + 1) / 2;
     if (t >= Ns) {  // padding slot of the smaller half
         d.active[idx] = 0; d.partner[idx] = 0; d.zz[idx] = 1.0; d.factor[idx] = 0.0; d.logu[idx] = 0.0;
         return;
     }
-    const long long A_inv = d.perm[3 * k + 1], B = d.perm[3 * k + 2];
-    const unsigned int step = (unsigned int)(d.step0 + k);
-    const unsigned int c2 = (unsigned int)h | ((unsigned int)e << 1);
-    const Philox4 r0 = philox4x32_10((unsigned int)t, step, c2, 0u, d.seed_lo, d.seed_hi);
-    const Philox4 r1 = philox4x32_10((unsigned int)t, step, c2, 1u, d.seed_lo, d.seed_hi);
-    const double uz = u53(r0.v[0], r0.v[1]);
-    const long long r = (long long)(((unsigned long long)r0.v[2] * (unsigned long long)Nc) >> 32);
-    const double v = (d.a - 1.0) * uz + 1.0;
-    const double z = (v * v) / d.a;
-    d.active[idx] = (int)(e * d.W) + perm_inverse(2 * t + h, d.W, A_inv, B);
-    d.partner[idx] = (int)(e * d.W) + perm_inverse(2 * r + (1 - h), d.W, A_inv, B);
-    d.zz[idx] = z;
-    d.factor[idx] = d.ndim_m1 * log(z);
-    d.logu[idx] = log(u53(r1.v[0], r1.v[1]));
+    const SlotDraw s = draw_slot(d.W, d.a, d.ndim_m1, d.seed_lo, d.seed_hi, (unsigned)(d.step0 + k), h,
+                                 (unsigned)e, t, d.perm[3 * k + 1], d.perm[3 * k + 2]);
+    d.active[idx] = (int)(e * d.W) + s.active;
+    d.partner[idx] = (int)(e * d.W) + s.partner;
+    d.zz[idx] = s.z;
+    d.factor[idx] = s.factor;
+    d.logu[idx] = s.logu;
+}
+
+// ---------------------------------------------------------------------------------
+// Persistent sampler: ONE WORKGROUP PER ENSEMBLE runs every iteration of a chunk inside
+// one launch.  The ensemble (positions + log-probs) lives in LDS, the random stream is
+// drawn in-kernel from the same philox counters as k_stretch_draw, the two half-steps of
+// an iteration are separated by a workgroup barrier (no launch, no grid sync), and only
+// the stored chain rows go to HBM.  Bit-identical to draw + launch-per-half-step.
+// Needs W*(NDIM+1)*8 B of LDS and ceil(W/2) <= blockDim.x lanes.
+// ---------------------------------------------------------------------------------
+struct PersistArgs {
+    double *coords;      // (E*W, NDIM) in/out (global state)
+    double *logp;        // (E*W,)
+    long long W;         // walkers per ensemble
+    long long n_steps, step0, thin_by;
+    double a, ndim_m1;
+    unsigned int seed_lo, seed_hi;
+    const int *perm;     // (n_steps, 3)
+    double *chain;       // (n_steps/thin_by, E*W, NDIM) or null
+    double *logp_chain;  // (n_steps/thin_by, E*W) or null
+    int *naccept;        // (E*W,) or null
+    int *status;
+    long long E;
+};
+
+template <class LP>
+__global__ __launch_bounds__(1024) void k_stretch_persistent(const PersistArgs a, const LP lp)
+{
+    constexpr int NDIM = LP::NDIM;
+    extern __shared__ __attribute__((aligned(16))) double lds_state[];  // W*NDIM coords | W logp
+    double *xs = lds_state;
+    double *ls = lds_state + a.W * NDIM;
+    const long long e = blockIdx.x;
+    const long long base = e * a.W;           // first global walker of this ensemble
+    for (long long i = threadIdx.x; i < a.W * NDIM; i += blockDim.x) xs[i] = a.coords[base * NDIM + i];
+    for (long long i = threadIdx.x; i < a.W; i += blockDim.x) ls[i] = a.logp[base + i];
+    __syncthreads();
+    const long long t = threadIdx.x;
+    for (long long k = 0; k < a.n_steps; ++k) {
+        const long long A_inv = a.perm[3 * k + 1], B = a.perm[3 * k + 2];
+        const bool store = ((k + 1) % a.thin_by) == 0;
+        const long long srow = k / a.thin_by;
+        for (int h = 0; h < 2; ++h) {
+            const long long Ns = h ? a.W / 2 : (a.W + 1) / 2;
+            if (t < Ns) {
+                const SlotDraw d = draw_slot<true>(a.W, a.a, a.ndim_m1, a.seed_lo, a.seed_hi,
+                                                   (unsigned)(a.step0 + k), h, (unsigned)e, t, A_inv, B);
+                const int i = d.active;
+                double row[NDIM], lp_row;
+                const bool acc = stretch_move(xs + (long long)i * NDIM, xs + (long long)d.partner * NDIM,
+                                              ls[i], d.z, d.factor, d.logu, lp, (int)(base + i), a.status,
+                                              row, lp_row);
+                if (acc) {   // own row only; partners are never active in this half
+#pragma unroll
+                    for (int q = 0; q < NDIM; ++q) xs[(long long)i * NDIM + q] = row[q];
+                    ls[i] = lp_row;
+                    if (a.naccept) atomicAdd(a.naccept + base + i, 1);
+                }
+                if (store && a.chain) {
+                    double *cr = a.chain + (srow * a.E * a.W + base + i) * NDIM;
+#pragma unroll
+                    for (int q = 0; q < NDIM; ++q) cr[q] = row[q];
+                }
+                if (store && a.logp_chain) a.logp_chain[srow * a.E * a.W + base + i] = lp_row;
+            }
+            __syncthreads();   // the other half reads the rows just written
+        }
+    }
+    for (long long i = threadIdx.x; i < a.W * NDIM; i += blockDim.x) a.coords[base * NDIM + i] = xs[i];
+    for (long long i = threadIdx.x; i < a.W; i += blockDim.x) a.logp[base + i] = ls[i];
 }
 
 }  // namespace bisip

@@ -26,7 +26,8 @@ single implementation of that order.
 per-slot quantities come from a counter-based Philox4x32-10 stream generated on the
 device (contract in bisip_amd/csrc/sampler_kernels.h: key = seed, counter = (slot,
 step, half, purpose)); only the per-step split -- an affine bijection (A, B) of the
-walker indices drawn by ``affine_splits`` -- is drawn on the host.
+walker indices, ``affine_splits``, itself a pure function of (seed, step) -- is computed
+on the host.
 
 Sampler parity with emcee itself is UNPINNED (no emcee here, and the reference's
 tests assert nothing at this boundary); tests pin the two drivers against each other
@@ -80,18 +81,57 @@ def draw_step(rng, nwalkers, ndim, a=2.0):
     return halves
 
 
-def affine_splits(rng, nwalkers, nsteps):
+def _mod_inverse(a, W):
+    """Vectorised modular inverse of a (coprime to W) by the extended Euclid iteration."""
+    a = np.asarray(a, dtype=np.int64)
+    r0, r1 = np.full_like(a, W), a % W
+    t0, t1 = np.zeros_like(a), np.ones_like(a)
+    while np.any(r1 != 0):
+        live = r1 != 0
+        q = np.where(live, r0 // np.where(live, r1, 1), 0)
+        r0, r1 = np.where(live, r1, r0), np.where(live, r0 - q * r1, r1)
+        t0, t1 = np.where(live, t1, t0), np.where(live, t0 - q * t1, t1)
+    return t0 % W
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Philox4x32-10 (Salmon et al., SC'11) vectorised over uint64 arrays holding 32-bit
+    words; the host twin of bisip_amd/csrc/philox.h (cross-checked in the tests)."""
+    M0, M1, W0, W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
+    mask = np.uint64(0xffffffff)
+    c0, c1, c2, c3 = [np.asarray(x, dtype=np.uint64) & mask for x in np.broadcast_arrays(c0, c1, c2, c3)]
+    k0, k1 = np.uint64(k0), np.uint64(k1)
+    for _ in range(10):
+        p0 = np.uint64(M0) * c0
+        p1 = np.uint64(M1) * c2
+        c0, c1, c2, c3 = ((p1 >> np.uint64(32)) ^ c1 ^ k0) & mask, p1 & mask, \
+                         ((p0 >> np.uint64(32)) ^ c3 ^ k1) & mask, p0 & mask
+        k0 = (k0 + np.uint64(W0)) & mask
+        k1 = (k1 + np.uint64(W1)) & mask
+    return c0, c1, c2, c3
+
+
+def affine_splits(seed, nwalkers, step0, nsteps):
     """Per-step random balanced split for rng='philox': pi(i) = (A*i + B) mod W with
     gcd(A, W) = 1; walker i belongs to half pi(i) & 1.  Returns int32 (nsteps, 3) rows
-    (A, A^-1 mod W, B)."""
-    import math
+    (A, A^-1 mod W, B).  A pure function of (seed, step): for step k the philox block with
+    counter (k, attempt, 0, 2) gives A = 1 + x0 mod (W-1) (first attempt coprime to W wins)
+    and attempt 0's x1 gives B = x1 mod W -- so runs do not depend on how they are chunked."""
     W = int(nwalkers)
+    k0, k1 = int(seed) & 0xffffffff, int(seed) >> 32
+    steps = np.arange(step0, step0 + nsteps, dtype=np.uint64)
+    x0, x1, _, _ = philox4x32_10(steps, 0, 0, 2, k0, k1)
+    B = (x1 % np.uint64(W)).astype(np.int64)
+    A = (1 + x0 % np.uint64(max(W - 1, 1))).astype(np.int64)
+    bad = np.gcd(A, W) != 1
+    attempt = 1
+    while bad.any():
+        y0, _, _, _ = philox4x32_10(steps[bad], attempt, 0, 2, k0, k1)
+        A[bad] = (1 + y0 % np.uint64(max(W - 1, 1))).astype(np.int64)
+        bad = np.gcd(A, W) != 1
+        attempt += 1
     out = np.empty((nsteps, 3), dtype=np.int32)
-    for k in range(nsteps):
-        A = int(rng.randint(1, W))
-        while math.gcd(A, W) != 1:
-            A = int(rng.randint(1, W))
-        out[k] = (A, pow(A, -1, W), int(rng.randint(W)))
+    out[:, 0], out[:, 1], out[:, 2] = A, _mod_inverse(A, W), B
     return out
 
 
@@ -346,6 +386,24 @@ class HipStretchBackend:
         self.ctx.stretch_run_dev(self._args(st, 0, 0, (W + 1) // 2, base=True), W, n_steps,
                                  st.get('thin', 1), self.stream())
 
+    def run_persistent(self, st, wp, a, seed, step0, n_steps):
+        """One launch for the whole chunk (workgroup per ensemble, state in LDS, stream drawn
+        in-kernel).  Returns False when the ensemble does not fit a workgroup."""
+        from ._hip import PersistArgs
+        p = PersistArgs()
+        p.coords = st['coords'].data_ptr()
+        p.logp = st['logp'].data_ptr()
+        p.n_walkers = st['coords'].shape[0]
+        p.walkers_per_ensemble = wp
+        p.n_steps, p.step0, p.thin_by = n_steps, step0, st.get('thin', 1)
+        p.a, p.seed = a, seed
+        p.perm = st['perm'].data_ptr()
+        p.chain = st['chain'].data_ptr()
+        p.logp_chain = st['logp_chain'].data_ptr()
+        p.naccept = st['naccept'].data_ptr()
+        p.status = st['status'].data_ptr()
+        return self.ctx.stretch_persistent_dev(p, self.stream())
+
     def host_buffer(self, shape):
         """Pinned host memory for big chains: slabs come back at PCIe rate (~55 GB/s vs ~13
         pageable); small chains stay pageable (pinning costs more than it saves)."""
@@ -386,7 +444,7 @@ class DeviceEnsembleSampler(_SamplerBase):
 
     def __init__(self, nwalkers, ndim, ctx=None, a=2.0, live_dangerously=False, group=None,
                  distributed=False, backend=None, chunk=None, rng='numpy', seed=None,
-                 n_ensembles=1, force_sharded_path=False):
+                 n_ensembles=1, force_sharded_path=False, persistent=False):
         if rng not in ('numpy', 'philox'):
             raise ValueError("rng must be 'numpy' or 'philox'")
         # n_ensembles > 1: independent ensembles of `nwalkers` walkers each (batch of spectra),
@@ -405,6 +463,11 @@ class DeviceEnsembleSampler(_SamplerBase):
         self.rng = rng
         # run eval -> all_gather -> apply even with one rank (benchmarks the sharded path)
         self.force_sharded_path = bool(force_sharded_path)
+        # rng='philox', one rank, ensemble fits a workgroup: ONE launch per chunk (workgroup per
+        # ensemble).  Bit-identical to the default path; measured no faster (the in-kernel
+        # stream is drawn serially by one wave), so it is opt-in.
+        self.persistent = bool(persistent)
+        self.last_path = None
         super().__init__(int(nwalkers) * self.n_ensembles, ndim, a, live_dangerously, group, distributed)
         # philox key: explicit seed, else drawn from the (seeded) private RandomState
         # (never in 'numpy' mode: that stream must stay aligned with EnsembleSampler's)
@@ -495,19 +558,30 @@ class DeviceEnsembleSampler(_SamplerBase):
             else:
                 # only the per-step split is drawn on the host; the stream is generated on
                 # the device from (seed, step, half, slot) counters
-                st['perm'] = be.tensor(affine_splits(self._random, self.walkers_per_ensemble, n))
+                st['perm'] = be.tensor(affine_splits(self.seed, self.walkers_per_ensemble, it0, n))
+            st['chain'] = be.empty((ns, W, ndim), torch.float64)
+            st['logp_chain'] = be.empty((ns, W), torch.float64)
+            t_b = time.perf_counter()
+            single = self._world == 1 and not self.force_sharded_path
+            ran = False
+            if single and self.rng == 'philox' and self.persistent:
+                ran = be.run_persistent(st, self.walkers_per_ensemble, self.a, self.seed, it0, n)
+                if ran:
+                    self.last_path = 'persistent'
+            if not ran and self.rng == 'philox':
                 for name, dt in (('active', torch.int32), ('partner', torch.int32),
                                  ('zz', torch.float64), ('factor', torch.float64),
                                  ('logu', torch.float64)):
                     st[name] = be.empty((n, 2, nh), dt)
                 be.draw(st, self.walkers_per_ensemble, self.a, self.seed, it0, n)
-            st['chain'] = be.empty((ns, W, ndim), torch.float64)
-            st['logp_chain'] = be.empty((ns, W), torch.float64)
-            t_b = time.perf_counter()
-            if self._world == 1 and not self.force_sharded_path:
+            if ran:
+                pass
+            elif single:
                 be.run(st, n)
+                self.last_path = 'launch-per-half-step'
             else:
                 import torch.distributed as dist
+                self.last_path = 'sharded'
                 for k in range(n):
                     for h in (0, 1):
                         m = nh if h == 0 else W // 2

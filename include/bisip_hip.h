@@ -174,6 +174,30 @@ int bisip_stretch_draw_dev(bisip_ctx *ctx, int64_t W, double a, uint64_t seed, i
                            int32_t *d_partner, double *d_zz, double *d_factor, double *d_logu,
                            void *stream);
 
+/* Persistent sampler: one workgroup per ensemble runs n_steps iterations inside ONE launch
+ * (ensemble in LDS, philox stream drawn in-kernel, workgroup barrier between half-steps).
+ * Same stream contract as bisip_stretch_draw_dev + bisip_stretch_run_dev, bit-identical
+ * results.  Requires walkers_per_ensemble*(ndim+1)*8 <= 65536 bytes of LDS and
+ * ceil(walkers_per_ensemble/2) <= 1024; otherwise returns BISIP_EUNSUPPORTED (use the
+ * launch-per-half-step path).  n_walkers = n_ensembles * walkers_per_ensemble. */
+typedef struct bisip_persist_args {
+    double *coords;              /* (n_walkers, ndim) in/out */
+    double *logp;                /* (n_walkers,)      in/out */
+    int64_t n_walkers;
+    int64_t walkers_per_ensemble;
+    int64_t n_steps;
+    int64_t step0;               /* philox step counter of the first iteration */
+    int64_t thin_by;
+    double a;                    /* stretch scale */
+    uint64_t seed;
+    const int32_t *perm;         /* (n_steps, 3) device: A, A^-1 mod W, B */
+    double *chain;               /* (n_steps/thin_by, n_walkers, ndim) or NULL */
+    double *logp_chain;          /* (n_steps/thin_by, n_walkers) or NULL */
+    int32_t *naccept;            /* (n_walkers,) or NULL */
+    int32_t *status;             /* required */
+} bisip_persist_args;
+int bisip_stretch_persistent_dev(bisip_ctx *ctx, const bisip_persist_args *args, void *stream);
+
 /* Host: one Philox4x32-10 block (counter[4], key[2]) -> out[4]; for known-answer tests. */
 void bisip_philox4x32(const uint32_t *counter, const uint32_t *key, uint32_t *out);
 

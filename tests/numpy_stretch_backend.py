@@ -105,6 +105,18 @@ class NumpyStretchBackend:
             st['logp_chain'].numpy()[k // thin][idx] = lps
         st['naccept'].numpy()[idx[acc]] += 1
 
+    def run_persistent(self, st, wp, a, seed, step0, n_steps):
+        if wp * (st['coords'].shape[1] + 1) * 8 > 65536 or (wp + 1) // 2 > 1024:
+            return False
+        W = st['coords'].shape[0]
+        nh = (W + 1) // 2
+        for name, dt in (('active', torch.int32), ('partner', torch.int32), ('zz', torch.float64),
+                         ('factor', torch.float64), ('logu', torch.float64)):
+            st[name] = torch.zeros((n_steps, 2, nh), dtype=dt)
+        self.draw(st, wp, a, seed, step0, n_steps)
+        self.run(st, n_steps)
+        return True
+
     def host_buffer(self, shape):
         return torch.zeros(shape, dtype=torch.float64)
 

@@ -118,3 +118,28 @@ def test_cfg5_scaled_shape_runs():
     ch = batch.get_chain()
     assert np.all(ch > lo) and np.all(ch < hi)
     assert lp[-1].mean() > lp[0].mean() - 50
+
+
+def test_batch_persistent_equals_launch_path():
+    """E ensembles: one workgroup each (persistent) == one launch per half-step over all."""
+    import bisip_amd
+    from bisip_amd.sampler import DeviceEnsembleSampler
+    for model, kw, ndim in [('PeltonColeCole', dict(n_modes=2), 7), ('PolynomialDecomposition', {}, 7)]:
+        for E, Wp in [(7, 64), (3, 30), (5, 256)]:
+            batch = bisip_amd.SpectraBatch(model, _tables(E), nwalkers=Wp, nsteps=12, **kw)
+            rng = np.random.RandomState(E + Wp)
+            if model == 'PeltonColeCole':
+                centre = np.array([1.0, 0.15, 0.5, -1.5, -12.0, 0.45, 0.6])
+            else:
+                centre = np.array([1.0, 0.005, -0.003, -0.001, 0.0005, 0.0002, 0.00001])
+            p0 = (centre + 1e-4 * rng.randn(E, Wp, ndim)).reshape(E * Wp, ndim)
+            chains = []
+            for persistent in (True, False):
+                np.random.seed(4)
+                s = DeviceEnsembleSampler(Wp, ndim, batch.ctx, rng='philox', seed=31, n_ensembles=E,
+                                          persistent=persistent)
+                s.run_mcmc(p0, 12)
+                chains.append((s.get_chain(), s.get_log_prob(), s.acceptance_fraction, s.last_path))
+            assert chains[0][3] == 'persistent' and chains[1][3] == 'launch-per-half-step'
+            for x, y in zip(chains[0][:3], chains[1][:3]):
+                assert np.array_equal(x, y)

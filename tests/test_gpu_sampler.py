@@ -165,7 +165,7 @@ def test_philox_draw_kernel_matches_contract():
     g = np.load(_case('case16_'))
     ctx = make_ctx(g, 'PeltonColeCole')
     for W, n, step0, seed in [(32, 9, 0, 1), (33, 5, 1000, 0xdeadbeefcafe), (4096, 3, 7, 42)]:
-        perm = affine_splits(np.random.RandomState(W), W, n)
+        perm = affine_splits(seed, W, step0, n)
         nh = (W + 1) // 2
         dperm = torch.from_numpy(perm).cuda()
         bufs = {k: torch.empty((n, 2, nh), dtype=dt, device='cuda')
@@ -231,4 +231,44 @@ def test_philox_mode_chain_replay_and_posterior():
     sd = fb.std(axis=0)
     assert np.all(np.abs(fa.mean(0) - fb.mean(0)) < 0.25 * sd)
     assert np.all(np.abs(fa.std(0) / sd - 1) < 0.25)
+    ctx.close()
+
+
+@pytest.mark.parametrize('prefix,model,variant', CASES)
+def test_persistent_kernel_equals_launch_per_half_step(prefix, model, variant):
+    """rng='philox': the one-launch-per-chunk persistent kernel (workgroup per ensemble, state
+    in LDS, in-kernel stream) reproduces the draw + launch-per-half-step path bit for bit."""
+    from bisip_amd.sampler import DeviceEnsembleSampler
+    g = np.load(_case(prefix))
+    ctx = make_ctx(g, model, variant)
+    ndim = g['bounds'].shape[1]
+    for W, nsteps, chunk, thin in [(32, 80, None, 1), (33, 30, 7, 1), (64, 24, 5, 3), (510, 6, None, 1)]:
+        if W < 2 * ndim:
+            continue
+        p0 = _start(g, W, 300 + W)
+        out = []
+        for persistent in (True, False):
+            np.random.seed(17)
+            s = DeviceEnsembleSampler(W, ndim, ctx, rng='philox', seed=99, chunk=chunk, persistent=persistent)
+            s.run_mcmc(p0, nsteps, thin_by=thin)
+            s.run_mcmc(None, 4, thin_by=thin)       # continuation keeps the counters aligned
+            out.append(s)
+        a, b = out
+        assert a.last_path == 'persistent' and b.last_path == 'launch-per-half-step'
+        assert np.array_equal(a.get_chain(), b.get_chain())
+        assert np.array_equal(a.get_log_prob(), b.get_log_prob())
+        assert np.array_equal(a.acceptance_fraction, b.acceptance_fraction)
+    ctx.close()
+
+
+def test_persistent_falls_back_when_ensemble_too_large():
+    from bisip_amd.sampler import DeviceEnsembleSampler
+    g = np.load(_case('case15_'))
+    ctx = make_ctx(g, 'PeltonColeCole')
+    W = 4096                                    # nh = 2048 > 1024 lanes
+    p0 = _start(g, W, 9)
+    np.random.seed(2)
+    s = DeviceEnsembleSampler(W, 4, ctx, rng='philox', seed=5)
+    s.run_mcmc(p0, 3)
+    assert s.last_path == 'launch-per-half-step'
     ctx.close()

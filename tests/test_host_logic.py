@@ -167,6 +167,7 @@ def test_philox_known_answers():
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     from bisip_amd import _hip
     from numpy_stretch_backend import philox4x32_10
+    from bisip_amd.sampler import philox4x32_10 as product_philox
     kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
            ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
            ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
@@ -174,6 +175,7 @@ def test_philox_known_answers():
     for ctr, key, want in kat:
         assert tuple(_hip.philox4x32(ctr, key)) == want
         assert tuple(int(x) for x in philox4x32_10(*ctr, *key)) == want
+        assert tuple(int(x) for x in product_philox(*ctr, *key)) == want
     rng = np.random.RandomState(0)
     for _ in range(50):
         ctr = rng.randint(0, 2 ** 32, 4, dtype=np.uint64)
@@ -184,7 +186,10 @@ def test_philox_known_answers():
 def test_affine_splits_are_bijections():
     from bisip_amd.sampler import affine_splits
     for W in (14, 15, 32, 33, 256, 1000):
-        perm = affine_splits(np.random.RandomState(W), W, 20)
+        perm = affine_splits(1234 + W, W, 5, 20)
+        # a pure function of (seed, step): chunking a run does not change it
+        assert np.array_equal(perm, np.concatenate([affine_splits(1234 + W, W, 5, 7),
+                                                    affine_splits(1234 + W, W, 12, 13)]))
         for A, Ainv, B in perm:
             assert (int(A) * int(Ainv)) % W == 1 and 0 <= B < W
             pi = (int(A) * np.arange(W) + int(B)) % W
