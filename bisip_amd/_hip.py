@@ -301,24 +301,20 @@ class HipContext:
         _check(self._lib.bisip_stretch_run_dev(self._h, ctypes.byref(first_args), int(W),
                                                int(n_steps), int(thin_by), ctypes.c_void_p(stream)))
 
+    def stretch_persistent_dev(self, args, stream=0):
+        """Returns False when the ensemble does not fit one workgroup (status -4)."""
+        rc = self._lib.bisip_stretch_persistent_dev(self._h, ctypes.byref(args), ctypes.c_void_p(stream))
+        if rc == -4:
+            return False
+        _check(rc)
+        return True
+
     def stretch_draw_dev(self, W, a, seed, step0, n_steps, perm, active, partner, zz, factor, logu,
                          stream=0):
         _check(self._lib.bisip_stretch_draw_dev(self._h, int(W), float(a), int(seed), int(step0),
                                                 int(n_steps), *[ctypes.c_void_p(p) for p in
                                                                 (perm, active, partner, zz, factor, logu)],
                                                 ctypes.c_void_p(stream)))
-
-
-def _persist_method(self, args, stream=0):
-    """Returns False when the ensemble does not fit one workgroup (status -4)."""
-    rc = self._lib.bisip_stretch_persistent_dev(self._h, ctypes.byref(args), ctypes.c_void_p(stream))
-    if rc == -4:
-        return False
-    _check(rc)
-    return True
-
-
-HipContext.stretch_persistent_dev = _persist_method
 
 
 def philox4x32(counter, key):

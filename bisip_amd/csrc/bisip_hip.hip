@@ -376,14 +376,20 @@ StretchArgs to_device_args(const bisip_stretch_args *u)
 
 enum StretchKind { STRETCH_HALF, STRETCH_EVAL, STRETCH_PERSIST };
 
-// persistent launch parameters travel beside the (unused) StretchArgs through the dispatch
-thread_local const PersistArgs *g_persist = nullptr;
+// what one stretch dispatch launches: a half-step / eval kernel over StretchArgs, or the
+// persistent kernel over PersistArgs
+struct StretchWork {
+    StretchKind kind;
+    const StretchArgs *half;
+    const PersistArgs *persist;
+};
 
 template <class LP>
-int launch_stretch(const StretchArgs &a, const LP &lp, StretchKind kind, hipStream_t st)
+int launch_stretch(const StretchWork &work, const LP &lp, hipStream_t st)
 {
+    const StretchKind kind = work.kind;
     if (kind == STRETCH_PERSIST) {
-        const PersistArgs &p = *g_persist;
+        const PersistArgs &p = *work.persist;
         const long long nh = (p.W + 1) / 2;
         const unsigned threads = (unsigned)(((nh + 63) / 64) * 64);
         const size_t lds = (size_t)p.W * (LP::NDIM + 1) * sizeof(double);
@@ -391,6 +397,7 @@ int launch_stretch(const StretchArgs &a, const LP &lp, StretchKind kind, hipStre
         HIP_TRY(hipGetLastError());
         return BISIP_OK;
     }
+    const StretchArgs &a = *work.half;
     if (kind == STRETCH_HALF) {
         const unsigned grid = (unsigned)((a.n_slots + 63) / 64);
         hipLaunchKernelGGL((k_stretch_half<LP>), dim3(grid), dim3(64), 0, st, a, lp);
@@ -403,16 +410,16 @@ int launch_stretch(const StretchArgs &a, const LP &lp, StretchKind kind, hipStre
 }
 
 template <class M>
-int stretch_generic(const bisip_ctx *c, const StretchArgs &a, StretchKind kind, hipStream_t st)
+int stretch_generic(const bisip_ctx *c, const StretchWork &a, hipStream_t st)
 {
     GenericLP<M> lp;
     lp.o = ModelOperands{c->d_cb_lp ? c->d_cb_lp : c->d_cb, c->N, c->lconst};
     lp.b = c->bounds;
-    return launch_stretch(a, lp, kind, st);
+    return launch_stretch(a, lp, st);
 }
 
 template <int P>
-int stretch_reduced(const bisip_ctx *c, const StretchArgs &a, StretchKind kind, hipStream_t st)
+int stretch_reduced(const bisip_ctx *c, const StretchWork &a, hipStream_t st)
 {
     ReducedLP<P> lp;
     std::memcpy(lp.r.R, c->Rpacked.data(), sizeof(lp.r.R));
@@ -421,35 +428,35 @@ int stretch_reduced(const bisip_ctx *c, const StretchArgs &a, StretchKind kind, 
     lp.r.rest = c->rest;
     lp.lconst = c->lconst;
     lp.b = c->bounds;
-    return launch_stretch(a, lp, kind, st);
+    return launch_stretch(a, lp, st);
 }
 
 template <class M, bool U>
-int stretch_generic_batch(const bisip_ctx *c, const StretchArgs &a, long long Wp, StretchKind kind, hipStream_t st)
+int stretch_generic_batch(const bisip_ctx *c, const StretchWork &a, long long Wp, hipStream_t st)
 {
     BatchGenericLP<M, U> lp;
     lp.cb = c->d_cb_lp ? c->d_cb_lp : c->d_cb; lp.cb_stride = c->cb_stride; lp.Wp = Wp; lp.lconst = c->d_lconst; lp.N = c->N;
     lp.b = c->bounds;
-    return launch_stretch(a, lp, kind, st);
+    return launch_stretch(a, lp, st);
 }
 
 template <int P, bool U>
-int stretch_reduced_batch(const bisip_ctx *c, const StretchArgs &a, long long Wp, StretchKind kind, hipStream_t st)
+int stretch_reduced_batch(const bisip_ctx *c, const StretchWork &a, long long Wp, hipStream_t st)
 {
     BatchReducedLP<P, U> lp;
     lp.red = reinterpret_cast<const ReducedArgs<P> *>(c->d_red); lp.Wp = Wp; lp.lconst = c->d_lconst;
     lp.b = c->bounds;
-    return launch_stretch(a, lp, kind, st);
+    return launch_stretch(a, lp, st);
 }
 
 // batch of spectra: Wp walkers per spectrum; a wave of 64 slots stays inside one spectrum
 // iff (Wp/2) % 64 == 0
-int dispatch_stretch_batch(const bisip_ctx *c, const StretchArgs &a, long long Wp, StretchKind kind, hipStream_t st)
+int dispatch_stretch_batch(const bisip_ctx *c, const StretchWork &a, long long Wp, hipStream_t st)
 {
     // in the persistent kernel a workgroup IS one ensemble, so the spectrum is always uniform
-    const bool u = (Wp % 128) == 0 || kind == STRETCH_PERSIST;
-#define GEN(M) return u ? stretch_generic_batch<M, true>(c, a, Wp, kind, st) : stretch_generic_batch<M, false>(c, a, Wp, kind, st);
-#define RED(p) return u ? stretch_reduced_batch<p, true>(c, a, Wp, kind, st) : stretch_reduced_batch<p, false>(c, a, Wp, kind, st);
+    const bool u = (Wp % 128) == 0 || a.kind == STRETCH_PERSIST;
+#define GEN(M) return u ? stretch_generic_batch<M, true>(c, a, Wp, st) : stretch_generic_batch<M, false>(c, a, Wp, st);
+#define RED(p) return u ? stretch_reduced_batch<p, true>(c, a, Wp, st) : stretch_reduced_batch<p, false>(c, a, Wp, st);
     switch (c->model_id) {
     case BISIP_MODEL_POLYDECOMP:
         if (effective_variant(c) == BISIP_VARIANT_REDUCED) {
@@ -481,23 +488,23 @@ int dispatch_stretch_batch(const bisip_ctx *c, const StretchArgs &a, long long W
     return fail(BISIP_EUNSUPPORTED, "no batch stretch kernel for this model shape");
 }
 
-int dispatch_stretch(const bisip_ctx *c, const StretchArgs &a, long long Wp, StretchKind kind, hipStream_t st)
+int dispatch_stretch(const bisip_ctx *c, const StretchWork &a, long long Wp, hipStream_t st)
 {
     if (c->E > 1) {
         if (Wp < 2 || (Wp & 1)) return fail(BISIP_EINVAL, "batch context: walkers_per_spectrum must be even and >= 2, got %lld", Wp);
-        return dispatch_stretch_batch(c, a, Wp, kind, st);
+        return dispatch_stretch_batch(c, a, Wp, st);
     }
     switch (c->model_id) {
     case BISIP_MODEL_POLYDECOMP:
         if (effective_variant(c) == BISIP_VARIANT_REDUCED) {
             switch (c->P) {
-#define X(p) case p: return stretch_reduced<p>(c, a, kind, st);
+#define X(p) case p: return stretch_reduced<p>(c, a, st);
                 PD_CASES(X)
 #undef X
             }
         } else {  // collapsed (the faithful formulation has no sampler kernel)
             switch (c->P) {
-#define X(p) case p: return stretch_generic<PDCollapsed<p>>(c, a, kind, st);
+#define X(p) case p: return stretch_generic<PDCollapsed<p>>(c, a, st);
                 PD_CASES(X)
 #undef X
             }
@@ -505,13 +512,13 @@ int dispatch_stretch(const bisip_ctx *c, const StretchArgs &a, long long Wp, Str
         break;
     case BISIP_MODEL_COLECOLE:
         switch (c->D) {
-#define X(d) case d: return stretch_generic<ColeCole<d>>(c, a, kind, st);
+#define X(d) case d: return stretch_generic<ColeCole<d>>(c, a, st);
             CC_CASES(X)
 #undef X
         }
         break;
-    case BISIP_MODEL_DIAS2000: return stretch_generic<Dias>(c, a, kind, st);
-    case BISIP_MODEL_SHIN2015: return stretch_generic<Shin>(c, a, kind, st);
+    case BISIP_MODEL_DIAS2000: return stretch_generic<Dias>(c, a, st);
+    case BISIP_MODEL_SHIN2015: return stretch_generic<Shin>(c, a, st);
     }
     return fail(BISIP_EUNSUPPORTED, "no stretch kernel for this model shape");
 }
@@ -832,7 +839,8 @@ int bisip_stretch_half_dev(bisip_ctx *c, const bisip_stretch_args *u, void *stre
     if (rc != BISIP_OK || u->n_slots == 0) return rc;
     if (!u->partner || !u->zz || !u->factor || !u->logu) return fail(BISIP_EINVAL, "null RNG stream");
     HIP_TRY(hipSetDevice(c->device));
-    return dispatch_stretch(c, to_device_args(u), u->walkers_per_spectrum, STRETCH_HALF, (hipStream_t)stream);
+    const StretchArgs a = to_device_args(u);
+    return dispatch_stretch(c, StretchWork{STRETCH_HALF, &a, nullptr}, u->walkers_per_spectrum, (hipStream_t)stream);
 }
 
 int bisip_stretch_eval_dev(bisip_ctx *c, const bisip_stretch_args *u, void *stream)
@@ -845,7 +853,8 @@ int bisip_stretch_eval_dev(bisip_ctx *c, const bisip_stretch_args *u, void *stre
                     (long long)u->slot_hi, (long long)u->n_slots);
     if (u->slot_lo == u->slot_hi) return BISIP_OK;
     HIP_TRY(hipSetDevice(c->device));
-    return dispatch_stretch(c, to_device_args(u), u->walkers_per_spectrum, STRETCH_EVAL, (hipStream_t)stream);
+    const StretchArgs a = to_device_args(u);
+    return dispatch_stretch(c, StretchWork{STRETCH_EVAL, &a, nullptr}, u->walkers_per_spectrum, (hipStream_t)stream);
 }
 
 int bisip_stretch_apply_dev(bisip_ctx *c, const bisip_stretch_args *u, void *stream)
@@ -881,7 +890,8 @@ int bisip_stretch_run_dev(bisip_ctx *c, const bisip_stretch_args *first, int64_t
             const int64_t srow = k / thin_by;
             u.chain_row = (store && first->chain_row) ? first->chain_row + srow * W * c->ndim : nullptr;
             u.logp_row = (store && first->logp_row) ? first->logp_row + srow * W : nullptr;
-            int rc = dispatch_stretch(c, to_device_args(&u), u.walkers_per_spectrum, STRETCH_HALF, (hipStream_t)stream);
+            const StretchArgs a = to_device_args(&u);
+            int rc = dispatch_stretch(c, StretchWork{STRETCH_HALF, &a, nullptr}, u.walkers_per_spectrum, (hipStream_t)stream);
             if (rc != BISIP_OK) return rc;
         }
     }
@@ -934,11 +944,7 @@ int bisip_stretch_persistent_dev(bisip_ctx *c, const bisip_persist_args *u, void
     p.seed_lo = (unsigned int)(u->seed & 0xffffffffu); p.seed_hi = (unsigned int)(u->seed >> 32);
     p.perm = u->perm; p.chain = u->chain; p.logp_chain = u->logp_chain; p.naccept = u->naccept;
     p.status = u->status; p.E = E;
-    g_persist = &p;
-    StretchArgs dummy{};
-    const int rc = dispatch_stretch(c, dummy, Wp, STRETCH_PERSIST, (hipStream_t)stream);
-    g_persist = nullptr;
-    return rc;
+    return dispatch_stretch(c, StretchWork{STRETCH_PERSIST, nullptr, &p}, Wp, (hipStream_t)stream);
 }
 
 void bisip_philox4x32(const uint32_t *counter, const uint32_t *key, uint32_t *out)
