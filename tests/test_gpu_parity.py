@@ -456,3 +456,47 @@ def test_plain_c_consumer(tmp_path):
     assert_logp_close(got, want, 1e-9)     # the C demo builds its spectrum with its own libm calls
     assert np.isneginf(got[3]) and np.isneginf(got[4])
     assert abs(got[0] - vals['const']) < 1e-6
+
+
+def test_polydecomp_random_spectra_fuzz():
+    """Random problems (frequencies, spectrum, errors over four decades, degree, exponent):
+    every formulation against the oracle, on walkers clustered at the least-squares optimum
+    -- where y - Z cancels hardest and the QR-reduced form has the least slack."""
+    import oracle
+    from bisip_amd import _hip
+    rng = np.random.RandomState(20260101)
+    worst = {}
+    for trial in range(24):
+        N = int(rng.randint(4, 48))
+        P = int(rng.randint(1, 7))
+        c_exp = float(rng.choice([1.0, 0.5, rng.uniform(0.2, 1.0)]))
+        w = np.sort(2 * np.pi * 10 ** rng.uniform(-2, 4, N))[::-1].copy()
+        per = np.log10(1. / w)
+        lt = np.linspace(np.floor(per.min() - 1), np.floor(per.max() + 1), 2 * N)
+        taus, log_taus = 10 ** lt, np.array([lt ** i for i in range(P + 1)])
+        bounds = np.array([[0.5] + [-5.0] * (P + 1), [1.5] + [5.0] * (P + 1)])
+        # a plausible spectrum: a random polynomial model + noise, errors over 4 decades
+        th_true = np.r_[rng.uniform(0.9, 1.1), rng.randn(P + 1) * 10.0 ** -np.arange(2, P + 3)]
+        err = 10 ** rng.uniform(-4.5, -1.0, (2, N))
+        prob0 = oracle.OracleProblem('PolynomialDecomposition', w, np.zeros((2, N)), err, bounds,
+                                     taus=taus, log_taus=log_taus, c_exp=c_exp)
+        zn = oracle.forward(prob0, th_true[None, :])[0] + err * rng.randn(2, N)
+        prob = oracle.OracleProblem('PolynomialDecomposition', w, zn, err, bounds, taus=taus,
+                                    log_taus=log_taus, c_exp=c_exp)
+        # least-squares centre through the linear structure (forward of unit vectors)
+        base = oracle.forward(prob, np.r_[1.0, np.zeros(P + 1)][None, :])[0].ravel()
+        cols = [base] + [oracle.forward(prob, np.r_[1.0, np.eye(P + 1)[p]][None, :])[0].ravel() - base
+                         for p in range(P + 1)]
+        A = np.array(cols).T / err.ravel()[:, None]
+        b = np.linalg.lstsq(A, zn.ravel() / err.ravel(), rcond=None)[0]
+        centre = np.r_[b[0], b[1:] / b[0]]
+        theta = centre + 1e-5 * np.abs(centre) * rng.randn(200, P + 2)
+        theta = np.vstack([theta, rng.uniform(bounds[0], bounds[1], (100, P + 2))])
+        want = oracle.logprob(prob, theta, n_threads=4)
+        for v in ('reduced', 'collapsed', 'faithful', 'wave'):
+            ctx = _hip.HipContext(0, w, zn, err, bounds, poly_deg=P, c_exp=c_exp, taus=taus,
+                                  log_taus=log_taus, variant=v)
+            e = assert_logp_close(ctx.logprob(theta), want)
+            worst[v] = max(worst.get(v, 0.0), e)
+            ctx.close()
+    print('worst relative error per formulation:', {k: f'{v:.2e}' for k, v in worst.items()})
