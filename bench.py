@@ -114,6 +114,10 @@ def main():
     ap.add_argument('--variant', default='auto')
     ap.add_argument('--prime-seconds', type=float, default=0.5,
                     help='untimed device warm-up before the W warm-up steps')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                    help='process-group backend; gloo + --same-device rehearses the multi-rank '
+                         'control flow on a one-GPU box (RCCL refuses two ranks on one device)')
+    ap.add_argument('--same-device', action='store_true', help='all ranks use cuda:0 (rehearsal only)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-variants', action='store_true')
     args = ap.parse_args()
@@ -123,14 +127,19 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     dist = None
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if 'RANK' in os.environ:   # launched by torch.distributed.run: one rank per GPU over RCCL
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', rank=rank, world_size=world,
-                                device_id=torch.device('cuda', local_rank))
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world,
+                                    device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
     if args.gpus != world and rank == 0:
         print(f'warning: --gpus {args.gpus} but WORLD_SIZE {world}', file=sys.stderr)
 
@@ -159,7 +168,8 @@ def main():
 
     wall, kern_ms = time_launches(ctx, theta_t, out_t, args.steps, args.warmup, torch, dist)
     if dist is not None:
-        t = torch.tensor([wall, kern_ms], dtype=torch.float64, device=f'cuda:{local_rank}')
+        t = torch.tensor([wall, kern_ms], dtype=torch.float64,
+                         device=f'cuda:{local_rank}' if args.backend == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, kern_ms = float(t[0]), float(t[1])
 

@@ -50,6 +50,15 @@ class Inversion(_utils.utils):
 
         self._data = self.load_data(self.filepath, self.headers, self.ph_units)
 
+    def __getattr__(self, name):
+        # the reference mixes matplotlib figures in (src/bisip/plotlib.py); they are outside
+        # the hot path this package replaces -- say so instead of a bare AttributeError
+        if name.startswith('plot_') or name == 'print_latex_parameters':
+            raise NotImplementedError(
+                f'{name} is part of bisip\'s plotting/notebook layer, which bisip_amd does not '
+                'reimplement; pass model.get_chain(...) / get_model_percentile(...) to bisip.plotlib')
+        raise AttributeError(f'{type(self).__name__!s} object has no attribute {name!r}')
+
     # -- device contexts ----------------------------------------------------------------
     def _desc(self):
         """Model-specific kwargs of HipContext; overridden by subclasses."""

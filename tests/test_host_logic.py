@@ -99,6 +99,11 @@ def test_model_surface_matches_reference():
     assert s.param_names == ['R1', 'R2', 'log_Q1', 'log_Q2', 'n1', 'n2']
     assert np.array_equal(s.param_bounds, [[0, 0, -15, -7, 0, 0], [1, 1, -13, -5, 1, 1]])
 
+    with pytest.raises(NotImplementedError, match='plotting'):
+        cc.plot_fit()
+    with pytest.raises(AttributeError):
+        cc.no_such_attribute
+
     # the standalone prior is host logic: open box, vectorised
     b = cc.param_bounds
     inside = 0.5 * (b[0] + b[1])
