@@ -78,6 +78,8 @@ SYMBOLS = {
                                               ctypes.c_uint64, ctypes.c_int64, ctypes.c_int64] +
                                [ctypes.c_void_p] * 7),
     'bisip_stretch_persistent_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(PersistArgs), ctypes.c_void_p]),
+    'bisip_numpy_stretch_stream': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32), ctypes.c_int64,
+                                                  ctypes.c_double, ctypes.c_int64] + [ctypes.c_void_p] * 4),
     'bisip_philox4x32': (None, [ctypes.POINTER(ctypes.c_uint32)] * 3),
     'bisip_ctx_ndim': (ctypes.c_int, [ctypes.c_void_p]),
     'bisip_ctx_nfreq': (ctypes.c_int, [ctypes.c_void_p]),
@@ -315,6 +317,28 @@ class HipContext:
                                                 int(n_steps), *[ctypes.c_void_p(p) for p in
                                                                 (perm, active, partner, zz, factor, logu)],
                                                 ctypes.c_void_p(stream)))
+
+
+def numpy_stretch_stream(rng, W, a, n_steps):
+    """n_steps iterations of the stretch move's RandomState stream, generated in C; ``rng``
+    (a numpy.random.RandomState) is advanced exactly as draw_step would advance it.
+    Returns active, partner (int32) and zz, u (float64), each (n_steps, 2, (W+1)//2)."""
+    lib = load_library()
+    name, key, pos, has_gauss, cached = rng.get_state()
+    if name != 'MT19937':
+        raise ValueError('expected an MT19937 RandomState')
+    key = np.ascontiguousarray(key, dtype=np.uint32).copy()
+    cpos = ctypes.c_int32(int(pos))
+    nh = (int(W) + 1) // 2
+    active = np.empty((n_steps, 2, nh), np.int32)
+    partner = np.empty((n_steps, 2, nh), np.int32)
+    zz = np.empty((n_steps, 2, nh))
+    u = np.empty((n_steps, 2, nh))
+    _check(lib.bisip_numpy_stretch_stream(key.ctypes.data, ctypes.byref(cpos), int(W), float(a),
+                                          int(n_steps), active.ctypes.data, partner.ctypes.data,
+                                          zz.ctypes.data, u.ctypes.data))
+    rng.set_state((name, key, int(cpos.value), has_gauss, cached))
+    return active, partner, zz, u
 
 
 def philox4x32(counter, key):

@@ -198,6 +198,15 @@ typedef struct bisip_persist_args {
 } bisip_persist_args;
 int bisip_stretch_persistent_dev(bisip_ctx *ctx, const bisip_persist_args *args, void *stream);
 
+/* Host: the stretch move's random stream in numpy.random.RandomState order for n_steps
+ * iterations of a W-walker ensemble (the contract is bisip_amd/sampler.py:draw_step).
+ * mt_key[624] / *mt_pos are RandomState.get_state()[1:3], advanced in place exactly as
+ * NumPy would.  Outputs are (n_steps, 2, (W+1)/2): active and partner walker ids, stretch
+ * factor zz and accept uniform u (the caller takes the logs). */
+int bisip_numpy_stretch_stream(uint32_t *mt_key, int32_t *mt_pos, int64_t W, double a,
+                               int64_t n_steps, int32_t *active, int32_t *partner, double *zz,
+                               double *u);
+
 /* Host: one Philox4x32-10 block (counter[4], key[2]) -> out[4]; for known-answer tests. */
 void bisip_philox4x32(const uint32_t *counter, const uint32_t *key, uint32_t *out);
 

@@ -200,3 +200,27 @@ def test_affine_splits_are_bijections():
             pi = (int(A) * np.arange(W) + int(B)) % W
             assert sorted(pi) == list(range(W))
             assert abs(int((pi % 2 == 0).sum()) - (W + 1) // 2) == 0
+
+
+def test_c_stream_replays_numpy_randomstate():
+    """bisip_numpy_stretch_stream against NumPy itself: same integers, same doubles, same
+    RandomState afterwards -- for even and odd ensembles, from an arbitrary stream position."""
+    from bisip_amd import _hip
+    from bisip_amd.sampler import draw_step
+    for W in (14, 15, 32, 33, 64, 257, 1000):
+        n = 60
+        r1, r2 = np.random.RandomState(W), np.random.RandomState(W)
+        r1.rand(W % 7)
+        r2.rand(W % 7)
+        act, par, zz, u = _hip.numpy_stretch_stream(r1, W, 2.0, n)
+        for k in range(n):
+            for h, half in enumerate(draw_step(r2, W, 5, 2.0)):
+                m = len(half['active'])
+                assert np.array_equal(act[k, h, :m], half['active'])
+                assert np.array_equal(par[k, h, :m], half['partner'])
+                assert np.array_equal(zz[k, h, :m], half['zz'])
+                with np.errstate(divide='ignore'):
+                    assert np.array_equal(np.log(u[k, h, :m]), half['logu'])
+        s1, s2 = r1.get_state(), r2.get_state()
+        assert s1[2] == s2[2] and np.array_equal(s1[1], s2[1])
+        assert r1.rand() == r2.rand() and r1.randint(1000) == r2.randint(1000)
