@@ -109,6 +109,61 @@ __global__ __launch_bounds__(128) void k_two_rows(const LaunchArgs a, const Redu
     }
 }
 
+// 128 threads, 256 rows per block, lane l owns rows 2l and 2l+1 -> one 16-byte store per lane
+__global__ __launch_bounds__(128) void k_pair_rows(const LaunchArgs a, const ReducedArgs<5> r)
+{
+    constexpr int NDIM = 7;
+    __shared__ __attribute__((aligned(16))) double lds[256 * NDIM];
+    const long long row0 = (long long)blockIdx.x * 256;
+    const dbl2 *src = reinterpret_cast<const dbl2 *>(a.theta + row0 * NDIM);
+    dbl2 *dst = reinterpret_cast<dbl2 *>(lds);
+#pragma unroll
+    for (int q = 0; q < 7; ++q) dst[q * 128 + threadIdx.x] = __builtin_nontemporal_load(src + q * 128 + threadIdx.x);
+    __syncthreads();
+    dbl2 o;
+    {
+        double th[NDIM];
+#pragma unroll
+        for (int q = 0; q < NDIM; ++q) th[q] = lds[(2 * threadIdx.x) * NDIM + q];
+        o.x = logprob_row_reduced<5>(th, r, a.lconst, a.b);
+#pragma unroll
+        for (int q = 0; q < NDIM; ++q) th[q] = lds[(2 * threadIdx.x + 1) * NDIM + q];
+        o.y = logprob_row_reduced<5>(th, r, a.lconst, a.b);
+    }
+    __builtin_nontemporal_store(o, reinterpret_cast<dbl2 *>(a.out + row0) + threadIdx.x);
+}
+
+// product structure, BLK=128, non-temporal output store
+__global__ __launch_bounds__(128) void k_nt_store(const LaunchArgs a, const ReducedArgs<5> r)
+{
+    constexpr int NDIM = 7;
+    __shared__ __attribute__((aligned(16))) double lds[128 * NDIM];
+    const long long row0 = (long long)blockIdx.x * 128;
+    stage_theta<NDIM, 128, true>(a.theta, a.W, row0, lds);
+    __syncthreads();
+    double th[NDIM];
+#pragma unroll
+    for (int q = 0; q < NDIM; ++q) th[q] = lds[threadIdx.x * NDIM + q];
+    __builtin_nontemporal_store(logprob_row_reduced<5>(th, r, a.lconst, a.b), a.out + row0 + threadIdx.x);
+}
+
+// product structure, BLK=128, plain (temporal) loads
+__global__ __launch_bounds__(128) void k_plain_loads(const LaunchArgs a, const ReducedArgs<5> r)
+{
+    constexpr int NDIM = 7;
+    __shared__ __attribute__((aligned(16))) double lds[128 * NDIM];
+    const long long row0 = (long long)blockIdx.x * 128;
+    const dbl2 *src = reinterpret_cast<const dbl2 *>(a.theta + row0 * NDIM);
+    dbl2 *dst = reinterpret_cast<dbl2 *>(lds);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { int i = q * 128 + threadIdx.x; if (i < 448) dst[i] = src[i]; }
+    __syncthreads();
+    double th[NDIM];
+#pragma unroll
+    for (int q = 0; q < NDIM; ++q) th[q] = lds[threadIdx.x * NDIM + q];
+    a.out[row0 + threadIdx.x] = logprob_row_reduced<5>(th, r, a.lconst, a.b);
+}
+
 template <class F>
 float timeit(F f, int reps = 20)
 {
@@ -140,16 +195,19 @@ int main()
     auto rep = [&](const char *name, float ms) { printf("%-34s %8.1f us  %7.1f GB/s  frac %.3f\n", name, ms * 1e3, bytes / ms / 1e6, bytes / ms / 1e6 / 8000); };
     // interleaved A/B rounds (same process), median of 7
     {
-        const char *names[5] = {"stream", "blk64", "blk128", "blk256(product)", "blk128x2rows"};
-        std::vector<float> t[5];
+        const char *names[8] = {"stream", "blk64", "blk128", "product(blk128)", "blk128x2rows", "pair_rows_16B_store", "blk128_nt_store", "blk128_plain_loads"};
+        std::vector<float> t[8];
         for (int round = 0; round < 7; ++round) {
             t[0].push_back(timeit([&] { hipLaunchKernelGGL(k_stream_sum, dim3(W / 256), dim3(256), 0, 0, (const dbl2 *)theta, out, W * 7 / 2); }, 10));
             t[1].push_back(timeit([&] { hipLaunchKernelGGL((k_lds_blk<64>), dim3(W / 64), dim3(64), 0, 0, a, r); }, 10));
             t[2].push_back(timeit([&] { hipLaunchKernelGGL((k_lds_blk<128>), dim3(W / 128), dim3(128), 0, 0, a, r); }, 10));
             t[3].push_back(timeit([&] { hipLaunchKernelGGL((k_logprob_pd_reduced<5, 128, true>), dim3(W / 128), dim3(128), 0, 0, a, r); }, 10));
             t[4].push_back(timeit([&] { hipLaunchKernelGGL((k_two_rows), dim3(W / 256), dim3(128), 0, 0, a, r); }, 10));
+            t[5].push_back(timeit([&] { hipLaunchKernelGGL((k_pair_rows), dim3(W / 256), dim3(128), 0, 0, a, r); }, 10));
+            t[6].push_back(timeit([&] { hipLaunchKernelGGL((k_nt_store), dim3(W / 128), dim3(128), 0, 0, a, r); }, 10));
+            t[7].push_back(timeit([&] { hipLaunchKernelGGL((k_plain_loads), dim3(W / 128), dim3(128), 0, 0, a, r); }, 10));
         }
-        for (int v = 0; v < 5; ++v) { std::sort(t[v].begin(), t[v].end()); printf("AB %-18s median %7.1f us  min %7.1f  frac(median) %.3f\n", names[v], t[v][3] * 1e3, t[v][0] * 1e3, bytes / t[v][3] / 1e6 / 8000); }
+        for (int v = 0; v < 8; ++v) { std::sort(t[v].begin(), t[v].end()); printf("AB %-18s median %7.1f us  min %7.1f  frac(median) %.3f\n", names[v], t[v][3] * 1e3, t[v][0] * 1e3, bytes / t[v][3] / 1e6 / 8000); }
     }
     rep("stream_sum ceiling probe", timeit([&] { hipLaunchKernelGGL(k_stream_sum, dim3(W / 256), dim3(256), 0, 0, (const dbl2 *)theta, out, W * 7 / 2); }));
     rep("product k_logprob_pd_reduced", timeit([&] { hipLaunchKernelGGL((k_logprob_pd_reduced<5, 128, true>), dim3(W / 128), dim3(128), 0, 0, a, r); }));
