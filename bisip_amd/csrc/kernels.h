@@ -408,7 +408,10 @@ struct ModelOperands {
     double lconst;
 };
 
-template <class M>
+// LATENCY = true: few walkers per launch (one wave per SIMD at best), so the frequency loop
+// is unrolled deeper to give the lone wave independent dependency chains to interleave;
+// the summation order is unchanged (same two accumulators, same j order).
+template <class M, bool LATENCY = false>
 __device__ __forceinline__ double logprob_row(const double (&th)[M::NDIM], const ModelOperands &o,
                                               const Bounds &b)
 {
@@ -416,7 +419,8 @@ __device__ __forceinline__ double logprob_row(const double (&th)[M::NDIM], const
     const typename M::Setup s = M::setup(th);
     double acc0 = 0.0, acc1 = 0.0;
     const double *__restrict__ rec = o.cb;
-#pragma unroll 2
+    constexpr int UNROLL = LATENCY ? 4 : 2;
+#pragma unroll UNROLL
     for (int j = 0; j < o.N; ++j, rec += M::REC) {
         double rr, ri;
         M::residual(s, rec, rr, ri);
@@ -448,7 +452,7 @@ __global__ __launch_bounds__(BLK) void k_logprob(const LaunchArgs a)
 #pragma unroll
     for (int q = 0; q < NDIM; ++q) th[q] = lds[threadIdx.x * NDIM + q];
     const ModelOperands o{a.cb, a.N, a.lconst};
-    a.out[row] = logprob_row<M>(th, o, a.b);
+    a.out[row] = logprob_row<M, (BLK < 256)>(th, o, a.b);
 }
 
 // ---------------------------------------------------------------------------------

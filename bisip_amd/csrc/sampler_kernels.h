@@ -47,7 +47,7 @@ struct GenericLP {
     Bounds b;
     __device__ __forceinline__ double operator()(const double (&th)[NDIM], int) const
     {
-        return logprob_row<M>(th, o, b);
+        return logprob_row<M, true>(th, o, b);  // half-steps are latency-bound: deeper unroll
     }
 };
 
@@ -76,7 +76,7 @@ struct BatchGenericLP {
     {
         const long long e = spectrum_of<UNIFORM>(walker, Wp);
         const ModelOperands o{cb + e * cb_stride, N, lconst[e]};
-        return logprob_row<M>(th, o, b);
+        return logprob_row<M, true>(th, o, b);
     }
 };
 
