@@ -200,7 +200,10 @@ def main():
                        'kernel': ctx.kernel_name, 'variant': ctx.variant},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'bytes_per_eval': bytes_per_eval, 'kernel_ms': kern_ms},
+                         'bytes_per_eval': bytes_per_eval, 'kernel_ms': kern_ms,
+                         'traffic_source': 'profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / '
+                                           'WRITE_SIZE passes of this command (FETCH_SIZE x2, gfx950)'
+                                           if traffic is not None else None},
         }
         if world == 1:
             gpu_logp = out_t.cpu().numpy()
