@@ -43,7 +43,35 @@
 #define ADDU32(x) asm volatile("v_add_u32 %0, %0, %1" : "+v"(iv) : "v"(iv));
 #define FMA32(x) { float f = (float)x; asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(f)); x = f; }
 
+#define FMAS(x) asm volatile("v_fma_f64 %0, %1, %0, %0" : "+v"(x) : "s"(sb));
+#define FMACS(x) asm volatile("v_fmac_f64 %0, %1, %2" : "+v"(x) : "s"(sb), "v"(b));
+#define MOVS(x) { int lo_; asm volatile("v_mov_b32 %0, %1" : "=v"(lo_) : "s"(si)); iv += lo_; }
 KERNEL(k_fma, OP8(FMA))
+__global__ void k_fma_sgpr(double *out, double seed)
+{
+    double a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    double sb = __builtin_amdgcn_readfirstlane((int)seed) * 0.5 + 0.25;
+    sb = __longlong_as_double(((long long)__builtin_amdgcn_readfirstlane((int)(__double_as_longlong(sb) >> 32)) << 32) |
+                              (unsigned)__builtin_amdgcn_readfirstlane((int)__double_as_longlong(sb)));
+    for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+        for (int r = 0; r < REP / 8; ++r) { OP8(FMAS) }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+}
+__global__ void k_fmac_sgpr(double *out, double seed)
+{
+    double a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    double b = seed * 0.5 + 0.25;
+    double sb = b;
+    sb = __longlong_as_double(((long long)__builtin_amdgcn_readfirstlane((int)(__double_as_longlong(sb) >> 32)) << 32) |
+                              (unsigned)__builtin_amdgcn_readfirstlane((int)__double_as_longlong(sb)));
+    for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+        for (int r = 0; r < REP / 8; ++r) { OP8(FMACS) }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+}
 KERNEL(k_mul, OP8(MUL))
 KERNEL(k_add, OP8(ADD))
 KERNEL(k_rcp, OP8(RCP))
@@ -86,6 +114,8 @@ int main()
 {
     double *d_out; hipMalloc(&d_out, sizeof(double) * 256 * 4 * 256);
     run("v_fma_f64", k_fma, d_out);
+    run("v_fma_f64 sgpr", k_fma_sgpr, d_out);
+    run("v_fmac_f64 sgpr", k_fmac_sgpr, d_out);
     run("v_mul_f64", k_mul, d_out);
     run("v_add_f64", k_add, d_out);
     run("v_max_f64", k_max, d_out);

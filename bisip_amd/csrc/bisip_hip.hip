@@ -115,6 +115,20 @@ int launch_logprob(const bisip_ctx *c, const double *theta, int64_t W, double *o
     return BISIP_OK;
 }
 
+// PolynomialDecomposition collapsed, many walkers: two rows per lane (see k_logprob_x2)
+template <int P>
+int launch_collapsed(const bisip_ctx *c, const double *theta, int64_t W, double *out, hipStream_t st)
+{
+    if (W < SMALL_W) return launch_logprob<PDCollapsed<P>>(c, theta, W, out, st);
+    const LaunchArgs a = make_args(c, theta, out, W, c->d_cb_lp);
+    const bool vec = ((uintptr_t)theta % 16) == 0;
+    const unsigned grid = (unsigned)((W + 2 * BLK_STREAM - 1) / (2 * BLK_STREAM));
+    if (vec) hipLaunchKernelGGL((k_logprob_x2<PDCollapsed<P>, BLK_STREAM, true>), dim3(grid), dim3(BLK_STREAM), 0, st, a);
+    else hipLaunchKernelGGL((k_logprob_x2<PDCollapsed<P>, BLK_STREAM, false>), dim3(grid), dim3(BLK_STREAM), 0, st, a);
+    HIP_TRY(hipGetLastError());
+    return BISIP_OK;
+}
+
 template <int P>
 int launch_reduced(const bisip_ctx *c, const double *theta, int64_t W, double *out, hipStream_t st)
 {
@@ -294,7 +308,7 @@ int dispatch_logprob(const bisip_ctx *c, const double *theta, int64_t W, double 
             }
         } else if (v == BISIP_VARIANT_COLLAPSED) {
             switch (c->P) {
-#define X(p) case p: return launch_logprob<PDCollapsed<p>>(c, theta, W, out, st);
+#define X(p) case p: return launch_collapsed<p>(c, theta, W, out, st);
                 PD_CASES(X)
 #undef X
             }

@@ -42,11 +42,13 @@ struct LaunchArgs {
 // ---------------------------------------------------------------------------------
 // theta staging: BLK rows, coalesced global -> LDS, then one row per lane.
 // ---------------------------------------------------------------------------------
-template <int NDIM, int BLK, bool VEC>
+// ROWS rows are staged by THREADS lanes (THREADS == ROWS unless a lane owns several rows)
+template <int NDIM, int ROWS, bool VEC, int THREADS = ROWS>
 __device__ __forceinline__ void stage_theta(const double *__restrict__ theta, long long W,
                                             long long row0, double *lds)
 {
-    constexpr int CHUNK = BLK * NDIM;  // doubles per block
+    constexpr int BLK = THREADS;
+    constexpr int CHUNK = ROWS * NDIM;  // doubles per block
     const int t = threadIdx.x;
     const long long base = row0 * NDIM;
     const long long avail = (W - row0) * (long long)NDIM;  // doubles left from row0
@@ -70,7 +72,7 @@ __device__ __forceinline__ void stage_theta(const double *__restrict__ theta, lo
     } else {
         if (avail >= CHUNK) {
 #pragma unroll
-            for (int r = 0; r < NDIM; ++r)
+            for (int r = 0; r < CHUNK / BLK; ++r)
                 lds[r * BLK + t] = __builtin_nontemporal_load(theta + base + r * BLK + t);
         } else {
             for (int i = t; i < CHUNK; i += BLK)
@@ -453,6 +455,54 @@ __global__ __launch_bounds__(BLK) void k_logprob(const LaunchArgs a)
     for (int q = 0; q < NDIM; ++q) th[q] = lds[threadIdx.x * NDIM + q];
     const ModelOperands o{a.cb, a.N, a.lconst};
     a.out[row] = logprob_row<M, (BLK < 256)>(th, o, a.b);
+}
+
+// ---------------------------------------------------------------------------------
+// Two walkers per lane.  For PDCollapsed the scalar cache, not the VALU, is the limiter with
+// one walker per lane: every frequency needs 128 B of operands for only 15 FMAs.  Evaluating
+// two rows in lockstep reuses each operand loaded into SGPRs for two FMAs, halving the
+// scalar traffic per FMA.  Same per-row arithmetic and order as logprob_row.
+// ---------------------------------------------------------------------------------
+template <class M, int BLK, bool VEC>
+__global__ __launch_bounds__(BLK) void k_logprob_x2(const LaunchArgs a)
+{
+    constexpr int NDIM = M::NDIM;
+    __shared__ __attribute__((aligned(16))) double lds[2 * BLK * NDIM];
+    const long long row0 = (long long)blockIdx.x * (2 * BLK);
+    stage_theta<NDIM, 2 * BLK, VEC, BLK>(a.theta, a.W, row0, lds);
+    __syncthreads();
+    double th[2][NDIM];
+    bool ok[2];
+    typename M::Setup s[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+#pragma unroll
+        for (int q = 0; q < NDIM; ++q) th[r][q] = lds[(threadIdx.x + r * BLK) * NDIM + q];
+        ok[r] = in_prior<NDIM>(th[r], a.b) && (row0 + threadIdx.x + r * BLK < a.W);
+        s[r] = M::setup(th[r]);
+    }
+    double acc0[2] = {0.0, 0.0}, acc1[2] = {0.0, 0.0};
+    const double *__restrict__ rec = a.cb;
+#pragma unroll 2
+    for (int j = 0; j < a.N; ++j, rec += M::REC) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            double rr, ri;
+            M::residual(s[r], rec, rr, ri);
+            if constexpr (M::WEIGHTED) {
+                acc0[r] = fma(rr, rr, acc0[r]);
+                acc1[r] = fma(ri, ri, acc1[r]);
+            } else {
+                acc0[r] = fma(rr * rr, rec[2], acc0[r]);
+                acc1[r] = fma(ri * ri, rec[3], acc1[r]);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const long long row = row0 + threadIdx.x + r * BLK;
+        if (row < a.W) a.out[row] = ok[r] ? fma(-0.5, acc0[r] + acc1[r], a.lconst) : -__builtin_inf();
+    }
 }
 
 // ---------------------------------------------------------------------------------
