@@ -182,7 +182,9 @@ template <class M>
 int launch_forward(const bisip_ctx *c, const double *theta, int64_t W, double *Z, hipStream_t st)
 {
     const LaunchArgs a = make_args(c, theta, Z, W, c->d_cb);
-    const unsigned grid = (unsigned)((W + 63) / 64);
+    long long blocks = (W + 63) / 64;
+    if (blocks > 256 * 9) blocks = 256 * 9;   // persistent waves: LDS admits 9 per CU
+    const unsigned grid = (unsigned)blocks;
     if (((uintptr_t)theta % 16) == 0) hipLaunchKernelGGL((k_forward_tiled<M, true>), dim3(grid), dim3(64), 0, st, a);
     else hipLaunchKernelGGL((k_forward_tiled<M, false>), dim3(grid), dim3(64), 0, st, a);
     HIP_TRY(hipGetLastError());

@@ -208,17 +208,17 @@ struct PDCollapsed {
             ri = fma(s.b[p], rec[4 + P + 1 + p], ri);
         }
     }
+    // Z = r0 - sum_p b_p G_p  (m = unweighted G_re[0..P], G_im[0..P])
     __device__ static __forceinline__ void eval(const Setup &s, const double *__restrict__ m,
                                                 double &zr, double &zi)
     {
-        double gr = 0.0, gi = 0.0;
+        zr = s.r0;
+        zi = 0.0;
 #pragma unroll
         for (int p = 0; p <= P; ++p) {
-            gr = fma(s.a[p], m[p], gr);
-            gi = fma(s.a[p], m[P + 1 + p], gi);
+            zr = fma(-s.b[p], m[p], zr);
+            zi = fma(-s.b[p], m[P + 1 + p], zi);
         }
-        zr = s.r0 * (1.0 - gr);
-        zi = s.r0 * (0.0 - gi);
     }
 };
 
@@ -269,22 +269,22 @@ struct ColeCole {
             ri = fma(t, di, ri);
         }
     }
+    // Z = (r0 - sum A_i) + sum A_i conj(1+x_i)/|1+x_i|^2   (m = w, ln w, sqrt w)
     __device__ static __forceinline__ void eval(const Setup &s, const double *__restrict__ m,
                                                 double &zr, double &zi)
     {
         const double lnw = m[1];
-        double sr = 0.0, si = 0.0;
+        zr = s.C;
+        zi = 0.0;
 #pragma unroll
         for (int i = 0; i < D; ++i) {
-            const double e = exp_finite(s.c[i] * (lnw + s.lt[i]));
+            const double e = exp2_finite(fma(s.c2[i], lnw, s.clt2[i]));
             const double dr = fma(e, s.cs[i], 1.0);  // 1 + x, >= 1 because cos(c pi/2) >= 0
             const double di = e * s.sn[i];
-            const double inv = rcp_nr(fma(dr, dr, di * di));
-            sr = fma(s.m[i], 1.0 - dr * inv, sr);  // m*(1 - 1/(1+x))
-            si = fma(s.m[i], di * inv, si);
+            const double t = s.A[i] * rcp_nr(fma(dr, dr, di * di));
+            zr = fma(t, dr, zr);
+            zi = fma(-t, di, zi);
         }
-        zr = s.r0 * (1.0 - sr);
-        zi = s.r0 * (0.0 - si);
     }
 };
 
@@ -325,21 +325,19 @@ struct Dias {
         rr = fma(-t, dr, rec[0] - s.C);
         ri = fma(t, di, rec[1]);
     }
+    // Z = r0 (1-m) + r0 m conj(den)/|den|^2   (m = w, ln w, sqrt w)
     __device__ static __forceinline__ void eval(const Setup &s, const double *__restrict__ m,
                                                 double &zr, double &zi)
     {
         const double w = m[0];
-        // (i w tau'')^0.5 = sqrt(w tau'') (cos(pi/4) + i sin(pi/4))
-        const double sq = sqrt(w * s.taupp) * 0.70710678118654752440;
-        const double mur = sq, mui = fma(w, s.tau, sq);
+        const double mur = m[2] * s.teh, mui = fma(w, s.tau, mur);
         const double inv = rcp_nr(fma(mur, mur, mui * mui));       // |mu| >= w tau > 0
-        const double tr = fma(mur, inv, 1.0), ti = -(mui * inv);  // 1 + 1/mu
+        const double tr = fma(mur, inv, 1.0), nti = mui * inv;     // 1 + 1/mu = tr - i nti
         const double a = w * s.taup;
-        const double dr = fma(-a, ti, 1.0), di = a * tr;          // 1 + i a (tr + i ti)
-        const double inv2 = rcp_nr(fma(dr, dr, di * di));         // Re(den) >= 1
-        const double fr = 1.0 - dr * inv2, fi = di * inv2;        // 1 - 1/den
-        zr = s.r0 * (1.0 - s.m * fr);
-        zi = s.r0 * (0.0 - s.m * fi);
+        const double dr = fma(a, nti, 1.0), di = a * tr;           // den = 1 + i a (1 + 1/mu), Re >= 1
+        const double t = s.A * rcp_nr(fma(dr, dr, di * di));
+        zr = fma(t, dr, s.C);
+        zi = -(t * di);
     }
 };
 
@@ -382,6 +380,7 @@ struct Shin {
             ri = fma(yi, inv, ri);
         }
     }
+    // Z = sum_i conj(y_i)/|y_i|^2,  y_i = Q (iw)^n + 1/R   (m = w, ln w, sqrt w)
     __device__ static __forceinline__ void eval(const Setup &s, const double *__restrict__ m,
                                                 double &zr, double &zi)
     {
@@ -390,7 +389,7 @@ struct Shin {
         zi = 0.0;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const double p = s.Q[i] * exp_finite(s.n[i] * lnw);  // Q (iw)^n = p (cs + i sn)
+            const double p = exp2_finite(fma(s.n2[i], lnw, s.lq2[i]));
             const double yr = fma(p, s.cs[i], s.invR[i]), yi = p * s.sn[i];  // yr >= 1/R > 1
             const double inv = rcp_nr(fma(yr, yr, yi * yi));
             zr = fma(yr, inv, zr);
@@ -765,64 +764,79 @@ __global__ __launch_bounds__(256) void k_forward_batch(const BatchArgs a)
 // 64 walkers into an LDS tile and streams the tile out so that every store instruction
 // writes whole 128-byte runs of Z.  Bound by writing Z (16*N B per walker).
 // ---------------------------------------------------------------------------------
+// The workgroup of k_forward_tiled is ONE wave, whose LDS operations execute in order; all
+// it needs between writing a tile and reading it back is "LDS results have landed" plus a
+// compiler barrier.  __syncthreads() would also wait vmcnt(0), i.e. for the previous tile's
+// global stores to be acknowledged, serialising store latency with the next tile's
+// arithmetic (measured: 2.9 -> see DESIGN.md TB/s).
+__device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 template <class M, bool VEC>
 __global__ __launch_bounds__(64) void k_forward_tiled(const LaunchArgs a)
 {
     constexpr int NDIM = M::NDIM;
     constexpr int JC = 16;             // frequencies per tile
     constexpr int ROW = 2 * JC + 1;    // padded tile row (doubles): conflict-light ds_write_b64
-    __shared__ __attribute__((aligned(16))) double lds[64 * NDIM > 64 * ROW ? 64 * NDIM : 64 * ROW];
-    const long long row0 = (long long)blockIdx.x * 64;
-    stage_theta<NDIM, 64, VEC>(a.theta, a.W, row0, lds);
-    __syncthreads();
+    __shared__ __attribute__((aligned(16))) double lds[64 * ROW];
     const int lane = threadIdx.x;
-    const long long rows_here = (a.W - row0) < 64 ? (a.W - row0) : 64;
-    double th[NDIM];
-#pragma unroll
-    for (int q = 0; q < NDIM; ++q) th[q] = lds[lane * NDIM + q];
-    __syncthreads();
-    const typename M::Setup s = M::setup(th);
     const int N = a.N;
     const bool wide = ((N & 1) == 0) && ((reinterpret_cast<unsigned long long>(a.out) & 15) == 0);
-    for (int j0 = 0; j0 < N; j0 += JC) {
-        const int jn = (N - j0) < JC ? (N - j0) : JC;
-        const double *__restrict__ rec = a.cb + (long long)j0 * M::REC;
-        for (int jj = 0; jj < jn; ++jj, rec += M::REC) {
-            double zr, zi;
-            M::eval(s, rec + 4, zr, zi);
-            lds[lane * ROW + jj] = zr;
-            lds[lane * ROW + JC + jj] = zi;
-        }
-        __syncthreads();
-        // stream the tile out: runs of jn doubles per (walker, part)
-        if (jn == JC && wide) {  // full tile, 16-byte stores (N even, Z 16-byte aligned)
-            const int total2 = (int)rows_here * JC;  // pairs of doubles
+    const long long nblocks = (a.W + 63) / 64;
+    // persistent: each wave walks blocks of 64 walkers; the next block's theta rows are
+    // requested (strided per-lane loads, 8*NDIM B each) before this block is evaluated
+    double th_next[NDIM];
+    auto request = [&](long long blk) {
+        const long long row = blk * 64 + lane;
+        const long long r = row < a.W ? row : a.W - 1;
+#pragma unroll
+        for (int q = 0; q < NDIM; ++q) th_next[q] = a.theta[r * NDIM + q];
+    };
+    long long blk = blockIdx.x;
+    if (blk < nblocks) request(blk);
+    for (; blk < nblocks; blk += gridDim.x) {
+        const long long row0 = blk * 64;
+        const long long rows_here = (a.W - row0) < 64 ? (a.W - row0) : 64;
+        double th[NDIM];
+#pragma unroll
+        for (int q = 0; q < NDIM; ++q) th[q] = th_next[q];
+        if (blk + gridDim.x < nblocks) request(blk + gridDim.x);
+        const typename M::Setup s = M::setup(th);
+        for (int j0 = 0; j0 < N; j0 += JC) {
+            const int jn = (N - j0) < JC ? (N - j0) : JC;
+            const double *__restrict__ rec = a.cb + (long long)j0 * M::REC;
+            for (int jj = 0; jj < jn; ++jj, rec += M::REC) {
+                double zr, zi;
+                M::eval(s, rec + 4, zr, zi);
+                lds[lane * ROW + jj] = zr;
+                lds[lane * ROW + JC + jj] = zi;
+            }
+            wave_lds_fence();
+            // stream the tile out: runs of jn doubles per (walker, part)
+            if (jn == JC && wide) {  // full tile, 16-byte stores (N even, Z 16-byte aligned)
+                // lane l always writes the same two columns c, c+1 of walkers (l>>4) + 4*it: all
+                // index arithmetic is loop-invariant, the loop is two LDS reads and one store
+                const int c = (lane & 15) << 1;
+                const double *src = lds + (lane >> 4) * ROW + c;
+                double *dst = a.out + (row0 + (lane >> 4)) * 2 * N + (long long)(c >> 4) * N + j0 + (c & 15);
+                const int nw = (int)rows_here;
 #pragma unroll 4
-            for (int flat = lane; flat < total2; flat += 64) {
-                const int w = flat >> 4, c = (flat & 15) << 1;
-                dbl2 v;
-                v.x = lds[w * ROW + c];
-                v.y = lds[w * ROW + c + 1];
-                __builtin_nontemporal_store(v, reinterpret_cast<dbl2 *>(
-                    a.out + (row0 + w) * 2 * N + (long long)(c >> 4) * N + j0 + (c & 15)));
+                for (int w = lane >> 4; w < nw; w += 4, src += 4 * ROW, dst += 8 * (long long)N) {
+                    dbl2 v;
+                    v.x = src[0];
+                    v.y = src[1];
+                    __builtin_nontemporal_store(v, reinterpret_cast<dbl2 *>(dst));
+                }
+            } else {
+                const int per_walker = 2 * jn;
+                const int total = (int)rows_here * per_walker;
+                for (int flat = lane; flat < total; flat += 64) {
+                    const int w = flat / per_walker, c = flat - w * per_walker;
+                    const int part = c / jn, jj = c - part * jn;
+                    a.out[(row0 + w) * 2 * N + (long long)part * N + j0 + jj] = lds[w * ROW + part * JC + jj];
+                }
             }
-        } else if (jn == JC) {  // full tile: index arithmetic is shifts and masks
-            const int total = (int)rows_here * 2 * JC;
-#pragma unroll 4
-            for (int flat = lane; flat < total; flat += 64) {
-                const int w = flat >> 5, c = flat & 31;
-                a.out[(row0 + w) * 2 * N + (long long)(c >> 4) * N + j0 + (c & 15)] = lds[w * ROW + c];
-            }
-        } else {
-            const int per_walker = 2 * jn;
-            const int total = (int)rows_here * per_walker;
-            for (int flat = lane; flat < total; flat += 64) {
-                const int w = flat / per_walker, c = flat - w * per_walker;
-                const int part = c / jn, jj = c - part * jn;
-                a.out[(row0 + w) * 2 * N + (long long)part * N + j0 + jj] = lds[w * ROW + part * JC + jj];
-            }
+            wave_lds_fence();
         }
-        __syncthreads();
     }
 }
 
