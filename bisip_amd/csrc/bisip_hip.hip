@@ -183,7 +183,7 @@ int launch_forward(const bisip_ctx *c, const double *theta, int64_t W, double *Z
 {
     const LaunchArgs a = make_args(c, theta, Z, W, c->d_cb);
     long long blocks = (W + 63) / 64;
-    if (blocks > 256 * 9) blocks = 256 * 9;   // persistent waves: LDS admits 9 per CU
+    if (blocks > 256 * 16) blocks = 256 * 16;   // persistent single-wave workgroups, 16 per CU
     const unsigned grid = (unsigned)blocks;
     if (((uintptr_t)theta % 16) == 0) hipLaunchKernelGGL((k_forward_tiled<M, true>), dim3(grid), dim3(64), 0, st, a);
     else hipLaunchKernelGGL((k_forward_tiled<M, false>), dim3(grid), dim3(64), 0, st, a);

@@ -775,8 +775,10 @@ template <class M, bool VEC>
 __global__ __launch_bounds__(64) void k_forward_tiled(const LaunchArgs a)
 {
     constexpr int NDIM = M::NDIM;
-    constexpr int JC = 16;             // frequencies per tile
-    constexpr int ROW = 2 * JC + 1;    // padded tile row (doubles): conflict-light ds_write_b64
+    constexpr int JC = 16;          // frequencies per tile
+    constexpr int ROW = JC + 1;     // padded tile row (doubles): conflict-free ds_write_b64
+    // one (64 walkers x 16 frequencies) tile of ONE part at a time: the real parts go through
+    // LDS first while the imaginary parts wait in registers -- half the LDS, twice the waves
     __shared__ __attribute__((aligned(16))) double lds[64 * ROW];
     const int lane = threadIdx.x;
     const int N = a.N;
@@ -791,11 +793,34 @@ __global__ __launch_bounds__(64) void k_forward_tiled(const LaunchArgs a)
 #pragma unroll
         for (int q = 0; q < NDIM; ++q) th_next[q] = a.theta[r * NDIM + q];
     };
+    // stream the LDS tile (jn columns of `part`) to Z: runs of jn doubles per walker
+    auto stream_out = [&](long long row0, int rows_here, int part, int j0, int jn) {
+        if (jn == JC && wide) {
+            // lane l always writes columns c, c+1 of walkers (l>>3) + 8*it: loop-invariant
+            // addressing, the loop is two LDS reads and one 16-byte store
+            const int c = (lane & 7) << 1;
+            const double *src = lds + (lane >> 3) * ROW + c;
+            double *dst = a.out + (row0 + (lane >> 3)) * 2 * N + (long long)part * N + j0 + c;
+#pragma unroll 4
+            for (int w = lane >> 3; w < rows_here; w += 8, src += 8 * ROW, dst += 16 * (long long)N) {
+                dbl2 v;
+                v.x = src[0];
+                v.y = src[1];
+                __builtin_nontemporal_store(v, reinterpret_cast<dbl2 *>(dst));
+            }
+        } else {
+            const int total = rows_here * jn;
+            for (int flat = lane; flat < total; flat += 64) {
+                const int w = flat / jn, jj = flat - w * jn;
+                a.out[(row0 + w) * 2 * N + (long long)part * N + j0 + jj] = lds[w * ROW + jj];
+            }
+        }
+    };
     long long blk = blockIdx.x;
     if (blk < nblocks) request(blk);
     for (; blk < nblocks; blk += gridDim.x) {
         const long long row0 = blk * 64;
-        const long long rows_here = (a.W - row0) < 64 ? (a.W - row0) : 64;
+        const int rows_here = (int)((a.W - row0) < 64 ? (a.W - row0) : 64);
         double th[NDIM];
 #pragma unroll
         for (int q = 0; q < NDIM; ++q) th[q] = th_next[q];
@@ -804,37 +829,21 @@ __global__ __launch_bounds__(64) void k_forward_tiled(const LaunchArgs a)
         for (int j0 = 0; j0 < N; j0 += JC) {
             const int jn = (N - j0) < JC ? (N - j0) : JC;
             const double *__restrict__ rec = a.cb + (long long)j0 * M::REC;
-            for (int jj = 0; jj < jn; ++jj, rec += M::REC) {
-                double zr, zi;
-                M::eval(s, rec + 4, zr, zi);
+            double zim[JC];
+#pragma unroll
+            for (int jj = 0; jj < JC; ++jj) {
+                double zr = 0.0, zi = 0.0;
+                if (jj < jn) M::eval(s, rec + (long long)jj * M::REC + 4, zr, zi);
                 lds[lane * ROW + jj] = zr;
-                lds[lane * ROW + JC + jj] = zi;
+                zim[jj] = zi;
             }
             wave_lds_fence();
-            // stream the tile out: runs of jn doubles per (walker, part)
-            if (jn == JC && wide) {  // full tile, 16-byte stores (N even, Z 16-byte aligned)
-                // lane l always writes the same two columns c, c+1 of walkers (l>>4) + 4*it: all
-                // index arithmetic is loop-invariant, the loop is two LDS reads and one store
-                const int c = (lane & 15) << 1;
-                const double *src = lds + (lane >> 4) * ROW + c;
-                double *dst = a.out + (row0 + (lane >> 4)) * 2 * N + (long long)(c >> 4) * N + j0 + (c & 15);
-                const int nw = (int)rows_here;
-#pragma unroll 4
-                for (int w = lane >> 4; w < nw; w += 4, src += 4 * ROW, dst += 8 * (long long)N) {
-                    dbl2 v;
-                    v.x = src[0];
-                    v.y = src[1];
-                    __builtin_nontemporal_store(v, reinterpret_cast<dbl2 *>(dst));
-                }
-            } else {
-                const int per_walker = 2 * jn;
-                const int total = (int)rows_here * per_walker;
-                for (int flat = lane; flat < total; flat += 64) {
-                    const int w = flat / per_walker, c = flat - w * per_walker;
-                    const int part = c / jn, jj = c - part * jn;
-                    a.out[(row0 + w) * 2 * N + (long long)part * N + j0 + jj] = lds[w * ROW + part * JC + jj];
-                }
-            }
+            stream_out(row0, rows_here, 0, j0, jn);
+            wave_lds_fence();
+#pragma unroll
+            for (int jj = 0; jj < JC; ++jj) lds[lane * ROW + jj] = zim[jj];
+            wave_lds_fence();
+            stream_out(row0, rows_here, 1, j0, jn);
             wave_lds_fence();
         }
     }
