@@ -1,3 +1,5 @@
+"""Device->host copy rate of a chain slab into pageable vs pinned host memory (why the device
+sampler returns big chains through pinned buffers)."""
 import torch, time, numpy as np
 n = 200*32768*7
 dev = torch.empty(n, dtype=torch.float64, device='cuda'); dev.normal_()

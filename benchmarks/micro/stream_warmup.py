@@ -1,5 +1,8 @@
+"""Kernel time of the headline launch on the null stream vs a side stream, round after round:
+shows the 5-8 % warm-up effect (first ~0.1 s after idle) that bench.py primes away."""
 import sys, os, json
-sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo')); sys.path.insert(0, os.path.join(os.environ.get('GRAFT_REPO_ROOT', '/root/repo'), 'benchmarks'))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'benchmarks'))
 import torch, numpy as np
 from sweep import problem
 from bisip_amd.synthetic import synthetic_theta
