@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""BASELINE config 5 (per-GPU share): a batch of independent synthetic spectra x 256 walkers
+each, double Cole-Cole, all ensembles advanced together on one MI355X (512 spectra per GPU
+when 4096 are sharded over 8).  Prints one JSON line."""
+import argparse, json, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--spectra', type=int, default=512)
+    ap.add_argument('--walkers', type=int, default=256)
+    ap.add_argument('--steps', type=int, default=100, help='stored samples')
+    ap.add_argument('--thin-by', type=int, default=10)
+    args = ap.parse_args()
+    import bisip_amd
+    from bisip_amd.synthetic import synthetic_columns
+    E, Wp = args.spectra, args.walkers
+    tables = [synthetic_columns(32, i) for i in range(E)]
+    batch = bisip_amd.SpectraBatch('PeltonColeCole', tables, nwalkers=Wp, nsteps=args.steps, n_modes=2)
+    rng = np.random.RandomState(0)
+    centre = np.array([1.0, 0.15, 0.5, -1.5, -12.0, 0.45, 0.6])
+    p0 = centre + 1e-3 * rng.randn(E, Wp, 7)
+    from bisip_amd.sampler import DeviceEnsembleSampler
+    batch.ctx.set_bounds(batch.param_bounds)
+
+    def make():
+        return DeviceEnsembleSampler(Wp, 7, batch.ctx, rng='philox', seed=3, n_ensembles=E)
+    make().run_mcmc(p0.reshape(-1, 7), 2, thin_by=args.thin_by)
+    s = make()
+    t0 = time.perf_counter()
+    s.run_mcmc(p0.reshape(-1, 7), args.steps, thin_by=args.thin_by)
+    dt = time.perf_counter() - t0
+    iters = args.steps * args.thin_by
+    print(json.dumps({'config': 'cfg5 slice: double Cole-Cole, 32 frequencies', 'spectra': E, 'walkers_per_spectrum': Wp,
+                      'iterations': iters, 'stored': args.steps, 'thin_by': args.thin_by, 'seconds': round(dt, 4),
+                      'it_per_s': round(iters / dt, 1),
+                      'walker_steps_per_s': float('%.4g' % (iters * E * Wp / dt)),
+                      'timing_s': {k: round(v, 4) for k, v in s.timing.items()},
+                      'acceptance': round(float(s.acceptance_fraction.mean()), 3)}))
+
+
+if __name__ == '__main__':
+    main()

@@ -63,6 +63,8 @@ CASES = [
     ('cfg4 PD P5 N20 W=4096 reduced', 'pd', 20, 4096, dict(variant='reduced')),
     ('cfg2 CC D1 N32 W=4096', 'cc', 32, 4096, dict(n_modes=1)),
     ('CC D1 N32 W=4M', 'cc', 32, 1 << 22, dict(n_modes=1)),
+    ('CC D2 N32 W=16384', 'cc', 32, 16384, dict(n_modes=2)),
+    ('CC D2 N32 W=65536', 'cc', 32, 65536, dict(n_modes=2)),
     ('cfg5 CC D2 N32 W=1M (=4096x256)', 'cc', 32, 1 << 20, dict(n_modes=2)),
     ('CC D2 N32 W=4M', 'cc', 32, 1 << 22, dict(n_modes=2)),
     ('CC D3 N32 W=4M', 'cc', 32, 1 << 22, dict(n_modes=3)),

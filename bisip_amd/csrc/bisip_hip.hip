@@ -39,6 +39,8 @@ int fail(int code, const char *fmt, ...)
                         __FILE__, __LINE__);                                           \
     } while (0)
 
+int lanes_per_walker(long long walkers);
+
 constexpr int BLK_SMALL = 64;    // few walkers: spread them over more CUs
 constexpr int BLK_LARGE = 256;
 constexpr int BLK_STREAM = 128;  // HBM-bound reduced kernel: 128-lane workgroups stream ~3 % faster
@@ -101,15 +103,32 @@ LaunchArgs make_args(const bisip_ctx *c, const double *theta, double *out, int64
     return a;
 }
 
+template <class M> struct CoopLimit { static constexpr long long value = 1LL << 40; };
+// PDCollapsed spends 15 FMAs per frequency: passing the running sums between lanes costs as
+// much as the residual it parallelises (measured 5.7 vs 5.2 us at 4096 walkers), so one lane.
+template <int P> struct CoopLimit<PDCollapsed<P>> { static constexpr long long value = 0; };
+
+template <class M, int L>
+int launch_logprob_small(const LaunchArgs &a, bool vec, hipStream_t st)
+{
+    const unsigned grid = (unsigned)((a.W * L + BLK_SMALL - 1) / BLK_SMALL);
+    if (vec) hipLaunchKernelGGL((k_logprob<M, BLK_SMALL, true, L>), dim3(grid), dim3(BLK_SMALL), 0, st, a);
+    else hipLaunchKernelGGL((k_logprob<M, BLK_SMALL, false, L>), dim3(grid), dim3(BLK_SMALL), 0, st, a);
+    return BISIP_OK;
+}
+
 template <class M>
 int launch_logprob(const bisip_ctx *c, const double *theta, int64_t W, double *out, hipStream_t st)
 {
     const LaunchArgs a = make_args(c, theta, out, W, c->d_cb_lp ? c->d_cb_lp : c->d_cb);
     const bool vec = ((uintptr_t)theta % 16) == 0;
     if (W < SMALL_W) {
-        const unsigned grid = (unsigned)((W + BLK_SMALL - 1) / BLK_SMALL);
-        if (vec) hipLaunchKernelGGL((k_logprob<M, BLK_SMALL, true>), dim3(grid), dim3(BLK_SMALL), 0, st, a);
-        else hipLaunchKernelGGL((k_logprob<M, BLK_SMALL, false>), dim3(grid), dim3(BLK_SMALL), 0, st, a);
+        // few walkers: several lanes per walker so the launch still covers the chip
+        switch (W <= CoopLimit<M>::value ? lanes_per_walker(W) : 1) {
+        case 4: launch_logprob_small<M, 4>(a, vec, st); break;
+        case 2: launch_logprob_small<M, 2>(a, vec, st); break;
+        default: launch_logprob_small<M, 1>(a, vec, st); break;
+        }
     } else {
         const unsigned grid = (unsigned)((W + BLK_LARGE - 1) / BLK_LARGE);
         if (vec) hipLaunchKernelGGL((k_logprob<M, BLK_LARGE, true>), dim3(grid), dim3(BLK_LARGE), 0, st, a);
@@ -419,23 +438,40 @@ int launch_stretch(const StretchWork &work, const LP &lp, hipStream_t st)
     }
     const StretchArgs &a = *work.half;
     if (kind == STRETCH_HALF) {
-        const unsigned grid = (unsigned)((a.n_slots + 63) / 64);
+        const unsigned grid = (unsigned)((a.n_slots * LP::L + 63) / 64);
         hipLaunchKernelGGL((k_stretch_half<LP>), dim3(grid), dim3(64), 0, st, a, lp);
     } else {
-        const unsigned grid = (unsigned)((a.slot_hi - a.slot_lo + 63) / 64);
+        const unsigned grid = (unsigned)(((a.slot_hi - a.slot_lo) * LP::L + 63) / 64);
         hipLaunchKernelGGL((k_stretch_eval<LP>), dim3(grid), dim3(64), 0, st, a, lp);
     }
     HIP_TRY(hipGetLastError());
     return BISIP_OK;
 }
 
+// Lanes per walker for launches that cannot fill the chip with one lane per walker (1024
+// SIMDs x 64 lanes): up to 4 below 8 Ki walkers, 2 below 32 Ki, else 1.  The value never changes
+// a result (logprob_row is bit-identical for every L), only the wave count.
+int lanes_per_walker(long long walkers)
+{
+    return walkers <= 8192 ? 4 : (walkers <= 32768 ? 2 : 1);
+}
+
+long long stretch_walkers(const StretchWork &w)
+{
+    if (w.kind == STRETCH_PERSIST) return 1LL << 40;   // persistent kernel: one lane per walker
+    return w.kind == STRETCH_HALF ? w.half->n_slots : w.half->slot_hi - w.half->slot_lo;
+}
+
 template <class M>
 int stretch_generic(const bisip_ctx *c, const StretchWork &a, hipStream_t st)
 {
-    GenericLP<M> lp;
-    lp.o = ModelOperands{c->d_cb_lp ? c->d_cb_lp : c->d_cb, c->N, c->lconst};
-    lp.b = c->bounds;
-    return launch_stretch(a, lp, st);
+    const ModelOperands o{c->d_cb_lp ? c->d_cb_lp : c->d_cb, c->N, c->lconst};
+    const long long nw = stretch_walkers(a);
+    switch (nw <= CoopLimit<M>::value ? lanes_per_walker(nw) : 1) {
+    case 4: { GenericLP<M, 4> lp; lp.o = o; lp.b = c->bounds; return launch_stretch(a, lp, st); }
+    case 2: { GenericLP<M, 2> lp; lp.o = o; lp.b = c->bounds; return launch_stretch(a, lp, st); }
+    default: { GenericLP<M, 1> lp; lp.o = o; lp.b = c->bounds; return launch_stretch(a, lp, st); }
+    }
 }
 
 template <int P>
@@ -451,13 +487,23 @@ int stretch_reduced(const bisip_ctx *c, const StretchWork &a, hipStream_t st)
     return launch_stretch(a, lp, st);
 }
 
-template <class M, bool U>
-int stretch_generic_batch(const bisip_ctx *c, const StretchWork &a, long long Wp, hipStream_t st)
+template <class M, bool U, int L>
+int stretch_generic_batch_l(const bisip_ctx *c, const StretchWork &a, long long Wp, hipStream_t st)
 {
-    BatchGenericLP<M, U> lp;
+    BatchGenericLP<M, U, L> lp;
     lp.cb = c->d_cb_lp ? c->d_cb_lp : c->d_cb; lp.cb_stride = c->cb_stride; lp.Wp = Wp; lp.lconst = c->d_lconst; lp.N = c->N;
     lp.b = c->bounds;
     return launch_stretch(a, lp, st);
+}
+
+template <class M, bool U>
+int stretch_generic_batch(const bisip_ctx *c, const StretchWork &a, long long Wp, hipStream_t st)
+{
+    // a wave of 64/L slots must stay inside one spectrum for the uniform (scalar) operand path
+    const int want = lanes_per_walker(stretch_walkers(a));
+    if (want == 4 && (!U || (Wp / 2) % 16 == 0)) return stretch_generic_batch_l<M, U, 4>(c, a, Wp, st);
+    if (want >= 2 && (!U || (Wp / 2) % 32 == 0)) return stretch_generic_batch_l<M, U, 2>(c, a, Wp, st);
+    return stretch_generic_batch_l<M, U, 1>(c, a, Wp, st);
 }
 
 template <int P, bool U>

@@ -72,8 +72,10 @@ __device__ __forceinline__ void stage_theta(const double *__restrict__ theta, lo
     } else {
         if (avail >= CHUNK) {
 #pragma unroll
-            for (int r = 0; r < CHUNK / BLK; ++r)
-                lds[r * BLK + t] = __builtin_nontemporal_load(theta + base + r * BLK + t);
+            for (int r = 0; r < (CHUNK + BLK - 1) / BLK; ++r) {
+                const int i = r * BLK + t;
+                if ((r + 1) * BLK <= CHUNK || i < CHUNK) lds[i] = __builtin_nontemporal_load(theta + base + i);
+            }
         } else {
             for (int i = t; i < CHUNK; i += BLK)
                 if (i < avail) lds[i] = theta[base + i];
@@ -409,28 +411,79 @@ struct ModelOperands {
     double lconst;
 };
 
-// LATENCY = true: few walkers per launch (one wave per SIMD at best), so the frequency loop
-// is unrolled deeper to give the lone wave independent dependency chains to interleave;
-// the summation order is unchanged (same two accumulators, same j order).
-template <class M, bool LATENCY = false>
-__device__ __forceinline__ double logprob_row(const double (&th)[M::NDIM], const ModelOperands &o,
-                                              const Bounds &b)
+// Summation order (the same in every kernel, whatever L): ONE pair of running sums -- real
+// and imaginary squared residuals -- accumulated in ascending frequency order.
+//
+// L = 1: a plain loop in one lane.
+// L in {2, 4}: L adjacent lanes (an aligned pair / quad) cooperate on one walker for launches
+// with too few walkers to fill the chip.  In each round lane g evaluates the residual of
+// frequency j0+g -- the expensive part, in parallel -- and then the running sums travel
+// through the group: for step = 0..L-1 every lane forms "its term added to the sums" and all
+// lanes adopt the result of lane `step` (a DPP quad broadcast, no LDS).  The additions are
+// therefore performed in exactly the order and with exactly the operands of the L = 1 loop,
+// so the result is BIT-IDENTICAL for every L: a walker's log-probability does not depend on
+// how many lanes evaluated it, and launches of any size and the sampler kernels agree exactly.
+template <int STEP, int L>
+__device__ __forceinline__ double group_broadcast(double x)
 {
+    // quad_perm selecting lane STEP of each aligned group of L inside a quad
+    constexpr int P0 = STEP, P1 = (L == 4) ? STEP : STEP, P2 = (L == 4) ? STEP : 2 + STEP,
+                  P3 = (L == 4) ? STEP : 2 + STEP;
+    constexpr int CTRL = P0 | (P1 << 2) | (P2 << 4) | (P3 << 6);
+    const long long bits = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)bits, CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(bits >> 32), CTRL, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+template <class M, int L, int STEP>
+__device__ __forceinline__ void rotate_sums(double rr, double ri, const double *__restrict__ rec,
+                                            int j0, int N, double &acc0, double &acc1)
+{
+    if constexpr (STEP < L) {
+        double c0, c1;
+        if constexpr (M::WEIGHTED) {
+            c0 = fma(rr, rr, acc0);
+            c1 = fma(ri, ri, acc1);
+        } else {
+            c0 = fma(rr * rr, rec[2], acc0);
+            c1 = fma(ri * ri, rec[3], acc1);
+        }
+        const double n0 = group_broadcast<STEP, L>(c0), n1 = group_broadcast<STEP, L>(c1);
+        if (j0 + STEP < N) { acc0 = n0; acc1 = n1; }   // uniform inside the group
+        rotate_sums<M, L, STEP + 1>(rr, ri, rec, j0, N, acc0, acc1);
+    }
+}
+
+template <class M, int L = 1>
+__device__ __forceinline__ double logprob_row(const double (&th)[M::NDIM], const ModelOperands &o,
+                                              const Bounds &b, const int g = 0)
+{
+    static_assert(L == 1 || L == 2 || L == 4, "lanes per walker");
     if (!in_prior<M::NDIM>(th, b)) return -__builtin_inf();  // never touches the forward model
     const typename M::Setup s = M::setup(th);
     double acc0 = 0.0, acc1 = 0.0;
-    const double *__restrict__ rec = o.cb;
-    constexpr int UNROLL = LATENCY ? 4 : 2;
-#pragma unroll UNROLL
-    for (int j = 0; j < o.N; ++j, rec += M::REC) {
-        double rr, ri;
-        M::residual(s, rec, rr, ri);
-        if constexpr (M::WEIGHTED) {
-            acc0 = fma(rr, rr, acc0);
-            acc1 = fma(ri, ri, acc1);
-        } else {
-            acc0 = fma(rr * rr, rec[2], acc0);
-            acc1 = fma(ri * ri, rec[3], acc1);
+    if constexpr (L == 1) {
+        const double *__restrict__ rec = o.cb;
+#pragma unroll 2
+        for (int j = 0; j < o.N; ++j, rec += M::REC) {
+            double rr, ri;
+            M::residual(s, rec, rr, ri);
+            if constexpr (M::WEIGHTED) {
+                acc0 = fma(rr, rr, acc0);
+                acc1 = fma(ri, ri, acc1);
+            } else {
+                acc0 = fma(rr * rr, rec[2], acc0);
+                acc1 = fma(ri * ri, rec[3], acc1);
+            }
+        }
+    } else {
+        for (int j0 = 0; j0 < o.N; j0 += L) {
+            const int j = (j0 + g < o.N) ? j0 + g : o.N - 1;   // clamp: its result is never adopted
+            const double *__restrict__ rec = o.cb + (long long)j * M::REC;
+            double rr, ri;
+            M::residual(s, rec, rr, ri);
+            rotate_sums<M, L, 0>(rr, ri, rec, j0, o.N, acc0, acc1);
         }
     }
     return fma(-0.5, acc0 + acc1, o.lconst);
@@ -439,21 +492,24 @@ __device__ __forceinline__ double logprob_row(const double (&th)[M::NDIM], const
 // ---------------------------------------------------------------------------------
 // log-probability, one lane per walker, any model above.
 // ---------------------------------------------------------------------------------
-template <class M, int BLK, bool VEC>
+template <class M, int BLK, bool VEC, int L = 1>
 __global__ __launch_bounds__(BLK) void k_logprob(const LaunchArgs a)
 {
     constexpr int NDIM = M::NDIM;
-    __shared__ __attribute__((aligned(16))) double lds[BLK * NDIM];
-    const long long row0 = (long long)blockIdx.x * BLK;
-    stage_theta<NDIM, BLK, VEC>(a.theta, a.W, row0, lds);
+    constexpr int ROWS = BLK / L;  // walkers per workgroup
+    __shared__ __attribute__((aligned(16))) double lds[ROWS * NDIM];
+    const long long row0 = (long long)blockIdx.x * ROWS;
+    stage_theta<NDIM, ROWS, VEC, BLK>(a.theta, a.W, row0, lds);
     __syncthreads();
-    const long long row = row0 + threadIdx.x;
-    if (row >= a.W) return;
+    const int r = threadIdx.x / L, g = threadIdx.x % L;
+    const long long row = row0 + r;
+    const bool live = row < a.W;   // every lane stays for the wavefront exchanges of L > 1
     double th[NDIM];
 #pragma unroll
-    for (int q = 0; q < NDIM; ++q) th[q] = lds[threadIdx.x * NDIM + q];
+    for (int q = 0; q < NDIM; ++q) th[q] = lds[(live ? r : 0) * NDIM + q];
     const ModelOperands o{a.cb, a.N, a.lconst};
-    a.out[row] = logprob_row<M, (BLK < 256)>(th, o, a.b);
+    const double lp = logprob_row<M, L>(th, o, a.b, g);
+    if (live && g == 0) a.out[row] = lp;
 }
 
 // ---------------------------------------------------------------------------------
@@ -480,6 +536,7 @@ __global__ __launch_bounds__(BLK) void k_logprob_x2(const LaunchArgs a)
         ok[r] = in_prior<NDIM>(th[r], a.b) && (row0 + threadIdx.x + r * BLK < a.W);
         s[r] = M::setup(th[r]);
     }
+    // same summation order as logprob_row (ascending frequency), two rows in lockstep
     double acc0[2] = {0.0, 0.0}, acc1[2] = {0.0, 0.0};
     const double *__restrict__ rec = a.cb;
 #pragma unroll 2
@@ -722,7 +779,7 @@ __global__ __launch_bounds__(64) void k_logprob_batch(const BatchArgs a)
     for (int q = 0; q < NDIM; ++q) th[q] = a.theta[row * NDIM + q];
     const long long e = spectrum_of<UNIFORM>(row, a.Wp);
     const ModelOperands o{a.cb + e * a.cb_stride, a.N, a.lconst[e]};
-    a.out[row] = logprob_row<M>(th, o, a.b);
+    a.out[row] = logprob_row<M, 1>(th, o, a.b);
 }
 
 template <int P, bool UNIFORM>

@@ -40,54 +40,59 @@ struct StretchArgs {
     long long pad, base, extra;
 };
 
-template <class M>
+// L = lanes per walker (see logprob_row); g = this lane's index inside its group
+template <class M, int L_ = 1>
 struct GenericLP {
     static constexpr int NDIM = M::NDIM;
+    static constexpr int L = L_;
     ModelOperands o;
     Bounds b;
-    __device__ __forceinline__ double operator()(const double (&th)[NDIM], int) const
+    __device__ __forceinline__ double operator()(const double (&th)[NDIM], int, int g) const
     {
-        return logprob_row<M, true>(th, o, b);  // half-steps are latency-bound: deeper unroll
+        return logprob_row<M, L>(th, o, b, g);
     }
 };
 
 template <int P>
 struct ReducedLP {
     static constexpr int NDIM = P + 2;
+    static constexpr int L = 1;
     ReducedArgs<P> r;
     double lconst;
     Bounds b;
-    __device__ __forceinline__ double operator()(const double (&th)[NDIM], int) const
+    __device__ __forceinline__ double operator()(const double (&th)[NDIM], int, int) const
     {
         return logprob_row_reduced<P>(th, r, lconst, b);
     }
 };
 
 // batch of spectra: operands of the spectrum that owns walker i (i / Wp)
-template <class M, bool UNIFORM>
+template <class M, bool UNIFORM, int L_ = 1>
 struct BatchGenericLP {
     static constexpr int NDIM = M::NDIM;
+    static constexpr int L = L_;
     const double *cb;
     long long cb_stride, Wp;
     const double *lconst;
     int N;
     Bounds b;
-    __device__ __forceinline__ double operator()(const double (&th)[NDIM], int walker) const
+    __device__ __forceinline__ double operator()(const double (&th)[NDIM], int walker, int g) const
     {
         const long long e = spectrum_of<UNIFORM>(walker, Wp);
         const ModelOperands o{cb + e * cb_stride, N, lconst[e]};
-        return logprob_row<M, true>(th, o, b);
+        return logprob_row<M, L>(th, o, b, g);
     }
 };
 
 template <int P, bool UNIFORM>
 struct BatchReducedLP {
     static constexpr int NDIM = P + 2;
+    static constexpr int L = 1;
     const ReducedArgs<P> *red;
     long long Wp;
     const double *lconst;
     Bounds b;
-    __device__ __forceinline__ double operator()(const double (&th)[NDIM], int walker) const
+    __device__ __forceinline__ double operator()(const double (&th)[NDIM], int walker, int) const
     {
         const long long e = spectrum_of<UNIFORM>(walker, Wp);
         return logprob_row_reduced<P>(th, red[e], lconst[e], b);
@@ -100,7 +105,7 @@ struct BatchReducedLP {
 template <class LP>
 __device__ __forceinline__ bool stretch_move(const double *s_row, const double *c_row, double old_lp,
                                              double z, double factor, double logu, const LP &lp,
-                                             int walker, int *status, double (&row)[LP::NDIM],
+                                             int walker, int g, int *status, double (&row)[LP::NDIM],
                                              double &lp_row)
 {
     constexpr int NDIM = LP::NDIM;
@@ -112,7 +117,7 @@ __device__ __forceinline__ bool stretch_move(const double *s_row, const double *
         const double d = c - s[k];
         q[k] = c - d * z;
     }
-    const double new_lp = lp(q, walker);
+    const double new_lp = lp(q, walker, g);
     if (new_lp != new_lp) atomicOr(status, 1);
     const bool acc = (factor + new_lp) - old_lp > logu;
 #pragma unroll
@@ -121,16 +126,17 @@ __device__ __forceinline__ bool stretch_move(const double *s_row, const double *
     return acc;
 }
 
-// proposal + log-prob + accept for slot t of a launch-per-half-step kernel
+// proposal + log-prob + accept for slot t of a launch-per-half-step kernel; the LP::L lanes of
+// a slot all run it (they share the proposal and split the log-probability's frequencies)
 template <class LP>
-__device__ __forceinline__ bool stretch_slot(const StretchArgs &a, const LP &lp, long long t,
+__device__ __forceinline__ bool stretch_slot(const StretchArgs &a, const LP &lp, long long t, int g,
                                              int &walker, double (&row)[LP::NDIM], double &lp_row)
 {
     constexpr int NDIM = LP::NDIM;
     const int i = a.active[t], p = a.partner[t];
     walker = i;
     return stretch_move(a.coords + (long long)i * NDIM, a.coords + (long long)p * NDIM, a.logp[i],
-                        a.zz[t], a.factor[t], a.logu[t], lp, i, a.status, row, lp_row);
+                        a.zz[t], a.factor[t], a.logu[t], lp, i, g, a.status, row, lp_row);
 }
 
 template <int NDIM>
@@ -150,16 +156,24 @@ __device__ __forceinline__ void commit_row(const StretchArgs &a, int i, const do
     if (a.naccept && acc) a.naccept[i] += 1;
 }
 
-// single-rank half-step: evaluate every slot and update the state in place
+// single-rank half-step: evaluate every slot and update the state in place.
+// LP::L lanes per slot; a wave holds 64/L slots.  When a wave's last slots do not exist the
+// lanes still run (clamped to the last slot) so the wavefront exchanges stay uniform; only
+// lane 0 of a live slot commits.  All lanes of a wave read their rows before any commits
+// (same instruction stream), and no other wave touches them.
 template <class LP>
 __global__ __launch_bounds__(64) void k_stretch_half(const StretchArgs a, const LP lp)
 {
-    const long long t = (long long)blockIdx.x * 64 + threadIdx.x;
-    if (t >= a.n_slots) return;
+    constexpr int L = LP::L;
+    const long long tid = (long long)blockIdx.x * 64 + threadIdx.x;
+    const long long slot = tid / L;
+    const int g = (int)(tid % L);
+    const bool live = slot < a.n_slots;
+    const long long t = live ? slot : a.n_slots - 1;
     int i;
     double row[LP::NDIM], lp_row;
-    const bool acc = stretch_slot(a, lp, t, i, row, lp_row);
-    commit_row<LP::NDIM>(a, i, row, lp_row, acc);
+    const bool acc = stretch_slot(a, lp, t, g, i, row, lp_row);
+    if (live && g == 0) commit_row<LP::NDIM>(a, i, row, lp_row, acc);
 }
 
 // sharded half-step, part 1: this rank's slots -> block rows (row, logp, accepted)
@@ -167,11 +181,16 @@ template <class LP>
 __global__ __launch_bounds__(64) void k_stretch_eval(const StretchArgs a, const LP lp)
 {
     constexpr int NDIM = LP::NDIM;
-    const long long t = a.slot_lo + (long long)blockIdx.x * 64 + threadIdx.x;
-    if (t >= a.slot_hi) return;
+    constexpr int L = LP::L;
+    const long long tid = (long long)blockIdx.x * 64 + threadIdx.x;
+    const long long slot = a.slot_lo + tid / L;
+    const int g = (int)(tid % L);
+    const bool live = slot < a.slot_hi;
+    const long long t = live ? slot : a.slot_hi - 1;
     int i;
     double row[NDIM], lp_row;
-    const bool acc = stretch_slot(a, lp, t, i, row, lp_row);
+    const bool acc = stretch_slot(a, lp, t, g, i, row, lp_row);
+    if (!live || g != 0) return;
     double *out = a.block + (t - a.slot_lo) * (NDIM + 2);
 #pragma unroll
     for (int k = 0; k < NDIM; ++k) out[k] = row[k];
@@ -347,7 +366,7 @@ __global__ __launch_bounds__(1024) void k_stretch_persistent(const PersistArgs a
                 const int i = d.active;
                 double row[NDIM], lp_row;
                 const bool acc = stretch_move(xs + (long long)i * NDIM, xs + (long long)d.partner * NDIM,
-                                              ls[i], d.z, d.factor, d.logu, lp, (int)(base + i), a.status,
+                                              ls[i], d.z, d.factor, d.logu, lp, (int)(base + i), 0, a.status,
                                               row, lp_row);
                 if (acc) {   // own row only; partners are never active in this half
 #pragma unroll
