@@ -500,3 +500,32 @@ def test_polydecomp_random_spectra_fuzz():
             worst[v] = max(worst.get(v, 0.0), e)
             ctx.close()
     print('worst relative error per formulation:', {k: f'{v:.2e}' for k, v in worst.items()})
+
+
+# ----------------------------------------------------------------------------------
+# the reference's compiled-function names on top of the HIP forward kernels
+# (src/bisip/cython_funcs.pyx:49,64,75,96) -- one parameter vector per call
+# ----------------------------------------------------------------------------------
+
+@pytest.mark.parametrize('path', golden_cases()[::3], ids=case_id)
+def test_cyth_named_functions_match_reference_golden(path):
+    from bisip_amd import cython_funcs as cf
+    g = np.load(path)
+    model = case_model(path)
+    w = g['w']
+    for row in (0, 5, 41, 60):
+        th = g['theta'][row]
+        if not np.all(np.isfinite(th)):
+            continue
+        if model == 'PolynomialDecomposition':
+            Z = cf.Decomp_cyth(w, g['taus'], g['log_taus'], float(g['c_exp']), R0=th[0], a=th[1:].copy())
+        elif model == 'PeltonColeCole':
+            D = int(g['n_modes'])
+            Z = cf.ColeCole_cyth(w, th[0], th[1:1 + D].copy(), th[1 + D:1 + 2 * D].copy(),
+                                 th[1 + 2 * D:].copy())
+        elif model == 'Dias2000':
+            Z = cf.Dias2000_cyth(w, *th)
+        else:
+            Z = cf.Shin2015_cyth(w, th[0:2].copy(), th[2:4].copy(), th[4:6].copy())
+        assert Z.shape == (2, w.size) and Z.dtype == np.float64
+        assert_Z_close(Z[None], g['Z'][row][None])

@@ -224,3 +224,26 @@ def test_c_stream_replays_numpy_randomstate():
         s1, s2 = r1.get_state(), r2.get_state()
         assert s1[2] == s2[2] and np.array_equal(s1[1], s2[1])
         assert r1.rand() == r2.rand() and r1.randint(1000) == r2.randint(1000)
+
+
+def test_cyth_named_functions_reject_what_the_typed_buffers_reject():
+    """The reference's def-boundary checks (np.ndarray[DTYPE_t, ndim=1] arguments,
+    src/bisip/cython_funcs.pyx:49-52): not an array -> TypeError, wrong dtype or rank ->
+    ValueError; raised before any device work."""
+    from bisip_amd import cython_funcs as cf
+    w = np.logspace(3, -2, 8)
+    one = np.array([0.5])
+    with pytest.raises(TypeError):
+        cf.ColeCole_cyth(list(w), 1.0, one, one, one)
+    with pytest.raises(ValueError, match='dtype mismatch'):
+        cf.ColeCole_cyth(w.astype(np.float32), 1.0, one, one, one)
+    with pytest.raises(ValueError, match='dimensions'):
+        cf.ColeCole_cyth(w[None, :], 1.0, one, one, one)
+    with pytest.raises(ValueError):
+        cf.ColeCole_cyth(w, 1.0, one, np.array([0.1, 0.2]), one)
+    with pytest.raises(ValueError, match='dimensions'):
+        cf.Decomp_cyth(w, w, w, 1.0, 1.0, one)
+    with pytest.raises(ValueError, match='shape'):
+        cf.Decomp_cyth(w, w, np.ones((3, 8)), 1.0, 1.0, np.ones(2))
+    with pytest.raises(ValueError):
+        cf.Shin2015_cyth(w, np.ones(3), np.ones(2), np.ones(2))
