@@ -14,6 +14,8 @@ def main():
     ap.add_argument('--walkers', type=int, default=256)
     ap.add_argument('--steps', type=int, default=100, help='stored samples')
     ap.add_argument('--thin-by', type=int, default=10)
+    ap.add_argument('--chain', default='host', choices=['host', 'device'],
+                    help="'device': stored samples stay in HBM; posterior mean/std are computed there")
     args = ap.parse_args()
     import bisip_amd
     from bisip_amd.synthetic import synthetic_columns
@@ -27,14 +29,23 @@ def main():
     batch.ctx.set_bounds(batch.param_bounds)
 
     def make():
-        return DeviceEnsembleSampler(Wp, 7, batch.ctx, rng='philox', seed=3, n_ensembles=E)
+        return DeviceEnsembleSampler(Wp, 7, batch.ctx, rng='philox', seed=3, n_ensembles=E,
+                                     chain_on_device=(args.chain == 'device'))
     make().run_mcmc(p0.reshape(-1, 7), 2, thin_by=args.thin_by)
     s = make()
     t0 = time.perf_counter()
     s.run_mcmc(p0.reshape(-1, 7), args.steps, thin_by=args.thin_by)
     dt = time.perf_counter() - t0
+    summary_s = None
+    if args.chain == 'device':        # posterior mean / std of every spectrum, second half of the chain
+        t1 = time.perf_counter()
+        mean, std = s.param_moments(discard=args.steps // 2)
+        summary_s = time.perf_counter() - t1
+        dt += summary_s
+        assert mean.shape == (E, 7) and np.all(np.isfinite(std))
     iters = args.steps * args.thin_by
     print(json.dumps({'config': 'cfg5 slice: double Cole-Cole, 32 frequencies', 'spectra': E, 'walkers_per_spectrum': Wp,
+                      'chain': args.chain, 'summary_s': None if summary_s is None else round(summary_s, 5),
                       'iterations': iters, 'stored': args.steps, 'thin_by': args.thin_by, 'seconds': round(dt, 4),
                       'it_per_s': round(iters / dt, 1),
                       'walker_steps_per_s': float('%.4g' % (iters * E * Wp / dt)),

@@ -78,6 +78,9 @@ SYMBOLS = {
                                               ctypes.c_uint64, ctypes.c_int64, ctypes.c_int64] +
                                [ctypes.c_void_p] * 7),
     'bisip_stretch_persistent_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(PersistArgs), ctypes.c_void_p]),
+    'bisip_chain_moments_workspace': (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int64, ctypes.c_int]),
+    'bisip_chain_moments_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                               ctypes.c_int64, ctypes.c_int] + [ctypes.c_void_p] * 4),
     'bisip_numpy_stretch_stream': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32), ctypes.c_int64,
                                                   ctypes.c_double, ctypes.c_int64] + [ctypes.c_void_p] * 4),
     'bisip_philox4x32': (None, [ctypes.POINTER(ctypes.c_uint32)] * 3),
@@ -317,6 +320,18 @@ class HipContext:
                                                 int(n_steps), *[ctypes.c_void_p(p) for p in
                                                                 (perm, active, partner, zz, factor, logu)],
                                                 ctypes.c_void_p(stream)))
+
+
+def chain_moments_workspace(n_samples, n_ensembles, ndim):
+    return int(load_library().bisip_chain_moments_workspace(n_samples, n_ensembles, ndim))
+
+
+def chain_moments_dev(d_chain_ptr, n_samples, sample_stride, n_ensembles, walkers_per_ensemble, ndim,
+                      d_mean_ptr, d_std_ptr, d_work_ptr, stream=0):
+    """Device pointers (ints); asynchronous on ``stream``."""
+    _check(load_library().bisip_chain_moments_dev(d_chain_ptr, n_samples, sample_stride, n_ensembles,
+                                                  walkers_per_ensemble, ndim, d_mean_ptr, d_std_ptr,
+                                                  d_work_ptr, stream))
 
 
 def numpy_stretch_stream(rng, W, a, n_steps):

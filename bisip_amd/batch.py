@@ -121,16 +121,40 @@ class SpectraBatch:
         Z = self.ctx.forward(theta.reshape(-1, self.ndim))
         return Z.reshape(theta.shape[0], theta.shape[1], 2, self.N)
 
-    def fit(self, p0=None, seed=None):
-        """Run E independent stretch-move ensembles on the device (rng='philox')."""
+    def fit(self, p0=None, seed=None, thin_by=1, chain='host'):
+        """Run E independent stretch-move ensembles on the device (rng='philox').
+
+        ``thin_by``: store one sample every ``thin_by`` iterations (``nsteps`` samples are
+        stored).  ``chain='device'`` keeps the stored samples in HBM: ``get_param_mean`` /
+        ``get_param_std`` then summarise them on the device and ``get_chain`` copies them to
+        the host only when called."""
+        if chain not in ('host', 'device'):
+            raise ValueError("chain must be 'host' or 'device'")
         E, Wp, ndim = self.n_spectra, self.nwalkers, self.ndim
         if p0 is None:
             p0 = np.random.uniform(*self.param_bounds, (E, Wp, ndim))
         self.ctx.set_bounds(self.param_bounds)
         self._sampler = DeviceEnsembleSampler(Wp, ndim, self.ctx, rng='philox', seed=seed,
-                                              n_ensembles=E)
-        self._sampler.run_mcmc(np.asarray(p0).reshape(E * Wp, ndim), self.nsteps)
+                                              n_ensembles=E, chain_on_device=(chain == 'device'))
+        self._sampler.run_mcmc(np.asarray(p0).reshape(E * Wp, ndim), self.nsteps, thin_by=thin_by)
         return self
+
+    def _moments(self, discard, thin):
+        if self._sampler is None:
+            raise AssertionError('Model is not fitted!')
+        if self._sampler.chain_on_device:
+            return self._sampler.param_moments(discard=discard, thin=thin)
+        flat = self.get_chain(discard=discard, thin=thin, flat=True)   # (E, n, ndim)
+        return flat.mean(axis=1), flat.std(axis=1)
+
+    def get_param_mean(self, discard=0, thin=1):
+        """Posterior mean of every parameter of every spectrum, ``(E, ndim)`` -- per spectrum
+        what the reference's ``get_param_mean`` returns (src/bisip/utils.py:55-69)."""
+        return self._moments(discard, thin)[0]
+
+    def get_param_std(self, discard=0, thin=1):
+        """Posterior standard deviation, ``(E, ndim)`` (src/bisip/utils.py:71-85)."""
+        return self._moments(discard, thin)[1]
 
     def get_chain(self, discard=0, thin=1, flat=False):
         """(nsteps', E, Wp, ndim); flat=True -> (E, nsteps'*Wp, ndim)."""

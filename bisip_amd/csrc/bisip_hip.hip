@@ -15,6 +15,7 @@
 #include "host_precompute.h"
 #include "kernels.h"
 #include "sampler_kernels.h"
+#include "chain_kernels.h"
 
 using namespace bisip;
 
@@ -986,6 +987,46 @@ int bisip_stretch_draw_dev(bisip_ctx *c, int64_t W, double a, uint64_t seed, int
     const long long total = n_steps * 2 * d.E * d.nh;
     hipLaunchKernelGGL(k_stretch_draw, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, d);
+    HIP_TRY(hipGetLastError());
+    return BISIP_OK;
+}
+
+static int moment_splits(int64_t n_samples, int64_t E)
+{
+    // enough workgroups to fill the chip (256 CUs x 8), never more than one per sample
+    int64_t s = (2048 + E - 1) / E;
+    if (s > n_samples) s = n_samples;
+    return (int)(s < 1 ? 1 : s);
+}
+
+int64_t bisip_chain_moments_workspace(int64_t n_samples, int64_t n_ensembles, int ndim)
+{
+    if (n_samples < 1 || n_ensembles < 1 || ndim < 1) return 0;
+    return n_ensembles * moment_splits(n_samples, n_ensembles) * (int64_t)ndim;
+}
+
+int bisip_chain_moments_dev(const double *d_chain, int64_t n_samples, int64_t sample_stride,
+                            int64_t n_ensembles, int64_t walkers_per_ensemble, int ndim,
+                            double *d_mean, double *d_std, double *d_work, void *stream)
+{
+    if (!d_chain || !d_mean || !d_std || !d_work) return fail(BISIP_EINVAL, "null argument");
+    if (ndim < 1 || ndim > BISIP_MAX_NDIM) return fail(BISIP_EINVAL, "ndim=%d out of range", ndim);
+    if (n_samples < 1 || n_ensembles < 1 || n_ensembles > 0x7fffffffLL || walkers_per_ensemble < 1)
+        return fail(BISIP_EINVAL, "bad chain shape");
+    if (sample_stride < n_ensembles * walkers_per_ensemble * ndim)
+        return fail(BISIP_EINVAL, "sample_stride smaller than one sample");
+    MomentArgs a;
+    a.chain = d_chain; a.n_samples = n_samples; a.sample_stride = sample_stride;
+    a.E = n_ensembles; a.Wp = walkers_per_ensemble; a.ndim = ndim;
+    a.splits = moment_splits(n_samples, n_ensembles);
+    a.mean = d_mean; a.std = d_std; a.partial = d_work;
+    const dim3 grid((unsigned)n_ensembles, (unsigned)a.splits);
+    const dim3 fin((unsigned)((n_ensembles * ndim + 255) / 256));
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_moments_partial<0>, grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_moments_finish<0>, fin, dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_moments_partial<1>, grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_moments_finish<1>, fin, dim3(256), 0, st, a);
     HIP_TRY(hipGetLastError());
     return BISIP_OK;
 }

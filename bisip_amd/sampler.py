@@ -136,6 +136,32 @@ def affine_splits(seed, nwalkers, step0, nsteps):
     return out
 
 
+class _DeviceSlabs:
+    """Stored samples that stay in device memory (one torch tensor per chunk).  Behaves like
+    a chain part for the bookkeeping (``shape``) and becomes a host array the first time the
+    host asks for it."""
+
+    def __init__(self, tensors):
+        self.tensors = list(tensors)
+
+    @property
+    def shape(self):
+        return (sum(int(t.shape[0]) for t in self.tensors),) + tuple(self.tensors[0].shape[1:])
+
+    def tensor(self):
+        if len(self.tensors) > 1:
+            import torch
+            self.tensors = [torch.cat(self.tensors, dim=0)]
+        return self.tensors[0]
+
+    def materialize(self):
+        return self.tensor().cpu().numpy()
+
+
+def _host_parts(parts):
+    return [p.materialize() if isinstance(p, _DeviceSlabs) else p for p in parts]
+
+
 class _SamplerBase:
     """Chain bookkeeping shared by the two drivers (emcee backend semantics)."""
 
@@ -168,12 +194,14 @@ class _SamplerBase:
 
     @property
     def _chain(self):
+        self._chain_parts = _host_parts(self._chain_parts)
         if len(self._chain_parts) > 1:
             self._chain_parts = [np.concatenate(self._chain_parts, axis=0)]
         return self._chain_parts[0] if self._chain_parts else np.empty((0, self.nwalkers, self.ndim))
 
     @property
     def _log_prob(self):
+        self._log_prob_parts = _host_parts(self._log_prob_parts)
         if len(self._log_prob_parts) > 1:
             self._log_prob_parts = [np.concatenate(self._log_prob_parts, axis=0)]
         return self._log_prob_parts[0] if self._log_prob_parts else np.empty((0, self.nwalkers))
@@ -445,7 +473,7 @@ class DeviceEnsembleSampler(_SamplerBase):
 
     def __init__(self, nwalkers, ndim, ctx=None, a=2.0, live_dangerously=False, group=None,
                  distributed=False, backend=None, chunk=None, rng='numpy', seed=None,
-                 n_ensembles=1, force_sharded_path=False, persistent=False):
+                 n_ensembles=1, force_sharded_path=False, persistent=False, chain_on_device=False):
         if rng not in ('numpy', 'philox'):
             raise ValueError("rng must be 'numpy' or 'philox'")
         # n_ensembles > 1: independent ensembles of `nwalkers` walkers each (batch of spectra),
@@ -468,6 +496,9 @@ class DeviceEnsembleSampler(_SamplerBase):
         # ensemble).  Bit-identical to the default path; measured no faster (the in-kernel
         # stream is drawn serially by one wave), so it is opt-in.
         self.persistent = bool(persistent)
+        # keep the stored samples in HBM: nothing is copied to the host until get_chain() /
+        # get_log_prob() ask for it, and param_moments() summarises the chain where it lies
+        self.chain_on_device = bool(chain_on_device)
         self.last_path = None
         super().__init__(int(nwalkers) * self.n_ensembles, ndim, a, live_dangerously, group, distributed)
         # philox key: explicit seed, else drawn from the (seeded) private RandomState
@@ -509,6 +540,7 @@ class DeviceEnsembleSampler(_SamplerBase):
         return to pinned host memory asynchronously while the next chunk runs."""
         import time
         import torch
+        t_start = time.perf_counter()
         be = self.backend
         W, ndim = self.nwalkers, self.ndim
         if initial_state is None:
@@ -534,10 +566,19 @@ class DeviceEnsembleSampler(_SamplerBase):
             raise ValueError('thin_by must be >= 1')
         nh = (W + 1) // 2                       # slots per half (the first half gets the odd one)
         chain_host = logp_host = None
+        dev_chain = dev_logp = None              # chain_on_device: the whole run's samples, one block
+        stream_bufs = None                       # philox stream arrays, allocated once per run
+        perm_all = None
+        if self.rng == 'philox' and nsteps > 0:
+            # the per-step splits of the WHOLE run (12 B per iteration) go up in one copy: a
+            # host->device copy per chunk would wait for the previous chunk's kernels
+            perm_all = be.tensor(affine_splits(self.seed, self.walkers_per_ensemble,
+                                               self._iterations_run, nsteps * thin_by))
         # where a run spends its time
-        self.timing = dict(stream_s=0.0, enqueue_s=0.0, alloc_s=0.0, drain_s=0.0)
+        self.timing = dict(setup_s=0.0, stream_s=0.0, enqueue_s=0.0, alloc_s=0.0, drain_s=0.0, finish_s=0.0)
         done = 0                                 # stored samples so far
         it0 = self._iterations_run
+        self.timing['setup_s'] = time.perf_counter() - t_start
         while done < nsteps:
             t_a = time.perf_counter()
             ns = min(max(1, self._chunk_steps(nsteps * thin_by) // thin_by), nsteps - done)
@@ -561,9 +602,16 @@ class DeviceEnsembleSampler(_SamplerBase):
             else:
                 # only the per-step split is drawn on the host; the stream is generated on
                 # the device from (seed, step, half, slot) counters
-                st['perm'] = be.tensor(affine_splits(self.seed, self.walkers_per_ensemble, it0, n))
-            st['chain'] = be.empty((ns, W, ndim), torch.float64)
-            st['logp_chain'] = be.empty((ns, W), torch.float64)
+                off = it0 - self._iterations_run
+                st['perm'] = perm_all[off:off + n]
+            if self.chain_on_device:
+                if dev_chain is None:
+                    dev_chain = be.empty((nsteps, W, ndim), torch.float64)
+                    dev_logp = be.empty((nsteps, W), torch.float64)
+                st['chain'], st['logp_chain'] = dev_chain[done:done + ns], dev_logp[done:done + ns]
+            else:
+                st['chain'] = be.empty((ns, W, ndim), torch.float64)
+                st['logp_chain'] = be.empty((ns, W), torch.float64)
             t_b = time.perf_counter()
             single = self._world == 1 and not self.force_sharded_path
             ran = False
@@ -572,10 +620,12 @@ class DeviceEnsembleSampler(_SamplerBase):
                 if ran:
                     self.last_path = 'persistent'
             if not ran and self.rng == 'philox':
-                for name, dt in (('active', torch.int32), ('partner', torch.int32),
-                                 ('zz', torch.float64), ('factor', torch.float64),
-                                 ('logu', torch.float64)):
-                    st[name] = be.empty((n, 2, nh), dt)
+                if stream_bufs is None:          # the first chunk is the largest; later ones reuse it
+                    stream_bufs = {name: be.empty((n, 2, nh), dt) for name, dt in (
+                        ('active', torch.int32), ('partner', torch.int32), ('zz', torch.float64),
+                        ('factor', torch.float64), ('logu', torch.float64))}
+                for name, buf in stream_bufs.items():
+                    st[name] = buf[:n]
                 be.draw(st, self.walkers_per_ensemble, self.a, self.seed, it0, n)
             if ran:
                 pass
@@ -595,6 +645,12 @@ class DeviceEnsembleSampler(_SamplerBase):
                         gathered = be.empty((self._world * pad, ndim + 2), torch.float64)
                         dist.all_gather_into_tensor(gathered, block, group=self._group)
                         be.apply(st, k, h, m, gathered, pad, self._world)
+            if self.chain_on_device:
+                done += ns
+                it0 += n
+                self.timing['stream_s'] += t_b - t_a
+                self.timing['enqueue_s'] += time.perf_counter() - t_b
+                continue
             if chain_host is None:
                 # pinning a big host chain takes tens of ms: do it while the first chunk runs
                 t_h = time.perf_counter()
@@ -609,17 +665,59 @@ class DeviceEnsembleSampler(_SamplerBase):
             t_c = time.perf_counter()
             self.timing['stream_s'] += t_b - t_a
             self.timing['enqueue_s'] += t_c - t_b
-        if chain_host is None:                   # nsteps == 0
+        if chain_host is None and dev_chain is None:  # nsteps == 0
             chain_host, logp_host = be.host_buffer((0, W, ndim)), be.host_buffer((0, W))
         t_d = time.perf_counter()
         be.synchronize()
-        self.timing['drain_s'] = time.perf_counter() - t_d
+        t_e = time.perf_counter()
+        self.timing['drain_s'] = t_e - t_d
         self._iterations_run = it0
         if int(self._dev['status'].cpu()[0]) & 1:
             raise ValueError('Probability function returned NaN')
-        self._append(chain_host.numpy(), logp_host.numpy())
+        if dev_chain is not None:
+            self._append(_DeviceSlabs([dev_chain]), _DeviceSlabs([dev_logp]))
+        else:
+            self._append(chain_host.numpy(), logp_host.numpy())
         self._moves_done += nsteps * thin_by
         self._accepted = self._dev['naccept'].cpu().numpy().astype(np.float64)
         self._coords = self._dev['coords'].cpu().numpy()
         self._lp = self._dev['logp'].cpu().numpy()
+        self.timing['finish_s'] = time.perf_counter() - t_e
         return self._coords.copy(), self._lp.copy()
+
+    # -- summaries of a device-resident chain -------------------------------------------
+    def device_chain(self):
+        """All stored samples as ONE torch tensor (iteration, W, ndim) on the device
+        (``chain_on_device=True`` runs only)."""
+        parts = self._chain_parts
+        if not parts or not all(isinstance(p, _DeviceSlabs) for p in parts):
+            raise AttributeError('the chain is not resident on the device '
+                                 '(run with chain_on_device=True)')
+        if len(parts) > 1:
+            self._chain_parts = parts = [_DeviceSlabs(t for p in parts for t in p.tensors)]
+        return parts[0].tensor()
+
+    def param_moments(self, discard=0, thin=1):
+        """Mean and standard deviation of every parameter over
+        ``chain[discard + thin - 1::thin]`` flattened over the walkers of each ensemble --
+        ``np.mean`` / ``np.std`` of ``get_chain(discard, thin, flat=True)`` (reference:
+        src/bisip/utils.py:55-85) -- computed on the device, only the two
+        ``(n_ensembles, ndim)`` results come back.  Returns ``(mean, std)``."""
+        import torch
+        from . import _hip
+        t = self.device_chain()
+        n_total, W, ndim = (int(x) for x in t.shape)
+        discard, thin = int(discard), int(thin)
+        first = discard + thin - 1
+        n = len(range(first, n_total, thin))
+        if thin < 1 or discard < 0 or n < 1:
+            raise ValueError(f'no samples left with discard={discard}, thin={thin} of {n_total} stored')
+        be = self.backend
+        E, Wp = self.n_ensembles, self.walkers_per_ensemble
+        mean = be.empty((E, ndim), torch.float64)
+        std = be.empty((E, ndim), torch.float64)
+        work = be.empty((max(1, _hip.chain_moments_workspace(n, E, ndim)),), torch.float64)
+        _hip.chain_moments_dev(t.data_ptr() + 8 * first * W * ndim, n, thin * W * ndim, E, Wp, ndim,
+                               mean.data_ptr(), std.data_ptr(), work.data_ptr(), be.stream())
+        be.synchronize()
+        return mean.cpu().numpy(), std.cpu().numpy()

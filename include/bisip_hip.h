@@ -198,6 +198,20 @@ typedef struct bisip_persist_args {
 } bisip_persist_args;
 int bisip_stretch_persistent_dev(bisip_ctx *ctx, const bisip_persist_args *args, void *stream);
 
+/* Posterior mean and (population) standard deviation of every parameter, per ensemble, of a
+ * chain resident in device memory -- the device form of get_param_mean / get_param_std
+ * (src/bisip/utils.py:55-85: np.mean / np.std over the flattened chain) for batches whose
+ * chains are too big to be worth copying to the host.
+ * d_chain points at the first sample to use; sample k is at d_chain + k*sample_stride
+ * doubles and holds (n_ensembles*walkers_per_ensemble, ndim) rows, ensemble e owning rows
+ * [e*Wp, (e+1)*Wp).  (discard/thin of get_chain: offset the pointer, multiply the stride.)
+ * d_mean, d_std: (n_ensembles, ndim).  d_work: bisip_chain_moments_workspace() doubles.
+ * Two passes (mean, then centred squares), fixed summation order, asynchronous on stream. */
+int64_t bisip_chain_moments_workspace(int64_t n_samples, int64_t n_ensembles, int ndim);
+int bisip_chain_moments_dev(const double *d_chain, int64_t n_samples, int64_t sample_stride,
+                            int64_t n_ensembles, int64_t walkers_per_ensemble, int ndim,
+                            double *d_mean, double *d_std, double *d_work, void *stream);
+
 /* Host: the stretch move's random stream in numpy.random.RandomState order for n_steps
  * iterations of a W-walker ensemble (the contract is bisip_amd/sampler.py:draw_step).
  * mt_key[624] / *mt_pos are RandomState.get_state()[1:3], advanced in place exactly as

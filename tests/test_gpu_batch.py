@@ -143,3 +143,70 @@ def test_batch_persistent_equals_launch_path():
             assert chains[0][3] == 'persistent' and chains[1][3] == 'launch-per-half-step'
             for x, y in zip(chains[0][:3], chains[1][:3]):
                 assert np.array_equal(x, y)
+
+
+# ----------------------------------------------------------------------------------
+# chain kept in HBM + posterior moments on the device (get_param_mean / get_param_std,
+# src/bisip/utils.py:55-85, per spectrum)
+# ----------------------------------------------------------------------------------
+
+MOMENT_TOL = 1e-12     # |d| <= tol * max(1, |value|): same numbers, different summation order
+
+
+def _close(a, b, tol=MOMENT_TOL):
+    assert a.shape == b.shape
+    assert np.all(np.abs(a - b) <= tol * np.maximum(1.0, np.abs(b))), np.max(np.abs(a - b))
+
+
+def test_device_chain_is_the_host_chain_and_moments_match_numpy():
+    import bisip_amd
+    E, Wp = 6, 32
+    rng = np.random.RandomState(11)
+    centre = np.array([1.0, 0.15, 0.5, -1.5, -12.0, 0.45, 0.6])
+    p0 = centre + 1e-3 * rng.randn(E, Wp, 7)
+    runs = {}
+    for where in ('host', 'device'):
+        b = bisip_amd.SpectraBatch('PeltonColeCole', _tables(E), nwalkers=Wp, nsteps=40, n_modes=2)
+        b.fit(p0, seed=5, thin_by=2, chain=where)
+        runs[where] = b
+    dev, host = runs['device'], runs['host']
+    # summaries first: nothing has been copied to the host yet
+    for discard, thin in ((0, 1), (10, 1), (7, 3), (39, 1)):
+        flat = host.get_chain(discard=discard, thin=thin, flat=True)           # (E, n, ndim)
+        _close(dev.get_param_mean(discard=discard, thin=thin), flat.mean(axis=1))
+        _close(dev.get_param_std(discard=discard, thin=thin), flat.std(axis=1))
+        _close(host.get_param_mean(discard=discard, thin=thin), flat.mean(axis=1))
+    with pytest.raises(ValueError):
+        dev.get_param_mean(discard=40)
+    assert np.array_equal(dev.get_chain(), host.get_chain())                   # same chain, bit for bit
+    assert np.array_equal(dev.get_log_prob(), host.get_log_prob())
+    assert np.array_equal(dev.acceptance_fraction, host.acceptance_fraction)
+
+
+@pytest.mark.parametrize('n,E,Wp,ndim,thin', [
+    (37, 1, 100, 4, 1),          # one ensemble: samples split over many workgroups
+    (5, 3, 7, 10, 2),            # fewer rows than lanes, strided samples
+    (64, 40, 256, 7, 1),
+    (3, 2500, 4, 5, 1),          # more ensembles than the split target
+    (2, 2, 3, 16, 1),            # ndim = BISIP_MAX_NDIM
+])
+def test_chain_moments_entry_point(n, E, Wp, ndim, thin):
+    import torch
+    from bisip_amd import _hip
+    rng = np.random.RandomState(n * 7 + E)
+    full = rng.standard_normal((n * thin, E * Wp, ndim)) * rng.uniform(0.1, 50, ndim) + rng.uniform(-20, 20, ndim)
+    t = torch.from_numpy(full).cuda()
+    mean = torch.empty((E, ndim), dtype=torch.float64, device='cuda')
+    std = torch.empty_like(mean)
+    work = torch.empty(_hip.chain_moments_workspace(n, E, ndim), dtype=torch.float64, device='cuda')
+    first = thin - 1
+    _hip.chain_moments_dev(t.data_ptr() + 8 * first * E * Wp * ndim, n, thin * E * Wp * ndim, E, Wp, ndim,
+                           mean.data_ptr(), std.data_ptr(), work.data_ptr(),
+                           torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    used = full[first::thin].reshape(n, E, Wp, ndim).transpose(1, 0, 2, 3).reshape(E, n * Wp, ndim)
+    _close(mean.cpu().numpy(), used.mean(axis=1))
+    _close(std.cpu().numpy(), used.std(axis=1))
+    with pytest.raises(ValueError):
+        _hip.chain_moments_dev(t.data_ptr(), n, 1, E, Wp, ndim, mean.data_ptr(), std.data_ptr(),
+                               work.data_ptr(), 0)
