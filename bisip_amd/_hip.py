@@ -44,10 +44,10 @@ class PersistArgs(ctypes.Structure):
     """``bisip_persist_args`` of include/bisip_hip.h."""
     _fields_ = [('coords', ctypes.c_void_p), ('logp', ctypes.c_void_p), ('n_walkers', ctypes.c_int64),
                 ('walkers_per_ensemble', ctypes.c_int64), ('n_steps', ctypes.c_int64),
-                ('step0', ctypes.c_int64), ('thin_by', ctypes.c_int64), ('a', ctypes.c_double),
-                ('seed', ctypes.c_uint64), ('perm', ctypes.c_void_p), ('chain', ctypes.c_void_p),
-                ('logp_chain', ctypes.c_void_p), ('naccept', ctypes.c_void_p),
-                ('status', ctypes.c_void_p)]
+                ('thin_by', ctypes.c_int64), ('active', ctypes.c_void_p), ('partner', ctypes.c_void_p),
+                ('zz', ctypes.c_void_p), ('factor', ctypes.c_void_p), ('logu', ctypes.c_void_p),
+                ('chain', ctypes.c_void_p), ('logp_chain', ctypes.c_void_p),
+                ('naccept', ctypes.c_void_p), ('status', ctypes.c_void_p)]
 
 
 # name -> (restype, argtypes); every symbol include/bisip_hip.h declares
@@ -334,10 +334,11 @@ def chain_moments_dev(d_chain_ptr, n_samples, sample_stride, n_ensembles, walker
                                                   d_work_ptr, stream))
 
 
-def numpy_stretch_stream(rng, W, a, n_steps):
+def numpy_stretch_stream(rng, W, a, n_steps, out=None):
     """n_steps iterations of the stretch move's RandomState stream, generated in C; ``rng``
     (a numpy.random.RandomState) is advanced exactly as draw_step would advance it.
-    Returns active, partner (int32) and zz, u (float64), each (n_steps, 2, (W+1)//2)."""
+    Returns active, partner (int32) and zz, u (float64), each (n_steps, 2, (W+1)//2);
+    ``out`` = four preallocated C-contiguous arrays of those shapes to fill instead."""
     lib = load_library()
     name, key, pos, has_gauss, cached = rng.get_state()
     if name != 'MT19937':
@@ -345,10 +346,13 @@ def numpy_stretch_stream(rng, W, a, n_steps):
     key = np.ascontiguousarray(key, dtype=np.uint32).copy()
     cpos = ctypes.c_int32(int(pos))
     nh = (int(W) + 1) // 2
-    active = np.empty((n_steps, 2, nh), np.int32)
-    partner = np.empty((n_steps, 2, nh), np.int32)
-    zz = np.empty((n_steps, 2, nh))
-    u = np.empty((n_steps, 2, nh))
+    shape = (int(n_steps), 2, nh)
+    if out is None:
+        out = (np.empty(shape, np.int32), np.empty(shape, np.int32), np.empty(shape), np.empty(shape))
+    active, partner, zz, u = out
+    for arr, dt in ((active, np.int32), (partner, np.int32), (zz, np.float64), (u, np.float64)):
+        if arr.shape != shape or arr.dtype != dt or not arr.flags.c_contiguous:
+            raise ValueError(f'out arrays must be C-contiguous {shape}: int32, int32, float64, float64')
     _check(lib.bisip_numpy_stretch_stream(key.ctypes.data, ctypes.byref(cpos), int(W), float(a),
                                           int(n_steps), active.ctypes.data, partner.ctypes.data,
                                           zz.ctypes.data, u.ctypes.data))

@@ -431,7 +431,7 @@ int launch_stretch(const StretchWork &work, const LP &lp, hipStream_t st)
     if (kind == STRETCH_PERSIST) {
         const PersistArgs &p = *work.persist;
         const long long nh = (p.W + 1) / 2;
-        const unsigned threads = (unsigned)(((nh + 63) / 64) * 64);
+        const unsigned threads = (unsigned)(((nh * LP::L + 63) / 64) * 64);   // <= 1024: stretch_lanes()
         const size_t lds = (size_t)p.W * (LP::NDIM + 1) * sizeof(double);
         hipLaunchKernelGGL((k_stretch_persistent<LP>), dim3((unsigned)p.E), dim3(threads), lds, st, p, lp);
         HIP_TRY(hipGetLastError());
@@ -457,18 +457,22 @@ int lanes_per_walker(long long walkers)
     return walkers <= 8192 ? 4 : (walkers <= 32768 ? 2 : 1);
 }
 
-long long stretch_walkers(const StretchWork &w)
+// lanes per slot of a stretch dispatch.  The persistent kernel is one workgroup per ensemble
+// and always latency-bound: as many lanes as fit its 1024-lane workgroup.
+int stretch_lanes(const StretchWork &w)
 {
-    if (w.kind == STRETCH_PERSIST) return 1LL << 40;   // persistent kernel: one lane per walker
-    return w.kind == STRETCH_HALF ? w.half->n_slots : w.half->slot_hi - w.half->slot_lo;
+    if (w.kind == STRETCH_PERSIST) {
+        const long long nh = (w.persist->W + 1) / 2;
+        return nh * 4 <= 1024 ? 4 : (nh * 2 <= 1024 ? 2 : 1);
+    }
+    return lanes_per_walker(w.kind == STRETCH_HALF ? w.half->n_slots : w.half->slot_hi - w.half->slot_lo);
 }
 
 template <class M>
 int stretch_generic(const bisip_ctx *c, const StretchWork &a, hipStream_t st)
 {
     const ModelOperands o{c->d_cb_lp ? c->d_cb_lp : c->d_cb, c->N, c->lconst};
-    const long long nw = stretch_walkers(a);
-    switch (nw <= CoopLimit<M>::value ? lanes_per_walker(nw) : 1) {
+    switch (CoopLimit<M>::value > 0 ? stretch_lanes(a) : 1) {
     case 4: { GenericLP<M, 4> lp; lp.o = o; lp.b = c->bounds; return launch_stretch(a, lp, st); }
     case 2: { GenericLP<M, 2> lp; lp.o = o; lp.b = c->bounds; return launch_stretch(a, lp, st); }
     default: { GenericLP<M, 1> lp; lp.o = o; lp.b = c->bounds; return launch_stretch(a, lp, st); }
@@ -501,9 +505,11 @@ template <class M, bool U>
 int stretch_generic_batch(const bisip_ctx *c, const StretchWork &a, long long Wp, hipStream_t st)
 {
     // a wave of 64/L slots must stay inside one spectrum for the uniform (scalar) operand path
-    const int want = lanes_per_walker(stretch_walkers(a));
-    if (want == 4 && (!U || (Wp / 2) % 16 == 0)) return stretch_generic_batch_l<M, U, 4>(c, a, Wp, st);
-    if (want >= 2 && (!U || (Wp / 2) % 32 == 0)) return stretch_generic_batch_l<M, U, 2>(c, a, Wp, st);
+    // (the persistent kernel's workgroup is one ensemble: always inside one spectrum)
+    const int want = CoopLimit<M>::value > 0 ? stretch_lanes(a) : 1;
+    const bool whole = !U || a.kind == STRETCH_PERSIST;
+    if (want == 4 && (whole || (Wp / 2) % 16 == 0)) return stretch_generic_batch_l<M, U, 4>(c, a, Wp, st);
+    if (want >= 2 && (whole || (Wp / 2) % 32 == 0)) return stretch_generic_batch_l<M, U, 2>(c, a, Wp, st);
     return stretch_generic_batch_l<M, U, 1>(c, a, Wp, st);
 }
 
@@ -1034,24 +1040,23 @@ int bisip_chain_moments_dev(const double *d_chain, int64_t n_samples, int64_t sa
 int bisip_stretch_persistent_dev(bisip_ctx *c, const bisip_persist_args *u, void *stream)
 {
     if (!c || !u) return fail(BISIP_EINVAL, "null argument");
-    if (!u->coords || !u->logp || !u->perm || !u->status) return fail(BISIP_EINVAL, "null buffer");
+    if (!u->coords || !u->logp || !u->status) return fail(BISIP_EINVAL, "null buffer");
+    if (!u->active || !u->partner || !u->zz || !u->factor || !u->logu) return fail(BISIP_EINVAL, "null RNG stream");
     const int64_t Wp = u->walkers_per_ensemble;
     if (Wp < 2 || u->n_walkers < Wp || u->n_walkers % Wp) return fail(BISIP_EINVAL, "bad walker counts");
     const int64_t E = u->n_walkers / Wp;
     if (E != c->E) return fail(BISIP_EINVAL, "n_walkers/walkers_per_ensemble=%lld but the context holds %d spectra", (long long)E, c->E);
     if (c->E > 1 && (Wp & 1)) return fail(BISIP_EINVAL, "batch context: walkers per spectrum must be even");
     if (u->thin_by < 1 || u->n_steps < 0 || u->n_steps % u->thin_by) return fail(BISIP_EINVAL, "n_steps must be a multiple of thin_by");
-    if (u->step0 < 0 || u->step0 + u->n_steps > 0xffffffffLL) return fail(BISIP_EINVAL, "step counter out of range");
     if ((size_t)Wp * (c->ndim + 1) * sizeof(double) > 65536 || (Wp + 1) / 2 > 1024)
         return fail(BISIP_EUNSUPPORTED, "ensemble of %lld walkers does not fit one workgroup", (long long)Wp);
     if (u->n_steps == 0) return BISIP_OK;
     HIP_TRY(hipSetDevice(c->device));
     PersistArgs p;
-    p.coords = u->coords; p.logp = u->logp; p.W = Wp; p.n_steps = u->n_steps; p.step0 = u->step0;
-    p.thin_by = u->thin_by; p.a = u->a; p.ndim_m1 = (double)(c->ndim - 1);
-    p.seed_lo = (unsigned int)(u->seed & 0xffffffffu); p.seed_hi = (unsigned int)(u->seed >> 32);
-    p.perm = u->perm; p.chain = u->chain; p.logp_chain = u->logp_chain; p.naccept = u->naccept;
-    p.status = u->status; p.E = E;
+    p.coords = u->coords; p.logp = u->logp; p.W = Wp; p.E = E; p.n_steps = u->n_steps;
+    p.thin_by = u->thin_by;
+    p.active = u->active; p.partner = u->partner; p.zz = u->zz; p.factor = u->factor; p.logu = u->logu;
+    p.chain = u->chain; p.logp_chain = u->logp_chain; p.naccept = u->naccept; p.status = u->status;
     return dispatch_stretch(c, StretchWork{STRETCH_PERSIST, nullptr, &p}, Wp, (hipStream_t)stream);
 }
 

@@ -248,27 +248,12 @@ __device__ __forceinline__ int perm_inverse(long long y, long long W, long long 
     return (int)((Ainv * v) % W);
 }
 
-// same value as perm_inverse for W <= 2048 (all products < 2^22): 32-bit integers and one
-// fp32 reciprocal multiply instead of two 64-bit software divisions -- the persistent
-// kernel is latency-bound on a single wave, and the divisions were a third of its path
-__device__ __forceinline__ int perm_inverse_small(int y, int W, int Ainv, int B, float invW)
-{
-    int v = y - B;
-    v += (v < 0) ? W : 0;
-    const int x = Ainv * v;
-    int r = x - (int)((float)x * invW) * W;
-    r += (r < 0) ? W : 0;
-    r -= (r >= W) ? W : 0;
-    return r;
-}
-
-// the per-slot draw of the philox contract (shared by k_stretch_draw and the persistent kernel)
+// the per-slot draw of the philox contract
 struct SlotDraw {
     int active, partner;  // walker indices inside the ensemble
     double z, factor, logu;
 };
 
-template <bool SMALL = false>
 __device__ __forceinline__ SlotDraw draw_slot(long long W, double a, double ndim_m1, unsigned seed_lo,
                                               unsigned seed_hi, unsigned step, int h, unsigned e,
                                               long long t, long long A_inv, long long B)
@@ -282,14 +267,8 @@ __device__ __forceinline__ SlotDraw draw_slot(long long W, double a, double ndim
     const double v = (a - 1.0) * uz + 1.0;
     SlotDraw d;
     d.z = (v * v) / a;
-    if constexpr (SMALL) {
-        const float invW = 1.0f / (float)W;
-        d.active = perm_inverse_small((int)(2 * t + h), (int)W, (int)A_inv, (int)B, invW);
-        d.partner = perm_inverse_small((int)(2 * r + (1 - h)), (int)W, (int)A_inv, (int)B, invW);
-    } else {
-        d.active = perm_inverse(2 * t + h, W, A_inv, B);
-        d.partner = perm_inverse(2 * r + (1 - h), W, A_inv, B);
-    }
+    d.active = perm_inverse(2 * t + h, W, A_inv, B);
+    d.partner = perm_inverse(2 * r + (1 - h), W, A_inv, B);
     d.factor = ndim_m1 * log(d.z);
     d.logu = log(u53(r1.v[0], r1.v[1]));
     return d;
@@ -320,31 +299,53 @@ __global__ __launch_bounds__(256) void k_stretch_draw(const DrawArgs d)
 
 // ---------------------------------------------------------------------------------
 // Persistent sampler: ONE WORKGROUP PER ENSEMBLE runs every iteration of a chunk inside
-// one launch.  The ensemble (positions + log-probs) lives in LDS, the random stream is
-// drawn in-kernel from the same philox counters as k_stretch_draw, the two half-steps of
-// an iteration are separated by a workgroup barrier (no launch, no grid sync), and only
-// the stored chain rows go to HBM.  Bit-identical to draw + launch-per-half-step.
-// Needs W*(NDIM+1)*8 B of LDS and ceil(W/2) <= blockDim.x lanes.
+// one launch.  The ensemble (positions + log-probs) lives in LDS; the random stream is the
+// same pre-drawn (n_steps, 2, E, nh) arrays the launch-per-half-step kernels read (NumPy
+// order or k_stretch_draw), so both stream modes share this path; the two half-steps of an
+// iteration are separated by a workgroup barrier (no launch, no grid sync) and only the
+// stored chain rows go to HBM.  LP::L lanes share a slot exactly as in k_stretch_half, and
+// the next half-step's stream entries are requested before the current one is evaluated,
+// so the critical path of a half-step is LDS -> proposal -> log-prob -> LDS -> barrier.
+// Bit-identical to the launch-per-half-step path.
+// Needs W*(NDIM+1)*8 B of LDS and ceil(W/2)*L <= 1024 lanes.
 // ---------------------------------------------------------------------------------
 struct PersistArgs {
     double *coords;      // (E*W, NDIM) in/out (global state)
     double *logp;        // (E*W,)
-    long long W;         // walkers per ensemble
-    long long n_steps, step0, thin_by;
-    double a, ndim_m1;
-    unsigned int seed_lo, seed_hi;
-    const int *perm;     // (n_steps, 3)
+    long long W, E;      // walkers per ensemble, ensembles
+    long long n_steps, thin_by;
+    const int *active, *partner;            // (n_steps, 2, E, nh): global walker ids
+    const double *zz, *factor, *logu;
     double *chain;       // (n_steps/thin_by, E*W, NDIM) or null
     double *logp_chain;  // (n_steps/thin_by, E*W) or null
     int *naccept;        // (E*W,) or null
     int *status;
-    long long E;
 };
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every
+// outstanding global access (s_waitcnt vmcnt(0)): here that would put the acknowledgement of
+// the chain-row stores and the prefetched stream loads on the critical path of every
+// half-step, and nothing after the barrier depends on them.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+struct SlotStream {
+    int active, partner;
+    double z, factor, logu;
+};
+
+__device__ __forceinline__ SlotStream load_slot(const PersistArgs &a, long long idx)
+{
+    SlotStream d;
+    d.active = a.active[idx]; d.partner = a.partner[idx];
+    d.z = a.zz[idx]; d.factor = a.factor[idx]; d.logu = a.logu[idx];
+    return d;
+}
 
 template <class LP>
 __global__ __launch_bounds__(1024) void k_stretch_persistent(const PersistArgs a, const LP lp)
 {
     constexpr int NDIM = LP::NDIM;
+    constexpr int L = LP::L;
     extern __shared__ __attribute__((aligned(16))) double lds_state[];  // W*NDIM coords | W logp
     double *xs = lds_state;
     double *ls = lds_state + a.W * NDIM;
@@ -353,21 +354,28 @@ __global__ __launch_bounds__(1024) void k_stretch_persistent(const PersistArgs a
     for (long long i = threadIdx.x; i < a.W * NDIM; i += blockDim.x) xs[i] = a.coords[base * NDIM + i];
     for (long long i = threadIdx.x; i < a.W; i += blockDim.x) ls[i] = a.logp[base + i];
     __syncthreads();
-    const long long t = threadIdx.x;
+    const long long nh = (a.W + 1) / 2;       // slots of half 0; half 1 has W/2
+    const long long slot = threadIdx.x / L;
+    const int g = threadIdx.x % L;
+    // lanes past the last slot of a half run clamped to it (the wavefront exchanges of
+    // L > 1 need whole groups) and never commit
+    const long long t0 = slot < nh ? slot : nh - 1;
+    const long long t1 = slot < a.W / 2 ? slot : a.W / 2 - 1;
+    SlotStream cur = load_slot(a, (0 * a.E + e) * nh + t0);
     for (long long k = 0; k < a.n_steps; ++k) {
-        const long long A_inv = a.perm[3 * k + 1], B = a.perm[3 * k + 2];
         const bool store = ((k + 1) % a.thin_by) == 0;
         const long long srow = k / a.thin_by;
         for (int h = 0; h < 2; ++h) {
-            const long long Ns = h ? a.W / 2 : (a.W + 1) / 2;
-            if (t < Ns) {
-                const SlotDraw d = draw_slot<true>(a.W, a.a, a.ndim_m1, a.seed_lo, a.seed_hi,
-                                                   (unsigned)(a.step0 + k), h, (unsigned)e, t, A_inv, B);
-                const int i = d.active;
-                double row[NDIM], lp_row;
-                const bool acc = stretch_move(xs + (long long)i * NDIM, xs + (long long)d.partner * NDIM,
-                                              ls[i], d.z, d.factor, d.logu, lp, (int)(base + i), 0, a.status,
-                                              row, lp_row);
+            // request the next half-step's entries now; they are consumed after the barrier
+            const long long kn = h ? (k + 1 < a.n_steps ? k + 1 : k) : k;
+            const SlotStream nxt = load_slot(a, ((kn * 2 + (1 - h)) * a.E + e) * nh + (h ? t0 : t1));
+            const bool live = slot < (h ? a.W / 2 : nh);
+            const int i = cur.active - (int)base, p = cur.partner - (int)base;
+            double row[NDIM], lp_row;
+            // every lane of a slot reads the rows before lane 0 writes (same wave, program order)
+            const bool acc = stretch_move(xs + (long long)i * NDIM, xs + (long long)p * NDIM, ls[i], cur.z,
+                                          cur.factor, cur.logu, lp, (int)(base + i), g, a.status, row, lp_row);
+            if (live && g == 0) {
                 if (acc) {   // own row only; partners are never active in this half
 #pragma unroll
                     for (int q = 0; q < NDIM; ++q) xs[(long long)i * NDIM + q] = row[q];
@@ -381,7 +389,8 @@ __global__ __launch_bounds__(1024) void k_stretch_persistent(const PersistArgs a
                 }
                 if (store && a.logp_chain) a.logp_chain[srow * a.E * a.W + base + i] = lp_row;
             }
-            __syncthreads();   // the other half reads the rows just written
+            cur = nxt;
+            lds_barrier();     // the other half reads the rows just written
         }
     }
     for (long long i = threadIdx.x; i < a.W * NDIM; i += blockDim.x) a.coords[base * NDIM + i] = xs[i];

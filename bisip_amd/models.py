@@ -156,7 +156,8 @@ class Inversion(_utils.utils):
             raise AssertionError('Model is not fitted! Fit the model to a '
                                  'dataset before attempting to plot results.')
 
-    def fit(self, p0=None, pool=None, moves=None, sampler='device', rng='numpy', thin_by=1):
+    def fit(self, p0=None, pool=None, moves=None, sampler='device', rng='numpy', thin_by=1,
+            persistent=True):
         """Sample the posterior with the stretch-move ensemble sampler.
 
         Args:
@@ -174,6 +175,9 @@ class Inversion(_utils.utils):
                 run); 'philox' generates it on the device (2-3x faster for small
                 ensembles, its own reproducible stream).  Device sampler only.
             thin_by (int): store one sample every ``thin_by`` iterations.
+            persistent (bool): device sampler, ensembles that fit one workgroup (up to a few
+                hundred walkers): run all iterations of a chunk inside one kernel launch
+                instead of one launch per half-step.  Same chain, bit for bit.
         """
         self._p0 = p0
         self.ndim = self.param_bounds.shape[1]
@@ -187,7 +191,8 @@ class Inversion(_utils.utils):
             self._sampler = emcee.EnsembleSampler(self.nwalkers, self.ndim, ctx.logprob,
                                                   moves=moves, vectorize=True)
         elif sampler == 'device':
-            self._sampler = DeviceEnsembleSampler(self.nwalkers, self.ndim, ctx, rng=rng)
+            self._sampler = DeviceEnsembleSampler(self.nwalkers, self.ndim, ctx, rng=rng,
+                                                  persistent=persistent)
         elif sampler == 'host':
             self._sampler = EnsembleSampler(self.nwalkers, self.ndim, ctx.logprob)
         else:

@@ -415,23 +415,44 @@ class HipStretchBackend:
         self.ctx.stretch_run_dev(self._args(st, 0, 0, (W + 1) // 2, base=True), W, n_steps,
                                  st.get('thin', 1), self.stream())
 
-    def run_persistent(self, st, wp, a, seed, step0, n_steps):
-        """One launch for the whole chunk (workgroup per ensemble, state in LDS, stream drawn
-        in-kernel).  Returns False when the ensemble does not fit a workgroup."""
+    def run_persistent(self, st, wp, n_steps):
+        """One launch for the whole chunk (workgroup per ensemble, state in LDS, same pre-drawn
+        stream as ``run``).  Returns False when the ensemble does not fit a workgroup."""
         from ._hip import PersistArgs
         p = PersistArgs()
         p.coords = st['coords'].data_ptr()
         p.logp = st['logp'].data_ptr()
         p.n_walkers = st['coords'].shape[0]
         p.walkers_per_ensemble = wp
-        p.n_steps, p.step0, p.thin_by = n_steps, step0, st.get('thin', 1)
-        p.a, p.seed = a, seed
-        p.perm = st['perm'].data_ptr()
+        p.n_steps, p.thin_by = n_steps, st.get('thin', 1)
+        for name in ('active', 'partner', 'zz', 'factor', 'logu'):
+            setattr(p, name, st[name].data_ptr())
         p.chain = st['chain'].data_ptr()
         p.logp_chain = st['logp_chain'].data_ptr()
         p.naccept = st['naccept'].data_ptr()
         p.status = st['status'].data_ptr()
         return self.ctx.stretch_persistent_dev(p, self.stream())
+
+    def stream_staging(self, n, nh):
+        """Pinned host arrays (n, 2, nh) for one chunk of the NumPy-order stream, reused from
+        chunk to chunk once the previous upload has left them."""
+        torch = self.torch
+        need = int(n) * 2 * int(nh)
+        kinds = (('active', torch.int32), ('partner', torch.int32), ('zz', torch.float64),
+                 ('factor', torch.float64), ('logu', torch.float64))
+        if getattr(self, '_stage_cap', 0) < need:
+            self._stage = {name: torch.empty(need, dtype=dt, pin_memory=True) for name, dt in kinds}
+            self._stage_cap, self._stage_event = need, None
+        if self._stage_event is not None:
+            self._stage_event.synchronize()
+        return {name: self._stage[name][:need].view(int(n), 2, int(nh)) for name, _ in kinds}
+
+    def upload_staged(self, stage):
+        """Asynchronous host->device copies of the staged stream on the compute stream."""
+        out = {name: t.to(self.device, non_blocking=True) for name, t in stage.items()}
+        self._stage_event = self.torch.cuda.Event()
+        self._stage_event.record(self.torch.cuda.current_stream(self.device))
+        return out
 
     def host_buffer(self, shape):
         """Pinned host memory for big chains: slabs come back at PCIe rate (~55 GB/s vs ~13
@@ -492,9 +513,9 @@ class DeviceEnsembleSampler(_SamplerBase):
         self.rng = rng
         # run eval -> all_gather -> apply even with one rank (benchmarks the sharded path)
         self.force_sharded_path = bool(force_sharded_path)
-        # rng='philox', one rank, ensemble fits a workgroup: ONE launch per chunk (workgroup per
-        # ensemble).  Bit-identical to the default path; measured no faster (the in-kernel
-        # stream is drawn serially by one wave), so it is opt-in.
+        # one rank and the ensemble fits a workgroup: ONE launch per chunk (workgroup per
+        # ensemble, state in LDS); bit-identical to the launch-per-half-step path, which is the
+        # automatic fallback for bigger ensembles
         self.persistent = bool(persistent)
         # keep the stored samples in HBM: nothing is copied to the host until get_chain() /
         # get_log_prob() ask for it, and param_moments() summarises the chain where it lies
@@ -591,14 +612,21 @@ class DeviceEnsembleSampler(_SamplerBase):
             if self.rng == 'numpy':
                 # RNG stream for n iterations in draw_step's order, generated in C from the
                 # RandomState's MT19937 state (bit-identical to calling draw_step n times,
-                # ~30x cheaper); the logs are NumPy's so they match the host sampler's
+                # ~30x cheaper) straight into pinned staging memory; the logs are NumPy's so
+                # they match the host sampler's.  Pinned staging keeps the upload asynchronous
+                # (the next chunk's stream is generated while this chunk's kernels run) and
+                # keeps the HIP runtime from pinning and unpinning pageable NumPy buffers.
                 from ._hip import numpy_stretch_stream
-                active, partner, zz, u = numpy_stretch_stream(self._random, W, self.a, n)
+                stage = be.stream_staging(n, nh)
+                _, _, zz, u = numpy_stretch_stream(
+                    self._random, W, self.a, n,
+                    out=tuple(stage[name].numpy() for name in ('active', 'partner', 'zz', 'logu')))
                 with np.errstate(divide='ignore'):
-                    host = dict(active=active, partner=partner, zz=zz,
-                                factor=(ndim - 1.0) * np.log(zz), logu=np.log(u))
-                for name, arr in host.items():
-                    st[name] = be.tensor(arr)
+                    factor = stage['factor'].numpy()
+                    np.log(zz, out=factor)
+                    factor *= ndim - 1.0
+                    np.log(u, out=u)             # 'logu' staging held u
+                st.update(be.upload_staged(stage))
             else:
                 # only the per-step split is drawn on the host; the stream is generated on
                 # the device from (seed, step, half, slot) counters
@@ -614,12 +642,7 @@ class DeviceEnsembleSampler(_SamplerBase):
                 st['logp_chain'] = be.empty((ns, W), torch.float64)
             t_b = time.perf_counter()
             single = self._world == 1 and not self.force_sharded_path
-            ran = False
-            if single and self.rng == 'philox' and self.persistent:
-                ran = be.run_persistent(st, self.walkers_per_ensemble, self.a, self.seed, it0, n)
-                if ran:
-                    self.last_path = 'persistent'
-            if not ran and self.rng == 'philox':
+            if self.rng == 'philox':
                 if stream_bufs is None:          # the first chunk is the largest; later ones reuse it
                     stream_bufs = {name: be.empty((n, 2, nh), dt) for name, dt in (
                         ('active', torch.int32), ('partner', torch.int32), ('zz', torch.float64),
@@ -627,6 +650,11 @@ class DeviceEnsembleSampler(_SamplerBase):
                 for name, buf in stream_bufs.items():
                     st[name] = buf[:n]
                 be.draw(st, self.walkers_per_ensemble, self.a, self.seed, it0, n)
+            ran = False
+            if single and self.persistent:
+                ran = be.run_persistent(st, self.walkers_per_ensemble, n)
+                if ran:
+                    self.last_path = 'persistent'
             if ran:
                 pass
             elif single:

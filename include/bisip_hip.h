@@ -175,22 +175,25 @@ int bisip_stretch_draw_dev(bisip_ctx *ctx, int64_t W, double a, uint64_t seed, i
                            void *stream);
 
 /* Persistent sampler: one workgroup per ensemble runs n_steps iterations inside ONE launch
- * (ensemble in LDS, philox stream drawn in-kernel, workgroup barrier between half-steps).
- * Same stream contract as bisip_stretch_draw_dev + bisip_stretch_run_dev, bit-identical
- * results.  Requires walkers_per_ensemble*(ndim+1)*8 <= 65536 bytes of LDS and
- * ceil(walkers_per_ensemble/2) <= 1024; otherwise returns BISIP_EUNSUPPORTED (use the
- * launch-per-half-step path).  n_walkers = n_ensembles * walkers_per_ensemble. */
+ * (ensemble in LDS, workgroup barrier between half-steps, several lanes per walker for the
+ * models with a frequency loop).  Reads the same pre-drawn random stream as
+ * bisip_stretch_run_dev -- arrays (n_steps, 2, E, nh), nh = (walkers_per_ensemble+1)/2,
+ * global walker ids -- and produces bit-identical results.  Requires
+ * walkers_per_ensemble*(ndim+1)*8 <= 65536 bytes of LDS and ceil(walkers_per_ensemble/2)
+ * <= 1024; otherwise returns BISIP_EUNSUPPORTED (use bisip_stretch_run_dev).
+ * n_walkers = n_ensembles * walkers_per_ensemble. */
 typedef struct bisip_persist_args {
     double *coords;              /* (n_walkers, ndim) in/out */
     double *logp;                /* (n_walkers,)      in/out */
     int64_t n_walkers;
     int64_t walkers_per_ensemble;
     int64_t n_steps;
-    int64_t step0;               /* philox step counter of the first iteration */
     int64_t thin_by;
-    double a;                    /* stretch scale */
-    uint64_t seed;
-    const int32_t *perm;         /* (n_steps, 3) device: A, A^-1 mod W, B */
+    const int32_t *active;       /* random stream, as in bisip_stretch_args */
+    const int32_t *partner;
+    const double *zz;
+    const double *factor;
+    const double *logu;
     double *chain;               /* (n_steps/thin_by, n_walkers, ndim) or NULL */
     double *logp_chain;          /* (n_steps/thin_by, n_walkers) or NULL */
     int32_t *naccept;            /* (n_walkers,) or NULL */

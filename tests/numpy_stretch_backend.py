@@ -105,17 +105,19 @@ class NumpyStretchBackend:
             st['logp_chain'].numpy()[k // thin][idx] = lps
         st['naccept'].numpy()[idx[acc]] += 1
 
-    def run_persistent(self, st, wp, a, seed, step0, n_steps):
+    def run_persistent(self, st, wp, n_steps):
         if wp * (st['coords'].shape[1] + 1) * 8 > 65536 or (wp + 1) // 2 > 1024:
             return False
-        W = st['coords'].shape[0]
-        nh = (W + 1) // 2
-        for name, dt in (('active', torch.int32), ('partner', torch.int32), ('zz', torch.float64),
-                         ('factor', torch.float64), ('logu', torch.float64)):
-            st[name] = torch.zeros((n_steps, 2, nh), dtype=dt)
-        self.draw(st, wp, a, seed, step0, n_steps)
         self.run(st, n_steps)
         return True
+
+    def stream_staging(self, n, nh):
+        kinds = (('active', torch.int32), ('partner', torch.int32), ('zz', torch.float64),
+                 ('factor', torch.float64), ('logu', torch.float64))
+        return {name: torch.zeros((n, 2, nh), dtype=dt) for name, dt in kinds}
+
+    def upload_staged(self, stage):
+        return dict(stage)
 
     def host_buffer(self, shape):
         return torch.zeros(shape, dtype=torch.float64)

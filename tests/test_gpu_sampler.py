@@ -236,20 +236,23 @@ def test_philox_mode_chain_replay_and_posterior():
 
 @pytest.mark.parametrize('prefix,model,variant', CASES)
 def test_persistent_kernel_equals_launch_per_half_step(prefix, model, variant):
-    """rng='philox': the one-launch-per-chunk persistent kernel (workgroup per ensemble, state
-    in LDS, in-kernel stream) reproduces the draw + launch-per-half-step path bit for bit."""
+    """The one-launch-per-chunk persistent kernel (workgroup per ensemble, state in LDS, 4 / 2 / 1
+    lanes per walker depending on the ensemble size) reproduces the launch-per-half-step path
+    bit for bit, for both random streams."""
     from bisip_amd.sampler import DeviceEnsembleSampler
     g = np.load(_case(prefix))
     ctx = make_ctx(g, model, variant)
     ndim = g['bounds'].shape[1]
-    for W, nsteps, chunk, thin in [(32, 80, None, 1), (33, 30, 7, 1), (64, 24, 5, 3), (510, 6, None, 1)]:
-        if W < 2 * ndim:
+    for W, nsteps, chunk, thin, rng in [(32, 80, None, 1, 'philox'), (33, 30, 7, 1, 'numpy'),
+                                        (64, 24, 5, 3, 'numpy'), (510, 6, None, 1, 'philox'),
+                                        (700, 4, None, 2, 'philox')]:
+        if W < 2 * ndim or W * (ndim + 1) * 8 > 65536:
             continue
         p0 = _start(g, W, 300 + W)
         out = []
         for persistent in (True, False):
             np.random.seed(17)
-            s = DeviceEnsembleSampler(W, ndim, ctx, rng='philox', seed=99, chunk=chunk, persistent=persistent)
+            s = DeviceEnsembleSampler(W, ndim, ctx, rng=rng, seed=99, chunk=chunk, persistent=persistent)
             s.run_mcmc(p0, nsteps, thin_by=thin)
             s.run_mcmc(None, 4, thin_by=thin)       # continuation keeps the counters aligned
             out.append(s)
