@@ -16,6 +16,7 @@ def main():
     ap.add_argument('--thin-by', type=int, default=10)
     ap.add_argument('--chain', default='host', choices=['host', 'device'],
                     help="'device': stored samples stay in HBM; posterior mean/std are computed there")
+    ap.add_argument('--persistent', action='store_true', help='force the persistent kernel (default: automatic)')
     args = ap.parse_args()
     import bisip_amd
     from bisip_amd.synthetic import synthetic_columns
@@ -30,7 +31,7 @@ def main():
 
     def make():
         return DeviceEnsembleSampler(Wp, 7, batch.ctx, rng='philox', seed=3, n_ensembles=E,
-                                     chain_on_device=(args.chain == 'device'))
+                                     chain_on_device=(args.chain == 'device'), persistent=True if args.persistent else None)
     make().run_mcmc(p0.reshape(-1, 7), 2, thin_by=args.thin_by)
     s = make()
     t0 = time.perf_counter()
@@ -45,7 +46,7 @@ def main():
         assert mean.shape == (E, 7) and np.all(np.isfinite(std))
     iters = args.steps * args.thin_by
     print(json.dumps({'config': 'cfg5 slice: double Cole-Cole, 32 frequencies', 'spectra': E, 'walkers_per_spectrum': Wp,
-                      'chain': args.chain, 'summary_s': None if summary_s is None else round(summary_s, 5),
+                      'chain': args.chain, 'path': s.last_path, 'summary_s': None if summary_s is None else round(summary_s, 5),
                       'iterations': iters, 'stored': args.steps, 'thin_by': args.thin_by, 'seconds': round(dt, 4),
                       'it_per_s': round(iters / dt, 1),
                       'walker_steps_per_s': float('%.4g' % (iters * E * Wp / dt)),

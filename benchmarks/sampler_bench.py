@@ -53,7 +53,7 @@ def main():
             else:
                 # 'device' = fit() defaults (NumPy-order stream, persistent kernel when it fits);
                 # 'device-launches' = same stream, one launch per half-step
-                kw_fit = dict(sampler='device', persistent=(sampler == 'device')) if sampler != 'host' else dict(sampler='host')
+                kw_fit = dict(sampler='device', persistent=(None if sampler == 'device' else False)) if sampler != 'host' else dict(sampler='host')
                 m.nsteps = 5
                 m.fit(p0=p0, **kw_fit)        # warm-up (context, kernels, allocator)
                 m.nsteps = nsteps

@@ -121,13 +121,14 @@ class SpectraBatch:
         Z = self.ctx.forward(theta.reshape(-1, self.ndim))
         return Z.reshape(theta.shape[0], theta.shape[1], 2, self.N)
 
-    def fit(self, p0=None, seed=None, thin_by=1, chain='host'):
+    def fit(self, p0=None, seed=None, thin_by=1, chain='host', persistent=None):
         """Run E independent stretch-move ensembles on the device (rng='philox').
 
         ``thin_by``: store one sample every ``thin_by`` iterations (``nsteps`` samples are
         stored).  ``chain='device'`` keeps the stored samples in HBM: ``get_param_mean`` /
         ``get_param_std`` then summarise them on the device and ``get_chain`` copies them to
-        the host only when called."""
+        the host only when called.  ``persistent``: one workgroup per spectrum runs all
+        iterations of a chunk in one launch (same chain; default: ensembles of <= 128 walkers)."""
         if chain not in ('host', 'device'):
             raise ValueError("chain must be 'host' or 'device'")
         E, Wp, ndim = self.n_spectra, self.nwalkers, self.ndim
@@ -135,7 +136,8 @@ class SpectraBatch:
             p0 = np.random.uniform(*self.param_bounds, (E, Wp, ndim))
         self.ctx.set_bounds(self.param_bounds)
         self._sampler = DeviceEnsembleSampler(Wp, ndim, self.ctx, rng='philox', seed=seed,
-                                              n_ensembles=E, chain_on_device=(chain == 'device'))
+                                              n_ensembles=E, chain_on_device=(chain == 'device'),
+                                              persistent=persistent)
         self._sampler.run_mcmc(np.asarray(p0).reshape(E * Wp, ndim), self.nsteps, thin_by=thin_by)
         return self
 

@@ -457,13 +457,16 @@ int lanes_per_walker(long long walkers)
     return walkers <= 8192 ? 4 : (walkers <= 32768 ? 2 : 1);
 }
 
-// lanes per slot of a stretch dispatch.  The persistent kernel is one workgroup per ensemble
-// and always latency-bound: as many lanes as fit its 1024-lane workgroup.
+// lanes per slot of a stretch dispatch: as many as lanes_per_walker() grants for the number of
+// slots evaluated at once (all ensembles' for the persistent kernel, whose workgroups run
+// concurrently), capped there by the 1024-lane workgroup that holds one ensemble's half.
 int stretch_lanes(const StretchWork &w)
 {
     if (w.kind == STRETCH_PERSIST) {
         const long long nh = (w.persist->W + 1) / 2;
-        return nh * 4 <= 1024 ? 4 : (nh * 2 <= 1024 ? 2 : 1);
+        const int fit = nh * 4 <= 1024 ? 4 : (nh * 2 <= 1024 ? 2 : 1);
+        const int want = lanes_per_walker(nh * w.persist->E);
+        return want < fit ? want : fit;
     }
     return lanes_per_walker(w.kind == STRETCH_HALF ? w.half->n_slots : w.half->slot_hi - w.half->slot_lo);
 }

@@ -494,7 +494,7 @@ class DeviceEnsembleSampler(_SamplerBase):
 
     def __init__(self, nwalkers, ndim, ctx=None, a=2.0, live_dangerously=False, group=None,
                  distributed=False, backend=None, chunk=None, rng='numpy', seed=None,
-                 n_ensembles=1, force_sharded_path=False, persistent=False, chain_on_device=False):
+                 n_ensembles=1, force_sharded_path=False, persistent=None, chain_on_device=False):
         if rng not in ('numpy', 'philox'):
             raise ValueError("rng must be 'numpy' or 'philox'")
         # n_ensembles > 1: independent ensembles of `nwalkers` walkers each (batch of spectra),
@@ -515,8 +515,12 @@ class DeviceEnsembleSampler(_SamplerBase):
         self.force_sharded_path = bool(force_sharded_path)
         # one rank and the ensemble fits a workgroup: ONE launch per chunk (workgroup per
         # ensemble, state in LDS); bit-identical to the launch-per-half-step path, which is the
-        # automatic fallback for bigger ensembles
-        self.persistent = bool(persistent)
+        # automatic fallback for bigger ensembles.  A workgroup lives on ONE compute unit, so
+        # this wins while a half-ensemble x 4 lanes is at most one wave per SIMD (<= 128
+        # walkers: 2-3x fewer microseconds per iteration); above that, launches that spread a
+        # half-step over the whole chip are as fast or faster (measured at 256 and 512
+        # walkers).  None = that rule; True / False force it.
+        self.persistent = (int(nwalkers) <= 128) if persistent is None else bool(persistent)
         # keep the stored samples in HBM: nothing is copied to the host until get_chain() /
         # get_log_prob() ask for it, and param_moments() summarises the chain where it lies
         self.chain_on_device = bool(chain_on_device)
