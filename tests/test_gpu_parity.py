@@ -330,6 +330,36 @@ def test_other_models_unusual_shapes(model, n_modes, n_freq):
     ctx.close()
 
 
+@pytest.mark.parametrize('model,n_modes,n_freq', [('PeltonColeCole', 2, 32), ('PeltonColeCole', 3, 21),
+                                                   ('PeltonColeCole', 1, 1), ('Dias2000', 0, 22),
+                                                   ('Shin2015', 0, 23), ('Dias2000', 0, 2)])
+def test_lanes_per_walker_do_not_change_bits(model, n_modes, n_freq):
+    """Launches of <= 8192 walkers use 4 lanes per walker, <= 32768 two, larger ones one
+    (bisip_hip.hip:lanes_per_walker); frequency counts that are not multiples of the lane count
+    leave a partial last round.  The running sums are handed from lane to lane in frequency
+    order, so every regime must return the SAME BITS for the same row."""
+    from bisip_amd import _hip
+    from bisip_amd.batch import default_params
+    d = _synthetic_problem(n_freq, 3)
+    bounds = np.array(list(default_params(model, n_modes=n_modes).values()), float).T
+    kw = dict(n_modes=n_modes) if model == 'PeltonColeCole' else {}
+    ctx = _hip.HipContext(MODEL_IDS[model], d['w'], d['zn'], d['zn_err'], bounds, **kw)
+    rng = np.random.RandomState(n_freq + 17)
+    theta = rng.uniform(bounds[0], bounds[1], (140000, bounds.shape[1]))
+    theta[5] = bounds[1]                               # an out-of-prior row inside a lane group
+    one = ctx.logprob(theta)                           # 1 lane per walker (and the 256-lane workgroups)
+    mid = ctx.logprob(theta[:40000])                   # 1 lane, 64-lane workgroups
+    two = ctx.logprob(theta[:20000])                   # 2 lanes
+    four = ctx.logprob(theta[:5000])                   # 4 lanes
+    tiny = ctx.logprob(theta[:3])                      # 4 lanes, one partial wave
+    assert np.isneginf(one[5]) and np.all(np.isfinite(one[:5]))
+    assert np.array_equal(mid, one[:40000])
+    assert np.array_equal(two, one[:20000])
+    assert np.array_equal(four, one[:5000])
+    assert np.array_equal(tiny, one[:3])
+    ctx.close()
+
+
 def test_unsupported_shapes_fail_loudly():
     from bisip_amd import _hip
     d = _synthetic_problem(8)

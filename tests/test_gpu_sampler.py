@@ -100,7 +100,7 @@ def test_eval_apply_path_single_rank():
     a = DeviceEnsembleSampler(W, ndim, ctx)
     a.run_mcmc(p0, 30)
     np.random.seed(3)
-    b = DeviceEnsembleSampler(W, ndim, backend=SplitBackend(ctx))
+    b = DeviceEnsembleSampler(W, ndim, backend=SplitBackend(ctx), persistent=False)
     b.run_mcmc(p0, 30)
     assert SplitBackend.calls == 60           # the eval/apply kernels really ran
     assert np.array_equal(a.get_chain(), b.get_chain())
@@ -113,7 +113,7 @@ def test_eval_apply_path_single_rank():
     assert np.array_equal(c.get_chain(), a.get_chain()[2::3])
     assert np.array_equal(c.get_log_prob(), a.get_log_prob()[2::3])
     np.random.seed(3)
-    d = DeviceEnsembleSampler(W, ndim, backend=SplitBackend(ctx))
+    d = DeviceEnsembleSampler(W, ndim, backend=SplitBackend(ctx), persistent=False)
     d.run_mcmc(p0, 10, thin_by=3)
     assert np.array_equal(d.get_chain(), c.get_chain())
     ctx.close()
