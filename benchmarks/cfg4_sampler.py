@@ -27,6 +27,8 @@ def main():
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--rng', default='philox')
     ap.add_argument('--fused', action='store_true', help='single-rank fused path (no collective)')
+    ap.add_argument('--chain', default='host', choices=['host', 'device'],
+                    help="'device': the chain stays in HBM (no pinned host buffer, no copy)")
     args = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -53,7 +55,8 @@ def main():
     def make():
         np.random.seed(7)
         return DeviceEnsembleSampler(args.walkers, 7, ctx, rng=args.rng, seed=11, distributed=True,
-                                     force_sharded_path=not args.fused)
+                                     force_sharded_path=not args.fused, persistent=False,
+                                     chain_on_device=(args.chain == 'device'))
     make().run_mcmc(p0, 5)
     s = make()
     dist.barrier(); torch.cuda.synchronize()
@@ -67,6 +70,9 @@ def main():
                           'path': 'fused (no collective)' if args.fused else 'eval -> all_gather -> apply',
                           'seconds': round(dt, 4), 'it_per_s': round(args.steps / dt, 1),
                           'walker_steps_per_s': float('%.4g' % (args.steps * args.walkers / dt)),
+                          'chain': args.chain,
+                          # kernels only when the chain stays on the device; with a host chain the
+                          # drain also covers the device->host copy of the chain
                           'us_per_half_step': round((s.timing['enqueue_s'] + s.timing['drain_s']) / args.steps / 2 * 1e6, 1),
                           'timing_s': {k: round(v, 4) for k, v in s.timing.items()},
                           'acceptance': round(float(s.acceptance_fraction.mean()), 3)}))

@@ -1,0 +1,42 @@
+#!/bin/bash
+# Collects the measurements kept under profiles/ (one MI355X).  Run from the repo root on the
+# GPU box:  bash benchmarks/collect_profiles.sh [bench|sweep|sampler|all]
+# Everything is written under gpurun_out/ (scratch); copy what should be judged into profiles/.
+set -e -o pipefail
+what=${1:-all}
+out=$PWD/gpurun_out
+mkdir -p "$out"
+export TMPDIR=/tmp
+repo=$PWD
+
+if [ "$what" = bench ] || [ "$what" = all ]; then
+  echo "== bench.py" | tee -a "$out/progress.log"
+  python3 bench.py > "$out/bench.json" 2> "$out/bench.err"
+  echo "== bench.py under rocprofv3 --kernel-trace --stats" | tee -a "$out/progress.log"
+  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof_bench" -- \
+      python3 "$repo/bench.py" --no-cpu-baseline --no-variants > "$out/bench_under_rocprof.json" 2> "$out/prof_bench.err")
+  for c in FETCH_SIZE WRITE_SIZE; do
+    echo "== bench.py --pmc $c" | tee -a "$out/progress.log"
+    (cd /tmp && rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$out/pmc_$c" -- \
+        python3 "$repo/bench.py" --no-cpu-baseline --no-variants --steps 20 --prime-seconds 0.1 > "$out/pmc_$c.json" 2> "$out/pmc_$c.err")
+  done
+fi
+if [ "$what" = sweep ] || [ "$what" = all ]; then
+  echo "== sweep" | tee -a "$out/progress.log"
+  python3 benchmarks/sweep.py > "$out/sweep.jsonl" 2> "$out/sweep.err"
+  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof_sweep" -- \
+      python3 "$repo/benchmarks/sweep.py" > "$out/sweep_under_rocprof.jsonl" 2> "$out/prof_sweep.err")
+  python3 benchmarks/host_path.py > "$out/host_path.jsonl" 2> "$out/host_path.err"
+fi
+if [ "$what" = sampler ] || [ "$what" = all ]; then
+  echo "== samplers" | tee -a "$out/progress.log"
+  python3 benchmarks/sampler_bench.py > "$out/sampler_bench.jsonl" 2> "$out/sampler.err"
+  python3 benchmarks/cfg4_sampler.py --steps 200 --fused | grep "^{" > "$out/cfg4_fused.json" 2> "$out/cfg4.err"
+  python3 benchmarks/cfg4_sampler.py --steps 200 --fused --chain device | grep "^{" > "$out/cfg4_fused_device_chain.json" 2>> "$out/cfg4.err"
+  python3 benchmarks/cfg4_sampler.py --steps 200 --chain device | grep "^{" > "$out/cfg4_sharded_path_1gpu.json" 2>> "$out/cfg4.err"
+  python3 benchmarks/cfg5_batch.py --chain device > "$out/cfg5_device_chain.json" 2> "$out/cfg5.err"
+  python3 benchmarks/cfg5_batch.py > "$out/cfg5_host_chain.json" 2>> "$out/cfg5.err"
+  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof_sampler" -- \
+      python3 "$repo/benchmarks/sampler_bench.py" > "$out/sampler_under_rocprof.jsonl" 2> "$out/prof_sampler.err")
+fi
+echo "== done" | tee -a "$out/progress.log"

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Turns the two rocprofv3 --pmc passes of bench.py (FETCH_SIZE, WRITE_SIZE; see
+benchmarks/collect_profiles.sh) into profiles/rNN_bench_pmc_summary.csv and
+profiles/pmc_traffic.json (the number bench.py reports as roofline.traffic).
+
+    python benchmarks/summarize_pmc.py gpurun_out profiles r01
+
+HBM bytes per launch = 2 * FETCH_SIZE[KB] * 1024 + WRITE_SIZE[KB] * 1024: on gfx950 the
+fetch counter tallies the 128-byte requests of a 16-B/lane coalesced stream at 64 B
+(MI355X_MICROARCH.md, HBM / rocprofv3 section); WRITE_SIZE is taken as is.
+"""
+import csv
+import glob
+import json
+import os
+import sys
+
+src, dst, tag = sys.argv[1:4]
+KERNEL = 'k_logprob_pd_reduced'
+rows = []
+mean = {}
+grid = None
+for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+    files = glob.glob(os.path.join(src, f'pmc_{counter}', '*', '*counter_collection.csv'))
+    if not files:
+        sys.exit(f'no counter_collection.csv for {counter} under {src}')
+    vals, name = [], None
+    for f in files:
+        for r in csv.DictReader(open(f)):
+            if KERNEL in r['Kernel_Name'] and r['Counter_Name'] == counter:
+                vals.append(float(r['Counter_Value']))
+                name, grid = r['Kernel_Name'], int(r['Grid_Size'])
+    mean[counter] = sum(vals) / len(vals)
+    rows.append([counter, len(vals), '%.3f' % min(vals), '%.3f' % max(vals), '%.3f' % mean[counter], name, grid])
+with open(os.path.join(dst, f'{tag}_bench_pmc_summary.csv'), 'w', newline='') as fh:
+    w = csv.writer(fh)
+    w.writerow(['counter', 'dispatches', 'min_KB', 'max_KB', 'mean_KB', 'kernel', 'grid_size'])
+    w.writerows(rows)
+fetch = 2.0 * mean['FETCH_SIZE'] * 1024.0
+write = mean['WRITE_SIZE'] * 1024.0
+W = grid
+rec = {
+    'walkers': W, 'kernel': KERNEL, 'hbm_bytes_per_launch': fetch + write,
+    'fetch_bytes_corrected': fetch, 'write_bytes': write,
+    'FETCH_SIZE_KB_raw': mean['FETCH_SIZE'], 'WRITE_SIZE_KB_raw': mean['WRITE_SIZE'],
+    'algorithmic_bytes_per_launch': 64 * W,
+    'note': f'separate rocprofv3 --pmc passes (profiles/{tag}_bench_pmc_summary.csv); FETCH_SIZE doubled per '
+            'MI355X_MICROARCH.md HBM section (gfx950 tallies 128-B requests of a 16-B/lane coalesced stream '
+            'at 64 B); WRITE_SIZE taken as is (equals 8 B x W exactly)',
+}
+json.dump(rec, open(os.path.join(dst, 'pmc_traffic.json'), 'w'), indent=1)
+print(json.dumps(rec))

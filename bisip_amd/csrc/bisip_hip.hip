@@ -449,12 +449,13 @@ int launch_stretch(const StretchWork &work, const LP &lp, hipStream_t st)
     return BISIP_OK;
 }
 
-// Lanes per walker for launches that cannot fill the chip with one lane per walker (1024
-// SIMDs x 64 lanes): up to 4 below 8 Ki walkers, 2 below 32 Ki, else 1.  The value never changes
-// a result (logprob_row is bit-identical for every L), only the wave count.
+// Lanes per walker for launches that cannot fill the chip with one lane per walker: as many
+// as keep the launch within one wave per SIMD (1024 SIMDs x 64 lanes = 65536 lanes) -- 4 up to
+// 16 Ki walkers, 2 up to 32 Ki, else 1.  The value never changes a result (logprob_row is
+// bit-identical for every L), only the wave count.
 int lanes_per_walker(long long walkers)
 {
-    return walkers <= 8192 ? 4 : (walkers <= 32768 ? 2 : 1);
+    return walkers <= 16384 ? 4 : (walkers <= 32768 ? 2 : 1);
 }
 
 // lanes per slot of a stretch dispatch: as many as lanes_per_walker() grants for the number of
