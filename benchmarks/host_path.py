@@ -10,7 +10,8 @@ from sweep import problem
 from bisip_amd.synthetic import synthetic_theta
 import torch
 
-for name, model, N, W, kw in [('PD reduced N32', 'pd', 32, 1 << 22, {}), ('CC D2 N32', 'cc', 32, 1 << 22, dict(n_modes=2))]:
+for name, model, N, W, kw in [('PD reduced N32', 'pd', 32, 1 << 22, {}), ('CC D2 N32', 'cc', 32, 1 << 22, dict(n_modes=2)),
+                              ('PD N20 (the bundled spectra)', 'pd', 20, 1 << 22, {}), ('CC D2 N64', 'cc', 64, 1 << 21, dict(n_modes=2))]:
     ctx, bounds = problem(model, N, **kw)
     theta = synthetic_theta(bounds[0], bounds[1], W)
     ctx.logprob(theta[:1024])
@@ -21,7 +22,7 @@ for name, model, N, W, kw in [('PD reduced N32', 'pd', 32, 1 << 22, {}), ('CC D2
     print(json.dumps({'case': name + ' bisip_logprob (host buffers, pageable)', 'W': W,
                       'evals_per_s': float('%.4g' % (W / dt)), 'GBs_over_pcie': round(W * 8 * (bounds.shape[1] + 1) / dt / 1e9, 2)}))
     # forward kernel, device resident
-    Wf = 1 << 21
+    Wf = min(1 << 21, W)
     th = torch.from_numpy(theta[:Wf]).cuda()
     Z = torch.empty((Wf, 2, N), dtype=torch.float64, device='cuda')
     st = torch.cuda.current_stream()

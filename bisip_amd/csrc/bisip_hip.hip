@@ -206,10 +206,13 @@ template <class M>
 int launch_forward(const bisip_ctx *c, const double *theta, int64_t W, double *Z, hipStream_t st)
 {
     const LaunchArgs a = make_args(c, theta, Z, W, c->d_cb);
-    long long blocks = (W + 63) / 64;
-    if (blocks > 256 * 16) blocks = 256 * 16;   // persistent single-wave workgroups, 16 per CU
-    const unsigned grid = (unsigned)blocks;
-    if (((uintptr_t)theta % 16) == 0) hipLaunchKernelGGL((k_forward_tiled<M, true>), dim3(grid), dim3(64), 0, st, a);
+    // one single-wave workgroup per 64 walkers; the grid is not capped at the resident count
+    // (a capped, looping grid measured 0-25 % slower depending on the box: benchmarks/micro/forward_variants.hip)
+    const unsigned grid = (unsigned)((W + 63) / 64);
+    const int N = c->N;
+    if (N % 16 != 0 && N <= 24) hipLaunchKernelGGL((k_forward_rows<M, 24>), dim3(grid), dim3(64), 0, st, a);
+    else if (N % 16 != 0 && N <= 32) hipLaunchKernelGGL((k_forward_rows<M, 32>), dim3(grid), dim3(64), 0, st, a);
+    else if (((uintptr_t)theta % 16) == 0) hipLaunchKernelGGL((k_forward_tiled<M, true>), dim3(grid), dim3(64), 0, st, a);
     else hipLaunchKernelGGL((k_forward_tiled<M, false>), dim3(grid), dim3(64), 0, st, a);
     HIP_TRY(hipGetLastError());
     return BISIP_OK;

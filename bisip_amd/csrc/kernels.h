@@ -820,6 +820,9 @@ __global__ __launch_bounds__(256) void k_forward_batch(const BatchArgs a)
 // is computed once, as in the log-prob kernels); a wave evaluates 16 frequencies for its
 // 64 walkers into an LDS tile and streams the tile out so that every store instruction
 // writes whole 128-byte runs of Z.  Bound by writing Z (16*N B per walker).
+// Used when N is a multiple of 16 (runs = whole cache lines) or N > 32; other N <= 32 --
+// the bundled spectra have N = 20 -- go through k_forward_rows below, because a 16+4 split
+// writes most cache lines in parts (measured 1.5 vs 3.3 TB/s at N = 20).
 // ---------------------------------------------------------------------------------
 // The workgroup of k_forward_tiled is ONE wave, whose LDS operations execute in order; all
 // it needs between writing a tile and reading it back is "LDS results have landed" plus a
@@ -901,6 +904,75 @@ __global__ __launch_bounds__(64) void k_forward_tiled(const LaunchArgs a)
             for (int jj = 0; jj < JC; ++jj) lds[lane * ROW + jj] = zim[jj];
             wave_lds_fence();
             stream_out(row0, rows_here, 1, j0, jn);
+            wave_lds_fence();
+        }
+    }
+}
+
+// Batched forward(), N <= JC: whole rows.  Lane = walker computes all N frequencies (2N doubles in
+// registers); SUB walkers at a time go through LDS laid out exactly like Z ([re 0..N) [im 0..N)
+// per walker), so the SUB*2N doubles of a pass are ONE contiguous span of Z and every store
+// instruction writes 1 KB (16-byte pieces) or 512 B (odd N) of consecutive addresses:
+// no cache line is ever written in parts.
+template <class M, int JC>
+__global__ __launch_bounds__(64) void k_forward_rows(const LaunchArgs a)
+{
+    constexpr int NDIM = M::NDIM;
+    constexpr int SUB = 32;
+    constexpr int ROWMAX = 2 * JC + 1;
+    __shared__ __attribute__((aligned(16))) double lds[SUB * ROWMAX];
+    const int lane = threadIdx.x;
+    const int N = a.N;
+    const int rowlen = (2 * N) | 1;   // odd stride: conflict-free column writes
+    const bool wide = ((N & 1) == 0) && ((reinterpret_cast<unsigned long long>(a.out) & 15) == 0);
+    const long long nblocks = (a.W + 63) / 64;
+    for (long long blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+        const long long row0 = blk * 64;
+        const int rows_here = (int)((a.W - row0) < 64 ? (a.W - row0) : 64);
+        const long long row = row0 + lane < a.W ? row0 + lane : a.W - 1;
+        double th[NDIM];
+#pragma unroll
+        for (int q = 0; q < NDIM; ++q) th[q] = a.theta[row * NDIM + q];
+        const typename M::Setup s = M::setup(th);
+        double zr[JC], zi[JC];
+#pragma unroll
+        for (int jj = 0; jj < JC; ++jj) {
+            zr[jj] = 0.0; zi[jj] = 0.0;
+            if (jj < N) M::eval(s, a.cb + (long long)jj * M::REC + 4, zr[jj], zi[jj]);
+        }
+#pragma unroll 1
+        for (int sub = 0; sub * SUB < rows_here; ++sub) {
+            if ((lane / SUB) == sub) {
+                double *r = lds + (lane % SUB) * rowlen;
+#pragma unroll
+                for (int jj = 0; jj < JC; ++jj)
+                    if (jj < N) { r[jj] = zr[jj]; r[N + jj] = zi[jj]; }
+            }
+            wave_lds_fence();
+            const int wn = (rows_here - sub * SUB) < SUB ? (rows_here - sub * SUB) : SUB;
+            double *dst0 = a.out + (row0 + sub * SUB) * 2 * N;
+            if (wide) {
+                // 16-byte piece q of the pass = walker q / N, doubles 2*(q % N)..+1
+                const int total = wn * N, dw = 64 / N, de = 64 - dw * N;
+                int w = lane / N, e = lane - w * N;
+                for (int q = lane; q < total; q += 64) {
+                    const double *src = lds + w * rowlen + 2 * e;
+                    dbl2 v;
+                    v.x = src[0];
+                    v.y = src[1];
+                    __builtin_nontemporal_store(v, reinterpret_cast<dbl2 *>(dst0 + 2 * (long long)q));
+                    w += dw; e += de;
+                    if (e >= N) { e -= N; ++w; }
+                }
+            } else {
+                const int M2 = 2 * N, total = wn * M2, dw = 64 / M2, de = 64 - dw * M2;
+                int w = lane / M2, e = lane - w * M2;
+                for (int f = lane; f < total; f += 64) {
+                    dst0[f] = lds[w * rowlen + e];
+                    w += dw; e += de;
+                    if (e >= M2) { e -= M2; ++w; }
+                }
+            }
             wave_lds_fence();
         }
     }
