@@ -69,9 +69,10 @@ extern "C" int bisip_numpy_stretch_stream(uint32_t *mt_key, int32_t *mt_pos, int
                                           int64_t n_steps, int32_t *active, int32_t *partner,
                                           double *zz, double *u)
 {
-    if (!mt_key || !mt_pos || !active || !partner || !zz || !u || W < 2 || W > 0x7fffffffLL ||
-        n_steps < 0 || *mt_pos < 0 || *mt_pos > 624)
+    if (!mt_key || !mt_pos || W < 2 || W > 0x7fffffffLL || n_steps < 0 || *mt_pos < 0 || *mt_pos > 624)
         return BISIP_EINVAL;
+    if (n_steps == 0) return BISIP_OK;   // nothing to draw: the output arrays may be empty
+    if (!active || !partner || !zz || !u) return BISIP_EINVAL;
     MT mt{mt_key, *mt_pos};
     const int64_t nh = (W + 1) / 2;
     std::vector<int32_t> inds(W), half[2];
