@@ -1,27 +1,19 @@
 // bisip_hip.hip -- C ABI (include/bisip_hip.h) over the kernels in kernels.h.
 // Host side: context = device copies of the walker-independent operands + the prior
 // box; every call is one kernel launch on the caller's stream.
-#include <hip/hip_runtime.h>
-
-#include <cmath>
-#include <cstdarg>
-#include <cstdint>
-#include <cstdio>
-#include <cstring>
-#include <new>
-#include <vector>
-
-#include "../../include/bisip_hip.h"
+#include "host.h"
 #include "host_precompute.h"
-#include "kernels.h"
-#include "sampler_kernels.h"
 #include "chain_kernels.h"
 
 using namespace bisip;
+using namespace bisip::host;
 
 namespace {
-
 thread_local char g_err[512] = "";
+}
+
+namespace bisip {
+namespace host {
 
 int fail(int code, const char *fmt, ...)
 {
@@ -30,58 +22,6 @@ int fail(int code, const char *fmt, ...)
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
     return code;
-}
-
-#define HIP_TRY(expr)                                                                  \
-    do {                                                                               \
-        hipError_t e_ = (expr);                                                        \
-        if (e_ != hipSuccess)                                                          \
-            return fail(BISIP_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
-                        __FILE__, __LINE__);                                           \
-    } while (0)
-
-int lanes_per_walker(long long walkers);
-
-constexpr int BLK_SMALL = 64;    // few walkers: spread them over more CUs
-constexpr int BLK_LARGE = 256;
-constexpr int BLK_STREAM = 128;  // HBM-bound reduced kernel: 128-lane workgroups stream ~3 % faster
-                                 // than 256 (interleaved A/B, benchmarks/micro/reduced_variants.hip)
-constexpr long long SMALL_W = 256LL * 256 * 2;  // below this, 64-lane workgroups
-
-}  // namespace
-
-struct bisip_ctx {
-    int device = 0, model_id = 0, N = 0, ndim = 0, variant = BISIP_VARIANT_AUTO;
-    int P = 0, D = 0, S = 0;
-    double c_exp = 1.0, lconst = 0.0;
-    Bounds bounds{};
-    int E = 1;                      // spectra in the context (batch of spectra: E > 1)
-    double *d_cb = nullptr;        // records for k_forward (and k_logprob of CC/Dias/Shin): (E, N, REC)
-    double *d_cb_lp = nullptr;     // PolynomialDecomposition: 1/sigma-weighted log-prob records (E, N, REC)
-    double *d_cb_faithful = nullptr;
-    double *d_lconst = nullptr;    // (E,)  batch only
-    void *d_red = nullptr;         // (E,) ReducedArgs<P>  batch only
-    long long cb_stride = 0;
-    std::vector<double> Rpacked, bhat, evec;
-    double rest = 0.0;
-    // workspace of the host-pointer entry points
-    double *d_ws = nullptr;
-    size_t ws_bytes = 0;
-    char *h_pin = nullptr;         // pinned, device-mapped staging for small host-buffer calls
-    char *d_pin = nullptr;         // its device-side address
-    static constexpr size_t PIN_BYTES = 1 << 20;
-    static constexpr size_t ZEROCOPY_BYTES = 64 << 10;
-    hipStream_t stream = nullptr;
-    const char *kernel_name = "";
-};
-
-namespace {
-
-int upload(double **dst, const std::vector<double> &src)
-{
-    HIP_TRY(hipMalloc((void **)dst, src.size() * sizeof(double)));
-    HIP_TRY(hipMemcpy(*dst, src.data(), src.size() * sizeof(double), hipMemcpyHostToDevice));
-    return BISIP_OK;
 }
 
 int effective_variant(const bisip_ctx *c)
@@ -104,120 +44,6 @@ LaunchArgs make_args(const bisip_ctx *c, const double *theta, double *out, int64
     return a;
 }
 
-template <class M> struct CoopLimit { static constexpr long long value = 1LL << 40; };
-// PDCollapsed spends 15 FMAs per frequency: passing the running sums between lanes costs as
-// much as the residual it parallelises (measured 5.7 vs 5.2 us at 4096 walkers), so one lane.
-template <int P> struct CoopLimit<PDCollapsed<P>> { static constexpr long long value = 0; };
-
-template <class M, int L>
-int launch_logprob_small(const LaunchArgs &a, bool vec, hipStream_t st)
-{
-    const unsigned grid = (unsigned)((a.W * L + BLK_SMALL - 1) / BLK_SMALL);
-    if (vec) hipLaunchKernelGGL((k_logprob<M, BLK_SMALL, true, L>), dim3(grid), dim3(BLK_SMALL), 0, st, a);
-    else hipLaunchKernelGGL((k_logprob<M, BLK_SMALL, false, L>), dim3(grid), dim3(BLK_SMALL), 0, st, a);
-    return BISIP_OK;
-}
-
-template <class M>
-int launch_logprob(const bisip_ctx *c, const double *theta, int64_t W, double *out, hipStream_t st)
-{
-    const LaunchArgs a = make_args(c, theta, out, W, c->d_cb_lp ? c->d_cb_lp : c->d_cb);
-    const bool vec = ((uintptr_t)theta % 16) == 0;
-    if (W < SMALL_W) {
-        // few walkers: several lanes per walker so the launch still covers the chip
-        switch (W <= CoopLimit<M>::value ? lanes_per_walker(W) : 1) {
-        case 4: launch_logprob_small<M, 4>(a, vec, st); break;
-        case 2: launch_logprob_small<M, 2>(a, vec, st); break;
-        default: launch_logprob_small<M, 1>(a, vec, st); break;
-        }
-    } else {
-        const unsigned grid = (unsigned)((W + BLK_LARGE - 1) / BLK_LARGE);
-        if (vec) hipLaunchKernelGGL((k_logprob<M, BLK_LARGE, true>), dim3(grid), dim3(BLK_LARGE), 0, st, a);
-        else hipLaunchKernelGGL((k_logprob<M, BLK_LARGE, false>), dim3(grid), dim3(BLK_LARGE), 0, st, a);
-    }
-    HIP_TRY(hipGetLastError());
-    return BISIP_OK;
-}
-
-// PolynomialDecomposition collapsed, many walkers: two rows per lane (see k_logprob_x2)
-template <int P>
-int launch_collapsed(const bisip_ctx *c, const double *theta, int64_t W, double *out, hipStream_t st)
-{
-    if (W < SMALL_W) return launch_logprob<PDCollapsed<P>>(c, theta, W, out, st);
-    const LaunchArgs a = make_args(c, theta, out, W, c->d_cb_lp);
-    const bool vec = ((uintptr_t)theta % 16) == 0;
-    const unsigned grid = (unsigned)((W + 2 * BLK_STREAM - 1) / (2 * BLK_STREAM));
-    if (vec) hipLaunchKernelGGL((k_logprob_x2<PDCollapsed<P>, BLK_STREAM, true>), dim3(grid), dim3(BLK_STREAM), 0, st, a);
-    else hipLaunchKernelGGL((k_logprob_x2<PDCollapsed<P>, BLK_STREAM, false>), dim3(grid), dim3(BLK_STREAM), 0, st, a);
-    HIP_TRY(hipGetLastError());
-    return BISIP_OK;
-}
-
-template <int P>
-int launch_reduced(const bisip_ctx *c, const double *theta, int64_t W, double *out, hipStream_t st)
-{
-    const LaunchArgs a = make_args(c, theta, out, W, nullptr);
-    ReducedArgs<P> r;
-    std::memcpy(r.R, c->Rpacked.data(), sizeof(r.R));
-    std::memcpy(r.bhat, c->bhat.data(), sizeof(r.bhat));
-    std::memcpy(r.e, c->evec.data(), sizeof(r.e));
-    r.rest = c->rest;
-    const bool vec = ((uintptr_t)theta % 16) == 0;
-    if (W < SMALL_W) {
-        const unsigned grid = (unsigned)((W + BLK_SMALL - 1) / BLK_SMALL);
-        if (vec) hipLaunchKernelGGL((k_logprob_pd_reduced<P, BLK_SMALL, true>), dim3(grid), dim3(BLK_SMALL), 0, st, a, r);
-        else hipLaunchKernelGGL((k_logprob_pd_reduced<P, BLK_SMALL, false>), dim3(grid), dim3(BLK_SMALL), 0, st, a, r);
-    } else {
-        const unsigned grid = (unsigned)((W + BLK_STREAM - 1) / BLK_STREAM);
-        if (vec) hipLaunchKernelGGL((k_logprob_pd_reduced<P, BLK_STREAM, true>), dim3(grid), dim3(BLK_STREAM), 0, st, a, r);
-        else hipLaunchKernelGGL((k_logprob_pd_reduced<P, BLK_STREAM, false>), dim3(grid), dim3(BLK_STREAM), 0, st, a, r);
-    }
-    HIP_TRY(hipGetLastError());
-    return BISIP_OK;
-}
-
-template <int P>
-int launch_faithful(const bisip_ctx *c, const double *theta, int64_t W, double *out, hipStream_t st)
-{
-    const LaunchArgs a = make_args(c, theta, out, W, c->d_cb_faithful);
-    const bool vec = ((uintptr_t)theta % 16) == 0;
-    const unsigned grid = (unsigned)((W + BLK_SMALL - 1) / BLK_SMALL);
-    if (vec) hipLaunchKernelGGL((k_logprob_pd_faithful<P, BLK_SMALL, true>), dim3(grid), dim3(BLK_SMALL), 0, st, a, c->S);
-    else hipLaunchKernelGGL((k_logprob_pd_faithful<P, BLK_SMALL, false>), dim3(grid), dim3(BLK_SMALL), 0, st, a, c->S);
-    HIP_TRY(hipGetLastError());
-    return BISIP_OK;
-}
-
-template <int P>
-int launch_wave(const bisip_ctx *c, const double *theta, int64_t W, double *out, hipStream_t st)
-{
-    const LaunchArgs a = make_args(c, theta, out, W, c->d_cb_lp);
-    const size_t lds = (size_t)c->N * (4 + 2 * (P + 1)) * sizeof(double);
-    // persistent waves: 8 workgroups of 4 waves per CU, fewer when there are fewer walkers
-    long long blocks = (W + 3) / 4;
-    if (blocks > 256 * 8) blocks = 256 * 8;
-    if (2 * c->N <= 64) hipLaunchKernelGGL((k_logprob_pd_wave<P, 1>), dim3((unsigned)blocks), dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((k_logprob_pd_wave<P, 2>), dim3((unsigned)blocks), dim3(256), lds, st, a);
-    HIP_TRY(hipGetLastError());
-    return BISIP_OK;
-}
-
-template <class M>
-int launch_forward(const bisip_ctx *c, const double *theta, int64_t W, double *Z, hipStream_t st)
-{
-    const LaunchArgs a = make_args(c, theta, Z, W, c->d_cb);
-    // one single-wave workgroup per 64 walkers; the grid is not capped at the resident count
-    // (a capped, looping grid measured 0-25 % slower depending on the box: benchmarks/micro/forward_variants.hip)
-    const unsigned grid = (unsigned)((W + 63) / 64);
-    const int N = c->N;
-    if (N % 16 != 0 && N <= 24) hipLaunchKernelGGL((k_forward_rows<M, 24>), dim3(grid), dim3(64), 0, st, a);
-    else if (N % 16 != 0 && N <= 32) hipLaunchKernelGGL((k_forward_rows<M, 32>), dim3(grid), dim3(64), 0, st, a);
-    else if (((uintptr_t)theta % 16) == 0) hipLaunchKernelGGL((k_forward_tiled<M, true>), dim3(grid), dim3(64), 0, st, a);
-    else hipLaunchKernelGGL((k_forward_tiled<M, false>), dim3(grid), dim3(64), 0, st, a);
-    HIP_TRY(hipGetLastError());
-    return BISIP_OK;
-}
-
 BatchArgs make_batch_args(const bisip_ctx *c, const double *theta, double *out, int64_t W)
 {
     BatchArgs a;
@@ -227,392 +53,15 @@ BatchArgs make_batch_args(const bisip_ctx *c, const double *theta, double *out, 
     return a;
 }
 
-template <class M>
-int launch_logprob_batch(const bisip_ctx *c, const double *theta, int64_t W, double *out, hipStream_t st)
+}  // namespace host
+}  // namespace bisip
+
+namespace {
+
+int upload(double **dst, const std::vector<double> &src)
 {
-    BatchArgs a = make_batch_args(c, theta, out, W);
-    if (c->d_cb_lp) a.cb = c->d_cb_lp;
-    const unsigned grid = (unsigned)((W + 63) / 64);
-    if (a.Wp % 64 == 0) hipLaunchKernelGGL((k_logprob_batch<M, true>), dim3(grid), dim3(64), 0, st, a);
-    else hipLaunchKernelGGL((k_logprob_batch<M, false>), dim3(grid), dim3(64), 0, st, a);
-    HIP_TRY(hipGetLastError());
-    return BISIP_OK;
-}
-
-template <int P>
-int launch_reduced_batch(const bisip_ctx *c, const double *theta, int64_t W, double *out, hipStream_t st)
-{
-    const BatchArgs a = make_batch_args(c, theta, out, W);
-    const unsigned grid = (unsigned)((W + 63) / 64);
-    if (a.Wp % 64 == 0) hipLaunchKernelGGL((k_logprob_batch_reduced<P, true>), dim3(grid), dim3(64), 0, st, a);
-    else hipLaunchKernelGGL((k_logprob_batch_reduced<P, false>), dim3(grid), dim3(64), 0, st, a);
-    HIP_TRY(hipGetLastError());
-    return BISIP_OK;
-}
-
-template <class M>
-int launch_forward_batch(const bisip_ctx *c, const double *theta, int64_t W, double *Z, hipStream_t st)
-{
-    const BatchArgs a = make_batch_args(c, theta, Z, W);
-    const long long total = (long long)W * c->N;
-    hipLaunchKernelGGL((k_forward_batch<M>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
-    HIP_TRY(hipGetLastError());
-    return BISIP_OK;
-}
-
-int dispatch_logprob_batch(const bisip_ctx *c, const double *theta, int64_t W, double *out, hipStream_t st)
-{
-    switch (c->model_id) {
-    case BISIP_MODEL_POLYDECOMP:
-        if (effective_variant(c) == BISIP_VARIANT_REDUCED) {
-            switch (c->P) {
-#define X(p) case p: return launch_reduced_batch<p>(c, theta, W, out, st);
-                X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10)
-#undef X
-            }
-        } else {
-            switch (c->P) {
-#define X(p) case p: return launch_logprob_batch<PDCollapsed<p>>(c, theta, W, out, st);
-                X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10)
-#undef X
-            }
-        }
-        break;
-    case BISIP_MODEL_COLECOLE:
-        switch (c->D) {
-#define X(d) case d: return launch_logprob_batch<ColeCole<d>>(c, theta, W, out, st);
-            X(1) X(2) X(3) X(4) X(5)
-#undef X
-        }
-        break;
-    case BISIP_MODEL_DIAS2000: return launch_logprob_batch<Dias>(c, theta, W, out, st);
-    case BISIP_MODEL_SHIN2015: return launch_logprob_batch<Shin>(c, theta, W, out, st);
-    }
-    return fail(BISIP_EUNSUPPORTED, "no batch kernel for this model shape");
-}
-
-int dispatch_forward_batch(const bisip_ctx *c, const double *theta, int64_t W, double *Z, hipStream_t st)
-{
-    switch (c->model_id) {
-    case BISIP_MODEL_POLYDECOMP:
-        switch (c->P) {
-#define X(p) case p: return launch_forward_batch<PDCollapsed<p>>(c, theta, W, Z, st);
-            X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10)
-#undef X
-        }
-        break;
-    case BISIP_MODEL_COLECOLE:
-        switch (c->D) {
-#define X(d) case d: return launch_forward_batch<ColeCole<d>>(c, theta, W, Z, st);
-            X(1) X(2) X(3) X(4) X(5)
-#undef X
-        }
-        break;
-    case BISIP_MODEL_DIAS2000: return launch_forward_batch<Dias>(c, theta, W, Z, st);
-    case BISIP_MODEL_SHIN2015: return launch_forward_batch<Shin>(c, theta, W, Z, st);
-    }
-    return fail(BISIP_EUNSUPPORTED, "no batch forward kernel for this model shape");
-}
-
-#define PD_CASES(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10)
-#define CC_CASES(X) X(1) X(2) X(3) X(4) X(5)
-
-int dispatch_logprob(const bisip_ctx *c, const double *theta, int64_t W, double *out, hipStream_t st)
-{
-    if (W == 0) return BISIP_OK;
-    if ((W + BLK_SMALL - 1) / BLK_SMALL > 0x7fffffffLL)
-        return fail(BISIP_EINVAL, "W=%lld exceeds the launch grid limit", (long long)W);
-    if (c->E > 1) {
-        if (W % c->E) return fail(BISIP_EINVAL, "W=%lld is not a multiple of n_spectra=%d", (long long)W, c->E);
-        return dispatch_logprob_batch(c, theta, W, out, st);
-    }
-    switch (c->model_id) {
-    case BISIP_MODEL_POLYDECOMP: {
-        const int v = effective_variant(c);
-        if (v == BISIP_VARIANT_REDUCED) {
-            switch (c->P) {
-#define X(p) case p: return launch_reduced<p>(c, theta, W, out, st);
-                PD_CASES(X)
-#undef X
-            }
-        } else if (v == BISIP_VARIANT_COLLAPSED) {
-            switch (c->P) {
-#define X(p) case p: return launch_collapsed<p>(c, theta, W, out, st);
-                PD_CASES(X)
-#undef X
-            }
-        } else if (v == BISIP_VARIANT_WAVE) {
-            switch (c->P) {
-#define X(p) case p: return launch_wave<p>(c, theta, W, out, st);
-                PD_CASES(X)
-#undef X
-            }
-        } else if (v == BISIP_VARIANT_FAITHFUL) {
-            if (!c->d_cb_faithful) return fail(BISIP_EUNSUPPORTED, "the faithful formulation is not available for this context");
-            switch (c->P) {
-#define X(p) case p: return launch_faithful<p>(c, theta, W, out, st);
-                PD_CASES(X)
-#undef X
-            }
-        }
-        return fail(BISIP_EUNSUPPORTED, "no kernel for poly_deg=%d variant=%d", c->P, v);
-    }
-    case BISIP_MODEL_COLECOLE:
-        switch (c->D) {
-#define X(d) case d: return launch_logprob<ColeCole<d>>(c, theta, W, out, st);
-            CC_CASES(X)
-#undef X
-        }
-        return fail(BISIP_EUNSUPPORTED, "no kernel for n_modes=%d", c->D);
-    case BISIP_MODEL_DIAS2000: return launch_logprob<Dias>(c, theta, W, out, st);
-    case BISIP_MODEL_SHIN2015: return launch_logprob<Shin>(c, theta, W, out, st);
-    }
-    return fail(BISIP_EINVAL, "bad model_id %d", c->model_id);
-}
-
-int dispatch_forward(const bisip_ctx *c, const double *theta, int64_t W, double *Z, hipStream_t st)
-{
-    if (W == 0) return BISIP_OK;
-    if (((long long)W * c->N + 255) / 256 > 0x7fffffffLL)
-        return fail(BISIP_EINVAL, "W=%lld exceeds the launch grid limit", (long long)W);
-    if (((uintptr_t)theta % 8) || ((uintptr_t)Z % 8)) return fail(BISIP_EINVAL, "buffers must be 8-byte aligned");
-    if (c->E > 1) {
-        if (W % c->E) return fail(BISIP_EINVAL, "W=%lld is not a multiple of n_spectra=%d", (long long)W, c->E);
-        return dispatch_forward_batch(c, theta, W, Z, st);
-    }
-    switch (c->model_id) {
-    case BISIP_MODEL_POLYDECOMP:
-        switch (c->P) {
-#define X(p) case p: return launch_forward<PDCollapsed<p>>(c, theta, W, Z, st);
-            PD_CASES(X)
-#undef X
-        }
-        break;
-    case BISIP_MODEL_COLECOLE:
-        switch (c->D) {
-#define X(d) case d: return launch_forward<ColeCole<d>>(c, theta, W, Z, st);
-            CC_CASES(X)
-#undef X
-        }
-        break;
-    case BISIP_MODEL_DIAS2000: return launch_forward<Dias>(c, theta, W, Z, st);
-    case BISIP_MODEL_SHIN2015: return launch_forward<Shin>(c, theta, W, Z, st);
-    }
-    return fail(BISIP_EUNSUPPORTED, "no forward kernel for this model shape");
-}
-
-StretchArgs to_device_args(const bisip_stretch_args *u)
-{
-    StretchArgs a;
-    a.coords = u->coords; a.logp = u->logp;
-    a.active = u->active; a.partner = u->partner;
-    a.zz = u->zz; a.factor = u->factor; a.logu = u->logu;
-    a.n_slots = u->n_slots; a.slot_lo = u->slot_lo; a.slot_hi = u->slot_hi;
-    a.block = u->block; a.chain_row = u->chain_row; a.logp_row = u->logp_row;
-    a.naccept = u->naccept; a.status = u->status;
-    a.pad = u->pad;
-    const long long world = u->world > 0 ? u->world : 1;
-    a.base = u->n_slots / world;
-    a.extra = u->n_slots % world;
-    return a;
-}
-
-enum StretchKind { STRETCH_HALF, STRETCH_EVAL, STRETCH_PERSIST };
-
-// what one stretch dispatch launches: a half-step / eval kernel over StretchArgs, or the
-// persistent kernel over PersistArgs
-struct StretchWork {
-    StretchKind kind;
-    const StretchArgs *half;
-    const PersistArgs *persist;
-};
-
-template <class LP>
-int launch_stretch(const StretchWork &work, const LP &lp, hipStream_t st)
-{
-    const StretchKind kind = work.kind;
-    if (kind == STRETCH_PERSIST) {
-        const PersistArgs &p = *work.persist;
-        const long long nh = (p.W + 1) / 2;
-        const unsigned threads = (unsigned)(((nh * LP::L + 63) / 64) * 64);   // <= 1024: stretch_lanes()
-        const size_t lds = (size_t)p.W * (LP::NDIM + 1) * sizeof(double);
-        hipLaunchKernelGGL((k_stretch_persistent<LP>), dim3((unsigned)p.E), dim3(threads), lds, st, p, lp);
-        HIP_TRY(hipGetLastError());
-        return BISIP_OK;
-    }
-    const StretchArgs &a = *work.half;
-    if (kind == STRETCH_HALF) {
-        const unsigned grid = (unsigned)((a.n_slots * LP::L + 63) / 64);
-        hipLaunchKernelGGL((k_stretch_half<LP>), dim3(grid), dim3(64), 0, st, a, lp);
-    } else {
-        const unsigned grid = (unsigned)(((a.slot_hi - a.slot_lo) * LP::L + 63) / 64);
-        hipLaunchKernelGGL((k_stretch_eval<LP>), dim3(grid), dim3(64), 0, st, a, lp);
-    }
-    HIP_TRY(hipGetLastError());
-    return BISIP_OK;
-}
-
-// Lanes per walker for launches that cannot fill the chip with one lane per walker: as many
-// as keep the launch within one wave per SIMD (1024 SIMDs x 64 lanes = 65536 lanes) -- 4 up to
-// 16 Ki walkers, 2 up to 32 Ki, else 1.  The value never changes a result (logprob_row is
-// bit-identical for every L), only the wave count.
-int lanes_per_walker(long long walkers)
-{
-    return walkers <= 16384 ? 4 : (walkers <= 32768 ? 2 : 1);
-}
-
-// lanes per slot of a stretch dispatch: as many as lanes_per_walker() grants for the number of
-// slots evaluated at once (all ensembles' for the persistent kernel, whose workgroups run
-// concurrently), capped there by the 1024-lane workgroup that holds one ensemble's half.
-int stretch_lanes(const StretchWork &w)
-{
-    if (w.kind == STRETCH_PERSIST) {
-        const long long nh = (w.persist->W + 1) / 2;
-        const int fit = nh * 4 <= 1024 ? 4 : (nh * 2 <= 1024 ? 2 : 1);
-        const int want = lanes_per_walker(nh * w.persist->E);
-        return want < fit ? want : fit;
-    }
-    return lanes_per_walker(w.kind == STRETCH_HALF ? w.half->n_slots : w.half->slot_hi - w.half->slot_lo);
-}
-
-template <class M>
-int stretch_generic(const bisip_ctx *c, const StretchWork &a, hipStream_t st)
-{
-    const ModelOperands o{c->d_cb_lp ? c->d_cb_lp : c->d_cb, c->N, c->lconst};
-    switch (CoopLimit<M>::value > 0 ? stretch_lanes(a) : 1) {
-    case 4: { GenericLP<M, 4> lp; lp.o = o; lp.b = c->bounds; return launch_stretch(a, lp, st); }
-    case 2: { GenericLP<M, 2> lp; lp.o = o; lp.b = c->bounds; return launch_stretch(a, lp, st); }
-    default: { GenericLP<M, 1> lp; lp.o = o; lp.b = c->bounds; return launch_stretch(a, lp, st); }
-    }
-}
-
-template <int P>
-int stretch_reduced(const bisip_ctx *c, const StretchWork &a, hipStream_t st)
-{
-    ReducedLP<P> lp;
-    std::memcpy(lp.r.R, c->Rpacked.data(), sizeof(lp.r.R));
-    std::memcpy(lp.r.bhat, c->bhat.data(), sizeof(lp.r.bhat));
-    std::memcpy(lp.r.e, c->evec.data(), sizeof(lp.r.e));
-    lp.r.rest = c->rest;
-    lp.lconst = c->lconst;
-    lp.b = c->bounds;
-    return launch_stretch(a, lp, st);
-}
-
-template <class M, bool U, int L>
-int stretch_generic_batch_l(const bisip_ctx *c, const StretchWork &a, long long Wp, hipStream_t st)
-{
-    BatchGenericLP<M, U, L> lp;
-    lp.cb = c->d_cb_lp ? c->d_cb_lp : c->d_cb; lp.cb_stride = c->cb_stride; lp.Wp = Wp; lp.lconst = c->d_lconst; lp.N = c->N;
-    lp.b = c->bounds;
-    return launch_stretch(a, lp, st);
-}
-
-template <class M, bool U>
-int stretch_generic_batch(const bisip_ctx *c, const StretchWork &a, long long Wp, hipStream_t st)
-{
-    // a wave of 64/L slots must stay inside one spectrum for the uniform (scalar) operand path
-    // (the persistent kernel's workgroup is one ensemble: always inside one spectrum)
-    const int want = CoopLimit<M>::value > 0 ? stretch_lanes(a) : 1;
-    const bool whole = !U || a.kind == STRETCH_PERSIST;
-    if (want == 4 && (whole || (Wp / 2) % 16 == 0)) return stretch_generic_batch_l<M, U, 4>(c, a, Wp, st);
-    if (want >= 2 && (whole || (Wp / 2) % 32 == 0)) return stretch_generic_batch_l<M, U, 2>(c, a, Wp, st);
-    return stretch_generic_batch_l<M, U, 1>(c, a, Wp, st);
-}
-
-template <int P, bool U>
-int stretch_reduced_batch(const bisip_ctx *c, const StretchWork &a, long long Wp, hipStream_t st)
-{
-    BatchReducedLP<P, U> lp;
-    lp.red = reinterpret_cast<const ReducedArgs<P> *>(c->d_red); lp.Wp = Wp; lp.lconst = c->d_lconst;
-    lp.b = c->bounds;
-    return launch_stretch(a, lp, st);
-}
-
-// batch of spectra: Wp walkers per spectrum; a wave of 64 slots stays inside one spectrum
-// iff (Wp/2) % 64 == 0
-int dispatch_stretch_batch(const bisip_ctx *c, const StretchWork &a, long long Wp, hipStream_t st)
-{
-    // in the persistent kernel a workgroup IS one ensemble, so the spectrum is always uniform
-    const bool u = (Wp % 128) == 0 || a.kind == STRETCH_PERSIST;
-#define GEN(M) return u ? stretch_generic_batch<M, true>(c, a, Wp, st) : stretch_generic_batch<M, false>(c, a, Wp, st);
-#define RED(p) return u ? stretch_reduced_batch<p, true>(c, a, Wp, st) : stretch_reduced_batch<p, false>(c, a, Wp, st);
-    switch (c->model_id) {
-    case BISIP_MODEL_POLYDECOMP:
-        if (effective_variant(c) == BISIP_VARIANT_REDUCED) {
-            switch (c->P) {
-#define X(p) case p: RED(p)
-                X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10)
-#undef X
-            }
-        } else {
-            switch (c->P) {
-#define X(p) case p: GEN(PDCollapsed<p>)
-                X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10)
-#undef X
-            }
-        }
-        break;
-    case BISIP_MODEL_COLECOLE:
-        switch (c->D) {
-#define X(d) case d: GEN(ColeCole<d>)
-            X(1) X(2) X(3) X(4) X(5)
-#undef X
-        }
-        break;
-    case BISIP_MODEL_DIAS2000: GEN(Dias)
-    case BISIP_MODEL_SHIN2015: GEN(Shin)
-    }
-#undef GEN
-#undef RED
-    return fail(BISIP_EUNSUPPORTED, "no batch stretch kernel for this model shape");
-}
-
-int dispatch_stretch(const bisip_ctx *c, const StretchWork &a, long long Wp, hipStream_t st)
-{
-    if (c->E > 1) {
-        if (Wp < 2 || (Wp & 1)) return fail(BISIP_EINVAL, "batch context: walkers_per_spectrum must be even and >= 2, got %lld", Wp);
-        return dispatch_stretch_batch(c, a, Wp, st);
-    }
-    switch (c->model_id) {
-    case BISIP_MODEL_POLYDECOMP:
-        if (effective_variant(c) == BISIP_VARIANT_REDUCED) {
-            switch (c->P) {
-#define X(p) case p: return stretch_reduced<p>(c, a, st);
-                PD_CASES(X)
-#undef X
-            }
-        } else {  // collapsed (the faithful formulation has no sampler kernel)
-            switch (c->P) {
-#define X(p) case p: return stretch_generic<PDCollapsed<p>>(c, a, st);
-                PD_CASES(X)
-#undef X
-            }
-        }
-        break;
-    case BISIP_MODEL_COLECOLE:
-        switch (c->D) {
-#define X(d) case d: return stretch_generic<ColeCole<d>>(c, a, st);
-            CC_CASES(X)
-#undef X
-        }
-        break;
-    case BISIP_MODEL_DIAS2000: return stretch_generic<Dias>(c, a, st);
-    case BISIP_MODEL_SHIN2015: return stretch_generic<Shin>(c, a, st);
-    }
-    return fail(BISIP_EUNSUPPORTED, "no stretch kernel for this model shape");
-}
-
-int dispatch_apply(const bisip_ctx *c, const StretchArgs &a, hipStream_t st)
-{
-    const unsigned grid = (unsigned)((a.n_slots + 63) / 64);
-    switch (c->ndim) {
-#define X(n) case n: hipLaunchKernelGGL((k_stretch_apply<n>), dim3(grid), dim3(64), 0, st, a); break;
-        X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
-#undef X
-    default: return fail(BISIP_EUNSUPPORTED, "ndim=%d", c->ndim);
-    }
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMalloc((void **)dst, src.size() * sizeof(double)));
+    HIP_TRY(hipMemcpy(*dst, src.data(), src.size() * sizeof(double), hipMemcpyHostToDevice));
     return BISIP_OK;
 }
 
@@ -1141,3 +590,4 @@ int bisip_forward(bisip_ctx *c, const double *theta, int64_t W, double *Z)
 }
 
 }  // extern "C"
+

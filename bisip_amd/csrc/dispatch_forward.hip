@@ -1,0 +1,95 @@
+// dispatch_forward.hip -- batched forward() launches.
+#include "host.h"
+
+using namespace bisip;
+using namespace bisip::host;
+
+namespace {
+
+template <class M>
+int launch_forward(const bisip_ctx *c, const double *theta, int64_t W, double *Z, hipStream_t st)
+{
+    const LaunchArgs a = make_args(c, theta, Z, W, c->d_cb);
+    // one single-wave workgroup per 64 walkers; the grid is not capped at the resident count
+    // (a capped, looping grid measured 0-25 % slower depending on the box: benchmarks/micro/forward_variants.hip)
+    const unsigned grid = (unsigned)((W + 63) / 64);
+    const int N = c->N;
+    if (N % 16 != 0 && N <= 24) hipLaunchKernelGGL((k_forward_rows<M, 24>), dim3(grid), dim3(64), 0, st, a);
+    else if (N % 16 != 0 && N <= 32) hipLaunchKernelGGL((k_forward_rows<M, 32>), dim3(grid), dim3(64), 0, st, a);
+    else if (((uintptr_t)theta % 16) == 0) hipLaunchKernelGGL((k_forward_tiled<M, true>), dim3(grid), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL((k_forward_tiled<M, false>), dim3(grid), dim3(64), 0, st, a);
+    HIP_TRY(hipGetLastError());
+    return BISIP_OK;
+}
+
+template <class M>
+int launch_forward_batch(const bisip_ctx *c, const double *theta, int64_t W, double *Z, hipStream_t st)
+{
+    const BatchArgs a = make_batch_args(c, theta, Z, W);
+    const long long total = (long long)W * c->N;
+    hipLaunchKernelGGL((k_forward_batch<M>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
+    HIP_TRY(hipGetLastError());
+    return BISIP_OK;
+}
+
+int dispatch_forward_batch(const bisip_ctx *c, const double *theta, int64_t W, double *Z, hipStream_t st)
+{
+    switch (c->model_id) {
+    case BISIP_MODEL_POLYDECOMP:
+        switch (c->P) {
+#define X(p) case p: return launch_forward_batch<PDCollapsed<p>>(c, theta, W, Z, st);
+            X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10)
+#undef X
+        }
+        break;
+    case BISIP_MODEL_COLECOLE:
+        switch (c->D) {
+#define X(d) case d: return launch_forward_batch<ColeCole<d>>(c, theta, W, Z, st);
+            X(1) X(2) X(3) X(4) X(5)
+#undef X
+        }
+        break;
+    case BISIP_MODEL_DIAS2000: return launch_forward_batch<Dias>(c, theta, W, Z, st);
+    case BISIP_MODEL_SHIN2015: return launch_forward_batch<Shin>(c, theta, W, Z, st);
+    }
+    return fail(BISIP_EUNSUPPORTED, "no batch forward kernel for this model shape");
+}
+
+}  // namespace
+
+namespace bisip {
+namespace host {
+
+int dispatch_forward(const bisip_ctx *c, const double *theta, int64_t W, double *Z, hipStream_t st)
+{
+    if (W == 0) return BISIP_OK;
+    if (((long long)W * c->N + 255) / 256 > 0x7fffffffLL)
+        return fail(BISIP_EINVAL, "W=%lld exceeds the launch grid limit", (long long)W);
+    if (((uintptr_t)theta % 8) || ((uintptr_t)Z % 8)) return fail(BISIP_EINVAL, "buffers must be 8-byte aligned");
+    if (c->E > 1) {
+        if (W % c->E) return fail(BISIP_EINVAL, "W=%lld is not a multiple of n_spectra=%d", (long long)W, c->E);
+        return dispatch_forward_batch(c, theta, W, Z, st);
+    }
+    switch (c->model_id) {
+    case BISIP_MODEL_POLYDECOMP:
+        switch (c->P) {
+#define X(p) case p: return launch_forward<PDCollapsed<p>>(c, theta, W, Z, st);
+            PD_CASES(X)
+#undef X
+        }
+        break;
+    case BISIP_MODEL_COLECOLE:
+        switch (c->D) {
+#define X(d) case d: return launch_forward<ColeCole<d>>(c, theta, W, Z, st);
+            CC_CASES(X)
+#undef X
+        }
+        break;
+    case BISIP_MODEL_DIAS2000: return launch_forward<Dias>(c, theta, W, Z, st);
+    case BISIP_MODEL_SHIN2015: return launch_forward<Shin>(c, theta, W, Z, st);
+    }
+    return fail(BISIP_EUNSUPPORTED, "no forward kernel for this model shape");
+}
+
+}  // namespace host
+}  // namespace bisip

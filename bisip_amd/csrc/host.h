@@ -1,0 +1,105 @@
+// host.h -- what the translation units of libbisip_hip.so share: the context, the error
+// plumbing and the dispatch entry points.  The kernels are templates, so every dispatch_*.hip
+// instantiates only its own family and the four units compile in parallel.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/bisip_hip.h"
+#include "kernels.h"
+#include "sampler_kernels.h"
+
+namespace bisip {
+namespace host {
+
+int fail(int code, const char *fmt, ...);
+
+#define HIP_TRY(expr)                                                                  \
+    do {                                                                               \
+        hipError_t e_ = (expr);                                                        \
+        if (e_ != hipSuccess)                                                          \
+            return ::bisip::host::fail(BISIP_EHIP, "%s failed: %s (%s:%d)", #expr,     \
+                                       hipGetErrorString(e_), __FILE__, __LINE__);     \
+    } while (0)
+
+constexpr int BLK_SMALL = 64;    // few walkers: spread them over more CUs
+constexpr int BLK_LARGE = 256;
+constexpr int BLK_STREAM = 128;  // HBM-bound reduced kernel: 128-lane workgroups stream ~3 % faster
+                                 // than 256 (interleaved A/B, benchmarks/micro/reduced_variants.hip)
+constexpr long long SMALL_W = 256LL * 256 * 2;  // below this, 64-lane workgroups
+
+#define PD_CASES(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10)
+#define CC_CASES(X) X(1) X(2) X(3) X(4) X(5)
+
+}  // namespace host
+}  // namespace bisip
+
+struct bisip_ctx {
+    int device = 0, model_id = 0, N = 0, ndim = 0, variant = BISIP_VARIANT_AUTO;
+    int P = 0, D = 0, S = 0;
+    double c_exp = 1.0, lconst = 0.0;
+    bisip::Bounds bounds{};
+    int E = 1;                      // spectra in the context (batch of spectra: E > 1)
+    double *d_cb = nullptr;        // records for k_forward (and k_logprob of CC/Dias/Shin): (E, N, REC)
+    double *d_cb_lp = nullptr;     // PolynomialDecomposition: 1/sigma-weighted log-prob records (E, N, REC)
+    double *d_cb_faithful = nullptr;
+    double *d_lconst = nullptr;    // (E,)  batch only
+    void *d_red = nullptr;         // (E,) ReducedArgs<P>  batch only
+    long long cb_stride = 0;
+    std::vector<double> Rpacked, bhat, evec;
+    double rest = 0.0;
+    // workspace of the host-pointer entry points
+    double *d_ws = nullptr;
+    size_t ws_bytes = 0;
+    char *h_pin = nullptr;         // pinned, device-mapped staging for small host-buffer calls
+    char *d_pin = nullptr;         // its device-side address
+    static constexpr size_t PIN_BYTES = 1 << 20;
+    static constexpr size_t ZEROCOPY_BYTES = 64 << 10;
+    hipStream_t stream = nullptr;
+    const char *kernel_name = "";
+};
+
+namespace bisip {
+namespace host {
+
+int effective_variant(const bisip_ctx *c);
+LaunchArgs make_args(const bisip_ctx *c, const double *theta, double *out, int64_t W, const double *cb);
+BatchArgs make_batch_args(const bisip_ctx *c, const double *theta, double *out, int64_t W);
+
+// Lanes per walker for launches that cannot fill the chip with one lane per walker
+// (dispatch_logprob.hip); the value never changes a result, only the wave count.
+int lanes_per_walker(long long walkers);
+// models whose frequency loop is too cheap to split over lanes
+template <class M> struct CoopLimit { static constexpr long long value = 1LL << 40; };
+// PDCollapsed spends 15 FMAs per frequency: passing the running sums between lanes costs as
+// much as the residual it parallelises (measured 5.7 vs 5.2 us at 4096 walkers), so one lane.
+template <int P> struct CoopLimit<PDCollapsed<P>> { static constexpr long long value = 0; };
+
+// dispatch_logprob.hip / dispatch_forward.hip
+int dispatch_logprob(const bisip_ctx *c, const double *theta, int64_t W, double *out, hipStream_t st);
+int dispatch_forward(const bisip_ctx *c, const double *theta, int64_t W, double *Z, hipStream_t st);
+
+// dispatch_stretch.hip
+enum StretchKind { STRETCH_HALF, STRETCH_EVAL, STRETCH_PERSIST };
+
+// what one stretch dispatch launches: a half-step / eval kernel over StretchArgs, or the
+// persistent kernel over PersistArgs
+struct StretchWork {
+    StretchKind kind;
+    const StretchArgs *half;
+    const PersistArgs *persist;
+};
+
+StretchArgs to_device_args(const bisip_stretch_args *u);
+int dispatch_stretch(const bisip_ctx *c, const StretchWork &a, long long Wp, hipStream_t st);
+int dispatch_apply(const bisip_ctx *c, const StretchArgs &a, hipStream_t st);
+
+}  // namespace host
+}  // namespace bisip

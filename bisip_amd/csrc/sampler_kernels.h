@@ -274,7 +274,7 @@ __device__ __forceinline__ SlotDraw draw_slot(long long W, double a, double ndim
     return d;
 }
 
-__global__ __launch_bounds__(256) void k_stretch_draw(const DrawArgs d)
+static __global__ __launch_bounds__(256) void k_stretch_draw(const DrawArgs d)
 {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long total = d.n_steps * 2 * d.E * d.nh;

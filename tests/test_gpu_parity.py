@@ -335,7 +335,7 @@ def test_other_models_unusual_shapes(model, n_modes, n_freq):
                                                    ('Shin2015', 0, 23), ('Dias2000', 0, 2)])
 def test_lanes_per_walker_do_not_change_bits(model, n_modes, n_freq):
     """Launches of <= 16384 walkers use 4 lanes per walker, <= 32768 two, larger ones one
-    (bisip_hip.hip:lanes_per_walker); frequency counts that are not multiples of the lane count
+    (dispatch_logprob.hip:lanes_per_walker); frequency counts that are not multiples of the lane count
     leave a partial last round.  The running sums are handed from lane to lane in frequency
     order, so every regime must return the SAME BITS for the same row."""
     from bisip_amd import _hip
