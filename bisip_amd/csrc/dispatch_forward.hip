@@ -9,7 +9,8 @@ namespace {
 template <class M>
 int launch_forward(const bisip_ctx *c, const double *theta, int64_t W, double *Z, hipStream_t st)
 {
-    const LaunchArgs a = make_args(c, theta, Z, W, c->d_cb);
+    LaunchArgs a = make_args(c, theta, Z, W, c->d_cb);
+    if (c->E > 1) { a.Wp = W / c->E; a.cb_stride = c->cb_stride; }   // batch: caller checked Wp % 64 == 0
     // one single-wave workgroup per 64 walkers; the grid is not capped at the resident count
     // (a capped, looping grid measured 0-25 % slower depending on the box: benchmarks/micro/forward_variants.hip)
     const unsigned grid = (unsigned)((W + 63) / 64);
@@ -25,6 +26,8 @@ int launch_forward(const bisip_ctx *c, const double *theta, int64_t W, double *Z
 template <class M>
 int launch_forward_batch(const bisip_ctx *c, const double *theta, int64_t W, double *Z, hipStream_t st)
 {
+    // 64-walker blocks never straddle two spectra: the tiled / whole-row kernels apply
+    if ((W / c->E) % 64 == 0) return launch_forward<M>(c, theta, W, Z, st);
     const BatchArgs a = make_batch_args(c, theta, Z, W);
     const long long total = (long long)W * c->N;
     hipLaunchKernelGGL((k_forward_batch<M>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);

@@ -37,6 +37,10 @@ struct LaunchArgs {
     int N;
     double lconst;                     // -sum ln sigma^2
     Bounds b;
+    // forward kernels on a batch of spectra: rows [e*Wp, (e+1)*Wp) read the records of
+    // spectrum e at cb + e*cb_stride (Wp a multiple of 64, so a 64-walker block never
+    // straddles two spectra and the record pointer stays wave-uniform).  Wp = 0: one spectrum.
+    long long Wp = 0, cb_stride = 0;
 };
 
 // ---------------------------------------------------------------------------------
@@ -888,7 +892,7 @@ __global__ __launch_bounds__(64) void k_forward_tiled(const LaunchArgs a)
         const typename M::Setup s = M::setup(th);
         for (int j0 = 0; j0 < N; j0 += JC) {
             const int jn = (N - j0) < JC ? (N - j0) : JC;
-            const double *__restrict__ rec = a.cb + (long long)j0 * M::REC;
+            const double *__restrict__ rec = a.cb + (a.Wp ? (row0 / a.Wp) * a.cb_stride : 0) + (long long)j0 * M::REC;
             double zim[JC];
 #pragma unroll
             for (int jj = 0; jj < JC; ++jj) {
@@ -934,11 +938,12 @@ __global__ __launch_bounds__(64) void k_forward_rows(const LaunchArgs a)
 #pragma unroll
         for (int q = 0; q < NDIM; ++q) th[q] = a.theta[row * NDIM + q];
         const typename M::Setup s = M::setup(th);
+        const double *__restrict__ cb = a.cb + (a.Wp ? (row0 / a.Wp) * a.cb_stride : 0);
         double zr[JC], zi[JC];
 #pragma unroll
         for (int jj = 0; jj < JC; ++jj) {
             zr[jj] = 0.0; zi[jj] = 0.0;
-            if (jj < N) M::eval(s, a.cb + (long long)jj * M::REC + 4, zr[jj], zi[jj]);
+            if (jj < N) M::eval(s, cb + (long long)jj * M::REC + 4, zr[jj], zi[jj]);
         }
 #pragma unroll 1
         for (int sub = 0; sub * SUB < rows_here; ++sub) {

@@ -210,3 +210,30 @@ def test_chain_moments_entry_point(n, E, Wp, ndim, thin):
     with pytest.raises(ValueError):
         _hip.chain_moments_dev(t.data_ptr(), n, 1, E, Wp, ndim, mean.data_ptr(), std.data_ptr(),
                                work.data_ptr(), 0)
+
+
+@pytest.mark.parametrize('model,kw,n_freq', [('PeltonColeCole', dict(n_modes=2), 32), ('PeltonColeCole', dict(n_modes=1), 20),
+                                             ('PolynomialDecomposition', dict(poly_deg=5), 20), ('Dias2000', {}, 27),
+                                             ('Shin2015', {}, 48)])
+def test_batch_forward_whole_blocks_per_spectrum(model, kw, n_freq):
+    """n a multiple of 64 rows per spectrum: the batch takes the tiled / whole-row forward
+    kernels with a per-block record pointer; same numbers as the per-(row, frequency) kernel
+    used for ragged batches, and the oracle's."""
+    import bisip_amd
+    E, n = 5, 128
+    batch = bisip_amd.SpectraBatch(model, _tables(E, n_freq), nwalkers=n, **kw)
+    rng = np.random.RandomState(n_freq)
+    lo, hi = batch.param_bounds
+    theta = rng.uniform(lo, hi, (E, n, lo.size))
+    Z = batch.forward(theta)                       # uniform blocks
+    assert Z.shape == (E, n, 2, n_freq)
+    ragged = batch.forward(theta[:, :37])          # 37 rows per spectrum: blocks straddle spectra
+    assert np.array_equal(ragged, Z[:, :37])
+    okw = {}
+    if model == 'PolynomialDecomposition':
+        okw = dict(taus=batch.taus, log_taus=batch.log_taus, c_exp=batch.c_exp)
+    if model == 'PeltonColeCole':
+        okw = dict(n_modes=batch.n_modes)
+    for e in range(E):
+        prob = oracle.OracleProblem(batch.model, batch.w[e], batch.zn[e], batch.zn_err[e], batch.param_bounds, **okw)
+        assert_Z_close(Z[e], oracle.forward(prob, theta[e]))
