@@ -1,14 +1,16 @@
-"""Bundled example spectra (reference: src/bisip/data.py:13-19)."""
+"""Bundled example spectra, looked up by name -- the role of the reference's ``DataFiles``
+(src/bisip/data.py:13-19): ``DataFiles()['SIP-K389175']`` is the path of that data file."""
 
-import glob
-import os
+from pathlib import Path
+
+_DATA_DIR = Path(__file__).resolve().parent / 'data'
 
 
 class DataFiles(dict):
-    """Maps a data-file name (without extension) to its absolute path."""
+    """``{file stem: absolute path}`` of every ``*.dat`` spectrum shipped with the package;
+    extra entries may be passed like to ``dict``."""
 
     def __init__(self, *args, **kwargs):
-        super().__init__(*args, **kwargs)
-        here = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'data', '*.dat')
-        for path in sorted(glob.glob(here)):
-            self[os.path.splitext(os.path.basename(path))[0]] = path
+        bundled = {p.stem: str(p) for p in sorted(_DATA_DIR.glob('*.dat'))}
+        super().__init__(bundled)
+        self.update(*args, **kwargs)
