@@ -122,6 +122,8 @@ def main():
     ap.add_argument('--no-variants', action='store_true')
     args = ap.parse_args()
 
+    # read by the HSA runtime when the GPU is first touched: set before anything initialises it
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     import torch
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))

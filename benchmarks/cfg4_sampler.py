@@ -30,6 +30,7 @@ def main():
     ap.add_argument('--chain', default='host', choices=['host', 'device'],
                     help="'device': the chain stays in HBM (no pinned host buffer, no copy)")
     args = ap.parse_args()
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # before the GPU is first touched
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get('RANK', '0'))
@@ -38,7 +39,6 @@ def main():
     torch.cuda.set_device(local_rank)
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29512')
-    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
 
     import bisip_amd
