@@ -5,6 +5,8 @@
 #include "host_precompute.h"
 #include "chain_kernels.h"
 
+#include <exception>
+
 using namespace bisip;
 using namespace bisip::host;
 
@@ -104,6 +106,19 @@ const char *name_for(const bisip_ctx *c)
 
 }  // namespace
 
+// no C++ exception may cross the C ABI: the host-side precompute allocates (std::vector)
+template <class F>
+static int guarded(F &&body)
+{
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        return fail(BISIP_ENOMEM, "out of host memory");
+    } catch (const std::exception &ex) {
+        return fail(BISIP_EINVAL, "internal error: %s", ex.what());
+    }
+}
+
 extern "C" {
 
 int bisip_abi_version(void) { return BISIP_ABI_VERSION; }
@@ -126,17 +141,19 @@ int bisip_polydecomp_operands(int N, const double *w, const double *zn, const do
         return fail(BISIP_EINVAL, "null argument");
     if (N < 1 || desc->poly_deg < 0 || desc->poly_deg > BISIP_MAX_POLY_DEG || desc->n_taus < 1)
         return fail(BISIP_EINVAL, "bad shape");
-    PolyDecompOperands o;
-    const int D = desc->poly_deg + 1, n = D + 1;
-    polydecomp_operands(N, w, desc->n_taus, desc->taus, D, desc->log_taus, desc->c_exp, zn, zn_err, o);
-    std::memcpy(G_re, o.G_re.data(), sizeof(double) * (size_t)N * D);
-    std::memcpy(G_im, o.G_im.data(), sizeof(double) * (size_t)N * D);
-    std::memcpy(R, o.R.data(), sizeof(double) * (size_t)n * n);
-    std::memcpy(bhat, o.bhat.data(), sizeof(double) * n);
-    std::memcpy(e, o.e.data(), sizeof(double) * n);
-    *rest = o.rest;
-    *lconst = loglike_const(2 * N, zn_err);
-    return BISIP_OK;
+    return guarded([&] {
+        PolyDecompOperands o;
+        const int D = desc->poly_deg + 1, n = D + 1;
+        polydecomp_operands(N, w, desc->n_taus, desc->taus, D, desc->log_taus, desc->c_exp, zn, zn_err, o);
+        std::memcpy(G_re, o.G_re.data(), sizeof(double) * (size_t)N * D);
+        std::memcpy(G_im, o.G_im.data(), sizeof(double) * (size_t)N * D);
+        std::memcpy(R, o.R.data(), sizeof(double) * (size_t)n * n);
+        std::memcpy(bhat, o.bhat.data(), sizeof(double) * n);
+        std::memcpy(e, o.e.data(), sizeof(double) * n);
+        *rest = o.rest;
+        *lconst = loglike_const(2 * N, zn_err);
+        return (int)BISIP_OK;
+    });
 }
 
 static int build_context(bisip_ctx **out, int device, int model_id, int E, int N, const double *w,
@@ -284,14 +301,14 @@ int bisip_ctx_create(bisip_ctx **out, int device, int model_id, int N, const dou
                      const double *zn, const double *zn_err, int ndim, const double *lo,
                      const double *hi, const bisip_model_desc *desc)
 {
-    return build_context(out, device, model_id, 1, N, w, zn, zn_err, ndim, lo, hi, desc);
+    return guarded([&] { return build_context(out, device, model_id, 1, N, w, zn, zn_err, ndim, lo, hi, desc); });
 }
 
 int bisip_batch_create(bisip_ctx **out, int device, int model_id, int n_spectra, int N,
                        const double *w, const double *zn, const double *zn_err, int ndim,
                        const double *lo, const double *hi, const bisip_model_desc *desc)
 {
-    return build_context(out, device, model_id, n_spectra, N, w, zn, zn_err, ndim, lo, hi, desc);
+    return guarded([&] { return build_context(out, device, model_id, n_spectra, N, w, zn, zn_err, ndim, lo, hi, desc); });
 }
 
 int bisip_ctx_nspectra(const bisip_ctx *c) { return c ? c->E : BISIP_EINVAL; }
