@@ -44,9 +44,10 @@ int launch_collapsed(const bisip_ctx *c, const double *theta, int64_t W, double 
     if (W < SMALL_W) return launch_logprob<PDCollapsed<P>>(c, theta, W, out, st);
     const LaunchArgs a = make_args(c, theta, out, W, c->d_cb_lp);
     const bool vec = ((uintptr_t)theta % 16) == 0;
-    const unsigned grid = (unsigned)((W + 2 * BLK_STREAM - 1) / (2 * BLK_STREAM));
-    if (vec) hipLaunchKernelGGL((k_logprob_x2<PDCollapsed<P>, BLK_STREAM, true>), dim3(grid), dim3(BLK_STREAM), 0, st, a);
-    else hipLaunchKernelGGL((k_logprob_x2<PDCollapsed<P>, BLK_STREAM, false>), dim3(grid), dim3(BLK_STREAM), 0, st, a);
+    // 256-lane workgroups: 5 % faster than 128 here (benchmarks/micro/collapsed_variants.hip)
+    const unsigned grid = (unsigned)((W + 2 * BLK_LARGE - 1) / (2 * BLK_LARGE));
+    if (vec) hipLaunchKernelGGL((k_logprob_x2<PDCollapsed<P>, BLK_LARGE, true>), dim3(grid), dim3(BLK_LARGE), 0, st, a);
+    else hipLaunchKernelGGL((k_logprob_x2<PDCollapsed<P>, BLK_LARGE, false>), dim3(grid), dim3(BLK_LARGE), 0, st, a);
     HIP_TRY(hipGetLastError());
     return BISIP_OK;
 }
