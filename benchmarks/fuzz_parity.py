@@ -1,0 +1,145 @@
+#!/usr/bin/env python3
+"""Randomised parity campaign: HIP kernels (through the C ABI) against the CPU oracle on random
+models, shapes, error scales, prior boxes and batch sizes -- a wider net than the pytest suite
+(which has to finish in seconds).  Uses oracle/ as the checker, like tests/ do.
+
+    python benchmarks/fuzz_parity.py --cases 300 --seed 1 > gpurun_out/fuzz.jsonl
+
+One JSON line per case (worst relative log-prob / Z errors against the stated tolerances,
+-inf agreement), then a summary line; exits 1 on any violation.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+LOGP_TOL, Z_TOL = 1e-10, 1e-12
+NAMES = ['PolynomialDecomposition', 'PeltonColeCole', 'Dias2000', 'Shin2015']
+
+
+def draw_case(rng):
+    """One random problem: model, shape, spectrum, prior box, theta batch, rows to check."""
+    from bisip_amd.batch import default_params
+    from bisip_amd.synthetic import synthetic_columns
+    from bisip_amd.utils import columns_to_data
+    names = NAMES
+    model = names[rng.randint(4)]
+    N = int(rng.choice([1, 2, 3, 5, 16, 20, 21, 24, 30, 32, 33, 48, 64, 80]))
+    cols = synthetic_columns(N, int(rng.randint(0, 4096)))
+    cols[:, 3] *= 10.0 ** rng.uniform(-1, 1)          # amplitude errors x0.1 .. x10
+    cols[:, 4] *= 10.0 ** rng.uniform(-1, 1)          # phase errors
+    d = columns_to_data(cols, 'mrad')
+    kw, okw, variants = {}, {}, ['auto']
+    if model == 'PolynomialDecomposition':
+        P = int(rng.randint(0, 11))
+        c_exp = float(rng.choice([1.0, 0.5, rng.uniform(0.2, 1.0)]))
+        S = int(rng.choice([2 * N, 40, max(2, N)]))
+        per = np.log10(1. / d['w'])
+        lt = np.linspace(np.floor(per.min() - 1), np.floor(per.max() + 1), S)
+        taus, log_taus = 10 ** lt, np.array([lt ** i for i in range(P + 1)])
+        kw = dict(poly_deg=P, c_exp=c_exp, taus=taus, log_taus=log_taus)
+        okw = dict(taus=taus, log_taus=log_taus, c_exp=c_exp)
+        variants = ['reduced', 'collapsed'] + (['faithful'] if P <= 7 else []) + (['wave'] if N <= 64 else [])
+        params = default_params(model, poly_deg=P)
+    elif model == 'PeltonColeCole':
+        D = int(rng.randint(1, 6))
+        kw = okw = dict(n_modes=D)
+        params = default_params(model, n_modes=D)
+    else:
+        params = default_params(model)
+    bounds = np.array(list(params.values()), float).T
+    # sometimes a narrower prior box, so that a good share of the rows is outside
+    if rng.rand() < 0.3:
+        mid, half = bounds.mean(0), 0.5 * (bounds[1] - bounds[0])
+        bounds = np.array([mid - half * rng.uniform(0.3, 1.0, half.size), mid + half * rng.uniform(0.3, 1.0, half.size)])
+    ndim = bounds.shape[1]
+    W = int(rng.choice([1, 7, 63, 64, 65, 300, 4097, 9000, 20000, 40000]))
+    full = np.array(list(params.values()), float).T
+    theta = rng.uniform(full[0], full[1], (W, ndim))
+    if model == 'PolynomialDecomposition':
+        theta[: W // 2, 1:] *= 10.0 ** rng.uniform(-4, 0)   # clouds where the fit is decent
+    for _ in range(min(W, 12)):                      # edge rows: non-finite and on-bound components
+        r, q = rng.randint(W), rng.randint(ndim)
+        theta[r, q] = rng.choice([np.nan, np.inf, -np.inf, bounds[0, q], bounds[1, q], full[0, q], full[1, q]])
+    n_ref = min(W, 1500)
+    rows = np.sort(rng.choice(W, n_ref, replace=False))
+    return dict(model=model, N=N, d=d, kw=kw, okw=okw, variants=variants, bounds=bounds, W=W, theta=theta,
+                rows=rows, ndim=ndim)
+
+
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--cases', type=int, default=200)
+    ap.add_argument('--seed', type=int, default=0)
+    ap.add_argument('--only', type=int, default=None, help='evaluate just this case (same random stream) and print the worst rows')
+    args = ap.parse_args()
+    import oracle
+    from bisip_amd import _hip
+    rng = np.random.RandomState(args.seed)
+    MODEL_IDS = {name: i for i, name in enumerate(NAMES)}
+    worst = dict(logp=0.0, Z=0.0)
+    bad = 0
+    t_start = time.time()
+    for case in range(args.cases):
+        c = draw_case(rng)
+        model, N, d, kw, okw, variants = c['model'], c['N'], c['d'], c['kw'], c['okw'], c['variants']
+        bounds, W, theta, rows, ndim = c['bounds'], c['W'], c['theta'], c['rows'], c['ndim']
+        if args.only is not None and case != args.only:
+            continue
+        prob = oracle.OracleProblem(model, d['w'], d['zn'], d['zn_err'], bounds, **okw)
+        want = oracle.logprob(prob, theta[rows], n_threads=8)
+        rec = dict(case=case, model=model, N=N, W=W, ndim=ndim, **{k2: (v if np.isscalar(v) else None) for k2, v in kw.items() if k2 in ('poly_deg', 'c_exp', 'n_modes')})
+        errs = {}
+        for v in variants:
+            try:
+                ctx = _hip.HipContext(MODEL_IDS[model], d['w'], d['zn'], d['zn_err'], bounds, variant=v, **kw)
+                got = ctx.logprob(theta)[rows]
+            except RuntimeError as exc:      # a variant that does not support this shape says so
+                if 'status -4' not in str(exc):
+                    raise
+                rec.setdefault('unsupported', []).append(v)
+                continue
+            fin = np.isfinite(want)
+            same = np.array_equal(np.isneginf(got), np.isneginf(want)) and not np.any(np.isnan(got))
+            e = float(np.max(np.abs(got[fin] - want[fin]) / np.maximum(1.0, np.abs(want[fin])))) if fin.any() else 0.0
+            errs[ctx.kernel_name if v != 'auto' else 'auto'] = e
+            if args.only is not None and fin.any():
+                rel = np.abs(got - want) / np.maximum(1.0, np.abs(want))
+                rel[~fin] = 0
+                top = np.argsort(rel)[-3:]
+                print(v, 'worst rows', [(float(want[i]), float(got[i]), float(rel[i])) for i in top], 'bounds', bounds.tolist() if v == variants[0] else '', file=sys.stderr)
+            if not same or e > LOGP_TOL:
+                bad += 1
+                rec.setdefault('violations', []).append(dict(variant=v, err=e, neg_inf_match=bool(same)))
+            worst['logp'] = max(worst['logp'], e)
+            if v in ('auto', 'collapsed'):
+                ok_rows = rows[np.all(np.isfinite(theta[rows]), axis=1)][:200]
+                if ok_rows.size:
+                    Zw = oracle.forward(prob, theta[ok_rows])
+                    Zg = ctx.forward(theta)[ok_rows]
+                    finite = np.isfinite(Zw)
+                    ez = float(np.max(np.abs(Zg[finite] - Zw[finite])) / max(1.0, float(np.max(np.abs(Zw[finite]))))) if finite.any() else 0.0
+                    if ez > Z_TOL or not np.array_equal(np.isfinite(Zg), finite):
+                        bad += 1
+                        rec.setdefault('violations', []).append(dict(variant=v, forward_err=ez))
+                    worst['Z'] = max(worst['Z'], ez)
+                    errs['forward'] = ez
+            ctx.close()
+        rec['err'] = {k2: float('%.3g' % v2) for k2, v2 in errs.items()}
+        print(json.dumps(rec), flush=True)
+    print(json.dumps(dict(summary=True, cases=args.cases, seed=args.seed, violations=bad,
+                          worst_logp_rel_err=worst['logp'], worst_Z_rel_err=worst['Z'],
+                          tolerances=dict(logp=LOGP_TOL, Z=Z_TOL), seconds=round(time.time() - t_start, 1))))
+    return 1 if bad else 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())

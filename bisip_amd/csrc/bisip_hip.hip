@@ -29,7 +29,10 @@ int fail(int code, const char *fmt, ...)
 int effective_variant(const bisip_ctx *c)
 {
     if (c->model_id != BISIP_MODEL_POLYDECOMP) return BISIP_VARIANT_COLLAPSED;
-    return c->variant == BISIP_VARIANT_AUTO ? BISIP_VARIANT_REDUCED : c->variant;
+    if (c->variant != BISIP_VARIANT_AUTO) return c->variant;
+    // fewer data rows (2N) than unknowns (P+2): the QR reduction saves nothing and its worst
+    // observed error (6.5e-11, benchmarks/fuzz_parity.py) is close to the tolerance -- per-frequency form
+    return 2 * c->N < c->P + 2 ? BISIP_VARIANT_COLLAPSED : BISIP_VARIANT_REDUCED;
 }
 
 LaunchArgs make_args(const bisip_ctx *c, const double *theta, double *out, int64_t W,
@@ -105,6 +108,52 @@ const char *name_for(const bisip_ctx *c)
 }
 
 }  // namespace
+
+// PolynomialDecomposition, reduced form: (re)compute the expansion point bhat -- the least-squares
+// solution clamped into the image of the prior box, see reduced_center() -- and e for every
+// spectrum, refresh the kernarg copy of spectrum 0 and the device copies of a batch.
+static int recenter_reduced(bisip_ctx *c)
+{
+    if (c->model_id != BISIP_MODEL_POLYDECOMP || c->reduced.empty()) return BISIP_OK;
+    const int n = c->P + 2;
+    // b = R0 * (1, a_0..a_P): image of the theta box (infinite limits stay infinite = no clamp)
+    std::vector<double> blo(n), bhi(n);
+    const double r_lo = c->bounds.lo[0], r_hi = c->bounds.hi[0];
+    blo[0] = r_lo; bhi[0] = r_hi;
+    for (int p = 1; p < n; ++p) {
+        const double corners[4] = {r_lo * c->bounds.lo[p], r_lo * c->bounds.hi[p], r_hi * c->bounds.lo[p], r_hi * c->bounds.hi[p]};
+        double lo = INFINITY, hi = -INFINITY;
+        bool nan = false;
+        for (double v : corners) { if (v != v) nan = true; lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
+        if (nan || !(lo <= hi)) { lo = -INFINITY; hi = INFINITY; }   // 0 * inf: leave the component free
+        blo[p] = lo; bhi[p] = hi;
+    }
+    const size_t red_doubles = (size_t)n * (n + 1) / 2 + 2 * (size_t)n + 1;  // == sizeof(ReducedArgs<P>)/8
+    std::vector<double> red, bh(n), ev(n);
+    for (size_t e = 0; e < c->reduced.size(); ++e) {
+        const bisip_ctx::ReducedHost &rh = c->reduced[e];
+        reduced_center(n, rh.R, rh.qty, rh.bhat_ls, blo.data(), bhi.data(), bh.data(), ev.data());
+        std::vector<double> Rp;
+        for (int i = 0; i < n; ++i)
+            for (int j = i; j < n; ++j) Rp.push_back(rh.R[(size_t)i * n + j]);
+        if (e == 0) { c->Rpacked = Rp; c->bhat = bh; c->evec = ev; c->rest = rh.rest; }
+        if (c->E > 1) {  // ReducedArgs<P> image: R | bhat | e | rest
+            red.insert(red.end(), Rp.begin(), Rp.end());
+            red.insert(red.end(), bh.begin(), bh.end());
+            red.insert(red.end(), ev.begin(), ev.end());
+            red.push_back(rh.rest);
+        }
+    }
+    if (c->E > 1) {
+        if (red.size() != red_doubles * (size_t)c->E) return fail(BISIP_EHIP, "internal: reduced operand size mismatch");
+        HIP_TRY(hipSetDevice(c->device));
+        if (!c->d_red) HIP_TRY(hipMalloc(&c->d_red, red.size() * sizeof(double)));
+        // set_bounds between launches: the copy is ordered after earlier work by the sync
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(c->d_red, red.data(), red.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    return BISIP_OK;
+}
 
 // no C++ exception may cross the C ABI: the host-side precompute allocates (std::vector)
 template <class F>
@@ -211,9 +260,6 @@ static int build_context(bisip_ctx **out, int device, int model_id, int E, int N
     c->cb_stride = (long long)N * rec;
     std::vector<double> cb((size_t)E * N * rec, 0.0), lconsts(E), cb_lp;
     if (model_id == BISIP_MODEL_POLYDECOMP) cb_lp.assign((size_t)E * N * rec, 0.0);
-    const int n = P + 2;
-    const size_t red_doubles = (size_t)n * (n + 1) / 2 + 2 * (size_t)n + 1;  // == sizeof(ReducedArgs<P>)/8
-    std::vector<double> red;
     int rc = BISIP_OK;
     for (int e = 0; e < E; ++e) {
         const double *we = w + (size_t)e * N, *zne = zn + (size_t)e * 2 * N, *erre = zn_err + (size_t)e * 2 * N;
@@ -247,16 +293,9 @@ static int build_context(bisip_ctx **out, int device, int model_id, int E, int N
                     r[4 + P + 1 + p] = (double)(si * (long double)o.G_im[(size_t)j * (P + 1) + p]);
                 }
             }
-            std::vector<double> Rp;
-            for (int i = 0; i < n; ++i)
-                for (int j = i; j < n; ++j) Rp.push_back(o.R[(size_t)i * n + j]);
-            if (e == 0) { c->Rpacked = Rp; c->bhat = o.bhat; c->evec = o.e; c->rest = o.rest; }
-            if (E > 1) {  // ReducedArgs<P> image: R | bhat | e | rest
-                red.insert(red.end(), Rp.begin(), Rp.end());
-                red.insert(red.end(), o.bhat.begin(), o.bhat.end());
-                red.insert(red.end(), o.e.begin(), o.e.end());
-                red.push_back(o.rest);
-            }
+            bisip_ctx::ReducedHost rh;
+            rh.R = o.R; rh.qty = o.qty; rh.bhat_ls = o.bhat_ls; rh.rest = o.rest;
+            c->reduced.push_back(std::move(rh));
             if (E == 1) {  // loop-faithful records (see k_logprob_pd_faithful)
                 const int JB = 16, nb = (N + JB - 1) / JB;
                 const size_t blk_stride = 4 * (size_t)JB + (size_t)S * 2 * JB;
@@ -280,13 +319,8 @@ static int build_context(bisip_ctx **out, int device, int model_id, int E, int N
     c->lconst = lconsts[0];
     if (rc == BISIP_OK) rc = upload(&c->d_cb, cb);
     if (rc == BISIP_OK && !cb_lp.empty()) rc = upload(&c->d_cb_lp, cb_lp);
-    if (rc == BISIP_OK && E > 1) {
-        rc = upload(&c->d_lconst, lconsts);
-        if (rc == BISIP_OK && !red.empty()) {
-            if (red.size() != red_doubles * (size_t)E) rc = fail(BISIP_EHIP, "internal: reduced operand size mismatch");
-            else rc = upload((double **)&c->d_red, red);
-        }
-    }
+    if (rc == BISIP_OK && E > 1) rc = upload(&c->d_lconst, lconsts);
+    if (rc == BISIP_OK) rc = recenter_reduced(c);
     if (rc == BISIP_OK) {
         hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
         if (e != hipSuccess) rc = fail(BISIP_EHIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
@@ -331,8 +365,11 @@ void bisip_ctx_destroy(bisip_ctx *c)
 int bisip_ctx_set_bounds(bisip_ctx *c, const double *lo, const double *hi)
 {
     if (!c || !lo || !hi) return fail(BISIP_EINVAL, "null argument");
+    bool same = true;
+    for (int q = 0; q < c->ndim; ++q) same = same && c->bounds.lo[q] == lo[q] && c->bounds.hi[q] == hi[q];
+    if (same) return BISIP_OK;
     for (int q = 0; q < c->ndim; ++q) { c->bounds.lo[q] = lo[q]; c->bounds.hi[q] = hi[q]; }
-    return BISIP_OK;
+    return guarded([&] { return recenter_reduced(c); });   // the reduced form expands about a point of the box
 }
 
 int bisip_ctx_set_variant(bisip_ctx *c, int variant)

@@ -53,8 +53,15 @@ struct bisip_ctx {
     double *d_lconst = nullptr;    // (E,)  batch only
     void *d_red = nullptr;         // (E,) ReducedArgs<P>  batch only
     long long cb_stride = 0;
-    std::vector<double> Rpacked, bhat, evec;
+    std::vector<double> Rpacked, bhat, evec;   // spectrum 0, packed for the kernarg segment
     double rest = 0.0;
+    // per spectrum, for re-centring the reduced form when the prior box changes
+    struct ReducedHost {
+        std::vector<double> R;                  // (n,n)
+        std::vector<long double> qty, bhat_ls;  // (n,)
+        double rest = 0.0;
+    };
+    std::vector<ReducedHost> reduced;
     // workspace of the host-pointer entry points
     double *d_ws = nullptr;
     size_t ws_bytes = 0;

@@ -135,6 +135,37 @@ void polydecomp_operands(int N, const double *w, int S, const double *taus, int 
         for (int j = i; j < n; ++j) s -= (ld)o.R[(size_t)i * n + j] * (ld)o.bhat[j];
         o.e[i] = (double)s;
     }
+    o.qty.assign(n, 0.0L);
+    for (int i = 0; i < n && i < m; ++i) o.qty[i] = y[i];
+    o.bhat_ls = bh;
+}
+
+void reduced_center(int n, const std::vector<double> &R, const std::vector<long double> &qty,
+                    const std::vector<long double> &bhat_ls, const double *b_lo, const double *b_hi,
+                    double *out_bhat, double *out_e)
+{
+    // Is the least-squares solution where the walkers can be (within the box inflated 2x about
+    // its centre; |b| <= 1e3 for a component without finite limits)?
+    bool use_ls = true;
+    for (int j = 0; j < n; ++j) {
+        const ld lo = (ld)b_lo[j], hi = (ld)b_hi[j], b = bhat_ls[j];
+        if (std::isfinite(b_lo[j]) && std::isfinite(b_hi[j])) {
+            const ld c = 0.5L * (lo + hi), h = 0.5L * (hi - lo);
+            if (!(fabsl(b - c) <= 2.0L * h)) use_ls = false;
+        } else if (!(fabsl(b) <= 1e3L)) {
+            use_ls = false;
+        }
+    }
+    for (int j = 0; j < n; ++j) {
+        ld b = bhat_ls[j];
+        if (!use_ls) b = (std::isfinite(b_lo[j]) && std::isfinite(b_hi[j])) ? 0.5L * ((ld)b_lo[j] + (ld)b_hi[j]) : 0.0L;
+        out_bhat[j] = (double)b;
+    }
+    for (int i = 0; i < n; ++i) {
+        ld s = qty[i];
+        for (int j = i; j < n; ++j) s -= (ld)R[(size_t)i * n + j] * (ld)out_bhat[j];
+        out_e[i] = (double)s;
+    }
 }
 
 }  // namespace bisip

@@ -14,10 +14,26 @@ struct PolyDecompOperands {
     // QR-reduced chi^2 (n = D+1 unknowns b = R0*(1, a_0..a_P)):
     //   chi2(b) = rest + sum_i ( e_i + sum_{j>=i} R[i][j]*(bhat_j - b_j) )^2
     std::vector<double> R;            // (n,n) row-major upper triangle (zeros below)
-    std::vector<double> bhat;         // (n,)
-    std::vector<double> e;            // (n,)
+    std::vector<double> bhat;         // (n,)  expansion point (least-squares solution)
+    std::vector<double> e;            // (n,)  Q^T y - R bhat
     double rest = 0.0;
+    // unrounded, for reduced_center(): first n entries of Q^T y and the least-squares solution
+    std::vector<long double> qty, bhat_ls;
 };
+
+// Chooses the expansion point of the reduced form.  The identity
+//   chi2(b) = rest + | e + R (bhat - b) |^2,  e = Q^T y - R bhat
+// holds for ANY bhat; what bhat decides is the rounding error.  R has entries up to 1e10 for
+// high polynomial degrees (nearly collinear columns), so each row of R (bhat - b) cancels by
+// many orders of magnitude; the part of that cancellation that does not depend on the walker
+// is folded into e here, in long double, and what is left for the kernel grows with
+// |bhat - b|.  The least-squares solution is the best point when the walkers can reach it
+// (posterior rows: 1e-15), but when it lies far outside the prior box (ill-conditioned
+// designs: |bhat| ~ 1e2 .. 1e12, measured 2e-10 .. 1e-2 relative error) the centre of the box
+// is (5e-14 on the same rows).  [b_lo, b_hi] is the image of the prior box; out_* are (n,).
+void reduced_center(int n, const std::vector<double> &R, const std::vector<long double> &qty,
+                    const std::vector<long double> &bhat_ls, const double *b_lo, const double *b_hi,
+                    double *out_bhat, double *out_e);
 
 // reference: C_Debye at src/bisip/cython_funcs.pyx:46-47, Decomp_cyth :75-94,
 // likelihood weights at src/bisip/models.py:59-62.

@@ -309,7 +309,12 @@ struct Dias {
         s.r0 = th[0];
         s.m = th[1];
         s.tau = exp_finite(th[2]);
-        s.taup = s.tau * (1.0 / th[4] - 1.0) / (1.0 - s.m);
+        // delta = 0 or m = 1 (prior bounds; forward() may be asked for them) make tau' infinite;
+        // the reference's complex arithmetic then gives Z = r0 (1 - m).  A huge finite tau'
+        // reaches the same limit without inf * 0 (NaN, from 0/0, is kept).
+        double taup = s.tau * (1.0 / th[4] - 1.0) / (1.0 - s.m);
+        if (fabs(taup) > 1e120) taup = copysign(1e120, taup);
+        s.taup = taup;
         s.taupp = (s.tau * s.tau) * (th[3] * th[3]);
         s.A = th[0] * th[1];
         s.C = th[0] - s.A;
@@ -361,7 +366,12 @@ struct Shin {
         Setup s;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            s.invR[i] = 1.0 / th[i];
+            // R = 0 (a prior bound; forward() may be asked for it) makes the term vanish in the
+            // reference: 1/0 = inf, inf^-1 = 0.  Clamping 1/R keeps |y|^2 finite here and the
+            // term at <= 1e-150 instead of inf * 0.
+            double ir = 1.0 / th[i];
+            if (fabs(ir) > 1e150) ir = copysign(1e150, ir);
+            s.invR[i] = ir;
             s.Q[i] = exp_finite(th[2 + i]);
             s.n[i] = th[4 + i];
             sincospi(0.5 * s.n[i], &s.sn[i], &s.cs[i]);

@@ -360,6 +360,34 @@ def test_lanes_per_walker_do_not_change_bits(model, n_modes, n_freq):
     ctx.close()
 
 
+@pytest.mark.parametrize('n_freq,poly_deg,c_exp', [(5, 8, 0.3805172729737878), (3, 10, 1.0), (48, 9, 0.21152054037418078),
+                                                     (4, 6, 0.5), (2, 10, 0.3)])
+def test_reduced_form_on_ill_conditioned_designs(n_freq, poly_deg, c_exp):
+    """Few frequencies / high polynomial degree: the weighted design matrix is (nearly) rank
+    deficient and its least-squares solution is astronomically large.  The reduced form
+    expands about that solution CLAMPED INTO THE PRIOR BOX (host_precompute.h:reduced_center),
+    otherwise the cancellation inside R (bhat - b) costs up to 1e-2 of the log-probability
+    (found by benchmarks/fuzz_parity.py).  Also: moving the box moves the expansion point."""
+    import oracle
+    from bisip_amd import _hip
+    d = _synthetic_problem(n_freq, 5)
+    S = 2 * n_freq
+    per = np.log10(1. / d['w'])
+    lt = np.linspace(np.floor(per.min() - 1), np.floor(per.max() + 1), S)
+    taus, log_taus = 10 ** lt, np.array([lt ** i for i in range(poly_deg + 1)])
+    bounds = np.array([[0.9] + [-1.0] * (poly_deg + 1), [1.1] + [1.0] * (poly_deg + 1)])
+    rng = np.random.RandomState(n_freq * 31 + poly_deg)
+    ctx = _hip.HipContext(0, d['w'], d['zn'], d['zn_err'], bounds, poly_deg=poly_deg, c_exp=c_exp,
+                          taus=taus, log_taus=log_taus, variant='reduced')
+    for box in (bounds, bounds * np.r_[1.0, np.full(poly_deg + 1, 1e-3)], np.array([bounds[0] + 0.3 * (bounds[1] - bounds[0]), bounds[1]])):
+        ctx.set_bounds(box)
+        prob = oracle.OracleProblem('PolynomialDecomposition', d['w'], d['zn'], d['zn_err'], box,
+                                    taus=taus, log_taus=log_taus, c_exp=c_exp)
+        theta = rng.uniform(box[0], box[1], (4000, poly_deg + 2))
+        assert_logp_close(ctx.logprob(theta), oracle.logprob(prob, theta, n_threads=4))
+    ctx.close()
+
+
 def test_unsupported_shapes_fail_loudly():
     from bisip_amd import _hip
     d = _synthetic_problem(8)
