@@ -237,3 +237,19 @@ def test_batch_forward_whole_blocks_per_spectrum(model, kw, n_freq):
     for e in range(E):
         prob = oracle.OracleProblem(batch.model, batch.w[e], batch.zn[e], batch.zn_err[e], batch.param_bounds, **okw)
         assert_Z_close(Z[e], oracle.forward(prob, theta[e]))
+
+
+def test_batch_polydecomp_follows_a_changed_prior_box():
+    """The reduced form's expansion point depends on the prior box; a batch context keeps one
+    per spectrum on the device and must refresh them all when the bounds change."""
+    import bisip_amd
+    E, n = 7, 64
+    batch = bisip_amd.SpectraBatch('PolynomialDecomposition', _tables(E), nwalkers=n, poly_deg=6)
+    rng = np.random.RandomState(5)
+    for scale in (1.0, 1e-2, 0.4):
+        for name in batch.param_names[1:]:
+            batch.params[name] = [-scale, scale]
+        lo, hi = batch.param_bounds
+        theta = rng.uniform(lo, hi, (E, n, lo.size))
+        assert batch.ctx.variant == 'reduced'
+        assert_logp_close(batch.log_prob(theta), _oracle_logp(batch, theta))
