@@ -23,7 +23,7 @@ LOGP_TOL, Z_TOL = 1e-10, 1e-12
 NAMES = ['PolynomialDecomposition', 'PeltonColeCole', 'Dias2000', 'Shin2015']
 
 
-def draw_case(rng):
+def draw_case(rng, widen=1.0):
     """One random problem: model, shape, spectrum, prior box, theta batch, rows to check."""
     from bisip_amd.batch import default_params
     from bisip_amd.synthetic import synthetic_columns
@@ -54,6 +54,10 @@ def draw_case(rng):
     else:
         params = default_params(model)
     bounds = np.array(list(params.values()), float).T
+    if widen != 1.0:
+        mid0, half0 = bounds.mean(0), 0.5 * (bounds[1] - bounds[0])
+        bounds = np.array([mid0 - widen * half0, mid0 + widen * half0])
+        params = {k2: [bounds[0, i], bounds[1, i]] for i, k2 in enumerate(params)}
     # sometimes a narrower prior box, so that a good share of the rows is outside
     if rng.rand() < 0.3:
         mid, half = bounds.mean(0), 0.5 * (bounds[1] - bounds[0])
@@ -79,6 +83,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--cases', type=int, default=200)
     ap.add_argument('--seed', type=int, default=0)
+    ap.add_argument('--widen', type=float, default=1.0,
+                    help='scale every default prior box about its centre (a user may widen params bounds)')
     ap.add_argument('--only', type=int, default=None, help='evaluate just this case (same random stream) and print the worst rows')
     args = ap.parse_args()
     import oracle
@@ -89,7 +95,7 @@ def main():
     bad = 0
     t_start = time.time()
     for case in range(args.cases):
-        c = draw_case(rng)
+        c = draw_case(rng, args.widen)
         model, N, d, kw, okw, variants = c['model'], c['N'], c['d'], c['kw'], c['okw'], c['variants']
         bounds, W, theta, rows, ndim = c['bounds'], c['W'], c['theta'], c['rows'], c['ndim']
         if args.only is not None and case != args.only:
