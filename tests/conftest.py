@@ -24,6 +24,13 @@ def golden_cases():
     return sorted(glob.glob(os.path.join(GOLDEN, 'case*.npz')))
 
 
+def extended_cases():
+    """Shapes beyond the reference's tutorials (high / zero polynomial degree, small exponents,
+    fewer data rows than unknowns, 4-5 Cole-Cole modes) with forward() at every parameter's
+    bounds; written by the same script from the real reference."""
+    return sorted(glob.glob(os.path.join(GOLDEN, 'ext*.npz')))
+
+
 def case_model(path):
     return os.path.basename(path).split('_')[1]
 

@@ -155,6 +155,8 @@ def theta_sets(model, key, seed, n_prior=40, n_post=24):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--scratch', default='/tmp/bisip_ref_build')
+    ap.add_argument('--only-extended', action='store_true',
+                    help='regenerate only the ext*.npz cases (leaves the case*.npz files untouched)')
     args = ap.parse_args()
 
     pkg = build_reference(args.scratch)
@@ -167,14 +169,19 @@ def main():
                ['SIP-K389170', 'SIP-K389172', 'SIP-K389173', 'SIP-K389174',
                 'SIP-K389175', 'SIP-K389176']}
     synth = {}
-    for n_freq, idx in [(32, 0), (64, 0), (32, 7), (20, 3)]:
+    for n_freq, idx in [(32, 0), (64, 0), (32, 7), (20, 3), (5, 11), (3, 12)]:
         name = f'synthetic-N{n_freq}-i{idx}'
         synth[name] = write_spectrum_file(os.path.join(args.scratch, name + '.dat'), n_freq, idx)
+    base_synth = [k for k in synth if k not in ('synthetic-N5-i11', 'synthetic-N3-i12')]
+
+    if args.only_extended:
+        extended_cases(bisip, bundled, synth)
+        return
 
     # ---- (1) load_data fixtures (pins SURVEY §8 a12) -------------------------------
     ld = {}
     probe = bisip.Dias2000.__new__(bisip.Dias2000)  # load_data is a plain mixin method
-    for name, path in list(bundled.items()) + list(synth.items()):
+    for name, path in list(bundled.items()) + [(k, synth[k]) for k in base_synth]:
         for headers, units in [(1, 'mrad'), (9, 'mrad'), (1, 'rad'), (1, 'deg')]:
             if name.startswith('synthetic') and (headers != 1 or units != 'mrad'):
                 continue
@@ -256,6 +263,74 @@ def main():
                                         d['w'], d['zn'], d['zn_err'])
             fh.write(f'{aid}\t{cls}\t{kw}\t{th}\t{float(lp)!r}\n')
             print(aid, repr(lp))
+    extended_cases(bisip, bundled, synth)
+
+
+def extended_cases(bisip, bundled, synth):
+    """Shapes beyond the reference's tutorials -- high and zero polynomial degree, small
+    exponents, fewer data rows than unknowns, 4 and 5 Cole-Cole modes -- plus, for every
+    case, forward() at on-bound values of EVERY parameter (where its complex arithmetic goes
+    through 1/0 and inf^-1 and still returns finite numbers).  Files ext*.npz."""
+    k75 = bundled['SIP-K389175']
+    cases = [('SIP-K389175', k75, 'PolynomialDecomposition', dict(poly_deg=p, c_exp=c))
+             for p, c in [(0, 1.0), (1, 0.5), (8, 1.0), (8, 0.3805172729737878), (9, 0.21152054037418078), (10, 1.0), (10, 0.5)]]
+    cases += [('synthetic-N5-i11', synth['synthetic-N5-i11'], 'PolynomialDecomposition', dict(poly_deg=8, c_exp=0.3805172729737878)),
+              ('synthetic-N3-i12', synth['synthetic-N3-i12'], 'PolynomialDecomposition', dict(poly_deg=10, c_exp=1.0)),
+              ('synthetic-N64-i0', synth['synthetic-N64-i0'], 'PolynomialDecomposition', dict(poly_deg=9, c_exp=0.5)),
+              ('SIP-K389175', k75, 'PeltonColeCole', dict(n_modes=4)),
+              ('SIP-K389175', k75, 'PeltonColeCole', dict(n_modes=5)),
+              ('synthetic-N5-i11', synth['synthetic-N5-i11'], 'PeltonColeCole', dict(n_modes=2)),
+              ('SIP-K389173', bundled['SIP-K389173'], 'Dias2000', {}),
+              ('SIP-K389173', bundled['SIP-K389173'], 'Shin2015', {}),
+              ('synthetic-N3-i12', synth['synthetic-N3-i12'], 'Dias2000', {}),
+              ('synthetic-N3-i12', synth['synthetic-N3-i12'], 'Shin2015', {})]
+    manifest = []
+    for ci, (dname, path, cls, kw) in enumerate(cases):
+        model = getattr(bisip, cls)(path, nwalkers=32, nsteps=10, **kw)
+        lo, hi = (np.asarray(b, float) for b in model.param_bounds)
+        rng = np.random.RandomState(7000 + ci)
+        n_prior, n_post = 40, 24
+        prior = rng.uniform(lo, hi, (n_prior, lo.size))
+        if cls == 'PolynomialDecomposition':
+            centre = np.r_[1.0, np.zeros(lo.size - 1)]
+            post = centre + np.r_[1e-3, np.full(lo.size - 1, 1e-4)] * rng.randn(n_post, lo.size)   # clouds of small coefficients
+        else:
+            centre = 0.5 * (lo + hi)
+            post = centre + 0.05 * (hi - lo) * rng.randn(n_post, lo.size)
+        post = np.clip(post, lo + 1e-9 * (hi - lo), hi - 1e-9 * (hi - lo))
+        theta = np.ascontiguousarray(np.vstack([prior, post, edge_rows(lo, hi, post[0])]))
+        Z, logp = evaluate(model, theta)
+        # forward() at every parameter's bounds (one component at a time)
+        base = 0.5 * (lo + hi) if cls != 'PolynomialDecomposition' else np.r_[1.0, np.full(lo.size - 1, 0.01)]
+        fwd = []
+        for q in range(lo.size):
+            for v in (lo[q], hi[q]):
+                r = base.copy()
+                r[q] = v
+                fwd.append(r)
+        fwd = np.array(fwd)
+        w = model.data['w']
+        with np.errstate(all='ignore'):
+            Zf = np.array([model.forward(r, w) for r in fwd])
+        out = dict(theta=theta, Z=Z, logp=logp, theta_fwd_edges=fwd, Z_fwd_edges=Zf,
+                   w=w, zn=model.data['zn'], zn_err=model.data['zn_err'],
+                   bounds=np.asarray(model.param_bounds, float),
+                   n_prior=np.int64(n_prior), n_post=np.int64(n_post),
+                   raw=np.loadtxt(path, skiprows=1, delimiter=','))
+        if cls == 'PolynomialDecomposition':
+            out.update(log_tau=model.log_tau, log_taus=model.log_taus, taus=model.taus,
+                       poly_deg=np.int64(model.poly_deg), c_exp=np.float64(model.c_exp))
+        if cls == 'PeltonColeCole':
+            out.update(n_modes=np.int64(model.n_modes))
+        out['param_names'] = np.array(model.param_names)
+        fname = f'ext{ci:02d}_{cls}_{dname}.npz'
+        np.savez_compressed(os.path.join(HERE, fname), **out)
+        manifest.append(f'{fname}\t{cls}\t{dname}\t{kw}')
+        finite = np.isfinite(logp)
+        print(f'{fname}: rows={theta.shape[0]} finite logp={finite.sum()} finite fwd-edge values={np.isfinite(Zf).mean():.2f} '
+              f'logp[min,max]=({logp[finite].min():.6g},{logp[finite].max():.6g})')
+    with open(os.path.join(HERE, 'MANIFEST_EXT.tsv'), 'w') as fh:
+        fh.write('\n'.join(manifest) + '\n')
 
 
 if __name__ == '__main__':

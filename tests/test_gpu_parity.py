@@ -8,7 +8,7 @@ Tolerance: |dlogp| <= 1e-10*max(1,|logp|), |dZ| <= 1e-12*max(1
 import numpy as np
 import pytest
 
-from conftest import (assert_logp_close, assert_Z_close, case_id, case_model, golden_cases)
+from conftest import (assert_logp_close, assert_Z_close, case_id, case_model, extended_cases, golden_cases)
 
 pytestmark = pytest.mark.gpu
 
@@ -58,6 +58,26 @@ def test_forward_matches_reference_golden(path):
     rows = np.all(np.isfinite(g['theta']), axis=1)
     got = ctx.forward(g['theta'][rows])
     assert_Z_close(got, g['Z'][rows])
+    ctx.close()
+
+
+@pytest.mark.parametrize('path', extended_cases(), ids=case_id)
+def test_extended_shapes_match_reference_golden(path):
+    """Reference outputs for shapes outside its tutorials (polynomial degree 0 / 8-10, exponents
+    down to 0.21, 2N < P+2, 4-5 Cole-Cole modes) and forward() at every parameter's bounds."""
+    g = np.load(path)
+    model = case_model(path)
+    for variant in variants_for(g, model):
+        ctx = make_ctx(g, model, variant)
+        err = assert_logp_close(ctx.logprob(g['theta']), g['logp'])
+        print(f'{case_id(path)} [{ctx.kernel_name}] max rel err {err:.2e}')
+        ctx.close()
+    ctx = make_ctx(g, model)
+    rows = np.all(np.isfinite(g['theta']), axis=1)
+    assert_Z_close(ctx.forward(g['theta'][rows]), g['Z'][rows])
+    Zf = ctx.forward(g['theta_fwd_edges'])
+    assert np.all(np.isfinite(Zf))
+    assert_Z_close(Zf, g['Z_fwd_edges'])
     ctx.close()
 
 
