@@ -37,16 +37,21 @@ def main():
     t0 = time.perf_counter()
     s.run_mcmc(p0.reshape(-1, 7), args.steps, thin_by=args.thin_by)
     dt = time.perf_counter() - t0
-    summary_s = None
+    summary_s = percentile_s = None
     if args.chain == 'device':        # posterior mean / std of every spectrum, second half of the chain
         t1 = time.perf_counter()
         mean, std = s.param_moments(discard=args.steps // 2)
         summary_s = time.perf_counter() - t1
         dt += summary_s
+        t2 = time.perf_counter()
+        pct = s.param_percentiles((2.5, 50, 97.5), discard=args.steps // 2)     # not part of `seconds`
+        percentile_s = time.perf_counter() - t2
+        assert pct.shape == (3, E, 7) and np.all(pct[0] <= pct[1]) and np.all(pct[1] <= pct[2])
         assert mean.shape == (E, 7) and np.all(np.isfinite(std))
     iters = args.steps * args.thin_by
     print(json.dumps({'config': 'cfg5 slice: double Cole-Cole, 32 frequencies', 'spectra': E, 'walkers_per_spectrum': Wp,
                       'chain': args.chain, 'path': s.last_path, 'summary_s': None if summary_s is None else round(summary_s, 5),
+                      'percentile_s': None if percentile_s is None else round(percentile_s, 5),
                       'iterations': iters, 'stored': args.steps, 'thin_by': args.thin_by, 'seconds': round(dt, 4),
                       'it_per_s': round(iters / dt, 1),
                       'walker_steps_per_s': float('%.4g' % (iters * E * Wp / dt)),

@@ -81,6 +81,11 @@ SYMBOLS = {
     'bisip_chain_moments_workspace': (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int64, ctypes.c_int]),
     'bisip_chain_moments_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
                                                ctypes.c_int64, ctypes.c_int] + [ctypes.c_void_p] * 4),
+    'bisip_chain_percentiles_workspace': (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int,
+                                                           ctypes.c_int]),
+    'bisip_chain_percentiles_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                                   ctypes.c_int64, ctypes.c_int, _dp, ctypes.c_int, ctypes.c_void_p,
+                                                   ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
     'bisip_numpy_stretch_stream': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32), ctypes.c_int64,
                                                   ctypes.c_double, ctypes.c_int64] + [ctypes.c_void_p] * 4),
     'bisip_philox4x32': (None, [ctypes.POINTER(ctypes.c_uint32)] * 3),
@@ -332,6 +337,21 @@ def chain_moments_dev(d_chain_ptr, n_samples, sample_stride, n_ensembles, walker
     _check(load_library().bisip_chain_moments_dev(d_chain_ptr, n_samples, sample_stride, n_ensembles,
                                                   walkers_per_ensemble, ndim, d_mean_ptr, d_std_ptr,
                                                   d_work_ptr, stream))
+
+
+def chain_percentiles_workspace(n_samples, n_ensembles, walkers_per_ensemble, ndim, n_percentiles):
+    """Bytes of device scratch bisip_chain_percentiles_dev needs (0: shape not supported)."""
+    return int(load_library().bisip_chain_percentiles_workspace(n_samples, n_ensembles, walkers_per_ensemble,
+                                                                ndim, n_percentiles))
+
+
+def chain_percentiles_dev(d_chain_ptr, n_samples, sample_stride, n_ensembles, walkers_per_ensemble, ndim,
+                          percentiles, d_out_ptr, d_work_ptr, work_bytes, stream=0):
+    """Device pointers (ints); ``percentiles`` is a host array in [0, 100]."""
+    p = _c(percentiles).ravel()
+    _check(load_library().bisip_chain_percentiles_dev(d_chain_ptr, n_samples, sample_stride, n_ensembles,
+                                                      walkers_per_ensemble, ndim, _p(p), p.size, d_out_ptr,
+                                                      d_work_ptr, work_bytes, stream))
 
 
 def numpy_stretch_stream(rng, W, a, n_steps, out=None):

@@ -154,6 +154,16 @@ class SpectraBatch:
         what the reference's ``get_param_mean`` returns (src/bisip/utils.py:55-69)."""
         return self._moments(discard, thin)[0]
 
+    def get_param_percentile(self, p=(2.5, 50, 97.5), discard=0, thin=1):
+        """Percentiles of every parameter of every spectrum, ``(len(p), E, ndim)`` -- per spectrum
+        what the reference's ``get_param_percentile`` returns (src/bisip/utils.py:37-53)."""
+        if self._sampler is None:
+            raise AssertionError('Model is not fitted!')
+        if self._sampler.chain_on_device:
+            return self._sampler.param_percentiles(p, discard=discard, thin=thin)
+        flat = self.get_chain(discard=discard, thin=thin, flat=True)   # (E, n, ndim)
+        return np.percentile(flat, p, axis=1)
+
     def get_param_std(self, discard=0, thin=1):
         """Posterior standard deviation, ``(E, ndim)`` (src/bisip/utils.py:71-85)."""
         return self._moments(discard, thin)[1]

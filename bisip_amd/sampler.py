@@ -35,6 +35,8 @@ tests assert nothing at this boundary); tests pin the two drivers against each o
 and against an oracle-driven replay.
 """
 
+import os
+
 import numpy as np
 
 from .dist import all_gather_rows, shard_range
@@ -342,6 +344,19 @@ class EnsembleSampler(_SamplerBase):
         return self._coords.copy(), self._lp.copy()
 
 
+_PINNED = {}
+
+
+def _pinned_scratch(key, nbytes):
+    """Grow-only pinned host blocks shared by every sampler of the process (uint8 tensors)."""
+    import torch
+    blk = _PINNED.get(key)
+    if blk is None or blk.numel() < nbytes:
+        blk = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, pin_memory=True)
+        _PINNED[key] = blk
+    return blk
+
+
 class HipStretchBackend:
     """Device side of ``DeviceEnsembleSampler``: buffers are torch CUDA tensors (device
     memory + stream plumbing), the arithmetic is the HIP library's."""
@@ -353,8 +368,21 @@ class HipStretchBackend:
         self.device = torch.device('cuda', ctx.device)
 
     def tensor(self, array, dtype=None):
-        t = self.torch.as_tensor(np.ascontiguousarray(array), dtype=dtype)
-        return t.to(self.device)
+        torch = self.torch
+        t = torch.as_tensor(np.ascontiguousarray(array), dtype=dtype)
+        if t.numel() * t.element_size() < (256 << 10):
+            return t.to(self.device)
+        # big uploads (the ensemble's start positions) go through pinned memory of our own: the
+        # HIP runtime otherwise pins the caller's pageable pages on first sight of an address
+        # range, 7-30 ms for 7 MB (measured), 1 ms this way
+        # ... and that memory is a process-wide scratch block: on these hosts a fresh multi-MB
+        # allocation (pinned or not) sporadically stalls for 20-100 ms in the kernel
+        nbytes = t.numel() * t.element_size()
+        pinned = _pinned_scratch('upload', nbytes)[:nbytes].view(t.dtype).view(t.shape)
+        pinned.copy_(t)
+        dev = pinned.to(self.device, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()   # the scratch block is free again
+        return dev
 
     def empty(self, shape, dtype):
         return self.torch.empty(shape, dtype=dtype, device=self.device)
@@ -440,18 +468,21 @@ class HipStretchBackend:
         need = int(n) * 2 * int(nh)
         kinds = (('active', torch.int32), ('partner', torch.int32), ('zz', torch.float64),
                  ('factor', torch.float64), ('logu', torch.float64))
-        if getattr(self, '_stage_cap', 0) < need:
-            self._stage = {name: torch.empty(need, dtype=dt, pin_memory=True) for name, dt in kinds}
-            self._stage_cap, self._stage_event = need, None
-        if self._stage_event is not None:
-            self._stage_event.synchronize()
-        return {name: self._stage[name][:need].view(int(n), 2, int(nh)) for name, _ in kinds}
+        ev = _PINNED.get('stream_event')
+        if ev is not None:
+            ev.synchronize()
+        out = {}
+        for name, dt in kinds:
+            blk = _pinned_scratch('stream_' + name, need * 8)
+            out[name] = blk[:need * (4 if dt == torch.int32 else 8)].view(dt).view(int(n), 2, int(nh))
+        return out
 
     def upload_staged(self, stage):
         """Asynchronous host->device copies of the staged stream on the compute stream."""
         out = {name: t.to(self.device, non_blocking=True) for name, t in stage.items()}
-        self._stage_event = self.torch.cuda.Event()
-        self._stage_event.record(self.torch.cuda.current_stream(self.device))
+        ev = self.torch.cuda.Event()
+        ev.record(self.torch.cuda.current_stream(self.device))
+        _PINNED['stream_event'] = ev
         return out
 
     def host_buffer(self, shape):
@@ -575,7 +606,7 @@ class DeviceEnsembleSampler(_SamplerBase):
             if self.n_ensembles == 1:
                 p0 = self._check_initial(initial_state)
             else:
-                p0 = np.array(initial_state, dtype=np.float64, copy=True).reshape(W, ndim)
+                p0 = np.asarray(initial_state, dtype=np.float64).reshape(W, ndim)   # only read
                 Wp = self.walkers_per_ensemble
                 if not self.live_dangerously:
                     if Wp < 2 * ndim:
@@ -585,7 +616,9 @@ class DeviceEnsembleSampler(_SamplerBase):
                         if not walkers_independent(p0[e * Wp:(e + 1) * Wp]):
                             raise ValueError(f'Initial state of ensemble {e} has a large condition number.')
             self._check_coords(p0)
+            t_chk = time.perf_counter()
             self._upload_state(p0)
+            self._setup_detail = dict(check_s=t_chk - t_start, upload_s=time.perf_counter() - t_chk)
         nsteps, thin_by = int(nsteps), int(thin_by)
         if thin_by < 1:
             raise ValueError('thin_by must be >= 1')
@@ -604,6 +637,7 @@ class DeviceEnsembleSampler(_SamplerBase):
         done = 0                                 # stored samples so far
         it0 = self._iterations_run
         self.timing['setup_s'] = time.perf_counter() - t_start
+        self.timing.update(getattr(self, '_setup_detail', {}))
         while done < nsteps:
             t_a = time.perf_counter()
             ns = min(max(1, self._chunk_steps(nsteps * thin_by) // thin_by), nsteps - done)
@@ -753,3 +787,29 @@ class DeviceEnsembleSampler(_SamplerBase):
                                mean.data_ptr(), std.data_ptr(), work.data_ptr(), be.stream())
         be.synchronize()
         return mean.cpu().numpy(), std.cpu().numpy()
+
+    def param_percentiles(self, p=(2.5, 50, 97.5), discard=0, thin=1):
+        """``np.percentile(get_chain(discard, thin, flat=True), p, axis=0)`` per ensemble
+        (reference: src/bisip/utils.py:37-53), sorted and interpolated on the device; returns
+        ``(len(p), n_ensembles, ndim)``."""
+        import torch
+        from . import _hip
+        t = self.device_chain()
+        n_total, W, ndim = (int(x) for x in t.shape)
+        discard, thin = int(discard), int(thin)
+        first = discard + thin - 1
+        n = len(range(first, n_total, thin))
+        if thin < 1 or discard < 0 or n < 1:
+            raise ValueError(f'no samples left with discard={discard}, thin={thin} of {n_total} stored')
+        p = np.atleast_1d(np.asarray(p, dtype=np.float64))
+        be = self.backend
+        E, Wp = self.n_ensembles, self.walkers_per_ensemble
+        nbytes = _hip.chain_percentiles_workspace(n, E, Wp, ndim, p.size)
+        if nbytes <= 0:
+            raise ValueError('chain too large for one device sort (more than 2^31 values); thin it or use get_chain()')
+        work = be.empty((nbytes,), torch.uint8)
+        out = be.empty((p.size, E, ndim), torch.float64)
+        _hip.chain_percentiles_dev(t.data_ptr() + 8 * first * W * ndim, n, thin * W * ndim, E, Wp, ndim, p,
+                                   out.data_ptr(), work.data_ptr(), nbytes, be.stream())
+        be.synchronize()
+        return out.cpu().numpy()

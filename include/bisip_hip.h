@@ -215,6 +215,21 @@ int bisip_chain_moments_dev(const double *d_chain, int64_t n_samples, int64_t sa
                             int64_t n_ensembles, int64_t walkers_per_ensemble, int ndim,
                             double *d_mean, double *d_std, double *d_work, void *stream);
 
+/* Percentiles of every parameter, per ensemble, of a chain resident in device memory -- the
+ * device form of get_param_percentile (src/bisip/utils.py:37-53: np.percentile(chain, p,
+ * axis=0), linear interpolation; the reference's default p is [2.5, 50, 97.5]).  Chain layout,
+ * d_chain / sample_stride conventions as for bisip_chain_moments_dev.  percentiles: host array
+ * (n_percentiles,) in [0, 100].  d_out: (n_percentiles, n_ensembles, ndim).  d_work:
+ * bisip_chain_percentiles_workspace() BYTES of device memory (two column-major copies of the
+ * used samples + the sort's scratch; 0 is returned for a shape that is not supported:
+ * more than 2^31 values).  Asynchronous on stream after a short synchronous upload. */
+int64_t bisip_chain_percentiles_workspace(int64_t n_samples, int64_t n_ensembles,
+                                          int64_t walkers_per_ensemble, int ndim, int n_percentiles);
+int bisip_chain_percentiles_dev(const double *d_chain, int64_t n_samples, int64_t sample_stride,
+                                int64_t n_ensembles, int64_t walkers_per_ensemble, int ndim,
+                                const double *percentiles, int n_percentiles, double *d_out,
+                                void *d_work, int64_t work_bytes, void *stream);
+
 /* Host: the stretch move's random stream in numpy.random.RandomState order for n_steps
  * iterations of a W-walker ensemble (the contract is bisip_amd/sampler.py:draw_step).
  * mt_key[624] / *mt_pos are RandomState.get_state()[1:3], advanced in place exactly as

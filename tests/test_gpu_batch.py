@@ -253,3 +253,49 @@ def test_batch_polydecomp_follows_a_changed_prior_box():
         theta = rng.uniform(lo, hi, (E, n, lo.size))
         assert batch.ctx.variant == 'reduced'
         assert_logp_close(batch.log_prob(theta), _oracle_logp(batch, theta))
+
+
+@pytest.mark.parametrize('n,E,Wp,ndim,thin', [(37, 1, 100, 4, 1), (5, 3, 7, 10, 2), (40, 12, 64, 7, 1), (2, 2, 3, 16, 1),
+                                              (1, 1, 1, 1, 1)])
+def test_chain_percentiles_entry_point(n, E, Wp, ndim, thin):
+    """np.percentile(..., axis=0) of every (ensemble, parameter) column, default 'linear' rule,
+    computed where the chain lies (gather -> segmented radix sort -> interpolate)."""
+    import torch
+    from bisip_amd import _hip
+    rng = np.random.RandomState(n * 11 + E)
+    full = rng.standard_normal((n * thin, E * Wp, ndim)) * rng.uniform(0.1, 50, ndim) + rng.uniform(-20, 20, ndim)
+    full[0, 0, 0] = full[-1, -1, 0]                       # a tie
+    t = torch.from_numpy(full).cuda()
+    p = np.array([0.0, 2.5, 50.0, 33.3, 97.5, 100.0])
+    nbytes = _hip.chain_percentiles_workspace(n, E, Wp, ndim, p.size)
+    work = torch.empty(nbytes, dtype=torch.uint8, device='cuda')
+    out = torch.empty((p.size, E, ndim), dtype=torch.float64, device='cuda')
+    first = thin - 1
+    _hip.chain_percentiles_dev(t.data_ptr() + 8 * first * E * Wp * ndim, n, thin * E * Wp * ndim, E, Wp, ndim, p,
+                               out.data_ptr(), work.data_ptr(), nbytes, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    used = full[first::thin].reshape(n, E, Wp, ndim).transpose(1, 0, 2, 3).reshape(E, n * Wp, ndim)
+    want = np.percentile(used, p, axis=1)                # (n_p, E, ndim)
+    _close(out.cpu().numpy(), want, 1e-14)
+    with pytest.raises(ValueError):
+        _hip.chain_percentiles_dev(t.data_ptr(), n, thin * E * Wp * ndim, E, Wp, ndim, [101.0], out.data_ptr(),
+                                   work.data_ptr(), nbytes, 0)
+
+
+def test_batch_percentiles_from_the_device_chain():
+    import bisip_amd
+    E, Wp = 5, 32
+    rng = np.random.RandomState(3)
+    centre = np.array([1.0, 0.15, 0.5, -1.5, -12.0, 0.45, 0.6])
+    p0 = centre + 1e-3 * rng.randn(E, Wp, 7)
+    runs = {}
+    for where in ('host', 'device'):
+        b = bisip_amd.SpectraBatch('PeltonColeCole', _tables(E), nwalkers=Wp, nsteps=30, n_modes=2)
+        b.fit(p0, seed=9, chain=where)
+        runs[where] = b
+    for kw in (dict(), dict(discard=10, thin=2)):
+        got = runs['device'].get_param_percentile(**kw)
+        want = runs['host'].get_param_percentile(**kw)
+        assert got.shape == (3, E, 7)
+        _close(got, want, 1e-14)
+    _close(runs['device'].get_param_percentile([16, 84], discard=5), runs['host'].get_param_percentile([16, 84], discard=5), 1e-14)
