@@ -590,35 +590,90 @@ class DeviceEnsembleSampler(_SamplerBase):
         per_step = self.nwalkers * (8 * self.ndim + 8 + 3 * 8 + 2 * 4)
         return max(1, min(nsteps, (2 << 30) // per_step))
 
+    # -- run_mcmc and its stages ---------------------------------------------------------
+    def _start_from(self, initial_state):
+        """Validate a new initial state (emcee's checks) and make it the device-resident
+        ensemble; ``None`` continues from the current one."""
+        import time
+        t0 = time.perf_counter()
+        W, ndim = self.nwalkers, self.ndim
+        if initial_state is None:
+            if self._dev is None:
+                raise ValueError('Cannot have `initial_state=None` if run_mcmc has never been called.')
+            return {}
+        if self.n_ensembles == 1:
+            p0 = self._check_initial(initial_state)
+        else:
+            p0 = np.asarray(initial_state, dtype=np.float64).reshape(W, ndim)   # only read
+            Wp = self.walkers_per_ensemble
+            if not self.live_dangerously:
+                if Wp < 2 * ndim:
+                    raise RuntimeError('It is unadvisable to use a red-blue move with fewer '
+                                       'walkers than twice the number of dimensions.')
+                for e in np.unique(np.linspace(0, self.n_ensembles - 1, 32).astype(int)):
+                    if not walkers_independent(p0[e * Wp:(e + 1) * Wp]):
+                        raise ValueError(f'Initial state of ensemble {e} has a large condition number.')
+        self._check_coords(p0)
+        t1 = time.perf_counter()
+        self._upload_state(p0)
+        return dict(check_s=t1 - t0, upload_s=time.perf_counter() - t1)
+
+    def _numpy_stream(self, st, n, nh):
+        """Chunk of the NumPy-order stream: generated in C from the RandomState's MT19937 state
+        (bit-identical to calling draw_step n times, ~30x cheaper) straight into pinned staging
+        memory; the logs are NumPy's so they match the host sampler's.  Pinned staging keeps the
+        upload asynchronous (the next chunk's stream is generated while this chunk's kernels
+        run) and keeps the HIP runtime from pinning and unpinning pageable NumPy buffers."""
+        from ._hip import numpy_stretch_stream
+        be = self.backend
+        stage = be.stream_staging(n, nh)
+        _, _, zz, u = numpy_stretch_stream(
+            self._random, self.nwalkers, self.a, n,
+            out=tuple(stage[name].numpy() for name in ('active', 'partner', 'zz', 'logu')))
+        with np.errstate(divide='ignore'):
+            factor = stage['factor'].numpy()
+            np.log(zz, out=factor)
+            factor *= self.ndim - 1.0
+            np.log(u, out=u)             # 'logu' staging held u
+        st.update(be.upload_staged(stage))
+
+    def _advance(self, st, n, nh, it0):
+        """Enqueue the n iterations of a chunk: persistent kernel, fused launches, or (several
+        ranks) eval -> all-gather -> apply per half-step."""
+        import torch
+        be = self.backend
+        W, ndim = self.nwalkers, self.ndim
+        single = self._world == 1 and not self.force_sharded_path
+        if single and self.persistent and be.run_persistent(st, self.walkers_per_ensemble, n):
+            self.last_path = 'persistent'
+        elif single:
+            be.run(st, n)
+            self.last_path = 'launch-per-half-step'
+        else:
+            import torch.distributed as dist
+            self.last_path = 'sharded'
+            for k in range(n):
+                for h in (0, 1):
+                    m = nh if h == 0 else W // 2
+                    lo, hi = shard_range(m, self._world, self._rank)
+                    pad = -(-m // self._world)
+                    block = be.zeros((pad, ndim + 2), torch.float64)
+                    be.eval(st, k, h, m, lo, hi, block)
+                    gathered = be.empty((self._world * pad, ndim + 2), torch.float64)
+                    dist.all_gather_into_tensor(gathered, block, group=self._group)
+                    be.apply(st, k, h, m, gathered, pad, self._world)
+
     def run_mcmc(self, initial_state, nsteps, progress=False, thin_by=1, **kwargs):
         """Store ``nsteps`` samples, one every ``thin_by`` iterations; the ensemble, the
         random stream and the chain slab of each chunk stay on the device, chain slabs
-        return to pinned host memory asynchronously while the next chunk runs."""
+        return to pinned host memory asynchronously while the next chunk runs (or stay in
+        HBM with ``chain_on_device``)."""
         import time
         import torch
         t_start = time.perf_counter()
         be = self.backend
         W, ndim = self.nwalkers, self.ndim
-        if initial_state is None:
-            if self._dev is None:
-                raise ValueError('Cannot have `initial_state=None` if run_mcmc has never been called.')
-        else:
-            if self.n_ensembles == 1:
-                p0 = self._check_initial(initial_state)
-            else:
-                p0 = np.asarray(initial_state, dtype=np.float64).reshape(W, ndim)   # only read
-                Wp = self.walkers_per_ensemble
-                if not self.live_dangerously:
-                    if Wp < 2 * ndim:
-                        raise RuntimeError('It is unadvisable to use a red-blue move with fewer '
-                                           'walkers than twice the number of dimensions.')
-                    for e in np.unique(np.linspace(0, self.n_ensembles - 1, 32).astype(int)):
-                        if not walkers_independent(p0[e * Wp:(e + 1) * Wp]):
-                            raise ValueError(f'Initial state of ensemble {e} has a large condition number.')
-            self._check_coords(p0)
-            t_chk = time.perf_counter()
-            self._upload_state(p0)
-            self._setup_detail = dict(check_s=t_chk - t_start, upload_s=time.perf_counter() - t_chk)
+        setup_detail = self._start_from(initial_state)
         nsteps, thin_by = int(nsteps), int(thin_by)
         if thin_by < 1:
             raise ValueError('thin_by must be >= 1')
@@ -633,11 +688,10 @@ class DeviceEnsembleSampler(_SamplerBase):
             perm_all = be.tensor(affine_splits(self.seed, self.walkers_per_ensemble,
                                                self._iterations_run, nsteps * thin_by))
         # where a run spends its time
-        self.timing = dict(setup_s=0.0, stream_s=0.0, enqueue_s=0.0, alloc_s=0.0, drain_s=0.0, finish_s=0.0)
+        self.timing = dict(setup_s=time.perf_counter() - t_start, stream_s=0.0, enqueue_s=0.0, alloc_s=0.0,
+                           drain_s=0.0, finish_s=0.0, **setup_detail)
         done = 0                                 # stored samples so far
         it0 = self._iterations_run
-        self.timing['setup_s'] = time.perf_counter() - t_start
-        self.timing.update(getattr(self, '_setup_detail', {}))
         while done < nsteps:
             t_a = time.perf_counter()
             ns = min(max(1, self._chunk_steps(nsteps * thin_by) // thin_by), nsteps - done)
@@ -648,23 +702,7 @@ class DeviceEnsembleSampler(_SamplerBase):
             if self.n_ensembles > 1:
                 st['wp'] = self.walkers_per_ensemble
             if self.rng == 'numpy':
-                # RNG stream for n iterations in draw_step's order, generated in C from the
-                # RandomState's MT19937 state (bit-identical to calling draw_step n times,
-                # ~30x cheaper) straight into pinned staging memory; the logs are NumPy's so
-                # they match the host sampler's.  Pinned staging keeps the upload asynchronous
-                # (the next chunk's stream is generated while this chunk's kernels run) and
-                # keeps the HIP runtime from pinning and unpinning pageable NumPy buffers.
-                from ._hip import numpy_stretch_stream
-                stage = be.stream_staging(n, nh)
-                _, _, zz, u = numpy_stretch_stream(
-                    self._random, W, self.a, n,
-                    out=tuple(stage[name].numpy() for name in ('active', 'partner', 'zz', 'logu')))
-                with np.errstate(divide='ignore'):
-                    factor = stage['factor'].numpy()
-                    np.log(zz, out=factor)
-                    factor *= ndim - 1.0
-                    np.log(u, out=u)             # 'logu' staging held u
-                st.update(be.upload_staged(stage))
+                self._numpy_stream(st, n, nh)
             else:
                 # only the per-step split is drawn on the host; the stream is generated on
                 # the device from (seed, step, half, slot) counters
@@ -679,7 +717,6 @@ class DeviceEnsembleSampler(_SamplerBase):
                 st['chain'] = be.empty((ns, W, ndim), torch.float64)
                 st['logp_chain'] = be.empty((ns, W), torch.float64)
             t_b = time.perf_counter()
-            single = self._world == 1 and not self.force_sharded_path
             if self.rng == 'philox':
                 if stream_bufs is None:          # the first chunk is the largest; later ones reuse it
                     stream_bufs = {name: be.empty((n, 2, nh), dt) for name, dt in (
@@ -688,49 +725,22 @@ class DeviceEnsembleSampler(_SamplerBase):
                 for name, buf in stream_bufs.items():
                     st[name] = buf[:n]
                 be.draw(st, self.walkers_per_ensemble, self.a, self.seed, it0, n)
-            ran = False
-            if single and self.persistent:
-                ran = be.run_persistent(st, self.walkers_per_ensemble, n)
-                if ran:
-                    self.last_path = 'persistent'
-            if ran:
-                pass
-            elif single:
-                be.run(st, n)
-                self.last_path = 'launch-per-half-step'
-            else:
-                import torch.distributed as dist
-                self.last_path = 'sharded'
-                for k in range(n):
-                    for h in (0, 1):
-                        m = nh if h == 0 else W // 2
-                        lo, hi = shard_range(m, self._world, self._rank)
-                        pad = -(-m // self._world)
-                        block = be.zeros((pad, ndim + 2), torch.float64)
-                        be.eval(st, k, h, m, lo, hi, block)
-                        gathered = be.empty((self._world * pad, ndim + 2), torch.float64)
-                        dist.all_gather_into_tensor(gathered, block, group=self._group)
-                        be.apply(st, k, h, m, gathered, pad, self._world)
-            if self.chain_on_device:
-                done += ns
-                it0 += n
-                self.timing['stream_s'] += t_b - t_a
-                self.timing['enqueue_s'] += time.perf_counter() - t_b
-                continue
-            if chain_host is None:
-                # pinning a big host chain takes tens of ms: do it while the first chunk runs
-                t_h = time.perf_counter()
-                chain_host = be.host_buffer((nsteps, W, ndim))
-                logp_host = be.host_buffer((nsteps, W))
-                self.timing['alloc_s'] = time.perf_counter() - t_h
-                self.timing['enqueue_s'] -= self.timing['alloc_s']
-            be.copy_out(chain_host[done:done + ns], st['chain'])
-            be.copy_out(logp_host[done:done + ns], st['logp_chain'])
+            self._advance(st, n, nh, it0)
+            t_alloc = 0.0
+            if not self.chain_on_device:
+                if chain_host is None:
+                    # pinning a big host chain takes tens of ms: do it while the first chunk runs
+                    t_h = time.perf_counter()
+                    chain_host = be.host_buffer((nsteps, W, ndim))
+                    logp_host = be.host_buffer((nsteps, W))
+                    t_alloc = time.perf_counter() - t_h
+                    self.timing['alloc_s'] = t_alloc
+                be.copy_out(chain_host[done:done + ns], st['chain'])
+                be.copy_out(logp_host[done:done + ns], st['logp_chain'])
             done += ns
             it0 += n
-            t_c = time.perf_counter()
             self.timing['stream_s'] += t_b - t_a
-            self.timing['enqueue_s'] += t_c - t_b
+            self.timing['enqueue_s'] += time.perf_counter() - t_b - t_alloc
         if chain_host is None and dev_chain is None:  # nsteps == 0
             chain_host, logp_host = be.host_buffer((0, W, ndim)), be.host_buffer((0, W))
         t_d = time.perf_counter()
