@@ -363,6 +363,8 @@ class HipStretchBackend:
 
     def __init__(self, ctx):
         import torch
+        from .utils import respect_cpu_quota
+        respect_cpu_quota()
         self.torch = torch
         self.ctx = ctx
         self.device = torch.device('cuda', ctx.device)

@@ -110,3 +110,60 @@ class utils(object):
     def get_param_std(self, chain=None, **kwargs):
         """reference: src/bisip/utils.py:71-85"""
         return np.std(self.parse_chain(chain, **kwargs), axis=0)
+
+
+_QUOTA_APPLIED = False
+
+
+def cpu_quota():
+    """CPUs this process may use: the cgroup CFS quota (cpu.max / cfs_quota_us) when there is
+    one, else the affinity mask."""
+    import math
+    import os
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ('/sys/fs/cgroup/cpu.max',):
+        try:
+            quota, period = open(path).read().split()[:2]
+            if quota != 'max':
+                n = min(n, max(1, math.floor(int(quota) / int(period))))
+        except (OSError, ValueError):
+            pass
+    try:
+        q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+        p = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+        if q > 0 and p > 0:
+            n = min(n, max(1, q // p))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def respect_cpu_quota():
+    """Cap the host thread pools (torch intra-op, BLAS/OpenMP behind NumPy) at the container's
+    CPU quota, once per process.  On a 256-core host with a 16-CPU quota the default pools
+    (128 torch + 64 OpenBLAS threads) spend the quota of a 100 ms scheduler period in a few
+    milliseconds of a parallel memcpy or SVD and the whole process is then throttled for the
+    rest of the period: 20-95 ms stalls at random host-side places (measured: cpu.stat
+    nr_throttled).  Set BISIP_KEEP_THREADS=1 to leave the pools alone."""
+    global _QUOTA_APPLIED
+    import os
+    if _QUOTA_APPLIED or os.environ.get('BISIP_KEEP_THREADS'):
+        return
+    _QUOTA_APPLIED = True
+    n = cpu_quota()
+    if n >= (os.cpu_count() or 1):
+        return
+    try:
+        import torch
+        if torch.get_num_threads() > n:
+            torch.set_num_threads(n)
+    except Exception:
+        pass
+    try:
+        from threadpoolctl import threadpool_limits
+        respect_cpu_quota._limits = threadpool_limits(limits=n)   # kept alive: the cap stays
+    except Exception:
+        pass
