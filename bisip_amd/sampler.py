@@ -374,11 +374,9 @@ class HipStretchBackend:
         t = torch.as_tensor(np.ascontiguousarray(array), dtype=dtype)
         if t.numel() * t.element_size() < (256 << 10):
             return t.to(self.device)
-        # big uploads (the ensemble's start positions) go through pinned memory of our own: the
-        # HIP runtime otherwise pins the caller's pageable pages on first sight of an address
-        # range, 7-30 ms for 7 MB (measured), 1 ms this way
-        # ... and that memory is a process-wide scratch block: on these hosts a fresh multi-MB
-        # allocation (pinned or not) sporadically stalls for 20-100 ms in the kernel
+        # big uploads (the ensemble's start positions) go through a process-wide pinned scratch
+        # block: no per-call pinning of the caller's pageable pages by the HIP runtime, no fresh
+        # multi-MB allocation per run
         nbytes = t.numel() * t.element_size()
         pinned = _pinned_scratch('upload', nbytes)[:nbytes].view(t.dtype).view(t.shape)
         pinned.copy_(t)
@@ -624,8 +622,7 @@ class DeviceEnsembleSampler(_SamplerBase):
         """Chunk of the NumPy-order stream: generated in C from the RandomState's MT19937 state
         (bit-identical to calling draw_step n times, ~30x cheaper) straight into pinned staging
         memory; the logs are NumPy's so they match the host sampler's.  Pinned staging keeps the
-        upload asynchronous (the next chunk's stream is generated while this chunk's kernels
-        run) and keeps the HIP runtime from pinning and unpinning pageable NumPy buffers."""
+        upload asynchronous: the next chunk's stream is generated while this chunk's kernels run."""
         from ._hip import numpy_stretch_stream
         be = self.backend
         stage = be.stream_staging(n, nh)
