@@ -147,6 +147,10 @@ def main():
 
     from bisip_amd import _hip
     from bisip_amd.synthetic import synthetic_theta
+    from bisip_amd.utils import respect_cpu_quota
+    # host thread pools sized by the node's core count would be throttled by the container's
+    # CPU quota at some random moment, possibly inside the timed region
+    respect_cpu_quota()
 
     data, taus, log_taus, bounds = make_problem()
     ctx = _hip.HipContext(_hip.MODEL_POLYDECOMP, data['w'], data['zn'], data['zn_err'], bounds,
