@@ -94,6 +94,7 @@ SYMBOLS = {
     'bisip_ctx_device': (ctypes.c_int, [ctypes.c_void_p]),
     'bisip_ctx_loglike_const': (ctypes.c_double, [ctypes.c_void_p]),
     'bisip_ctx_kernel_name': (ctypes.c_char_p, [ctypes.c_void_p]),
+    'bisip_ctx_reduced_error': (ctypes.c_double, [ctypes.c_void_p]),
     'bisip_polydecomp_operands': (ctypes.c_int, [ctypes.c_int, _dp, _dp, _dp, ctypes.POINTER(ModelDesc),
                                                  _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
     'bisip_abi_version': (ctypes.c_int, []),
@@ -262,6 +263,11 @@ class HipContext:
     @property
     def kernel_name(self):
         return self._lib.bisip_ctx_kernel_name(self._h).decode()
+
+    @property
+    def reduced_error(self):
+        """Estimated worst relative log-prob error of the QR-reduced kernel for the current box."""
+        return float(self._lib.bisip_ctx_reduced_error(self._h))
 
     @property
     def loglike_const(self):

@@ -30,9 +30,12 @@ int effective_variant(const bisip_ctx *c)
 {
     if (c->model_id != BISIP_MODEL_POLYDECOMP) return BISIP_VARIANT_COLLAPSED;
     if (c->variant != BISIP_VARIANT_AUTO) return c->variant;
-    // fewer data rows (2N) than unknowns (P+2): the QR reduction saves nothing and its worst
-    // observed error (6.5e-11, benchmarks/fuzz_parity.py) is close to the tolerance -- per-frequency form
-    return 2 * c->N < c->P + 2 ? BISIP_VARIANT_COLLAPSED : BISIP_VARIANT_REDUCED;
+    // the QR-reduced form is the fast one, but only where it is accurate: fewer data rows (2N)
+    // than unknowns (P+2), or a host-side emulation of the kernel's arithmetic that deviates
+    // from long double by more than 1e-12 on the probe rows (ill-conditioned designs: high
+    // degree, small exponent) -> the per-frequency form, which mirrors the reference's sums
+    if (2 * c->N < c->P + 2 || !(c->reduced_err <= BISIP_REDUCED_ERR_MAX)) return BISIP_VARIANT_COLLAPSED;
+    return BISIP_VARIANT_REDUCED;
 }
 
 LaunchArgs make_args(const bisip_ctx *c, const double *theta, double *out, int64_t W,
@@ -109,30 +112,21 @@ const char *name_for(const bisip_ctx *c)
 
 }  // namespace
 
-// PolynomialDecomposition, reduced form: (re)compute the expansion point bhat -- the least-squares
-// solution clamped into the image of the prior box, see reduced_center() -- and e for every
-// spectrum, refresh the kernarg copy of spectrum 0 and the device copies of a batch.
+// PolynomialDecomposition, reduced form: (re)choose the expansion point bhat for the current
+// prior box (host_precompute.h:reduced_center), record the kernel's estimated rounding error,
+// refresh the kernarg copy of spectrum 0 and the device copies of a batch.
 static int recenter_reduced(bisip_ctx *c)
 {
     if (c->model_id != BISIP_MODEL_POLYDECOMP || c->reduced.empty()) return BISIP_OK;
     const int n = c->P + 2;
-    // b = R0 * (1, a_0..a_P): image of the theta box (infinite limits stay infinite = no clamp)
-    std::vector<double> blo(n), bhi(n);
-    const double r_lo = c->bounds.lo[0], r_hi = c->bounds.hi[0];
-    blo[0] = r_lo; bhi[0] = r_hi;
-    for (int p = 1; p < n; ++p) {
-        const double corners[4] = {r_lo * c->bounds.lo[p], r_lo * c->bounds.hi[p], r_hi * c->bounds.lo[p], r_hi * c->bounds.hi[p]};
-        double lo = INFINITY, hi = -INFINITY;
-        bool nan = false;
-        for (double v : corners) { if (v != v) nan = true; lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
-        if (nan || !(lo <= hi)) { lo = -INFINITY; hi = INFINITY; }   // 0 * inf: leave the component free
-        blo[p] = lo; bhi[p] = hi;
-    }
     const size_t red_doubles = (size_t)n * (n + 1) / 2 + 2 * (size_t)n + 1;  // == sizeof(ReducedArgs<P>)/8
     std::vector<double> red, bh(n), ev(n);
+    c->reduced_err = 0.0;
     for (size_t e = 0; e < c->reduced.size(); ++e) {
         const bisip_ctx::ReducedHost &rh = c->reduced[e];
-        reduced_center(n, rh.R, rh.qty, rh.bhat_ls, blo.data(), bhi.data(), bh.data(), ev.data());
+        const double est = reduced_center(n, rh.R, rh.qty, rh.bhat_ls, rh.rest, rh.lconst, c->bounds.lo, c->bounds.hi,
+                                          bh.data(), ev.data());
+        if (!(est <= c->reduced_err)) c->reduced_err = est;
         std::vector<double> Rp;
         for (int i = 0; i < n; ++i)
             for (int j = i; j < n; ++j) Rp.push_back(rh.R[(size_t)i * n + j]);
@@ -294,7 +288,7 @@ static int build_context(bisip_ctx **out, int device, int model_id, int E, int N
                 }
             }
             bisip_ctx::ReducedHost rh;
-            rh.R = o.R; rh.qty = o.qty; rh.bhat_ls = o.bhat_ls; rh.rest = o.rest;
+            rh.R = o.R; rh.qty = o.qty; rh.bhat_ls = o.bhat_ls; rh.rest = o.rest; rh.lconst = lconsts[e];
             c->reduced.push_back(std::move(rh));
             if (E == 1) {  // loop-faithful records (see k_logprob_pd_faithful)
                 const int JB = 16, nb = (N + JB - 1) / JB;
@@ -369,7 +363,9 @@ int bisip_ctx_set_bounds(bisip_ctx *c, const double *lo, const double *hi)
     for (int q = 0; q < c->ndim; ++q) same = same && c->bounds.lo[q] == lo[q] && c->bounds.hi[q] == hi[q];
     if (same) return BISIP_OK;
     for (int q = 0; q < c->ndim; ++q) { c->bounds.lo[q] = lo[q]; c->bounds.hi[q] = hi[q]; }
-    return guarded([&] { return recenter_reduced(c); });   // the reduced form expands about a point of the box
+    const int rc = guarded([&] { return recenter_reduced(c); });   // the reduced form expands about a point of the box
+    c->kernel_name = name_for(c);                                  // AUTO may change formulation with the box
+    return rc;
 }
 
 int bisip_ctx_set_variant(bisip_ctx *c, int variant)
@@ -397,6 +393,7 @@ int bisip_ctx_nfreq(const bisip_ctx *c) { return c ? c->N : BISIP_EINVAL; }
 int bisip_ctx_device(const bisip_ctx *c) { return c ? c->device : BISIP_EINVAL; }
 double bisip_ctx_loglike_const(const bisip_ctx *c) { return c ? c->lconst : NAN; }
 const char *bisip_ctx_kernel_name(const bisip_ctx *c) { return c ? c->kernel_name : ""; }
+double bisip_ctx_reduced_error(const bisip_ctx *c) { return c ? c->reduced_err : NAN; }
 
 int bisip_logprob_dev(bisip_ctx *c, const double *d_theta, int64_t W, double *d_logp, void *stream)
 {

@@ -34,6 +34,7 @@ constexpr int BLK_LARGE = 256;
 constexpr int BLK_STREAM = 128;  // HBM-bound reduced kernel: 128-lane workgroups stream ~3 % faster
                                  // than 256 (interleaved A/B, benchmarks/micro/reduced_variants.hip)
 constexpr long long SMALL_W = 256LL * 256 * 2;  // below this, 64-lane workgroups
+constexpr double BISIP_REDUCED_ERR_MAX = 1e-12;  // AUTO keeps the QR-reduced form below this estimate
 
 #define PD_CASES(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10)
 #define CC_CASES(X) X(1) X(2) X(3) X(4) X(5)
@@ -59,9 +60,10 @@ struct bisip_ctx {
     struct ReducedHost {
         std::vector<double> R;                  // (n,n)
         std::vector<long double> qty, bhat_ls;  // (n,)
-        double rest = 0.0;
+        double rest = 0.0, lconst = 0.0;
     };
     std::vector<ReducedHost> reduced;
+    double reduced_err = 0.0;      // worst estimated relative log-prob error of the reduced kernel (all spectra)
     // workspace of the host-pointer entry points
     double *d_ws = nullptr;
     size_t ws_bytes = 0;

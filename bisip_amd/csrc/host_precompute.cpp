@@ -140,32 +140,140 @@ void polydecomp_operands(int N, const double *w, int S, const double *taus, int 
     o.bhat_ls = bh;
 }
 
-void reduced_center(int n, const std::vector<double> &R, const std::vector<long double> &qty,
-                    const std::vector<long double> &bhat_ls, const double *b_lo, const double *b_hi,
-                    double *out_bhat, double *out_e)
+namespace {
+
+// logprob_row_reduced (kernels.h) in the same double arithmetic, operation for operation
+double reduced_chi2_double(int n, const std::vector<double> &R, const double *bhat, const double *e,
+                           double rest, const double *th)
 {
-    // Is the least-squares solution where the walkers can be (within the box inflated 2x about
-    // its centre; |b| <= 1e3 for a component without finite limits)?
-    bool use_ls = true;
-    for (int j = 0; j < n; ++j) {
-        const ld lo = (ld)b_lo[j], hi = (ld)b_hi[j], b = bhat_ls[j];
-        if (std::isfinite(b_lo[j]) && std::isfinite(b_hi[j])) {
-            const ld c = 0.5L * (lo + hi), h = 0.5L * (hi - lo);
-            if (!(fabsl(b - c) <= 2.0L * h)) use_ls = false;
-        } else if (!(fabsl(b) <= 1e3L)) {
-            use_ls = false;
+    std::vector<double> d(n);
+    d[0] = bhat[0] - th[0];
+    for (int q = 1; q < n; ++q) {
+        const double prod = th[0] * th[q];
+        d[q] = bhat[q] - prod;
+    }
+    double chi2 = rest;
+    for (int i = 0; i < n; ++i) {
+        double u = e[i];
+        for (int j = i; j < n; ++j) u = std::fma(R[(size_t)i * n + j], d[j], u);
+        chi2 = std::fma(u, u, chi2);
+    }
+    return chi2;
+}
+
+// the same quantity from the unrounded operands, in long double
+ld reduced_chi2_exact(int n, const std::vector<double> &R, const std::vector<ld> &qty, double rest,
+                      const double *th)
+{
+    ld chi2 = rest;
+    for (int i = 0; i < n; ++i) {
+        ld u = qty[i];
+        for (int j = i; j < n; ++j) u -= (ld)R[(size_t)i * n + j] * (j == 0 ? (ld)th[0] : (ld)th[0] * (ld)th[j]);
+        chi2 += u * u;
+    }
+    return chi2;
+}
+
+struct Lcg {   // deterministic probe points, no <random>
+    unsigned long long s = 0x9E3779B97F4A7C15ull;
+    double uni() { s = s * 6364136223846793005ull + 1442695040888963407ull; return (double)(s >> 11) / 9007199254740992.0; }
+    double sym() { return 2.0 * uni() - 1.0; }
+};
+
+}  // namespace
+
+double reduced_center(int n, const std::vector<double> &R, const std::vector<long double> &qty,
+                      const std::vector<long double> &bhat_ls, double rest, double lconst,
+                      const double *lo, const double *hi, double *out_bhat, double *out_e)
+{
+    bool finite_box = true;
+    for (int j = 0; j < n; ++j) finite_box = finite_box && std::isfinite(lo[j]) && std::isfinite(hi[j]);
+    // image of the theta box under b = R0 * (1, a)
+    std::vector<double> blo(n), bhi(n);
+    blo[0] = lo[0]; bhi[0] = hi[0];
+    for (int j = 1; j < n; ++j) {
+        const double c[4] = {lo[0] * lo[j], lo[0] * hi[j], hi[0] * lo[j], hi[0] * hi[j]};
+        double a = INFINITY, b = -INFINITY;
+        bool nan = false;
+        for (double v : c) { if (v != v) nan = true; a = v < a ? v : a; b = v > b ? v : b; }
+        if (nan || !(a <= b)) { a = -INFINITY; b = INFINITY; }
+        blo[j] = a; bhi[j] = b;
+    }
+    // probe rows: where walkers are going to be evaluated
+    std::vector<std::vector<double>> probes;
+    Lcg rng;
+    auto inside = [&](const std::vector<double> &t) {
+        for (int j = 0; j < n; ++j) if (!(lo[j] < t[j] && t[j] < hi[j])) return false;
+        return true;
+    };
+    const bool ls_ok = std::isfinite((double)bhat_ls[0]) && bhat_ls[0] != 0.0L;
+    if (finite_box) {
+        for (int k = 0; k < 48; ++k) {   // uniform in the prior box
+            std::vector<double> t(n);
+            for (int j = 0; j < n; ++j) t[j] = lo[j] + (hi[j] - lo[j]) * rng.uni();
+            probes.push_back(t);
+        }
+        for (int k = 0; k < 32; ++k) {   // small coefficients: where a decent fit usually lies
+            std::vector<double> t(n);
+            t[0] = lo[0] + (hi[0] - lo[0]) * rng.uni();
+            for (int j = 1; j < n; ++j) {
+                double v = 1e-3 * rng.sym();
+                v = v < lo[j] ? lo[j] : (v > hi[j] ? hi[j] : v);
+                t[j] = v;
+            }
+            if (inside(t)) probes.push_back(t);
         }
     }
-    for (int j = 0; j < n; ++j) {
-        ld b = bhat_ls[j];
-        if (!use_ls) b = (std::isfinite(b_lo[j]) && std::isfinite(b_hi[j])) ? 0.5L * ((ld)b_lo[j] + (ld)b_hi[j]) : 0.0L;
-        out_bhat[j] = (double)b;
+    if (ls_ok)
+        for (int k = 0; k < 32; ++k) {   // around the least-squares solution (the posterior mode)
+            const double s = k < 16 ? 1e-3 : 1e-2;
+            std::vector<double> t(n);
+            t[0] = (double)bhat_ls[0] * (1.0 + s * rng.sym());
+            bool fin = std::isfinite(t[0]);
+            for (int j = 1; j < n; ++j) {
+                t[j] = (double)(bhat_ls[j] / bhat_ls[0]) * (1.0 + s * rng.sym());
+                fin = fin && std::isfinite(t[j]);
+            }
+            if (fin && (!finite_box || inside(t))) probes.push_back(t);
+        }
+    // candidates for the expansion point
+    std::vector<std::vector<double>> cand;
+    {
+        bool ok = true;
+        std::vector<double> c(n);
+        for (int j = 0; j < n; ++j) { c[j] = (double)bhat_ls[j]; ok = ok && std::isfinite(c[j]) && std::fabs(c[j]) <= 1e6; }
+        if (ok) cand.push_back(c);
     }
-    for (int i = 0; i < n; ++i) {
-        ld s = qty[i];
-        for (int j = i; j < n; ++j) s -= (ld)R[(size_t)i * n + j] * (ld)out_bhat[j];
-        out_e[i] = (double)s;
+    if (finite_box) {
+        std::vector<double> c(n);
+        bool ok = true;
+        for (int j = 0; j < n; ++j) { c[j] = 0.5 * (blo[j] + bhi[j]); ok = ok && std::isfinite(c[j]); }
+        if (ok) cand.push_back(c);
     }
+    cand.push_back(std::vector<double>(n, 0.0));
+    double best = INFINITY;
+    std::vector<double> e(n);
+    for (const auto &c : cand) {
+        for (int i = 0; i < n; ++i) {
+            ld s = qty[i];
+            for (int j = i; j < n; ++j) s -= (ld)R[(size_t)i * n + j] * (ld)c[j];
+            e[i] = (double)s;
+        }
+        double worst = 0.0;
+        for (const auto &t : probes) {
+            const ld exact = reduced_chi2_exact(n, R, qty, rest, t.data());
+            const double got = reduced_chi2_double(n, R, c.data(), e.data(), rest, t.data());
+            const ld lp = -0.5L * exact + (ld)lconst;
+            const ld scale = fabsl(lp) > 1.0L ? fabsl(lp) : 1.0L;
+            const double rel = (double)(fabsl(-0.5L * ((ld)got - exact)) / scale);
+            if (!(rel <= worst)) worst = rel;   // NaN counts as worst
+        }
+        if (worst < best || best == INFINITY) {
+            best = worst;
+            for (int j = 0; j < n; ++j) { out_bhat[j] = c[j]; out_e[j] = e[j]; }
+        }
+    }
+    return best;
 }
 
 }  // namespace bisip

@@ -21,25 +21,29 @@ struct PolyDecompOperands {
     std::vector<long double> qty, bhat_ls;
 };
 
-// Chooses the expansion point of the reduced form.  The identity
-//   chi2(b) = rest + | e + R (bhat - b) |^2,  e = Q^T y - R bhat
-// holds for ANY bhat; what bhat decides is the rounding error.  R has entries up to 1e10 for
-// high polynomial degrees (nearly collinear columns), so each row of R (bhat - b) cancels by
-// many orders of magnitude; the part of that cancellation that does not depend on the walker
-// is folded into e here, in long double, and what is left for the kernel grows with
-// |bhat - b|.  The least-squares solution is the best point when the walkers can reach it
-// (posterior rows: 1e-15), but when it lies far outside the prior box (ill-conditioned
-// designs: |bhat| ~ 1e2 .. 1e12, measured 2e-10 .. 1e-2 relative error) the centre of the box
-// is (5e-14 on the same rows).  [b_lo, b_hi] is the image of the prior box; out_* are (n,).
-void reduced_center(int n, const std::vector<double> &R, const std::vector<long double> &qty,
-                    const std::vector<long double> &bhat_ls, const double *b_lo, const double *b_hi,
-                    double *out_bhat, double *out_e);
-
 // reference: C_Debye at src/bisip/cython_funcs.pyx:46-47, Decomp_cyth :75-94,
 // likelihood weights at src/bisip/models.py:59-62.
 void polydecomp_operands(int N, const double *w, int S, const double *taus, int D,
                          const double *log_taus, double c_exp, const double *zn,
                          const double *zn_err, PolyDecompOperands &out);
+
+// Chooses the expansion point of the reduced form and says how far the kernel can be trusted.
+// The identity
+//   chi2(b) = rest + | e + R (bhat - b) |^2,  e = Q^T y - R bhat
+// holds for ANY bhat; what bhat decides is the rounding error.  R has entries up to 1e10 for
+// high polynomial degrees (nearly collinear columns), each row of R (bhat - b) cancels by many
+// orders of magnitude, and forming bhat - b in double discards the low bits of a small b when
+// bhat is O(1).  No single rule is best everywhere (measured: least squares 2e-10 .. 8.6e-3
+// when it lies far outside the prior box; box centre 2.5e-10 where zero gives 4e-14; zero 3x
+// worse than least squares around a well-determined mode), so this function EMULATES the
+// kernel's double arithmetic on the host for ~140 probe rows -- uniform in the prior box
+// [lo, hi] (theta space), clouds of small coefficients, clouds around the least-squares
+// solution -- against long double, for each candidate (least squares, centre of the box's
+// image, zero), keeps the best, and returns its worst relative log-probability error.
+// The caller (AUTO variant) falls back to the per-frequency form when that exceeds 1e-12.
+double reduced_center(int n, const std::vector<double> &R, const std::vector<long double> &qty,
+                      const std::vector<long double> &bhat_ls, double rest, double lconst,
+                      const double *lo, const double *hi, double *out_bhat, double *out_e);
 
 // -0.5 * sum_i 2*ln(zn_err_i^2), the walker-independent term of src/bisip/models.py:62
 double loglike_const(int n2, const double *zn_err);

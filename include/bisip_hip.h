@@ -45,7 +45,7 @@ extern "C" {
 #define BISIP_MODEL_SHIN2015   3 /* Shin2015                -> Shin2015_cyth */
 
 /* kernel formulation for PolynomialDecomposition (other models have one) */
-#define BISIP_VARIANT_AUTO      0 /* fastest formulation that holds the parity tolerance */
+#define BISIP_VARIANT_AUTO      0 /* fastest formulation that holds the parity tolerance (see bisip_ctx_reduced_error) */
 #define BISIP_VARIANT_FAITHFUL  1 /* sum_k M_k*K[j,k], the reference's loop structure     */
 #define BISIP_VARIANT_COLLAPSED 2 /* Z_j = R0*(1 - sum_p a_p*G[j,p])                       */
 #define BISIP_VARIANT_REDUCED   3 /* QR-reduced chi^2: (P+2)x(P+2) triangular form         */
@@ -250,6 +250,11 @@ int bisip_ctx_device(const bisip_ctx *ctx);
 double bisip_ctx_loglike_const(const bisip_ctx *ctx);
 /* Name of the kernel bisip_logprob_dev launches for the current variant. */
 const char *bisip_ctx_kernel_name(const bisip_ctx *ctx);
+/* PolynomialDecomposition: worst relative log-probability error of the QR-reduced kernel for the
+ * current prior box, estimated by emulating its double arithmetic on the host against long
+ * double on ~140 probe rows per spectrum (0 for other models).  BISIP_VARIANT_AUTO uses the
+ * reduced form only while this is <= 1e-12 (and 2N >= poly_deg+2), else the collapsed form. */
+double bisip_ctx_reduced_error(const bisip_ctx *ctx);
 
 /* Host-only inspection of the walker-independent PolynomialDecomposition operands the
  * context precomputes (no GPU needed; used by the CPU-side tests).  Outputs:

@@ -408,6 +408,47 @@ def test_reduced_form_on_ill_conditioned_designs(n_freq, poly_deg, c_exp):
     ctx.close()
 
 
+def test_auto_variant_follows_the_reduced_kernels_error_estimate():
+    """AUTO = the QR-reduced kernel only where a host-side emulation of its double arithmetic
+    stays within 1e-12 of long double on probe rows (bisip_ctx_reduced_error), else the
+    per-frequency form; the estimate is refreshed when the prior box changes."""
+    from bisip_amd import _hip
+
+    def ctx_for(n_freq, poly_deg, c_exp, idx=5):
+        d = _synthetic_problem(n_freq, idx)
+        per = np.log10(1. / d['w'])
+        lt = np.linspace(np.floor(per.min() - 1), np.floor(per.max() + 1), 2 * n_freq)
+        bounds = np.array([[0.9] + [-1.0] * (poly_deg + 1), [1.1] + [1.0] * (poly_deg + 1)])
+        return _hip.HipContext(0, d['w'], d['zn'], d['zn_err'], bounds, poly_deg=poly_deg, c_exp=c_exp,
+                               taus=10 ** lt, log_taus=np.array([lt ** i for i in range(poly_deg + 1)])), bounds
+
+    ctx, _ = ctx_for(32, 5, 1.0, 0)                  # the headline shape
+    assert ctx.variant == 'reduced' and ctx.kernel_name == 'k_logprob_pd_reduced'
+    assert ctx.reduced_error < 1e-13
+    ctx.close()
+    picked = []
+    for n_freq, poly_deg, c_exp in [(32, 8, 1.0), (48, 7, 0.5), (80, 10, 0.5), (21, 10, 0.5), (64, 9, 0.3), (32, 6, 1.0)]:
+        ctx, _ = ctx_for(n_freq, poly_deg, c_exp, 0)
+        est = ctx.reduced_error
+        assert ctx.variant == ('reduced' if est <= 1e-12 else 'collapsed'), (n_freq, poly_deg, c_exp, est)
+        picked.append(ctx.variant)
+        if ctx.variant == 'collapsed':
+            ctx.set_variant('reduced')                # still available on request
+            assert ctx.variant == 'reduced' and ctx.kernel_name == 'k_logprob_pd_reduced'
+        ctx.close()
+    assert 'collapsed' in picked                      # nearly collinear designs do fall back
+    ctx, bounds = ctx_for(3, 10, 1.0)                 # fewer data rows than unknowns
+    assert ctx.variant == 'collapsed'
+    ctx.close()
+    ctx, bounds = ctx_for(32, 8, 1.0, 0)
+    before = ctx.reduced_error
+    ctx.set_bounds(bounds * np.r_[1.0, np.full(9, 1e-4)])       # the estimate follows the prior box
+    after = ctx.reduced_error
+    assert np.isfinite(after) and after != before
+    assert ctx.variant == ('reduced' if after <= 1e-12 else 'collapsed')
+    ctx.close()
+
+
 def test_unsupported_shapes_fail_loudly():
     from bisip_amd import _hip
     d = _synthetic_problem(8)
