@@ -154,6 +154,10 @@ def respect_cpu_quota():
         return
     _QUOTA_APPLIED = True
     n = cpu_quota()
+    try:   # one process per GPU under torchrun: the ranks of this node share the quota
+        n = max(1, n // max(1, int(os.environ.get('LOCAL_WORLD_SIZE', '1'))))
+    except ValueError:
+        pass
     if n >= (os.cpu_count() or 1):
         return
     try:
