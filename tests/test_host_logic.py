@@ -247,3 +247,11 @@ def test_cyth_named_functions_reject_what_the_typed_buffers_reject():
         cf.Decomp_cyth(w, w, np.ones((3, 8)), 1.0, 1.0, np.ones(2))
     with pytest.raises(ValueError):
         cf.Shin2015_cyth(w, np.ones(3), np.ones(2), np.ones(2))
+
+
+def test_cpu_quota_is_within_the_machine():
+    """cpu_quota() = min(affinity, cgroup CFS quota); respect_cpu_quota() caps the host thread
+    pools at it so that parallel memcpy / BLAS bursts are not throttled mid-run."""
+    from bisip_amd.utils import cpu_quota
+    n = cpu_quota()
+    assert isinstance(n, int) and 1 <= n <= (os.cpu_count() or 1)
