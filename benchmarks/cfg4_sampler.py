@@ -57,7 +57,9 @@ def main():
         return DeviceEnsembleSampler(args.walkers, 7, ctx, rng=args.rng, seed=11, distributed=True,
                                      force_sharded_path=not args.fused, persistent=False,
                                      chain_on_device=(args.chain == 'device'))
-    make().run_mcmc(p0, 5)
+    prime = time.perf_counter()           # warm-up + clocks up
+    while time.perf_counter() - prime < 0.25:
+        make().run_mcmc(p0, 20)
     s = make()
     dist.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -6,6 +6,11 @@ set -e -o pipefail
 what=${1:-all}
 out=$PWD/gpurun_out
 mkdir -p "$out"
+scratch=$(mktemp -d /tmp/bisip_prof.XXXXXX)   # full traces stay here: only summaries go to gpurun_out
+keep() {   # keep <trace dir> <name>: copy the small CSVs of a rocprofv3 run
+  mkdir -p "$out/$2/runc"
+  find "$1" \( -name '*kernel_stats.csv' -o -name '*domain_stats.csv' -o -name '*agent_info.csv' -o -name '*counter_collection.csv' \) -exec cp {} "$out/$2/runc/" \;
+}
 export TMPDIR=/tmp
 repo=$PWD
 
@@ -13,19 +18,22 @@ if [ "$what" = bench ] || [ "$what" = all ]; then
   echo "== bench.py" | tee -a "$out/progress.log"
   python3 bench.py > "$out/bench.json" 2> "$out/bench.err"
   echo "== bench.py under rocprofv3 --kernel-trace --stats" | tee -a "$out/progress.log"
-  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof_bench" -- \
+  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$scratch/prof_bench" -- \
       python3 "$repo/bench.py" --no-cpu-baseline --no-variants > "$out/bench_under_rocprof.json" 2> "$out/prof_bench.err")
+  keep "$scratch/prof_bench" prof_bench
   for c in FETCH_SIZE WRITE_SIZE; do
     echo "== bench.py --pmc $c" | tee -a "$out/progress.log"
-    (cd /tmp && rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$out/pmc_$c" -- \
+    (cd /tmp && rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$scratch/pmc_$c" -- \
         python3 "$repo/bench.py" --no-cpu-baseline --no-variants --steps 20 --prime-seconds 0.1 > "$out/pmc_$c.json" 2> "$out/pmc_$c.err")
+    keep "$scratch/pmc_$c" pmc_$c
   done
 fi
 if [ "$what" = sweep ] || [ "$what" = all ]; then
   echo "== sweep" | tee -a "$out/progress.log"
   python3 benchmarks/sweep.py > "$out/sweep.jsonl" 2> "$out/sweep.err"
-  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof_sweep" -- \
+  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$scratch/prof_sweep" -- \
       python3 "$repo/benchmarks/sweep.py" > "$out/sweep_under_rocprof.jsonl" 2> "$out/prof_sweep.err")
+  keep "$scratch/prof_sweep" prof_sweep
   python3 benchmarks/host_path.py > "$out/host_path.jsonl" 2> "$out/host_path.err"
 fi
 if [ "$what" = sampler ] || [ "$what" = all ]; then
@@ -36,7 +44,9 @@ if [ "$what" = sampler ] || [ "$what" = all ]; then
   python3 benchmarks/cfg4_sampler.py --steps 200 --chain device | grep "^{" > "$out/cfg4_sharded_path_1gpu.json" 2>> "$out/cfg4.err"
   python3 benchmarks/cfg5_batch.py --chain device > "$out/cfg5_device_chain.json" 2> "$out/cfg5.err"
   python3 benchmarks/cfg5_batch.py > "$out/cfg5_host_chain.json" 2>> "$out/cfg5.err"
-  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof_sampler" -- \
+  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$scratch/prof_sampler" -- \
       python3 "$repo/benchmarks/sampler_bench.py" > "$out/sampler_under_rocprof.jsonl" 2> "$out/prof_sampler.err")
+  keep "$scratch/prof_sampler" prof_sampler
 fi
+rm -rf "$scratch"
 echo "== done" | tee -a "$out/progress.log"
