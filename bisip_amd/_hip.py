@@ -69,6 +69,9 @@ SYMBOLS = {
     'bisip_forward': (ctypes.c_int, [ctypes.c_void_p, _dp, ctypes.c_int64, _dp]),
     'bisip_forward_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                          ctypes.c_void_p, ctypes.c_void_p]),
+    'bisip_loglike_z': (ctypes.c_int, [ctypes.c_void_p, _dp, ctypes.c_int64, _dp]),
+    'bisip_loglike_z_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                           ctypes.c_void_p, ctypes.c_void_p]),
     'bisip_stretch_half_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(StretchArgs), ctypes.c_void_p]),
     'bisip_stretch_eval_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(StretchArgs), ctypes.c_void_p]),
     'bisip_stretch_apply_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(StretchArgs), ctypes.c_void_p]),
@@ -292,6 +295,15 @@ class HipContext:
         theta = self._theta2d(theta)
         out = np.empty((theta.shape[0], 2, self.N), dtype=np.float64)
         _check(self._lib.bisip_forward(self._h, _p(theta), theta.shape[0], _p(out)))
+        return out
+
+    def loglike_z(self, Z):
+        """Gaussian log-likelihood of caller-computed responses: Z (W, 2, N) host -> (W,) host."""
+        Z = _c(Z)
+        if Z.ndim != 3 or Z.shape[1:] != (2, self.N):
+            raise ValueError(f'Z must have shape (W, 2, {self.N}), got {Z.shape}')
+        out = np.empty(Z.shape[0], dtype=np.float64)
+        _check(self._lib.bisip_loglike_z(self._h, _p(Z), Z.shape[0], _p(out)))
         return out
 
     def logprob_dev(self, d_theta_ptr, W, d_out_ptr, stream=0):

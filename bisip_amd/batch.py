@@ -12,7 +12,7 @@ import numpy as np
 from . import _hip
 from .dist import shard_range
 from .sampler import DeviceEnsembleSampler
-from .utils import columns_to_data, load_data
+from .utils import load_data_batch
 
 _MODELS = {
     'PolynomialDecomposition': _hip.MODEL_POLYDECOMP,
@@ -63,20 +63,13 @@ class SpectraBatch:
         self.model = 'PeltonColeCole' if model == 'ColeCole' else model
         lo, hi = shard_range(len(spectra), world, rank)
         self.spectrum_range = (lo, hi)
-        items = []
-        for sp in spectra[lo:hi]:
-            items.append(load_data(sp, headers, ph_units) if isinstance(sp, str)
-                         else columns_to_data(sp, ph_units))
-        if not items:
+        if hi <= lo:
             raise ValueError('no spectra for this rank')
-        if len({d['N'] for d in items}) != 1:
-            raise ValueError('all spectra of a batch must have the same number of frequencies')
-        self.n_spectra = len(items)
-        self.N = items[0]['N']
-        self.w = np.stack([d['w'] for d in items])
-        self.zn = np.stack([d['zn'] for d in items])
-        self.zn_err = np.stack([d['zn_err'] for d in items])
-        self.norm_factor = np.array([d['norm_factor'] for d in items])
+        batch = load_data_batch(spectra[lo:hi], headers, ph_units)
+        self.n_spectra = hi - lo
+        self.N = batch['N']
+        self.w, self.zn, self.zn_err = batch['w'], batch['zn'], batch['zn_err']
+        self.norm_factor = batch['norm_factor']
         self.nwalkers, self.nsteps = int(nwalkers), int(nsteps)
         self.n_modes, self.poly_deg, self.c_exp = n_modes, poly_deg, c_exp
         self.params = default_params(self.model, n_modes, poly_deg)

@@ -414,6 +414,43 @@ int bisip_forward_dev(bisip_ctx *c, const double *d_theta, int64_t W, double *d_
     return dispatch_forward(c, d_theta, W, d_Z, (hipStream_t)stream);
 }
 
+int bisip_loglike_z_dev(bisip_ctx *c, const double *d_Z, int64_t W, double *d_out, void *stream)
+{
+    if (!c) return fail(BISIP_EINVAL, "null context");
+    if (c->E > 1) return fail(BISIP_EUNSUPPORTED, "bisip_loglike_z takes a single-spectrum context");
+    if (W < 0) return fail(BISIP_EINVAL, "W=%lld < 0", (long long)W);
+    if (W == 0) return BISIP_OK;
+    if (!d_Z || !d_out) return fail(BISIP_EINVAL, "null buffer");
+    if ((W + 3) / 4 > 0x7fffffffLL) return fail(BISIP_EINVAL, "W=%lld exceeds the launch grid limit", (long long)W);
+    HIP_TRY(hipSetDevice(c->device));
+    const int rec = (int)(c->cb_stride / c->N);
+    hipLaunchKernelGGL(k_loglike_z, dim3((unsigned)((W + 3) / 4)), dim3(256), 0, (hipStream_t)stream, d_Z, d_out,
+                       (long long)W, c->d_cb, rec, c->N, c->lconst);
+    HIP_TRY(hipGetLastError());
+    return BISIP_OK;
+}
+
+int bisip_loglike_z(bisip_ctx *c, const double *Z, int64_t W, double *out)
+{
+    if (!c) return fail(BISIP_EINVAL, "null context");
+    if (W < 0) return fail(BISIP_EINVAL, "W=%lld < 0", (long long)W);
+    if (W == 0) return BISIP_OK;
+    if (!Z || !out) return fail(BISIP_EINVAL, "null buffer");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t zb = (size_t)W * 2 * c->N * sizeof(double), ob = (size_t)W * sizeof(double);
+    const size_t zb_al = (zb + 255) & ~(size_t)255;
+    int rc = ensure_ws(c, zb_al + ob);
+    if (rc != BISIP_OK) return rc;
+    double *d_Z = c->d_ws;
+    double *d_out = (double *)((char *)c->d_ws + zb_al);
+    HIP_TRY(hipMemcpyAsync(d_Z, Z, zb, hipMemcpyHostToDevice, c->stream));
+    rc = bisip_loglike_z_dev(c, d_Z, W, d_out, c->stream);
+    if (rc != BISIP_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(out, d_out, ob, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return BISIP_OK;
+}
+
 int bisip_stretch_half_dev(bisip_ctx *c, const bisip_stretch_args *u, void *stream)
 {
     int rc = check_stretch(c, u, false);

@@ -167,13 +167,19 @@ int dispatch_stretch(const bisip_ctx *c, const StretchWork &a, long long Wp, hip
     }
     switch (c->model_id) {
     case BISIP_MODEL_POLYDECOMP:
+        // the sampler kernels exist for the reduced and the collapsed formulation only; running
+        // another one here would store log-probabilities that bisip_logprob does not reproduce
+        // bit for bit, so say so and let the caller drive the move from the host
+        if (effective_variant(c) == BISIP_VARIANT_FAITHFUL || effective_variant(c) == BISIP_VARIANT_WAVE)
+            return fail(BISIP_EUNSUPPORTED, "the device stretch move has no kernel for the faithful / wave "
+                        "formulation: use variant auto, reduced or collapsed, or the host-loop sampler");
         if (effective_variant(c) == BISIP_VARIANT_REDUCED) {
             switch (c->P) {
 #define X(p) case p: return stretch_reduced<p>(c, a, st);
                 PD_CASES(X)
 #undef X
             }
-        } else {  // collapsed (the faithful formulation has no sampler kernel)
+        } else {
             switch (c->P) {
 #define X(p) case p: return stretch_generic<PDCollapsed<p>>(c, a, st);
                 PD_CASES(X)

@@ -253,6 +253,12 @@ double reduced_center(int n, const std::vector<double> &R, const std::vector<lon
     cand.push_back(std::vector<double>(n, 0.0));
     double best = INFINITY;
     std::vector<double> e(n);
+    if (probes.empty()) {
+        // nothing to measure the kernel against (a non-finite box with no usable least-squares
+        // solution): expand about zero and report "unknown", so AUTO takes the per-frequency form
+        for (int j = 0; j < n; ++j) { out_bhat[j] = 0.0; out_e[j] = (double)qty[j]; }
+        return INFINITY;
+    }
     for (const auto &c : cand) {
         for (int i = 0; i < n; ++i) {
             ld s = qty[i];

@@ -1,7 +1,7 @@
 // host_rng.cpp -- the stretch move's random stream in numpy.random.RandomState order,
 // generated in C for a whole chunk of iterations.
 //
-// bisip_amd/sampler.py:draw_step is the contract (one choice over the move list, a shuffle
+// bisip_amd/sampler.py:draw_step is the contract (one uniform double for the choice over the move list, a shuffle
 // of the split labels, then per half rand / randint / rand).  This file replays exactly the
 // MT19937 consumption of those legacy RandomState methods -- random_sample (two 32-bit words
 // per double), masked rejection for bounded integers and for the Fisher-Yates shuffle -- so
@@ -78,7 +78,7 @@ extern "C" int bisip_numpy_stretch_stream(uint32_t *mt_key, int32_t *mt_pos, int
     std::vector<int32_t> inds(W), half[2];
     half[0].reserve(nh); half[1].reserve(nh);
     for (int64_t k = 0; k < n_steps; ++k) {
-        // rng.choice(1): a one-element population consumes nothing
+        (void)mt.next_double();   // the weighted choice over the move list: one uniform double
         for (int64_t i = 0; i < W; ++i) inds[i] = (int32_t)(i & 1);
         for (int64_t i = W - 1; i >= 1; --i) {  // rng.shuffle(inds)
             const uint32_t j = mt.bounded((uint32_t)i);

@@ -756,6 +756,33 @@ __global__ __launch_bounds__(256) void k_logprob_pd_wave(const LaunchArgs a)
 }
 
 // ---------------------------------------------------------------------------------
+// Gaussian log-likelihood of a model response the CALLER computed: Z (W,2,N) -> (W,).
+// The reference's _log_likelihood takes any callable f (src/bisip/models.py:59-62); when f
+// is not one of the four built-in forward models the host evaluates it and only the
+// reduction runs here.  One wave per row: the 2N terms of a row are contiguous, lane l
+// takes elements l, l+64, ... (coalesced), then a fixed butterfly sums the 64 partials.
+// rec[0..3] of every frequency record = y_re, y_im, 1/s2_re, 1/s2_im.
+// ---------------------------------------------------------------------------------
+static __global__ __launch_bounds__(256) void k_loglike_z(const double *__restrict__ Z,
+                                                          double *__restrict__ out, long long W,
+                                                          const double *__restrict__ cb, int rec,
+                                                          int N, double lconst)
+{
+    const long long row = ((long long)blockIdx.x * 256 + threadIdx.x) >> 6;
+    if (row >= W) return;   // whole waves leave together
+    const int lane = threadIdx.x & 63;
+    const double *__restrict__ z = Z + row * 2 * N;
+    double acc = 0.0;
+    for (int i = lane; i < 2 * N; i += 64) {
+        const int part = i >= N, j = i - part * N;
+        const double r = cb[(long long)j * rec + part] - z[i];
+        acc = fma(r * r, cb[(long long)j * rec + 2 + part], acc);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) out[row] = fma(-0.5, acc, lconst);
+}
+
+// ---------------------------------------------------------------------------------
 // Batch of independent spectra (BASELINE config 5): E spectra share the model shape and
 // the prior box; rows [e*Wp, (e+1)*Wp) of theta belong to spectrum e, whose operands sit
 // at cb + e*cb_stride.  When a wave never straddles two spectra (UNIFORM: Wp % 64 == 0)

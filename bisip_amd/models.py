@@ -64,30 +64,36 @@ class Inversion(_utils.utils):
         """Model-specific kwargs of HipContext; overridden by subclasses."""
         return {}
 
-    def _context(self, x=None, y=None, yerr=None):
+    def _context(self, x=None, y=None, yerr=None, prior=True):
         """The HIP context holding (x, y, yerr) = (w, zn, zn_err).  Contexts are cached
         by operand bytes, so the usual call pattern (always the loaded data) builds
-        exactly one."""
+        exactly one.  ``prior=False``: a second context of the same operands whose box is
+        the whole space -- the likelihood alone -- so that ``_log_likelihood`` never touches
+        the bounds of the context ``fit()`` and ``_log_probability`` use."""
         d = self._data
         x = d['w'] if x is None else np.ascontiguousarray(x, dtype=np.float64)
         y = d['zn'] if y is None else np.ascontiguousarray(y, dtype=np.float64)
         yerr = d['zn_err'] if yerr is None else np.ascontiguousarray(yerr, dtype=np.float64)
         desc = self._desc()
-        key = (x.tobytes(), y.tobytes(), yerr.tobytes(),
+        key = (x.tobytes(), y.tobytes(), yerr.tobytes(), bool(prior),
                tuple(sorted((k, np.asarray(v).tobytes()) for k, v in desc.items())))
         ctx = self._ctx_cache.get(key)
         if ctx is None:
-            ctx = _hip.HipContext(self._model_id, x, y, yerr, self.param_bounds,
-                                  device=self.device, **desc)
+            bounds = self.param_bounds
+            if not prior:
+                bounds = np.array([np.full(bounds.shape[1], -np.inf), np.full(bounds.shape[1], np.inf)])
+                # no box to centre the QR-reduced form in: the per-frequency kernel is accurate
+                # for any theta
+                if desc.get('variant') == 'auto':
+                    desc = dict(desc, variant='collapsed')
+            ctx = _hip.HipContext(self._model_id, x, y, yerr, bounds, device=self.device, **desc)
             if len(self._ctx_cache) >= 8:
                 self._ctx_cache.pop(next(iter(self._ctx_cache))).close()
             self._ctx_cache[key] = ctx
         return ctx
 
-    def _check_model(self, f):
-        if f is not None and f != self.forward:
-            raise ValueError('the fused GPU log-likelihood evaluates this model\'s own '
-                             'forward(); pass model.forward (or None)')
+    def _is_own_forward(self, f):
+        return f is None or f == self.forward
 
     @staticmethod
     def _as_rows(theta):
@@ -102,16 +108,19 @@ class Inversion(_utils.utils):
     def _log_likelihood(self, theta, f, x, y, yerr):
         """Gaussian log-likelihood  -0.5*sum((y - f(theta,x))**2/yerr**2 + 2*log(yerr**2)).
 
-        ``theta`` may be one vector or an (n, ndim) ensemble."""
-        self._check_model(f)
+        ``theta`` may be one vector or an (n, ndim) ensemble.  ``f`` is the model callable
+        ``f(theta, x) -> (2, N)`` as in the reference (src/bisip/models.py:59-62): this
+        model's own ``forward`` (or None) runs the fused forward + reduction kernel; any
+        other callable is evaluated on the host, row by row as the reference does, and only
+        the residual reduction runs on the device (``bisip_loglike_z``)."""
         rows, single = self._as_rows(theta)
-        ctx = self._context(x, y, yerr)
-        open_box = np.array([np.full(rows.shape[1], -np.inf), np.full(rows.shape[1], np.inf)])
-        ctx.set_bounds(open_box)
-        try:
+        ctx = self._context(x, y, yerr, prior=False)
+        if self._is_own_forward(f):
             out = ctx.logprob(rows)
-        finally:
-            ctx.set_bounds(self.param_bounds)
+        else:
+            xs = self._data['w'] if x is None else x
+            Z = np.stack([np.asarray(f(t, xs), dtype=np.float64) for t in rows])
+            out = ctx.loglike_z(Z)
         return float(out[0]) if single else out
 
     def _log_prior(self, theta, bounds):
@@ -125,11 +134,17 @@ class Inversion(_utils.utils):
     def _log_probability(self, theta, model=None, bounds=None, x=None, y=None, yerr=None):
         """Bayes numerator: prior + likelihood, fused in one kernel launch.  Rows outside
         the prior return -inf without evaluating the forward model."""
-        self._check_model(model)
         rows, single = self._as_rows(theta)
-        ctx = self._context(x, y, yerr)
-        ctx.set_bounds(self.param_bounds if bounds is None else bounds)
-        out = ctx.logprob(rows)
+        bounds = self.param_bounds if bounds is None else np.asarray(bounds, dtype=np.float64)
+        if self._is_own_forward(model):
+            ctx = self._context(x, y, yerr)
+            ctx.set_bounds(bounds)
+            out = ctx.logprob(rows)
+        else:   # a foreign model callable: prior on the host, f only for the rows inside it
+            out = np.array(self._log_prior(rows, bounds), dtype=np.float64)
+            inside = np.isfinite(out)
+            if inside.any():
+                out[inside] += self._log_likelihood(rows[inside], model, x, y, yerr)
         return float(out[0]) if single else out
 
     # public aliases named by the north star
@@ -163,15 +178,17 @@ class Inversion(_utils.utils):
         Args:
             p0 (ndarray): starting positions (nwalkers, ndim); drawn uniformly from the
                 prior box with the global NumPy RNG when None.
-            pool: accepted for signature compatibility and ignored -- a whole
-                half-ensemble is evaluated by one kernel launch.
+            pool: accepted for signature compatibility and ignored: the reference hands it to
+                emcee to spread the per-walker Python calls over processes
+                (src/bisip/models.py:91-94,115); here a whole half-ensemble is one kernel launch.
             moves: an emcee ``moves`` object; requires emcee (the native samplers
-                implement the default StretchMove only).
+                implement the default StretchMove only) -- emcee then drives the vectorised
+                GPU log-probability (``vectorize=True``).
             sampler (str): 'device' (default) keeps the ensemble and the chain on the GPU
                 and runs one fused kernel per half-step; 'host' runs the stretch move in
                 NumPy around the vectorised GPU log-probability.  Same chain either way.
             rng (str): 'numpy' (default) draws the stretch-move random stream on the host
-                in emcee's order from NumPy's global state (``np.random.seed`` pins the
+                in emcee's consumption order from NumPy's global state (``np.random.seed`` pins the
                 run); 'philox' generates it on the device (2-3x faster for small
                 ensembles, its own reproducible stream).  Device sampler only.
             thin_by (int): store one sample every ``thin_by`` iterations.
@@ -191,6 +208,10 @@ class Inversion(_utils.utils):
             import emcee  # optional: non-default moves
             self._sampler = emcee.EnsembleSampler(self.nwalkers, self.ndim, ctx.logprob,
                                                   moves=moves, vectorize=True)
+        elif sampler == 'device' and ctx.variant in ('faithful', 'wave'):
+            # these formulations have no stretch-move kernel: the move runs on the host around
+            # the vectorised log-probability of exactly that formulation (same chain contract)
+            self._sampler = EnsembleSampler(self.nwalkers, self.ndim, ctx.logprob)
         elif sampler == 'device':
             self._sampler = DeviceEnsembleSampler(self.nwalkers, self.ndim, ctx, rng=rng,
                                                   persistent=persistent)

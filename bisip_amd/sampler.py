@@ -17,7 +17,8 @@ red/blue split -- in two drivers that produce THE SAME CH
 RNG contract (reproducible and shardable): a private ``numpy.random.RandomState``
 seeded from the global NumPy state at construction (so ``np.random.seed(42)`` before
 ``fit()`` pins a run, as in the reference's notebooks).  Per iteration it is consumed
-in this order: one ``choice`` over the move list, one ``shuffle`` of the split labels,
+in this order: one uniform double (emcee's weighted ``choice`` over its move list draws one even
+when the list has a single entry), one ``shuffle`` of the split labels,
 then for each of the two halves ``rand(Ns)`` (stretch factors), ``randint(Nc, Ns)``
 (partners) and ``rand(Ns)`` (accept uniforms, walker order).  ``draw_step`` states that
 order; ``bisip_numpy_stretch_stream`` (csrc/host_rng.cpp) replays it in C for whole chunks,
@@ -64,7 +65,9 @@ def draw_step(rng, nwalkers, ndim, a=2.0):
     slot), ``partner`` (walker of the complementary half it stretches from), ``zz``
     (stretch factor), ``factor`` = (ndim-1) ln zz and ``logu`` = ln u.
     """
-    rng.choice(1)  # the draw over the (single-entry) move list
+    # emcee picks the move with ``random.choice(moves, p=weights)``: with ``p`` given, the
+    # legacy RandomState draws ONE uniform double even for a single-entry list
+    rng.random_sample()
     all_inds = np.arange(nwalkers)
     inds = all_inds % 2
     rng.shuffle(inds)
@@ -569,6 +572,9 @@ class DeviceEnsembleSampler(_SamplerBase):
         import torch
         be = self.backend
         W = self.nwalkers
+        # the device counter restarts with every new initial state; acceptances of earlier runs
+        # stay in the numerator, as their iterations stay in the denominator (_moves_done)
+        self._accepted_before = np.asarray(self._accepted, dtype=np.float64).copy()
         dev = dict(coords=be.tensor(coords, torch.float64),
                    naccept=be.zeros((W,), torch.int32), status=be.zeros((1,), torch.int32))
         if lp is None:
@@ -754,7 +760,7 @@ class DeviceEnsembleSampler(_SamplerBase):
         else:
             self._append(chain_host.numpy(), logp_host.numpy())
         self._moves_done += nsteps * thin_by
-        self._accepted = self._dev['naccept'].cpu().numpy().astype(np.float64)
+        self._accepted = self._accepted_before + self._dev['naccept'].cpu().numpy()
         self._coords = self._dev['coords'].cpu().numpy()
         self._lp = self._dev['logp'].cpu().numpy()
         self.timing['finish_s'] = time.perf_counter() - t_e

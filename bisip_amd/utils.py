@@ -54,10 +54,16 @@ def load_data(filename, headers=1, ph_units='mrad'):
     return columns_to_data(np.atleast_2d(table), ph_units)
 
 
-def load_data_batch(filenames, headers=1, ph_units='mrad'):
-    """Load many spectra that share one frequency count -> stacked operands
-    ``w (B,N)``, ``zn (B,2,N)``, ``zn_err (B,2,N)``, ``norm_factor (B,)``."""
-    items = [load_data(f, headers, ph_units) for f in filenames]
+def load_data_batch(spectra, headers=1, ph_units='mrad'):
+    """Ingest many spectra that share one frequency count (BASELINE config 5):
+    every item is a file path (read as ``load_data`` reads it) or a raw (N,5) table
+    [freq, amp, pha, amp_err, pha_err].  Returns the stacked operands of a batch context --
+    ``w (E,N)``, ``zn (E,2,N)``, ``zn_err (E,2,N)``, ``norm_factor (E,)``, ``N`` -- each row
+    exactly what the reference's per-file ``load_data`` yields (src/bisip/utils.py:108-146)."""
+    items = [load_data(sp, headers, ph_units) if isinstance(sp, (str, bytes)) or hasattr(sp, '__fspath__')
+             else columns_to_data(sp, ph_units) for sp in spectra]
+    if not items:
+        raise ValueError('no spectra')
     n = {d['N'] for d in items}
     if len(n) != 1:
         raise ValueError(f'spectra have different frequency counts: {sorted(n)}')

@@ -113,6 +113,15 @@ int bisip_forward(bisip_ctx *ctx, const double *theta, int64_t W, double *Z);
 int bisip_forward_dev(bisip_ctx *ctx, const double *d_theta, int64_t W, double *d_Z,
                       void *stream);
 
+/* Gaussian log-likelihood of a model response the caller evaluated itself: Z (W,2,N)
+ * [row 0 real, row 1 imaginary per walker] -> (W,)  =  -0.5*sum((zn - Z)^2/zn_err^2 +
+ * 2 ln zn_err^2).  Inversion._log_likelihood(theta, f, x, y, yerr) with a callable f that is
+ * not the model's own forward: src/bisip/models.py:59-62 (the host runs f, the reduction is
+ * this kernel).  No prior.  Single-spectrum contexts only. */
+int bisip_loglike_z(bisip_ctx *ctx, const double *Z, int64_t W, double *loglike);
+int bisip_loglike_z_dev(bisip_ctx *ctx, const double *d_Z, int64_t W, double *d_loglike,
+                        void *stream);
+
 /* ---- device-resident stretch move (the emcee inner loop the reference runs around the
  * log-probability: src/bisip/models.py:111-118; algorithm: emcee StretchMove with a
  * red/blue split, a = stretch scale) -------------------------------------------------

@@ -255,8 +255,77 @@ def test_model_classes_drop_in():
     # forward on another frequency grid (denser, for plotting)
     w2 = np.logspace(5, -2, 50)
     assert m.forward(g['theta'][i], w2).shape == (2, 50)
+    # the likelihood never touches the box of the context fit() / _log_probability use
+    assert np.array_equal(m._context().logprob(g['theta']), m.log_prob(g['theta']))
+    assert m._context().variant == 'reduced' and m._context(prior=False).variant == 'collapsed'
+
+
+def test_foreign_model_callable():
+    """The reference's _log_likelihood / _log_probability take ANY callable f(theta, x) -> (2,N)
+    (src/bisip/models.py:59-76).  A callable that is not the model's own forward runs on the
+    host, row by row as in the reference, and the residual reduction on the device
+    (bisip_loglike_z); checked against the reference's own formula in NumPy."""
+    import bisip_amd
+    path = bisip_amd.DataFiles()['SIP-K389175']
+    m = bisip_amd.PeltonColeCole(path, nwalkers=32, nsteps=10, n_modes=1)
+    d = m.data
+    calls = []
+
+    def debye(theta, w):      # a user model with the Pelton parameter vector, c forced to 1
+        calls.append(1)
+        r0, m1, lt, _ = theta
+        z = r0 * (1 - m1 * (1 - 1 / (1 + 1j * w * np.exp(lt))))
+        return np.array([z.real, z.imag])
+
+    rng = np.random.RandomState(3)
+    lo, hi = m.param_bounds
+    theta = rng.uniform(lo, hi, (70, 4))
+    theta[5, 1] = 1.5          # outside the prior
+    theta[9, 0] = hi[0]        # on the bound
+
+    def ref_ll(t):
+        sigma2 = d['zn_err'] ** 2
+        return -0.5 * np.sum((d['zn'] - debye(t, d['w'])) ** 2 / sigma2 + 2 * np.log(sigma2))
+
+    want_ll = np.array([ref_ll(t) for t in theta])
+    calls.clear()
+    got = m._log_likelihood(theta, debye, d['w'], d['zn'], d['zn_err'])
+    assert len(calls) == 70
+    assert_logp_close(got, want_ll)
+    one = m._log_likelihood(theta[0], debye, d['w'], d['zn'], d['zn_err'])
+    assert isinstance(one, float) and abs(one - want_ll[0]) <= 1e-10 * max(1, abs(want_ll[0]))
+    inside = np.logical_and(lo < theta, theta < hi).all(axis=1)
+    want_lp = np.where(inside, want_ll, -np.inf)
+    calls.clear()
+    got_lp = m._log_probability(theta, debye, m.param_bounds, d['w'], d['zn'], d['zn_err'])
+    assert len(calls) == inside.sum() == 68      # out-of-prior rows never reach f
+    assert_logp_close(got_lp, want_lp)
+    # the context entry point itself: shapes, empty batch, bad shape
+    ctx = m._context(prior=False)
+    assert ctx.loglike_z(np.empty((0, 2, 20))).shape == (0,)
     with pytest.raises(ValueError):
-        m._log_probability(g['theta'][i], lambda t, w: None, m.param_bounds, d['w'], d['zn'], d['zn_err'])
+        ctx.loglike_z(np.zeros((3, 2, 19)))
+    # with the model's own forward handed in as Z the two routes agree to rounding
+    Z = m.forward(theta, d['w'])
+    assert_logp_close(ctx.loglike_z(Z), m._log_likelihood(theta, m.forward, d['w'], d['zn'], d['zn_err']))
+
+
+def test_faithful_variant_fit_uses_the_host_loop():
+    """The stretch-move kernels exist for the reduced / collapsed formulations; a model pinned
+    to `faithful` samples through the host loop around that very kernel, and the C entry
+    refuses instead of silently evaluating another formulation."""
+    import bisip_amd
+    from bisip_amd.sampler import DeviceEnsembleSampler, EnsembleSampler
+    path = bisip_amd.DataFiles()['SIP-K389175']
+    m = bisip_amd.PolynomialDecomposition(path, nwalkers=32, nsteps=12, variant='faithful')
+    np.random.seed(4)
+    m.fit()
+    assert isinstance(m.sampler, EnsembleSampler)
+    lp = m.sampler.get_log_prob()[-1]
+    assert np.array_equal(lp, m._context().logprob(m.get_chain()[-1]))   # the faithful kernel's bits
+    dev = DeviceEnsembleSampler(32, 7, m._context(), persistent=False)
+    with pytest.raises(RuntimeError, match='faithful'):
+        dev.run_mcmc(m.p0, 2)
 
 
 def test_fit_runs_and_matches_oracle_replay():

@@ -60,6 +60,12 @@ def test_device_sampler_equals_host_sampler(prefix, model, variant):
         host.run_mcmc(None, 5)
         dev.run_mcmc(None, 5)
         assert np.array_equal(dev.get_chain(), host.get_chain())
+        # a second run from a NEW initial state: acceptances and iterations both keep accumulating
+        p1 = _start(g, W, 200 + W)
+        host.run_mcmc(p1, 6)
+        dev.run_mcmc(p1, 6)
+        assert np.array_equal(dev.get_chain(), host.get_chain())
+        assert np.array_equal(dev.acceptance_fraction, host.acceptance_fraction)
     ctx.close()
 
 

@@ -54,6 +54,32 @@ def test_rng_contract_and_bookkeeping():
     assert a.get_chain().shape[0] == 45 and a.iteration == 45
 
 
+def test_stream_follows_emcees_consumption_order():
+    """emcee's per-iteration RNG use, restated here literally:
+    ``random.choice(moves, p=weights)`` -- one uniform double even for a single move --, a
+    shuffle of the alternating labels, then rand / randint / rand per half.  draw_step must
+    leave the RandomState exactly where that sequence leaves it, every iteration."""
+    from bisip_amd.sampler import draw_step
+    W, ndim, a = 21, 4, 2.0
+    r1, r2 = np.random.RandomState(99), np.random.RandomState(99)
+    moves, weights = [object()], [1.0]
+    for _ in range(25):
+        halves = draw_step(r1, W, ndim, a)
+        r2.choice(moves, p=weights)
+        inds = np.arange(W) % 2
+        r2.shuffle(inds)
+        for split, h in zip((0, 1), halves):
+            S1 = inds == split
+            Ns, Nc = int(S1.sum()), int((~S1).sum())
+            zz = ((a - 1.0) * r2.rand(Ns) + 1) ** 2.0 / a
+            rint = r2.randint(Nc, size=(Ns,))
+            lnu = np.log(r2.rand(Ns))
+            assert np.array_equal(h['active'], np.arange(W)[S1])
+            assert np.array_equal(h['partner'], np.arange(W)[~S1][rint])
+            assert np.array_equal(h['zz'], zz) and np.array_equal(h['logu'], lnu)
+        assert r1.rand() == r2.rand()
+
+
 def test_input_validation():
     s = EnsembleSampler(8, 3, gaussian_logp, args=(np.zeros(3), np.eye(3)))
     with pytest.raises(ValueError):
