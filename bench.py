@@ -8,32 +8,43 @@ log-probability kernel over theta (W, 7) already resident in HBM.  Walkers shard
 across ranks with no data-path collective, so scaling is weak:
 each GPU gets the same W.
 
-    python bench.py                                   # 1 GPU
+    python bench.py                       # 1 GPU
+    python bench.py --gpus N              # N GPUs: this process starts the N ranks itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0.
+With --gpus N > 1 and no RANK in the environment the parent -- before it imports torch or
+touches a GPU -- starts `python -m torch.distributed.run ... bench.py <same flags>` as a child
+process, relays rank 0's JSON line and exits with the child's status (a failed rank is a
+failed run; nothing is retried).  Prints ONE JSON line on rank 0.
 """
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+MAX_CLOCK_HZ = 2.4e9           # same guide: max engine clock
+N_SIMD = 256 * 4               # 256 CUs x 4 SIMDs
+# A wave64 fp64 (or fp32) VALU instruction occupies its SIMD's 16-lane pipe for 4 cycles, so the
+# chip issues at most N_SIMD * clock / 4 VALU wave-instructions per second.
+VALU_PEAK_WAVE_INSTR_S = N_SIMD * MAX_CLOCK_HZ / 4.0
 N_FREQ = 32
 POLY_DEG = 5
 C_EXP = 1.0
+METRIC = 'log-prob evals/sec (walker-steps/s), PolynomialDecomposition 32 freq fp64'
 
 
 def make_problem(n_freq=N_FREQ, poly_deg=POLY_DEG, c_exp=C_EXP, spectrum_index=0):
     """Synthetic spectrum of SURVEY.md §8(d) + the PolynomialDecomposition precompute."""
+    import numpy as np
     from bisip_amd.synthetic import synthetic_columns
     from bisip_amd.utils import columns_to_data
     data = columns_to_data(synthetic_columns(n_freq, spectrum_index), 'mrad')
@@ -45,13 +56,57 @@ def make_problem(n_freq=N_FREQ, poly_deg=POLY_DEG, c_exp=C_EXP, spectrum_index=0
     return data, taus, log_taus, bounds
 
 
-def time_launches(ctx, theta_t, out_t, steps, warmup, torch, dist=None):
-    """Times `steps` launches; returns (wall seconds bracketed by barrier+sync, mean
-    kernel duration in ms from HIP events on the launch stream)."""
-    W = theta_t.shape[0]
-    stream = torch.cuda.current_stream()
+# The other log-probability kernels of the path at the BASELINE shapes (N = 32 frequencies),
+# measured after the headline so that BENCH_r*.json carries an achieved fraction for the
+# compute-bound ones too.  label -> (model id name, context kwargs, bounds)
+def kernel_zoo():
+    import numpy as np
+    b = {
+        'colecole1': ('COLECOLE', dict(n_modes=1), [[0.9, 0, -15, 0], [1.1, 1, 5, 1]]),
+        'colecole2': ('COLECOLE', dict(n_modes=2), [[0.9, 0, 0, -15, -15, 0, 0], [1.1, 1, 1, 5, 5, 1, 1]]),
+        'dias2000': ('DIAS2000', {}, [[0.9, 0, -20, 0, 0], [1.1, 1, 0, 150, 1]]),
+        'shin2015': ('SHIN2015', {}, [[0, 0, -15, -7, 0, 0], [1, 1, -13, -5, 1, 1]]),
+    }
+    return {k: (m, kw, np.array(v, dtype=np.float64)) for k, (m, kw, v) in b.items()}
+
+
+def load_json(name):
+    try:
+        return json.load(open(os.path.join(ROOT, 'profiles', name)))
+    except (OSError, ValueError):
+        return None
+
+
+def valu_roofline(label, W, kernel_ms, counts):
+    """fp64 VALU-issue roofline of one launch from the PMC-measured instruction count
+    (profiles/valu_counts.json, written by benchmarks/summarize_pmc.py from a
+    `rocprofv3 --pmc SQ_INSTS_VALU` pass of `bench.py --pmc-pass`)."""
+    rec = (counts or {}).get(label)
+    if not rec:
+        return None
+    per_eval = float(rec['valu_wave_instr_per_eval'])
+    achieved = per_eval * W / (kernel_ms * 1e-3)
+    return {'bound': 'fp64-valu-issue', 'achieved': achieved, 'peak': VALU_PEAK_WAVE_INSTR_S,
+            'unit': 'VALU wave-instr/s', 'frac': achieved / VALU_PEAK_WAVE_INSTR_S,
+            'valu_wave_instr_per_eval': per_eval, 'kernel': rec.get('kernel'),
+            'source': 'profiles/valu_counts.json (SQ_INSTS_VALU per launch / walkers); peak = 1024 SIMDs x 2.4 GHz / 4 cycles'}
+
+
+def prime(fn, seconds, torch):
+    """Untimed back-to-back launches: the first ~0.1 s after an idle period run 5-25 % slower
+    (clock / fabric ramp, first touch of the buffers)."""
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(20):
+            fn()
+        torch.cuda.synchronize()
+
+
+def time_launches(fn, steps, warmup, torch, stream, dist=None):
+    """Times `steps` calls of fn (one kernel launch each); returns (wall seconds bracketed by
+    barrier+sync, mean kernel duration in ms from HIP events on the launch stream)."""
     for _ in range(warmup):
-        ctx.logprob_dev(theta_t.data_ptr(), W, out_t.data_ptr(), stream.cuda_stream)
+        fn()
     ev0 = torch.cuda.Event(enable_timing=True)
     ev1 = torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
@@ -61,7 +116,7 @@ def time_launches(ctx, theta_t, out_t, steps, warmup, torch, dist=None):
     t0 = time.perf_counter()
     ev0.record(stream)            # HIP events on the stream the kernel is launched on
     for _ in range(steps):
-        ctx.logprob_dev(theta_t.data_ptr(), W, out_t.data_ptr(), stream.cuda_stream)
+        fn()
     ev1.record(stream)
     torch.cuda.synchronize()
     if dist is not None:
@@ -75,20 +130,22 @@ def time_launches(ctx, theta_t, out_t, steps, warmup, torch, dist=None):
 def cpu_baseline(data, taus, log_taus, bounds, theta, gpu_logp):
     """Oracle (CPU restatement of the reference loop, libm cpow) on a bounded sample of
     the same workload, on this box's host cores.  Also the parity spot-check."""
+    import numpy as np
     import oracle
+    from bisip_amd.utils import cpu_quota
     prob = oracle.OracleProblem('PolynomialDecomposition', data['w'], data['zn'], data['zn_err'],
                                 bounds, taus=taus, log_taus=log_taus, c_exp=C_EXP)
     try:
-        cores = len(os.sched_getaffinity(0))
+        visible = len(os.sched_getaffinity(0))
     except AttributeError:
-        cores = os.cpu_count() or 1
-    threads = max(1, min(cores, 16, oracle.max_threads()))
+        visible = os.cpu_count() or 1
+    quota = cpu_quota()       # what the container may actually burn (CFS quota), <= visible
+    threads = max(1, min(quota, oracle.max_threads()))
     # calibrate on 1 core, then size the threaded sample for ~20 s of CPU work
     n1 = min(4096, theta.shape[0])
     t0 = time.perf_counter()
-    ref1 = oracle.logprob(prob, theta[:n1], n_threads=1)
-    t1 = time.perf_counter() - t0
-    rate1 = n1 / t1
+    oracle.logprob(prob, theta[:n1], n_threads=1)
+    rate1 = n1 / (time.perf_counter() - t0)
     n = int(min(theta.shape[0], max(n1, rate1 * 20.0)))
     t0 = time.perf_counter()
     ref = oracle.logprob(prob, theta[:n], n_threads=threads)
@@ -96,13 +153,61 @@ def cpu_baseline(data, taus, log_taus, bounds, theta, gpu_logp):
     fin = np.isfinite(ref)
     err = float(np.max(np.abs(gpu_logp[:n][fin] - ref[fin]) / np.maximum(1.0, np.abs(ref[fin]))))
     same_inf = bool(np.array_equal(np.isneginf(gpu_logp[:n]), np.isneginf(ref)))
-    return {
+    out = {
         'value': n / tn, 'unit': 'evals/s', 'cores': threads, 'kind': 'port',
         'sample': f'first {n} walkers of the same theta batch, oracle/bisip_oracle.c '
                   f'(loop-faithful, glibc cpow) with {threads} OpenMP threads',
         'value_1core': rate1, 'sample_1core': f'first {n1} walkers, 1 thread',
-        'host_cpus_visible': cores,
-    }, err, same_inf
+        'host_cpus_visible': visible, 'cpu_quota': quota,
+    }
+    cal = load_json('cpu_calibration.json')
+    if cal:
+        # the real reference (Cython + NumPy per-walker call) against this same oracle, one core,
+        # measured in the build container by benchmarks/cpu_calibration.py
+        r = float(cal['reference_over_oracle'])
+        out['reference_calibration'] = {
+            'reference_over_oracle_1core': r,
+            'reference_evals_per_s_1core_there': cal['reference_evals_per_s_1core'],
+            'oracle_evals_per_s_1core_there': cal['oracle_evals_per_s_1core'],
+            'estimated_reference_1core_here': rate1 * r,
+            'estimated_reference_all_cores_here': (n / tn) * r,
+            'source': 'profiles/cpu_calibration.json (build container, ' + cal['machine']['cpu'] + ')',
+        }
+    return out, err, same_inf
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(n, argv):
+    """Parent of a multi-GPU run: start the ranks, relay rank 0's line, exit with their status.
+    Nothing here imports torch or touches the GPU."""
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}',
+           '--master-addr', '127.0.0.1', '--master-port', str(free_port()),
+           os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '1')      # torchrun would set it anyway, with a warning
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    out, _ = proc.communicate()
+    lines = out.splitlines()
+    result = [ln for ln in lines if ln.startswith('{"metric"')]
+    for ln in lines:
+        if not ln.startswith('{"metric"'):
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0:
+        print(f'bench.py: the {n}-rank run failed with status {proc.returncode}', file=sys.stderr)
+        sys.exit(proc.returncode)
+    if len(result) != 1:
+        print(f'bench.py: expected one result line from rank 0, got {len(result)}', file=sys.stderr)
+        sys.exit(1)
+    print(result[0])
+    sys.exit(0)
 
 
 def main():
@@ -118,12 +223,24 @@ def main():
                     help='process-group backend; gloo + --same-device rehearses the multi-rank '
                          'control flow on a one-GPU box (RCCL refuses two ranks on one device)')
     ap.add_argument('--same-device', action='store_true', help='all ranks use cuda:0 (rehearsal only)')
+    ap.add_argument('--rehearse-cpu', action='store_true',
+                    help='control flow only (launch, rendezvous, barriers, reductions, the JSON line) with '
+                         'NO kernel: value is null.  For the CPU test of the multi-rank path; never a measurement')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-variants', action='store_true')
+    ap.add_argument('--pmc-pass', action='store_true',
+                    help='one launch of every kernel this file times, in a fixed order, nothing else: the '
+                         'target of `rocprofv3 --pmc SQ_INSTS_VALU` (benchmarks/collect_profiles.sh)')
     args = ap.parse_args()
+
+    if args.gpus < 1:
+        ap.error('--gpus must be >= 1')
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        self_launch(args.gpus, sys.argv[1:])     # does not return
 
     # read by the HSA runtime when the GPU is first touched: set before anything initialises it
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    import numpy as np
     import torch
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -131,107 +248,198 @@ def main():
     dist = None
     if args.same_device:
         local_rank = 0
-    torch.cuda.set_device(local_rank)
+    rehearse = args.rehearse_cpu
+    if rehearse and args.backend != 'gloo':
+        ap.error('--rehearse-cpu needs --backend gloo')
+    if not rehearse:
+        torch.cuda.set_device(local_rank)
     if 'RANK' in os.environ:   # launched by torch.distributed.run: one rank per GPU over RCCL
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         if args.backend == 'nccl':
             dist.init_process_group('nccl', rank=rank, world_size=world,
                                     device_id=torch.device('cuda', local_rank))
         else:
             dist.init_process_group('gloo', rank=rank, world_size=world)
-    if args.gpus != world and rank == 0:
-        print(f'warning: --gpus {args.gpus} but WORLD_SIZE {world}', file=sys.stderr)
+    if args.gpus != world:
+        # a line that says n_gpus = N must come from N ranks
+        if rank == 0:
+            print(f'bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}', file=sys.stderr)
+        sys.exit(2)
+    coll_dev = f'cuda:{local_rank}' if (args.backend == 'nccl' and not rehearse) else 'cpu'
 
-    from bisip_amd import _hip
-    from bisip_amd.synthetic import synthetic_theta
-    from bisip_amd.utils import respect_cpu_quota
-    # host thread pools sized by the node's core count would be throttled by the container's
-    # CPU quota at some random moment, possibly inside the timed region
-    respect_cpu_quota()
-
-    data, taus, log_taus, bounds = make_problem()
-    ctx = _hip.HipContext(_hip.MODEL_POLYDECOMP, data['w'], data['zn'], data['zn_err'], bounds,
-                          device=local_rank, poly_deg=POLY_DEG, c_exp=C_EXP, taus=taus,
-                          log_taus=log_taus, variant=args.variant)
     ndim = POLY_DEG + 2
     W = int(args.walkers)
-    # walker positions: uniform in the prior box (100 % in-prior: no early-exit savings)
-    theta = synthetic_theta(bounds[0], bounds[1], W, seed=2024 + rank)
-    theta_t = torch.from_numpy(theta).to(f'cuda:{local_rank}')
-    out_t = torch.empty(W, dtype=torch.float64, device=f'cuda:{local_rank}')
+    if rehearse:
+        wall, kern_ms = 0.0, 0.0
+        if dist is not None:
+            dist.barrier()
+            t0 = time.perf_counter()
+            dist.barrier()
+            wall = time.perf_counter() - t0
+        ctx = None
+    else:
+        from bisip_amd import _hip
+        from bisip_amd.synthetic import synthetic_theta
+        from bisip_amd.utils import respect_cpu_quota
+        # host thread pools sized by the node's core count would be throttled by the container's
+        # CPU quota at some random moment, possibly inside the timed region
+        respect_cpu_quota()
 
-    # Device warm-up (setup, untimed): the first ~0.1 s of launches after an idle period run
-    # 5-8 % slower (fabric/memory clocks ramping, first touch of a 1 GB buffer); prime the
-    # device so that the W warm-up steps and the K timed steps see steady state.
-    prime_t0 = time.perf_counter()
-    while time.perf_counter() - prime_t0 < args.prime_seconds:
-        for _ in range(50):
-            ctx.logprob_dev(theta_t.data_ptr(), W, out_t.data_ptr(), torch.cuda.current_stream().cuda_stream)
-        torch.cuda.synchronize()
+        data, taus, log_taus, bounds = make_problem()
+        ctx = _hip.HipContext(_hip.MODEL_POLYDECOMP, data['w'], data['zn'], data['zn_err'], bounds,
+                              device=local_rank, poly_deg=POLY_DEG, c_exp=C_EXP, taus=taus,
+                              log_taus=log_taus, variant=args.variant)
+        # walker positions: uniform in the prior box (100 % in-prior: no early-exit savings)
+        theta = synthetic_theta(bounds[0], bounds[1], W, seed=2024 + rank)
+        theta_t = torch.from_numpy(theta).to(f'cuda:{local_rank}')
+        out_t = torch.empty(W, dtype=torch.float64, device=f'cuda:{local_rank}')
+        stream = torch.cuda.current_stream()
 
-    wall, kern_ms = time_launches(ctx, theta_t, out_t, args.steps, args.warmup, torch, dist)
+        def step():
+            ctx.logprob_dev(theta_t.data_ptr(), W, out_t.data_ptr(), stream.cuda_stream)
+
+        if args.pmc_pass:
+            pmc_pass(ctx, step, theta_t, out_t, data, torch)
+            return
+        prime(step, args.prime_seconds, torch)
+        wall, kern_ms = time_launches(step, args.steps, args.warmup, torch, stream, dist)
+
+    ranks_seen, per_rank_kernel_ms = 1, [kern_ms]
     if dist is not None:
-        t = torch.tensor([wall, kern_ms], dtype=torch.float64,
-                         device=f'cuda:{local_rank}' if args.backend == 'nccl' else 'cpu')
+        t = torch.tensor([wall, kern_ms], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall, kern_ms = float(t[0]), float(t[1])
+        one = torch.ones(1, dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)     # every rank that ran adds itself
+        mine = torch.tensor([kern_ms], dtype=torch.float64, device=coll_dev)
+        every = torch.empty(world, dtype=torch.float64, device=coll_dev)
+        dist.all_gather_into_tensor(every, mine)
+        wall, kern_ms = float(t[0]), float(t[1])       # slowest rank
+        ranks_seen = int(round(float(one[0])))
+        per_rank_kernel_ms = [float(x) for x in every.cpu()]
 
     if rank == 0:
-        total_evals = float(W) * world * args.steps
-        value = total_evals / wall
-        bytes_per_eval = 8 * (ndim + 1)            # read one theta row, write one logp
-        achieved = bytes_per_eval * W / (kern_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-        if os.path.exists(tpath):
-            try:
-                rec = json.load(open(tpath))
-                if rec.get('walkers') == W and rec.get('kernel') == ctx.kernel_name:
-                    traffic = rec.get('hbm_bytes_per_launch')
-            except Exception:
-                traffic = None
         result = {
-            'metric': 'log-prob evals/sec (walker-steps/s), PolynomialDecomposition 32 freq fp64',
-            'value': value, 'unit': 'evals/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': wall / args.steps * 1e3,
+            'metric': METRIC, 'value': None, 'unit': 'evals/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': None,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': 'PolynomialDecomposition poly_deg=5 c_exp=1.0, 32 synthetic '
-                                   'frequencies (S=64 taus), ndim 7, theta uniform in the prior box',
-                       'walkers_per_gpu': W, 'global_walkers': W * world,
-                       'parallelism': f'walker-sharded x{world}, no data-path collective',
-                       'kernel': ctx.kernel_name, 'variant': ctx.variant},
-            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'bytes_per_eval': bytes_per_eval, 'kernel_ms': kern_ms,
-                         'traffic_source': 'profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / '
-                                           'WRITE_SIZE passes of this command (FETCH_SIZE x2, gfx950)'
-                                           if traffic is not None else None},
+            'dtype': 'f64', 'data': 'synthetic', 'ranks_seen': ranks_seen,
         }
-        if world == 1:
-            gpu_logp = out_t.cpu().numpy()
-            if not args.no_variants:
-                variants = {}
-                for v in ('reduced', 'collapsed', 'faithful', 'wave'):
-                    ctx.set_variant(v)
-                    k = max(3, min(args.steps, 10))
-                    _, ms = time_launches(ctx, theta_t, out_t, k, 2, torch)
-                    variants[v] = {'evals_per_s': W / (ms * 1e-3), 'kernel_ms': ms,
-                                   'kernel': ctx.kernel_name}
-                ctx.set_variant(args.variant)
-                result['variants'] = variants
-            if not args.no_cpu_baseline:
-                cb, err, same_inf = cpu_baseline(data, taus, log_taus, bounds, theta, gpu_logp)
-                result['cpu_baseline'] = cb
-                result['parity'] = {'max_rel_err_vs_oracle': err, 'neg_inf_rows_match': same_inf,
-                                    'tolerance': 1e-10}
+        if rehearse:
+            result['rehearsal'] = 'control flow only: no kernel ran, not a measurement'
+            result['config'] = {'workload': 'none (--rehearse-cpu)', 'backend': args.backend}
+        else:
+            bytes_per_eval = 8 * (ndim + 1)            # read one theta row, write one logp
+            achieved = bytes_per_eval * W / (kern_ms * 1e-3) / 1e9    # per GPU, slowest rank
+            traffic = None
+            rec = load_json('pmc_traffic.json')
+            if rec and rec.get('walkers') == W and rec.get('kernel') == ctx.kernel_name:
+                traffic = rec.get('hbm_bytes_per_launch')
+            result.update({
+                'value': float(W) * world * args.steps / wall,
+                'ms_per_step': wall / args.steps * 1e3,
+                'config': {'workload': 'PolynomialDecomposition poly_deg=5 c_exp=1.0, 32 synthetic '
+                                       'frequencies (S=64 taus), ndim 7, theta uniform in the prior box',
+                           'walkers_per_gpu': W, 'global_walkers': W * world,
+                           'parallelism': f'walker-sharded x{world}, no data-path collective',
+                           'backend': args.backend if dist is not None else None,
+                           'kernel': ctx.kernel_name, 'variant': ctx.variant},
+                'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                             'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                             'bytes_per_eval': bytes_per_eval, 'kernel_ms': kern_ms,
+                             'per': 'GPU (slowest rank)', 'per_rank_kernel_ms': per_rank_kernel_ms,
+                             'traffic_source': 'profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / '
+                                               'WRITE_SIZE passes of this command (FETCH_SIZE x2, gfx950)'
+                                               if traffic is not None else None},
+            })
+            if world == 1:
+                counts = load_json('valu_counts.json')
+                gpu_logp = out_t.cpu().numpy()
+                if not args.no_variants:
+                    result['variants'] = time_variants(ctx, args, step, W, torch, stream, counts)
+                    result['kernels'] = time_zoo(data, args, torch, stream, counts, local_rank)
+                if not args.no_cpu_baseline:
+                    cb, err, same_inf = cpu_baseline(data, taus, log_taus, bounds, theta, gpu_logp)
+                    result['cpu_baseline'] = cb
+                    result['parity'] = {'max_rel_err_vs_oracle': err, 'neg_inf_rows_match': same_inf,
+                                        'tolerance': 1e-10}
         print(json.dumps(result))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def time_variants(ctx, args, step, W, torch, stream, counts):
+    """The other formulations of the same log-probability (same theta, same W), each primed
+    like the headline before it is timed."""
+    variants = {}
+    for v in ('reduced', 'collapsed', 'faithful', 'wave'):
+        ctx.set_variant(v)
+        prime(step, min(args.prime_seconds, 0.3), torch)
+        k = max(3, min(args.steps, 10))
+        _, ms = time_launches(step, k, 2, torch, stream)
+        rec = {'evals_per_s': W / (ms * 1e-3), 'kernel_ms': ms, 'kernel': ctx.kernel_name,
+               'hbm_frac': 64 * W / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        rv = valu_roofline(v, W, ms, counts)
+        if rv:
+            rec['roofline_valu'] = rv
+        variants[v] = rec
+    ctx.set_variant(args.variant)
+    return variants
+
+
+def zoo_contexts(data, local_rank, W):
+    import torch
+    from bisip_amd import _hip
+    from bisip_amd.synthetic import synthetic_theta
+    for label, (model, kw, bounds) in kernel_zoo().items():
+        ctx = _hip.HipContext(getattr(_hip, 'MODEL_' + model), data['w'], data['zn'], data['zn_err'], bounds,
+                              device=local_rank, **kw)
+        th = torch.from_numpy(synthetic_theta(bounds[0], bounds[1], W, seed=7)).to(f'cuda:{local_rank}')
+        out = torch.empty(W, dtype=torch.float64, device=f'cuda:{local_rank}')
+        yield label, ctx, th, out, bounds.shape[1]
+
+
+ZOO_WALKERS = 1 << 22
+
+
+def time_zoo(data, args, torch, stream, counts, local_rank):
+    """The transcendental-bound models at N = 32 (cfg2 / cfg5's kernels), 4M walkers each."""
+    out = {}
+    for label, ctx, th, o, ndim in zoo_contexts(data, local_rank, ZOO_WALKERS):
+        def fn():
+            ctx.logprob_dev(th.data_ptr(), ZOO_WALKERS, o.data_ptr(), stream.cuda_stream)
+        prime(fn, min(args.prime_seconds, 0.3), torch)
+        _, ms = time_launches(fn, 10, 2, torch, stream)
+        rec = {'evals_per_s': ZOO_WALKERS / (ms * 1e-3), 'kernel_ms': ms, 'kernel': ctx.kernel_name,
+               'walkers': ZOO_WALKERS, 'n_freq': N_FREQ,
+               'hbm_frac': 8 * (ndim + 1) * ZOO_WALKERS / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        rv = valu_roofline(label, ZOO_WALKERS, ms, counts)
+        if rv:
+            rec['roofline_valu'] = rv
+        out[label] = rec
+        ctx.close()
+    return out
+
+
+def pmc_pass(ctx, step, theta_t, out_t, data, torch):
+    """ONE launch per kernel in a fixed order (the four PolynomialDecomposition formulations at
+    the headline W, then the zoo): under `rocprofv3 --pmc SQ_INSTS_VALU` each dispatch's counter
+    is that kernel's VALU wave-instruction count per launch."""
+    order = []
+    for v in ('reduced', 'collapsed', 'faithful', 'wave'):
+        ctx.set_variant(v)
+        step()
+        torch.cuda.synchronize()
+        order.append({'label': v, 'kernel': ctx.kernel_name, 'walkers': int(theta_t.shape[0])})
+    stream = torch.cuda.current_stream()
+    for label, zctx, th, o, _ in zoo_contexts(data, ctx.device, ZOO_WALKERS):
+        zctx.logprob_dev(th.data_ptr(), ZOO_WALKERS, o.data_ptr(), stream.cuda_stream)
+        torch.cuda.synchronize()
+        order.append({'label': label, 'kernel': zctx.kernel_name, 'walkers': ZOO_WALKERS})
+        zctx.close()
+    print(json.dumps({'pmc_pass': order}))
 
 
 if __name__ == '__main__':

@@ -27,6 +27,10 @@ if [ "$what" = bench ] || [ "$what" = all ]; then
         python3 "$repo/bench.py" --no-cpu-baseline --no-variants --steps 20 --prime-seconds 0.1 > "$out/pmc_$c.json" 2> "$out/pmc_$c.err")
     keep "$scratch/pmc_$c" pmc_$c
   done
+  echo "== bench.py --pmc-pass --pmc SQ_INSTS_VALU" | tee -a "$out/progress.log"
+  (cd /tmp && rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU --output-format csv -d "$scratch/pmc_valu" -- \
+      python3 "$repo/bench.py" --pmc-pass > "$out/pmc_valu.json" 2> "$out/pmc_valu.err")
+  keep "$scratch/pmc_valu" pmc_valu
 fi
 if [ "$what" = sweep ] || [ "$what" = all ]; then
   echo "== sweep" | tee -a "$out/progress.log"

@@ -5,6 +5,11 @@ profiles/pmc_traffic.json (the number bench.py reports as roofline.traffic).
 
     python benchmarks/summarize_pmc.py gpurun_out profiles r01
 
+When gpurun_out/pmc_valu/ holds a `rocprofv3 --pmc SQ_INSTS_VALU` pass of `bench.py --pmc-pass`
+(one launch per kernel, order printed by the run itself in gpurun_out/pmc_valu.json) it also
+writes profiles/valu_counts.json: VALU wave-instructions per eval of every kernel bench.py
+times, the numerator of `roofline_valu`.
+
 HBM bytes per launch = 2 * FETCH_SIZE[KB] * 1024 + WRITE_SIZE[KB] * 1024: on gfx950 the
 fetch counter tallies the 128-byte requests of a 16-B/lane coalesced stream at 64 B
 (MI355X_MICROARCH.md, HBM / rocprofv3 section); WRITE_SIZE is taken as is.
@@ -50,3 +55,45 @@ rec = {
 }
 json.dump(rec, open(os.path.join(dst, 'pmc_traffic.json'), 'w'), indent=1)
 print(json.dumps(rec))
+
+
+def valu_counts():
+    order_file = os.path.join(src, 'pmc_valu.json')
+    files = glob.glob(os.path.join(src, 'pmc_valu', '*', '*counter_collection.csv'))
+    if not files or not os.path.exists(order_file):
+        return
+    order = None
+    for line in open(order_file):
+        if line.startswith('{"pmc_pass"'):
+            order = json.loads(line)['pmc_pass']
+    if order is None:
+        sys.exit(f'no pmc_pass line in {order_file}')
+    disp = []
+    for f in files:
+        for r in csv.DictReader(open(f)):
+            if r['Counter_Name'] == 'SQ_INSTS_VALU' and 'k_logprob' in r['Kernel_Name']:
+                disp.append((int(r['Dispatch_Id']), r['Kernel_Name'], float(r['Counter_Value']), int(r['Grid_Size'])))
+    disp.sort()
+    # a dispatch may appear once per XCD/agent row: sum rows of one dispatch id
+    merged = {}
+    for d, name, val, grid in disp:
+        m = merged.setdefault(d, [name, 0.0, grid])
+        m[1] += val
+    rows = [merged[k] for k in sorted(merged)]
+    if len(rows) != len(order):
+        sys.exit(f'{len(rows)} log-prob dispatches in the counter file, {len(order)} in the pass order')
+    out = {}
+    for o, (name, val, grid) in zip(order, rows):
+        short = o['kernel'].split('<')[0]
+        if short not in name:
+            sys.exit(f'dispatch order mismatch: expected {o["kernel"]}, saw {name}')
+        out[o['label']] = {'kernel': name, 'walkers': o['walkers'], 'SQ_INSTS_VALU_per_launch': val,
+                           'valu_wave_instr_per_eval': val / o['walkers']}
+    out['_note'] = (f'rocprofv3 --pmc SQ_INSTS_VALU on `python3 bench.py --pmc-pass` ({tag}); one launch per kernel; '
+                    'wave-instructions summed over all waves of the launch')
+    json.dump(out, open(os.path.join(dst, 'valu_counts.json'), 'w'), indent=1)
+    print(json.dumps(out))
+
+
+valu_counts()
+

@@ -156,3 +156,34 @@ def test_batch_replica_sharding():
     blocks = [shard_range(n, 8, r) for r in range(8)]
     assert blocks[0] == (0, 512) and blocks[-1] == (3584, 4096)
     assert all(b - a == 512 for a, b in blocks)
+
+
+def _run_bench(*flags):
+    import subprocess
+    return subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), *flags], capture_output=True,
+                          text=True, timeout=600, cwd=ROOT)
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no RANK in the environment must itself become a 2-rank run
+    (the parent starts torch.distributed.run before touching any GPU) and say so: n_gpus 2,
+    ranks_seen 2 from an all-reduce over the ranks.  --rehearse-cpu runs the whole control flow
+    (launch, rendezvous, barriers, reductions, the one JSON line) with no kernel -- value is null."""
+    import json
+    r = _run_bench('--gpus', '2', '--backend', 'gloo', '--rehearse-cpu', '--steps', '3', '--warmup', '1')
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1                      # rank 0's line only; everything else went to stderr
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 2 and rec['ranks_seen'] == 2
+    assert rec['value'] is None and 'not a measurement' in rec['rehearsal']
+    assert rec['steps'] == 3 and rec['warmup'] == 1 and rec['scaling'] == 'weak'
+
+
+def test_bench_fails_when_a_rank_fails():
+    """A failed child is a failed run: non-zero exit, no result line, no retry."""
+    r = _run_bench('--gpus', '2', '--backend', 'nccl', '--rehearse-cpu')   # every rank rejects this combination
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert 'failed with status' in r.stderr
+

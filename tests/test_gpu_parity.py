@@ -717,3 +717,26 @@ def test_cyth_named_functions_match_reference_golden(path):
             Z = cf.Shin2015_cyth(w, th[0:2].copy(), th[2:4].copy(), th[4:6].copy())
         assert Z.shape == (2, w.size) and Z.dtype == np.float64
         assert_Z_close(Z[None], g['Z'][row][None])
+
+
+def test_bench_two_ranks_on_one_device():
+    """`python bench.py --gpus 2` from a plain shell: the parent starts the two ranks itself; here
+    both use cuda:0 over gloo (RCCL refuses two ranks on one device), each runs the real kernel on
+    its own walkers, and the line reports 2 ranks seen, a per-rank kernel time and their sum rate."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo',
+                        '--same-device', '--walkers', str(1 << 20), '--steps', '4', '--warmup', '1',
+                        '--prime-seconds', '0.05'], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 2 and rec['ranks_seen'] == 2 and rec['scaling'] == 'weak'
+    assert rec['config']['global_walkers'] == 2 << 20 and rec['config']['kernel'] == 'k_logprob_pd_reduced'
+    assert len(rec['roofline']['per_rank_kernel_ms']) == 2 and min(rec['roofline']['per_rank_kernel_ms']) > 0
+    assert rec['value'] > 1e8 and 'cpu_baseline' not in rec       # rank-0-at-N=1 extras stay out
+
