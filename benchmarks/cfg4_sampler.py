@@ -27,6 +27,9 @@ def main():
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--rng', default='philox')
     ap.add_argument('--fused', action='store_true', help='single-rank fused path (no collective)')
+    ap.add_argument('--loop', default='rccl', choices=['rccl', 'rccl-own', 'python'],
+                    help="who drives the sharded half-steps: one C call per chunk over RCCL (torch's "
+                         "communicator / one of its own) or the Python loop over torch.distributed")
     ap.add_argument('--chain', default='host', choices=['host', 'device'],
                     help="'device': the chain stays in HBM (no pinned host buffer, no copy)")
     args = ap.parse_args()
@@ -56,11 +59,13 @@ def main():
         np.random.seed(7)
         return DeviceEnsembleSampler(args.walkers, 7, ctx, rng=args.rng, seed=11, distributed=True,
                                      force_sharded_path=not args.fused, persistent=False,
-                                     chain_on_device=(args.chain == 'device'))
+                                     chain_on_device=(args.chain == 'device'), sharded_loop=args.loop)
     prime = time.perf_counter()           # warm-up + clocks up
     while time.perf_counter() - prime < 0.25:
         make().run_mcmc(p0, 20)
     s = make()
+    if not args.fused:
+        s._sharded_comm()   # communicator set-up (ncclCommInitRank for 'rccl-own': ~45 ms) is not a half-step
     dist.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     s.run_mcmc(p0, args.steps)
@@ -70,6 +75,7 @@ def main():
         print(json.dumps({'config': 'cfg4 Debye decomposition S=40 N=20 P=5', 'walkers': args.walkers,
                           'n_gpus': world, 'steps': args.steps, 'rng': args.rng,
                           'path': 'fused (no collective)' if args.fused else 'eval -> all_gather -> apply',
+                          'driver': s.last_path,
                           'seconds': round(dt, 4), 'it_per_s': round(args.steps / dt, 1),
                           'walker_steps_per_s': float('%.4g' % (args.steps * args.walkers / dt)),
                           'chain': args.chain,

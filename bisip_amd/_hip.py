@@ -77,6 +77,12 @@ SYMBOLS = {
     'bisip_stretch_apply_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(StretchArgs), ctypes.c_void_p]),
     'bisip_stretch_run_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(StretchArgs), ctypes.c_int64,
                                              ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]),
+    'bisip_stretch_run_sharded_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(StretchArgs),
+                                                     ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]),
+    'bisip_rccl_unique_id': (ctypes.c_int, [ctypes.c_void_p]),
+    'bisip_rccl_comm_create': (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int,
+                                              ctypes.c_void_p, ctypes.c_int]),
+    'bisip_rccl_comm_destroy': (ctypes.c_int, [ctypes.c_void_p]),
     'bisip_stretch_draw_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_double,
                                               ctypes.c_uint64, ctypes.c_int64, ctypes.c_int64] +
                                [ctypes.c_void_p] * 7),
@@ -329,6 +335,11 @@ class HipContext:
         _check(self._lib.bisip_stretch_run_dev(self._h, ctypes.byref(first_args), int(W),
                                                int(n_steps), int(thin_by), ctypes.c_void_p(stream)))
 
+    def stretch_run_sharded_dev(self, comm, first_args, W, n_steps, thin_by=1, stream=0):
+        """``comm``: an ncclComm_t as an integer (rccl_comm_create() or torch's _comm_ptr())."""
+        _check(self._lib.bisip_stretch_run_sharded_dev(self._h, ctypes.c_void_p(comm), ctypes.byref(first_args),
+                                                       int(W), int(n_steps), int(thin_by), ctypes.c_void_p(stream)))
+
     def stretch_persistent_dev(self, args, stream=0):
         """Returns False when the ensemble does not fit one workgroup (status -4)."""
         rc = self._lib.bisip_stretch_persistent_dev(self._h, ctypes.byref(args), ctypes.c_void_p(stream))
@@ -343,6 +354,30 @@ class HipContext:
                                                 int(n_steps), *[ctypes.c_void_p(p) for p in
                                                                 (perm, active, partner, zz, factor, logu)],
                                                 ctypes.c_void_p(stream)))
+
+
+RCCL_ID_BYTES = 128
+
+
+def rccl_unique_id():
+    """ncclGetUniqueId as bytes (rank 0 makes it, every rank passes it to rccl_comm_create)."""
+    buf = ctypes.create_string_buffer(RCCL_ID_BYTES)
+    _check(load_library().bisip_rccl_unique_id(buf))
+    return buf.raw
+
+
+def rccl_comm_create(world, rank, unique_id, device):
+    """ncclCommInitRank on ``device`` (collective over the ranks); returns the ncclComm_t as int."""
+    if len(unique_id) != RCCL_ID_BYTES:
+        raise ValueError(f'unique_id must be {RCCL_ID_BYTES} bytes')
+    comm = ctypes.c_void_p()
+    buf = ctypes.create_string_buffer(bytes(unique_id), RCCL_ID_BYTES)
+    _check(load_library().bisip_rccl_comm_create(ctypes.byref(comm), int(world), int(rank), buf, int(device)))
+    return comm.value
+
+
+def rccl_comm_destroy(comm):
+    _check(load_library().bisip_rccl_comm_destroy(ctypes.c_void_p(comm)))
 
 
 def chain_moments_workspace(n_samples, n_ensembles, ndim):

@@ -351,6 +351,7 @@ void bisip_ctx_destroy(bisip_ctx *c)
     if (c->d_lconst) (void)hipFree(c->d_lconst);
     if (c->d_red) (void)hipFree(c->d_red);
     if (c->d_ws) (void)hipFree(c->d_ws);
+    if (c->d_gather) (void)hipFree(c->d_gather);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;

@@ -67,6 +67,8 @@ struct bisip_ctx {
     // workspace of the host-pointer entry points
     double *d_ws = nullptr;
     size_t ws_bytes = 0;
+    double *d_gather = nullptr;    // sharded sampler: world slabs of ceil(slots/world) x (ndim+2)
+    size_t gather_bytes = 0;
     char *h_pin = nullptr;         // pinned, device-mapped staging for small host-buffer calls
     char *d_pin = nullptr;         // its device-side address
     static constexpr size_t PIN_BYTES = 1 << 20;

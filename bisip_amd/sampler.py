@@ -179,11 +179,13 @@ class _SamplerBase:
         # (all ranks must construct the sampler with the same NumPy RNG state)
         self._group = group
         self._world, self._rank = 1, 0
+        self._in_group = False      # True: collectives go through torch.distributed's `group`
         if distributed:
             import torch.distributed as dist
             if dist.is_initialized():
                 self._world = dist.get_world_size(group)
                 self._rank = dist.get_rank(group)
+                self._in_group = True
         self._random = np.random.mtrand.RandomState()
         self._random.set_state(np.random.get_state())
         self.reset()
@@ -446,6 +448,39 @@ class HipStretchBackend:
         self.ctx.stretch_run_dev(self._args(st, 0, 0, (W + 1) // 2, base=True), W, n_steps,
                                  st.get('thin', 1), self.stream())
 
+    def run_sharded(self, st, n_steps, comm):
+        """All n_steps iterations of a chunk with the walkers sharded over the ranks of the RCCL
+        communicator ``comm`` (an ncclComm_t as int): eval -> ncclAllGather -> apply per half-step,
+        enqueued by one C call on the compute stream."""
+        W = st['coords'].shape[0]
+        self.ctx.stretch_run_sharded_dev(comm, self._args(st, 0, 0, (W + 1) // 2, base=True), W, n_steps,
+                                         st.get('thin', 1), self.stream())
+
+    def rccl_comm(self, group, world, rank, prefer='torch', in_group=True):
+        """An ncclComm_t (int) spanning the ranks of ``group``, or None when the group does not
+        run over RCCL (gloo: the caller keeps the Python eval / all_gather / apply loop).
+        ``prefer='torch'`` hands the C loop the communicator torch.distributed already built for
+        this group; 'own' (and the fallback) creates one from a unique id broadcast through the
+        group.  Returns (comm, owned)."""
+        from . import _hip
+        if not in_group:      # a single process outside torch.distributed: a one-rank communicator
+            return _hip.rccl_comm_create(1, 0, _hip.rccl_unique_id(), self.ctx.device), True
+        import torch.distributed as dist
+        if dist.get_backend(group) != 'nccl':
+            return None, False
+        if prefer == 'torch':
+            try:
+                pg = group if group is not None else dist.distributed_c10d._get_default_group()
+                ptr = int(pg._get_backend(self.device)._comm_ptr())
+                if ptr:
+                    return ptr, False
+            except Exception:      # older / newer torch without the accessor, or a lazy communicator
+                pass
+        ids = [_hip.rccl_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=dist.get_global_rank(group, 0) if group is not None else 0,
+                                   group=group)
+        return _hip.rccl_comm_create(world, rank, ids[0], self.ctx.device), True
+
     def run_persistent(self, st, wp, n_steps):
         """One launch for the whole chunk (workgroup per ensemble, state in LDS, same pre-drawn
         stream as ``run``).  Returns False when the ensemble does not fit a workgroup."""
@@ -528,7 +563,8 @@ class DeviceEnsembleSampler(_SamplerBase):
 
     def __init__(self, nwalkers, ndim, ctx=None, a=2.0, live_dangerously=False, group=None,
                  distributed=False, backend=None, chunk=None, rng='numpy', seed=None,
-                 n_ensembles=1, force_sharded_path=False, persistent=None, chain_on_device=False):
+                 n_ensembles=1, force_sharded_path=False, persistent=None, chain_on_device=False,
+                 sharded_loop='rccl'):
         if rng not in ('numpy', 'philox'):
             raise ValueError("rng must be 'numpy' or 'philox'")
         # n_ensembles > 1: independent ensembles of `nwalkers` walkers each (batch of spectra),
@@ -547,6 +583,15 @@ class DeviceEnsembleSampler(_SamplerBase):
         self.rng = rng
         # run eval -> all_gather -> apply even with one rank (benchmarks the sharded path)
         self.force_sharded_path = bool(force_sharded_path)
+        # who runs the sharded half-step loop: 'rccl' = one C call per chunk enqueues eval ->
+        # ncclAllGather -> apply for every half-step (bisip_stretch_run_sharded_dev) on the
+        # communicator torch.distributed already has; 'rccl-own' = the same on a communicator
+        # of this sampler's own; 'python' = the per-half-step loop over torch.distributed (what
+        # gloo groups and injected test backends always use).  Same chain every way.
+        if sharded_loop not in ('rccl', 'rccl-own', 'python'):
+            raise ValueError("sharded_loop must be 'rccl', 'rccl-own' or 'python'")
+        self.sharded_loop = sharded_loop
+        self._comm, self._comm_owned, self._comm_tried = None, False, False
         # one rank and the ensemble fits a workgroup: ONE launch per chunk (workgroup per
         # ensemble, state in LDS); bit-identical to the launch-per-half-step path, which is the
         # automatic fallback for bigger ensembles.  A workgroup lives on ONE compute unit, so
@@ -567,6 +612,31 @@ class DeviceEnsembleSampler(_SamplerBase):
             self.seed = int(seed) if seed is not None else int(self._random.randint(0, 2 ** 31 - 1))
         self._dev = None
         self._iterations_run = 0   # philox counter: iterations done so far (stored or not)
+
+    def _sharded_comm(self):
+        """The RCCL communicator of the C half-step loop (made on first use), or None: groups
+        that do not run over RCCL and injected test backends keep the Python loop."""
+        if self._comm is None and not self._comm_tried:
+            self._comm_tried = True
+            if hasattr(self.backend, 'rccl_comm') and self.sharded_loop != 'python':
+                self._comm, self._comm_owned = self.backend.rccl_comm(
+                    self._group, self._world, self._rank,
+                    prefer='own' if self.sharded_loop == 'rccl-own' else 'torch', in_group=self._in_group)
+        return self._comm
+
+    def close(self):
+        """Release the communicator this sampler created (no-op otherwise)."""
+        if getattr(self, '_comm', None) is not None and self._comm_owned:
+            from . import _hip
+            self.backend.synchronize()
+            _hip.rccl_comm_destroy(self._comm)
+        self._comm, self._comm_owned = None, False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def _upload_state(self, coords, lp=None):
         import torch
@@ -654,6 +724,9 @@ class DeviceEnsembleSampler(_SamplerBase):
         elif single:
             be.run(st, n)
             self.last_path = 'launch-per-half-step'
+        elif self._sharded_comm() is not None:
+            be.run_sharded(st, n, self._comm)
+            self.last_path = 'sharded-rccl'
         else:
             import torch.distributed as dist
             self.last_path = 'sharded'

@@ -58,6 +58,7 @@ extern "C" {
 #define BISIP_EHIP       -2 /* a HIP runtime call failed                             */
 #define BISIP_ENOMEM     -3
 #define BISIP_EUNSUPPORTED -4
+#define BISIP_ERCCL     -5 /* an RCCL call failed                                   */
 
 #define BISIP_MAX_NDIM 16
 #define BISIP_MAX_MODES 5
@@ -173,6 +174,34 @@ int bisip_stretch_apply_dev(bisip_ctx *ctx, const bisip_stretch_args *args, void
  * n_steps/thin_by rows; n_steps must be a multiple of thin_by). */
 int bisip_stretch_run_dev(bisip_ctx *ctx, const bisip_stretch_args *first, int64_t W,
                           int64_t n_steps, int64_t thin_by, void *stream);
+
+/* ---- the same move with the walkers sharded over the GPUs of one node (one process per GPU,
+ * RCCL over xGMI; the reference's only parallel hook is fit(pool=...) -> emcee's pool.map over
+ * walkers, src/bisip/models.py:84,91-94,115).  Every rank holds the whole ensemble and the same
+ * random stream, evaluates slots [rank's block) of each half-step, and one all-gather per
+ * half-step rebuilds the state on every rank.
+ *
+ * bisip_stretch_run_sharded_dev: n_steps whole iterations, per half-step
+ *     eval (this rank's slots -> its slab of the gather buffer)  ->  ncclAllGather (in place)
+ *     ->  apply (every slot -> state + chain)
+ * all enqueued on `stream` with no host round trip.  Arguments as for bisip_stretch_run_dev
+ * (first->block / pad / world / slot_lo / slot_hi are ignored: the library owns the gather
+ * buffer, allocated once per context, ceil(slots/world)*(ndim+2) doubles per rank).  `comm` is
+ * an ncclComm_t whose ranks all make this call with the same arguments: one made by
+ * bisip_rccl_comm_create, or an existing one (e.g. PyTorch's ProcessGroupNCCL._comm_ptr()).
+ * The chain is bit-identical to bisip_stretch_run_dev's on every rank.  RCCL is bound at run
+ * time (dlopen of librccl.so.1); BISIP_EUNSUPPORTED when it is absent, BISIP_ERCCL when a call
+ * fails.  Single-spectrum contexts only (a batch of spectra shards as whole replicas). */
+int bisip_stretch_run_sharded_dev(bisip_ctx *ctx, void *comm, const bisip_stretch_args *first,
+                                  int64_t W, int64_t n_steps, int64_t thin_by, void *stream);
+
+/* Stand-alone communicator for callers without one: rank 0 fills a BISIP_RCCL_ID_BYTES id
+ * (ncclGetUniqueId), ships it to the other ranks by any means, and every rank creates its
+ * communicator on `device` (ncclCommInitRank: collective over the `world` ranks). */
+#define BISIP_RCCL_ID_BYTES 128
+int bisip_rccl_unique_id(void *id);
+int bisip_rccl_comm_create(void **comm, int world, int rank, const void *id, int device);
+int bisip_rccl_comm_destroy(void *comm);
 
 /* Fill the random-stream arrays on the device (counter-based Philox4x32-10; the contract
  * is documented in bisip_amd/csrc/sampler_kernels.h and bisip_amd/sampler.py).

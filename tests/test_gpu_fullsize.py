@@ -1,0 +1,118 @@
+"""BASELINE.json's full-size sampler configurations on one MI355X.
+
+cfg4: Debye decomposition (PolynomialDecomposition c_exp = 1, 40 relaxation times = the bundled
+20-frequency grid, poly_deg 5), 32768 walkers -- here on ONE GPU: the fused half-step, the
+sharded half-step driven from Python (eval -> all_gather -> apply) and the sharded half-step
+driven by the C loop over RCCL must give the same chain bit for bit, and the stored
+log-probabilities must be the oracle's values of the stored positions.
+cfg5: one GPU's share of the batch -- 512 spectra x 256 walkers, double Cole-Cole, 32 frequencies.
+"""
+
+import socket
+
+import numpy as np
+import pytest
+
+from conftest import assert_logp_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.fixture
+def one_rank_rccl_group():
+    """torch.distributed over RCCL with a single rank (what every rank of an N-GPU run sees)."""
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{_free_port()}', rank=0, world_size=1,
+                            device_id=torch.device('cuda', 0))
+    try:
+        yield dist
+    finally:
+        dist.destroy_process_group()
+
+
+def test_cfg4_full_size_fused_python_sharded_and_rccl_loop_agree(one_rank_rccl_group):
+    import bisip_amd
+    import oracle
+    from bisip_amd.sampler import DeviceEnsembleSampler
+    W, ndim, nsteps = 32768, 7, 20
+    m = bisip_amd.PolynomialDecomposition(bisip_amd.DataFiles()['SIP-K389175'], nwalkers=W, nsteps=nsteps)
+    assert m.taus.size == 40 and m.data['N'] == 20 and m.poly_deg == 5 and m.c_exp == 1.0
+    ctx = m._context()
+    rng = np.random.RandomState(2024)
+    centre = np.array([1.0, 0.005, -0.003, -0.001, 0.0005, 0.0002, 0.00001])
+    p0 = centre + 1e-4 * rng.randn(W, ndim)
+
+    def run(**kw):
+        np.random.seed(7)
+        s = DeviceEnsembleSampler(W, ndim, ctx, rng='philox', seed=11, persistent=False, **kw)
+        s.run_mcmc(p0, nsteps)
+        return s
+
+    fused = run()
+    assert fused.last_path == 'launch-per-half-step'
+    chain, logp = fused.get_chain(), fused.get_log_prob()
+    assert chain.shape == (nsteps, W, ndim)
+    results = {
+        'python loop': run(distributed=True, force_sharded_path=True, sharded_loop='python'),
+        'C loop, torch communicator': run(distributed=True, force_sharded_path=True, sharded_loop='rccl'),
+        'C loop, own communicator (group)': run(distributed=True, force_sharded_path=True, sharded_loop='rccl-own'),
+        'C loop, own communicator (no group)': run(force_sharded_path=True),
+    }
+    want_path = {'python loop': 'sharded'}
+    for name, s in results.items():
+        assert s.last_path == want_path.get(name, 'sharded-rccl'), name
+        assert np.array_equal(s.get_chain(), chain), name
+        assert np.array_equal(s.get_log_prob(), logp), name
+        assert np.array_equal(s.acceptance_fraction, fused.acceptance_fraction), name
+        s.close()
+    assert 0.2 < fused.acceptance_fraction.mean() < 0.8
+    assert not np.array_equal(chain[0], chain[-1])
+    # the stored log-probabilities are the oracle's log-probabilities of the stored positions
+    d = m.data
+    prob = oracle.OracleProblem('PolynomialDecomposition', d['w'], d['zn'], d['zn_err'], m.param_bounds,
+                                taus=m.taus, log_taus=m.log_taus, c_exp=1.0)
+    pick = rng.choice(W, 512, replace=False)
+    for k in (0, nsteps - 1):
+        assert_logp_close(logp[k, pick], oracle.logprob(prob, chain[k, pick]))
+
+
+def test_cfg5_full_size_batch_of_spectra():
+    import oracle
+    from bisip_amd.batch import SpectraBatch
+    from bisip_amd.synthetic import synthetic_columns
+    E, Wp, nsteps = 512, 256, 10
+    spectra = [synthetic_columns(32, i) for i in range(E)]
+    b = SpectraBatch('ColeCole', spectra, nwalkers=Wp, nsteps=nsteps, n_modes=2)
+    assert b.N == 32 and b.ndim == 7 and b.n_spectra == E
+    truth = np.array([1.0, 0.15, 0.5, -1.5, -12.0, 0.45, 0.6])
+    rng = np.random.RandomState(5)
+    p0 = truth + 1e-3 * rng.randn(E, Wp, 7)
+    b.fit(p0=p0, seed=99, chain='device')
+    mean_dev, std_dev = b.get_param_mean(), b.get_param_std()
+    pct_dev = b.get_param_percentile([2.5, 50, 97.5])
+    chain = b.get_chain()                       # (nsteps, E, Wp, ndim), copied from the device now
+    logp = b.get_log_prob()
+    assert chain.shape == (nsteps, E, Wp, 7) and logp.shape == (nsteps, E, Wp)
+    flat = b.get_chain(flat=True)               # (E, nsteps*Wp, ndim)
+    assert np.allclose(mean_dev, flat.mean(axis=1), rtol=1e-12, atol=1e-14)
+    assert np.allclose(std_dev, flat.std(axis=1), rtol=1e-9, atol=1e-14)
+    assert np.allclose(pct_dev, np.percentile(flat, [2.5, 50, 97.5], axis=1), rtol=1e-13, atol=1e-15)
+    acc = b.acceptance_fraction
+    assert acc.shape == (E, Wp) and 0.1 < acc.mean() < 0.9
+    # eight spectra spread over the batch: stored log-probs = oracle log-probs of the stored positions
+    for e in (0, 1, 63, 64, 255, 300, 510, 511):
+        prob = oracle.OracleProblem('PeltonColeCole', b.w[e], b.zn[e], b.zn_err[e], b.param_bounds, n_modes=2)
+        for k in (0, nsteps - 1):
+            assert_logp_close(logp[k, e], oracle.logprob(prob, chain[k, e]))
+    # and the batch log-probability entry on the final positions agrees with the chain's
+    last = np.ascontiguousarray(chain[-1])
+    assert np.array_equal(b.log_prob(last), logp[-1])
