@@ -226,6 +226,8 @@ def main():
     ap.add_argument('--rehearse-cpu', action='store_true',
                     help='control flow only (launch, rendezvous, barriers, reductions, the JSON line) with '
                          'NO kernel: value is null.  For the CPU test of the multi-rank path; never a measurement')
+    ap.add_argument('--no-sampler-extra', action='store_true',
+                    help='N > 1: skip the sharded-sampler (cfg4) measurement that follows the result line')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-variants', action='store_true')
     ap.add_argument('--pmc-pass', action='store_true',
@@ -364,17 +366,88 @@ def main():
                     result['cpu_baseline'] = cb
                     result['parity'] = {'max_rel_err_vs_oracle': err, 'neg_inf_rows_match': same_inf,
                                         'tolerance': 1e-10}
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
+    if dist is not None and world > 1 and not rehearse and not args.no_sampler_extra:
+        # AFTER the result line is out: the sampler-mode path of the north star (cfg4) on these
+        # same ranks.  Goes to stderr; cannot change the line above, and a watchdog ends the
+        # process cleanly should a collective ever hang.
+        sampler_extra(args, dist, torch, rank, world, local_rank)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def sampler_extra(args, dist, torch, rank, world, local_rank, walkers=32768, steps=200):
+    """BASELINE config 4 on the ranks of this run: Debye decomposition (S = 40 relaxation times,
+    the bundled 20-frequency grid, poly_deg 5), 32768 walkers sharded over the GPUs, one RCCL
+    all-gather per stretch half-step, driven by bisip_stretch_run_sharded_dev on the
+    communicator torch.distributed built.  One JSON line on rank 0's STDERR."""
+    import threading
+    import numpy as np
+    watchdog = threading.Timer(180.0, lambda: (print('bench.py: sampler extra timed out', file=sys.stderr,
+                                                     flush=True), os._exit(0)))
+    watchdog.daemon = True
+    watchdog.start()
+    try:
+        import bisip_amd
+        from bisip_amd.sampler import DeviceEnsembleSampler
+        m = bisip_amd.PolynomialDecomposition(bisip_amd.DataFiles()['SIP-K389175'], nwalkers=walkers,
+                                              nsteps=steps, device=local_rank)
+        ctx = m._context()
+        centre = np.array([1.0, 0.005, -0.003, -0.001, 0.0005, 0.0002, 0.00001])
+        p0 = centre + 1e-4 * np.random.RandomState(2024).randn(walkers, 7)
+
+        def run(n, **kw):
+            np.random.seed(7)
+            s = DeviceEnsembleSampler(walkers, 7, ctx, rng='philox', seed=11, persistent=False,
+                                      chain_on_device=True, **kw)
+            if kw:
+                s._sharded_comm()
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            s.run_mcmc(p0, n)
+            torch.cuda.synchronize()
+            dist.barrier()
+            return s, time.perf_counter() - t0
+
+        sharded = dict(distributed=True, force_sharded_path=True)
+        if args.same_device:
+            steps = 40                                 # rehearsal through host memory: keep it short
+        run(20, **sharded)                         # clocks, communicator, allocations
+        s, dt = run(steps, **sharded)
+        final = torch.from_numpy(np.ascontiguousarray(s._coords))
+        if args.backend == 'nccl':
+            final = final.to(f'cuda:{local_rank}')
+        every = torch.empty((world * final.shape[0], final.shape[1]), dtype=final.dtype, device=final.device)
+        dist.all_gather_into_tensor(every, final)      # rank r's state = rows [r*W, (r+1)*W)
+        every = every.view(world, final.shape[0], final.shape[1])
+        same = bool(all(torch.equal(every[0], every[r]) for r in range(world)))
+        run(20)
+        f, dtf = run(steps)                        # every rank alone, fused half-steps, same stream
+        rec = {'sampler_cfg4': {
+            'config': 'Debye decomposition S=40 N=20 poly_deg=5, stretch move', 'walkers': walkers,
+            'n_gpus': world, 'iterations': steps, 'driver': s.last_path,
+            'us_per_half_step': dt / steps / 2 * 1e6, 'walker_steps_per_s': walkers * steps / dt,
+            'payload_bytes_per_rank_per_half_step': -(-(walkers // 2) // world) * 9 * 8,
+            'state_identical_on_every_rank': same,
+            'equals_single_gpu_fused_chain': bool(np.array_equal(s._coords, f._coords)),
+            'single_gpu_fused_us_per_half_step': dtf / steps / 2 * 1e6,
+            'single_gpu_fused_walker_steps_per_s': walkers * steps / dtf}}
+        s.close()
+        if rank == 0:
+            print(json.dumps(rec), file=sys.stderr, flush=True)
+    except Exception as ex:      # never turns a measured headline into a failed run
+        print(f'bench.py: sampler extra failed on rank {rank}: {type(ex).__name__}: {ex}', file=sys.stderr, flush=True)
+    finally:
+        watchdog.cancel()
 
 
 def time_variants(ctx, args, step, W, torch, stream, counts):
     """The other formulations of the same log-probability (same theta, same W), each primed
     like the headline before it is timed."""
     variants = {}
-    for v in ('reduced', 'collapsed', 'faithful', 'wave'):
+    for v in ('reduced', 'reduced_comp', 'collapsed', 'faithful', 'wave'):
         ctx.set_variant(v)
         prime(step, min(args.prime_seconds, 0.3), torch)
         k = max(3, min(args.steps, 10))
@@ -428,7 +501,7 @@ def pmc_pass(ctx, step, theta_t, out_t, data, torch):
     the headline W, then the zoo): under `rocprofv3 --pmc SQ_INSTS_VALU` each dispatch's counter
     is that kernel's VALU wave-instruction count per launch."""
     order = []
-    for v in ('reduced', 'collapsed', 'faithful', 'wave'):
+    for v in ('reduced', 'reduced_comp', 'collapsed', 'faithful', 'wave'):
         ctx.set_variant(v)
         step()
         torch.cuda.synchronize()

@@ -47,7 +47,7 @@ def draw_case(rng, widen=1.0):
         okw = dict(taus=taus, log_taus=log_taus, c_exp=c_exp)
         # 'auto' = what the product runs: the QR-reduced kernel where its host-side error estimate
         # allows, else the per-frequency form
-        variants = ['auto', 'collapsed'] + (['faithful'] if P <= 7 else []) + (['wave'] if N <= 64 else [])
+        variants = ['auto', 'collapsed', 'reduced_comp'] + (['faithful'] if P <= 7 else []) + (['wave'] if N <= 64 else [])
         params = default_params(model, poly_deg=P)
     elif model == 'PeltonColeCole':
         D = int(rng.randint(1, 6))
@@ -95,6 +95,8 @@ def main():
     MODEL_IDS = {name: i for i, name in enumerate(NAMES)}
     worst = dict(logp=0.0, Z=0.0)
     bad = 0
+    # PolynomialDecomposition problems whose design has a triangle (2N >= P+2): which kernel AUTO ran
+    auto = dict(problems=0, reduced=0, reduced_comp=0, collapsed=0, worst_err_reduced=0.0, by_degree={})
     t_start = time.time()
     for case in range(args.cases):
         c = draw_case(rng, args.widen)
@@ -121,6 +123,15 @@ def main():
             errs[ctx.kernel_name if v != 'auto' else 'auto:' + ctx.kernel_name] = e
             if v == 'auto' and model == 'PolynomialDecomposition':
                 rec['reduced_error_estimate'] = float('%.3g' % ctx.reduced_error)
+                rec['auto_variant'] = ctx.variant
+                if 2 * N >= kw['poly_deg'] + 2:
+                    auto['problems'] += 1
+                    auto[ctx.variant] += 1
+                    deg = auto['by_degree'].setdefault(str(kw['poly_deg']), dict(problems=0, reduced=0, reduced_comp=0, collapsed=0))
+                    deg['problems'] += 1
+                    deg[ctx.variant] += 1
+                    if ctx.variant != 'collapsed':
+                        auto['worst_err_reduced'] = max(auto['worst_err_reduced'], e)
             if args.only is not None and fin.any():
                 rel = np.abs(got - want) / np.maximum(1.0, np.abs(want))
                 rel[~fin] = 0
@@ -147,7 +158,9 @@ def main():
         print(json.dumps(rec), flush=True)
     print(json.dumps(dict(summary=True, cases=args.cases, seed=args.seed, violations=bad,
                           worst_logp_rel_err=worst['logp'], worst_Z_rel_err=worst['Z'],
-                          tolerances=dict(logp=LOGP_TOL, Z=Z_TOL), seconds=round(time.time() - t_start, 1))))
+                          tolerances=dict(logp=LOGP_TOL, Z=Z_TOL), seconds=round(time.time() - t_start, 1),
+                          auto_on_polydecomp=dict(auto, frac_reduced=round((auto['reduced'] + auto['reduced_comp']) /
+                                                                            max(1, auto['problems']), 4)))))
     return 1 if bad else 0
 
 

@@ -15,9 +15,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libbisip_hip.so')
 
 MODEL_POLYDECOMP, MODEL_COLECOLE, MODEL_DIAS2000, MODEL_SHIN2015 = 0, 1, 2, 3
-VARIANT_AUTO, VARIANT_FAITHFUL, VARIANT_COLLAPSED, VARIANT_REDUCED, VARIANT_WAVE = 0, 1, 2, 3, 4
+VARIANT_AUTO, VARIANT_FAITHFUL, VARIANT_COLLAPSED, VARIANT_REDUCED, VARIANT_WAVE, VARIANT_REDUCED_COMP = 0, 1, 2, 3, 4, 5
 VARIANTS = {'auto': VARIANT_AUTO, 'faithful': VARIANT_FAITHFUL, 'collapsed': VARIANT_COLLAPSED,
-            'reduced': VARIANT_REDUCED, 'wave': VARIANT_WAVE}
+            'reduced': VARIANT_REDUCED, 'wave': VARIANT_WAVE, 'reduced_comp': VARIANT_REDUCED_COMP}
 
 _dp = ctypes.POINTER(ctypes.c_double)
 

@@ -30,12 +30,15 @@ int effective_variant(const bisip_ctx *c)
 {
     if (c->model_id != BISIP_MODEL_POLYDECOMP) return BISIP_VARIANT_COLLAPSED;
     if (c->variant != BISIP_VARIANT_AUTO) return c->variant;
-    // the QR-reduced form is the fast one, but only where it is accurate: fewer data rows (2N)
-    // than unknowns (P+2), or a host-side emulation of the kernel's arithmetic that deviates
-    // from long double by more than 1e-12 on the probe rows (ill-conditioned designs: high
-    // degree, small exponent) -> the per-frequency form, which mirrors the reference's sums
-    if (2 * c->N < c->P + 2 || !(c->reduced_err <= BISIP_REDUCED_ERR_MAX)) return BISIP_VARIANT_COLLAPSED;
-    return BISIP_VARIANT_REDUCED;
+    // the QR-reduced form is the fast one, but only where it is accurate: with fewer data rows
+    // (2N) than unknowns (P+2) there is no triangle; otherwise the plain kernel while the
+    // host-side emulation of its arithmetic stays within 1e-12 of long double on the probe rows,
+    // else the compensated kernel under the same test (ill-conditioned designs: high degree,
+    // small exponent), else the per-frequency form, which mirrors the reference's sums
+    if (2 * c->N < c->P + 2) return BISIP_VARIANT_COLLAPSED;
+    if (c->red[0].err <= BISIP_REDUCED_ERR_MAX) return BISIP_VARIANT_REDUCED;
+    if (c->red[1].err <= BISIP_REDUCED_ERR_MAX) return BISIP_VARIANT_REDUCED_COMP;
+    return BISIP_VARIANT_COLLAPSED;
 }
 
 LaunchArgs make_args(const bisip_ctx *c, const double *theta, double *out, int64_t W,
@@ -56,7 +59,8 @@ BatchArgs make_batch_args(const bisip_ctx *c, const double *theta, double *out, 
 {
     BatchArgs a;
     a.theta = theta; a.out = out; a.W = W; a.Wp = W / c->E;
-    a.cb = c->d_cb; a.cb_stride = c->cb_stride; a.lconst = c->d_lconst; a.red = c->d_red;
+    a.cb = c->d_cb; a.cb_stride = c->cb_stride; a.lconst = c->d_lconst;
+    a.red = c->red[effective_variant(c) == BISIP_VARIANT_REDUCED_COMP ? 1 : 0].d_red;
     a.N = c->N; a.b = c->bounds;
     return a;
 }
@@ -100,6 +104,7 @@ const char *name_for(const bisip_ctx *c)
     case BISIP_MODEL_POLYDECOMP:
         switch (effective_variant(c)) {
         case BISIP_VARIANT_REDUCED: return "k_logprob_pd_reduced";
+        case BISIP_VARIANT_REDUCED_COMP: return "k_logprob_pd_reduced_comp";
         case BISIP_VARIANT_FAITHFUL: return "k_logprob_pd_faithful";
         case BISIP_VARIANT_WAVE: return "k_logprob_pd_wave";
         default: return "k_logprob<PDCollapsed>";
@@ -119,32 +124,36 @@ static int recenter_reduced(bisip_ctx *c)
 {
     if (c->model_id != BISIP_MODEL_POLYDECOMP || c->reduced.empty()) return BISIP_OK;
     const int n = c->P + 2;
-    const size_t red_doubles = (size_t)n * (n + 1) / 2 + 2 * (size_t)n + 1;  // == sizeof(ReducedArgs<P>)/8
-    std::vector<double> red, bh(n), ev(n);
-    c->reduced_err = 0.0;
-    for (size_t e = 0; e < c->reduced.size(); ++e) {
-        const bisip_ctx::ReducedHost &rh = c->reduced[e];
-        const double est = reduced_center(n, rh.R, rh.qty, rh.bhat_ls, rh.rest, rh.lconst, c->bounds.lo, c->bounds.hi,
-                                          bh.data(), ev.data());
-        if (!(est <= c->reduced_err)) c->reduced_err = est;
-        std::vector<double> Rp;
-        for (int i = 0; i < n; ++i)
-            for (int j = i; j < n; ++j) Rp.push_back(rh.R[(size_t)i * n + j]);
-        if (e == 0) { c->Rpacked = Rp; c->bhat = bh; c->evec = ev; c->rest = rh.rest; }
-        if (c->E > 1) {  // ReducedArgs<P> image: R | bhat | e | rest
-            red.insert(red.end(), Rp.begin(), Rp.end());
-            red.insert(red.end(), bh.begin(), bh.end());
-            red.insert(red.end(), ev.begin(), ev.end());
-            red.push_back(rh.rest);
+    const size_t red_doubles = (size_t)n * (n + 1) / 2 + 3 * (size_t)n + 1;  // == sizeof(ReducedArgs<P>)/8
+    for (int tier = 0; tier < 2; ++tier) {
+        bisip_ctx::ReducedTier &T = c->red[tier];
+        std::vector<double> red, bh(n), ev(n), el(n);
+        T.err = 0.0;
+        for (size_t e = 0; e < c->reduced.size(); ++e) {
+            const bisip_ctx::ReducedHost &rh = c->reduced[e];
+            const double est = reduced_center(n, rh.R, rh.qty, rh.bhat_ls, rh.rest, rh.lconst, c->bounds.lo,
+                                              c->bounds.hi, tier == 1, bh.data(), ev.data(), el.data());
+            if (!(est <= T.err)) T.err = est;
+            std::vector<double> Rp;
+            for (int i = 0; i < n; ++i)
+                for (int j = i; j < n; ++j) Rp.push_back(rh.R[(size_t)i * n + j]);
+            if (e == 0) { c->Rpacked = Rp; T.bhat = bh; T.evec = ev; T.elo = el; c->rest = rh.rest; }
+            if (c->E > 1) {  // ReducedArgs<P> image: R | bhat | e | elo | rest
+                red.insert(red.end(), Rp.begin(), Rp.end());
+                red.insert(red.end(), bh.begin(), bh.end());
+                red.insert(red.end(), ev.begin(), ev.end());
+                red.insert(red.end(), el.begin(), el.end());
+                red.push_back(rh.rest);
+            }
         }
-    }
-    if (c->E > 1) {
-        if (red.size() != red_doubles * (size_t)c->E) return fail(BISIP_EHIP, "internal: reduced operand size mismatch");
-        HIP_TRY(hipSetDevice(c->device));
-        if (!c->d_red) HIP_TRY(hipMalloc(&c->d_red, red.size() * sizeof(double)));
-        // set_bounds between launches: the copy is ordered after earlier work by the sync
-        HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipMemcpy(c->d_red, red.data(), red.size() * sizeof(double), hipMemcpyHostToDevice));
+        if (c->E > 1) {
+            if (red.size() != red_doubles * (size_t)c->E) return fail(BISIP_EHIP, "internal: reduced operand size mismatch");
+            HIP_TRY(hipSetDevice(c->device));
+            if (!T.d_red) HIP_TRY(hipMalloc(&T.d_red, red.size() * sizeof(double)));
+            // set_bounds between launches: the copy is ordered after earlier work by the sync
+            HIP_TRY(hipDeviceSynchronize());
+            HIP_TRY(hipMemcpy(T.d_red, red.data(), red.size() * sizeof(double), hipMemcpyHostToDevice));
+        }
     }
     return BISIP_OK;
 }
@@ -349,7 +358,7 @@ void bisip_ctx_destroy(bisip_ctx *c)
     if (c->d_cb_lp) (void)hipFree(c->d_cb_lp);
     if (c->d_cb_faithful) (void)hipFree(c->d_cb_faithful);
     if (c->d_lconst) (void)hipFree(c->d_lconst);
-    if (c->d_red) (void)hipFree(c->d_red);
+    for (auto &t : c->red) if (t.d_red) (void)hipFree(t.d_red);
     if (c->d_ws) (void)hipFree(c->d_ws);
     if (c->d_gather) (void)hipFree(c->d_gather);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
@@ -372,7 +381,7 @@ int bisip_ctx_set_bounds(bisip_ctx *c, const double *lo, const double *hi)
 int bisip_ctx_set_variant(bisip_ctx *c, int variant)
 {
     if (!c) return fail(BISIP_EINVAL, "null context");
-    if (variant < BISIP_VARIANT_AUTO || variant > BISIP_VARIANT_WAVE)
+    if (variant < BISIP_VARIANT_AUTO || variant > BISIP_VARIANT_REDUCED_COMP)
         return fail(BISIP_EINVAL, "bad variant %d", variant);
     if (variant == BISIP_VARIANT_WAVE && (c->model_id != BISIP_MODEL_POLYDECOMP || c->E > 1 || c->N > 64))
         return fail(BISIP_EUNSUPPORTED, "the wave-per-walker formulation needs a single-spectrum PolynomialDecomposition with N <= 64");
@@ -394,7 +403,14 @@ int bisip_ctx_nfreq(const bisip_ctx *c) { return c ? c->N : BISIP_EINVAL; }
 int bisip_ctx_device(const bisip_ctx *c) { return c ? c->device : BISIP_EINVAL; }
 double bisip_ctx_loglike_const(const bisip_ctx *c) { return c ? c->lconst : NAN; }
 const char *bisip_ctx_kernel_name(const bisip_ctx *c) { return c ? c->kernel_name : ""; }
-double bisip_ctx_reduced_error(const bisip_ctx *c) { return c ? c->reduced_err : NAN; }
+double bisip_ctx_reduced_error(const bisip_ctx *c)
+{
+    if (!c) return NAN;
+    const int v = effective_variant(c);
+    if (v == BISIP_VARIANT_REDUCED) return c->red[0].err;
+    if (v == BISIP_VARIANT_REDUCED_COMP) return c->red[1].err;
+    return c->red[0].err <= c->red[1].err ? c->red[0].err : c->red[1].err;
+}
 
 int bisip_logprob_dev(bisip_ctx *c, const double *d_theta, int64_t W, double *d_logp, void *stream)
 {

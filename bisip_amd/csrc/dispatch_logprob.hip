@@ -52,24 +52,24 @@ int launch_collapsed(const bisip_ctx *c, const double *theta, int64_t W, double 
     return BISIP_OK;
 }
 
-template <int P>
+template <int P, bool COMP>
 int launch_reduced(const bisip_ctx *c, const double *theta, int64_t W, double *out, hipStream_t st)
 {
     const LaunchArgs a = make_args(c, theta, out, W, nullptr);
     ReducedArgs<P> r;
-    std::memcpy(r.R, c->Rpacked.data(), sizeof(r.R));
-    std::memcpy(r.bhat, c->bhat.data(), sizeof(r.bhat));
-    std::memcpy(r.e, c->evec.data(), sizeof(r.e));
-    r.rest = c->rest;
+    fill_reduced<P>(c, COMP, r);
     const bool vec = ((uintptr_t)theta % 16) == 0;
     if (W < SMALL_W) {
         const unsigned grid = (unsigned)((W + BLK_SMALL - 1) / BLK_SMALL);
-        if (vec) hipLaunchKernelGGL((k_logprob_pd_reduced<P, BLK_SMALL, true>), dim3(grid), dim3(BLK_SMALL), 0, st, a, r);
-        else hipLaunchKernelGGL((k_logprob_pd_reduced<P, BLK_SMALL, false>), dim3(grid), dim3(BLK_SMALL), 0, st, a, r);
+        if (vec) hipLaunchKernelGGL((k_logprob_pd_reduced<P, BLK_SMALL, true, COMP>), dim3(grid), dim3(BLK_SMALL), 0, st, a, r);
+        else hipLaunchKernelGGL((k_logprob_pd_reduced<P, BLK_SMALL, false, COMP>), dim3(grid), dim3(BLK_SMALL), 0, st, a, r);
     } else {
-        const unsigned grid = (unsigned)((W + BLK_STREAM - 1) / BLK_STREAM);
-        if (vec) hipLaunchKernelGGL((k_logprob_pd_reduced<P, BLK_STREAM, true>), dim3(grid), dim3(BLK_STREAM), 0, st, a, r);
-        else hipLaunchKernelGGL((k_logprob_pd_reduced<P, BLK_STREAM, false>), dim3(grid), dim3(BLK_STREAM), 0, st, a, r);
+        // the plain form is HBM-bound: 128-lane workgroups stream best; the compensated one is
+        // VALU-bound (~11 flops per matrix entry): 256 lanes, like the other compute-bound kernels
+        constexpr int BLK = COMP ? BLK_LARGE : BLK_STREAM;
+        const unsigned grid = (unsigned)((W + BLK - 1) / BLK);
+        if (vec) hipLaunchKernelGGL((k_logprob_pd_reduced<P, BLK, true, COMP>), dim3(grid), dim3(BLK), 0, st, a, r);
+        else hipLaunchKernelGGL((k_logprob_pd_reduced<P, BLK, false, COMP>), dim3(grid), dim3(BLK), 0, st, a, r);
     }
     HIP_TRY(hipGetLastError());
     return BISIP_OK;
@@ -113,13 +113,13 @@ int launch_logprob_batch(const bisip_ctx *c, const double *theta, int64_t W, dou
     return BISIP_OK;
 }
 
-template <int P>
+template <int P, bool COMP>
 int launch_reduced_batch(const bisip_ctx *c, const double *theta, int64_t W, double *out, hipStream_t st)
 {
     const BatchArgs a = make_batch_args(c, theta, out, W);
     const unsigned grid = (unsigned)((W + 63) / 64);
-    if (a.Wp % 64 == 0) hipLaunchKernelGGL((k_logprob_batch_reduced<P, true>), dim3(grid), dim3(64), 0, st, a);
-    else hipLaunchKernelGGL((k_logprob_batch_reduced<P, false>), dim3(grid), dim3(64), 0, st, a);
+    if (a.Wp % 64 == 0) hipLaunchKernelGGL((k_logprob_batch_reduced<P, true, COMP>), dim3(grid), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL((k_logprob_batch_reduced<P, false, COMP>), dim3(grid), dim3(64), 0, st, a);
     HIP_TRY(hipGetLastError());
     return BISIP_OK;
 }
@@ -130,7 +130,13 @@ int dispatch_logprob_batch(const bisip_ctx *c, const double *theta, int64_t W, d
     case BISIP_MODEL_POLYDECOMP:
         if (effective_variant(c) == BISIP_VARIANT_REDUCED) {
             switch (c->P) {
-#define X(p) case p: return launch_reduced_batch<p>(c, theta, W, out, st);
+#define X(p) case p: return launch_reduced_batch<p, false>(c, theta, W, out, st);
+                X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10)
+#undef X
+            }
+        } else if (effective_variant(c) == BISIP_VARIANT_REDUCED_COMP) {
+            switch (c->P) {
+#define X(p) case p: return launch_reduced_batch<p, true>(c, theta, W, out, st);
                 X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10)
 #undef X
             }
@@ -183,7 +189,13 @@ int dispatch_logprob(const bisip_ctx *c, const double *theta, int64_t W, double 
         const int v = effective_variant(c);
         if (v == BISIP_VARIANT_REDUCED) {
             switch (c->P) {
-#define X(p) case p: return launch_reduced<p>(c, theta, W, out, st);
+#define X(p) case p: return launch_reduced<p, false>(c, theta, W, out, st);
+                PD_CASES(X)
+#undef X
+            }
+        } else if (v == BISIP_VARIANT_REDUCED_COMP) {
+            switch (c->P) {
+#define X(p) case p: return launch_reduced<p, true>(c, theta, W, out, st);
                 PD_CASES(X)
 #undef X
             }

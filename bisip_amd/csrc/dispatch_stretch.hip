@@ -56,14 +56,11 @@ int stretch_generic(const bisip_ctx *c, const StretchWork &a, hipStream_t st)
     }
 }
 
-template <int P>
+template <int P, bool COMP>
 int stretch_reduced(const bisip_ctx *c, const StretchWork &a, hipStream_t st)
 {
-    ReducedLP<P> lp;
-    std::memcpy(lp.r.R, c->Rpacked.data(), sizeof(lp.r.R));
-    std::memcpy(lp.r.bhat, c->bhat.data(), sizeof(lp.r.bhat));
-    std::memcpy(lp.r.e, c->evec.data(), sizeof(lp.r.e));
-    lp.r.rest = c->rest;
+    ReducedLP<P, COMP> lp;
+    fill_reduced<P>(c, COMP, lp.r);
     lp.lconst = c->lconst;
     lp.b = c->bounds;
     return launch_stretch(a, lp, st);
@@ -90,11 +87,11 @@ int stretch_generic_batch(const bisip_ctx *c, const StretchWork &a, long long Wp
     return stretch_generic_batch_l<M, U, 1>(c, a, Wp, st);
 }
 
-template <int P, bool U>
+template <int P, bool U, bool COMP>
 int stretch_reduced_batch(const bisip_ctx *c, const StretchWork &a, long long Wp, hipStream_t st)
 {
-    BatchReducedLP<P, U> lp;
-    lp.red = reinterpret_cast<const ReducedArgs<P> *>(c->d_red); lp.Wp = Wp; lp.lconst = c->d_lconst;
+    BatchReducedLP<P, U, COMP> lp;
+    lp.red = reinterpret_cast<const ReducedArgs<P> *>(c->red[COMP ? 1 : 0].d_red); lp.Wp = Wp; lp.lconst = c->d_lconst;
     lp.b = c->bounds;
     return launch_stretch(a, lp, st);
 }
@@ -106,12 +103,18 @@ int dispatch_stretch_batch(const bisip_ctx *c, const StretchWork &a, long long W
     // in the persistent kernel a workgroup IS one ensemble, so the spectrum is always uniform
     const bool u = (Wp % 128) == 0 || a.kind == STRETCH_PERSIST;
 #define GEN(M) return u ? stretch_generic_batch<M, true>(c, a, Wp, st) : stretch_generic_batch<M, false>(c, a, Wp, st);
-#define RED(p) return u ? stretch_reduced_batch<p, true>(c, a, Wp, st) : stretch_reduced_batch<p, false>(c, a, Wp, st);
+#define RED(p, comp) return u ? stretch_reduced_batch<p, true, comp>(c, a, Wp, st) : stretch_reduced_batch<p, false, comp>(c, a, Wp, st);
     switch (c->model_id) {
     case BISIP_MODEL_POLYDECOMP:
         if (effective_variant(c) == BISIP_VARIANT_REDUCED) {
             switch (c->P) {
-#define X(p) case p: RED(p)
+#define X(p) case p: RED(p, false)
+                X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10)
+#undef X
+            }
+        } else if (effective_variant(c) == BISIP_VARIANT_REDUCED_COMP) {
+            switch (c->P) {
+#define X(p) case p: RED(p, true)
                 X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10)
 #undef X
             }
@@ -175,7 +178,13 @@ int dispatch_stretch(const bisip_ctx *c, const StretchWork &a, long long Wp, hip
                         "formulation: use variant auto, reduced or collapsed, or the host-loop sampler");
         if (effective_variant(c) == BISIP_VARIANT_REDUCED) {
             switch (c->P) {
-#define X(p) case p: return stretch_reduced<p>(c, a, st);
+#define X(p) case p: return stretch_reduced<p, false>(c, a, st);
+                PD_CASES(X)
+#undef X
+            }
+        } else if (effective_variant(c) == BISIP_VARIANT_REDUCED_COMP) {
+            switch (c->P) {
+#define X(p) case p: return stretch_reduced<p, true>(c, a, st);
                 PD_CASES(X)
 #undef X
             }

@@ -52,9 +52,16 @@ struct bisip_ctx {
     double *d_cb_lp = nullptr;     // PolynomialDecomposition: 1/sigma-weighted log-prob records (E, N, REC)
     double *d_cb_faithful = nullptr;
     double *d_lconst = nullptr;    // (E,)  batch only
-    void *d_red = nullptr;         // (E,) ReducedArgs<P>  batch only
     long long cb_stride = 0;
-    std::vector<double> Rpacked, bhat, evec;   // spectrum 0, packed for the kernarg segment
+    // QR-reduced form, two arithmetic tiers: [0] plain, [1] compensated (kernels.h:
+    // logprob_row_reduced<P, COMP>); each has its own expansion point
+    struct ReducedTier {
+        std::vector<double> bhat, evec, elo;   // spectrum 0, for the kernarg segment
+        double err = 0.0;                       // worst estimated relative log-prob error (all spectra)
+        void *d_red = nullptr;                  // (E,) ReducedArgs<P>  batch only
+    };
+    ReducedTier red[2];
+    std::vector<double> Rpacked;   // spectrum 0, packed upper triangle
     double rest = 0.0;
     // per spectrum, for re-centring the reduced form when the prior box changes
     struct ReducedHost {
@@ -63,7 +70,6 @@ struct bisip_ctx {
         double rest = 0.0, lconst = 0.0;
     };
     std::vector<ReducedHost> reduced;
-    double reduced_err = 0.0;      // worst estimated relative log-prob error of the reduced kernel (all spectra)
     // workspace of the host-pointer entry points
     double *d_ws = nullptr;
     size_t ws_bytes = 0;
@@ -81,6 +87,19 @@ namespace bisip {
 namespace host {
 
 int effective_variant(const bisip_ctx *c);
+inline bool is_reduced(int v) { return v == BISIP_VARIANT_REDUCED || v == BISIP_VARIANT_REDUCED_COMP; }
+
+// kernarg image of spectrum 0's reduced operands for the tier a variant runs
+template <int P>
+inline void fill_reduced(const bisip_ctx *c, bool comp, ReducedArgs<P> &r)
+{
+    const bisip_ctx::ReducedTier &t = c->red[comp ? 1 : 0];
+    std::memcpy(r.R, c->Rpacked.data(), sizeof(r.R));
+    std::memcpy(r.bhat, t.bhat.data(), sizeof(r.bhat));
+    std::memcpy(r.e, t.evec.data(), sizeof(r.e));
+    std::memcpy(r.elo, t.elo.data(), sizeof(r.elo));
+    r.rest = c->rest;
+}
 LaunchArgs make_args(const bisip_ctx *c, const double *theta, double *out, int64_t W, const double *cb);
 BatchArgs make_batch_args(const bisip_ctx *c, const double *theta, double *out, int64_t W);
 

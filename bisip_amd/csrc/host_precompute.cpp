@@ -142,20 +142,52 @@ void polydecomp_operands(int N, const double *w, int S, const double *taus, int 
 
 namespace {
 
-// logprob_row_reduced (kernels.h) in the same double arithmetic, operation for operation
+// logprob_row_reduced<P, COMP> (kernels.h) in the same double arithmetic, operation for operation
 double reduced_chi2_double(int n, const std::vector<double> &R, const double *bhat, const double *e,
-                           double rest, const double *th)
+                           const double *elo, double rest, const double *th, bool comp)
 {
-    std::vector<double> d(n);
-    d[0] = bhat[0] - th[0];
-    for (int q = 1; q < n; ++q) {
-        const double prod = th[0] * th[q];
-        d[q] = bhat[q] - prod;
-    }
     double chi2 = rest;
+    std::vector<double> d(n), dl(n);
+    auto two_diff = [](double a, double b, double &s, double &err) {
+        s = a - b;
+        const double bb = s - a;
+        err = (a - (s - bb)) + ((-b) - bb);
+    };
+    if (!comp) {
+        d[0] = bhat[0] - th[0];
+        for (int q = 1; q < n; ++q) {
+            const double prod = th[0] * th[q];
+            d[q] = bhat[q] - prod;
+        }
+        for (int i = 0; i < n; ++i) {
+            double u = e[i];
+            for (int j = i; j < n; ++j) u = std::fma(R[(size_t)i * n + j], d[j], u);
+            chi2 = std::fma(u, u, chi2);
+        }
+        return chi2;
+    }
+    two_diff(bhat[0], th[0], d[0], dl[0]);
+    for (int q = 1; q < n; ++q) {
+        const double p = th[0] * th[q];
+        const double pe = std::fma(th[0], th[q], -p);
+        double err;
+        two_diff(bhat[q], p, d[q], err);
+        dl[q] = err - pe;
+    }
     for (int i = 0; i < n; ++i) {
-        double u = e[i];
-        for (int j = i; j < n; ++j) u = std::fma(R[(size_t)i * n + j], d[j], u);
+        double s = e[i], c = elo[i];
+        for (int j = i; j < n; ++j) {
+            const double Rk = R[(size_t)i * n + j];
+            const double h = Rk * d[j];
+            const double l = std::fma(Rk, d[j], -h);
+            const double t = s + h;
+            const double bb = t - s;
+            const double er = (s - (t - bb)) + (h - bb);
+            s = t;
+            c += er + l;
+            c = std::fma(Rk, dl[j], c);
+        }
+        const double u = s + c;
         chi2 = std::fma(u, u, chi2);
     }
     return chi2;
@@ -184,7 +216,8 @@ struct Lcg {   // deterministic probe points, no <random>
 
 double reduced_center(int n, const std::vector<double> &R, const std::vector<long double> &qty,
                       const std::vector<long double> &bhat_ls, double rest, double lconst,
-                      const double *lo, const double *hi, double *out_bhat, double *out_e)
+                      const double *lo, const double *hi, bool comp, double *out_bhat, double *out_e,
+                      double *out_elo)
 {
     bool finite_box = true;
     for (int j = 0; j < n; ++j) finite_box = finite_box && std::isfinite(lo[j]) && std::isfinite(hi[j]);
@@ -236,6 +269,37 @@ double reduced_center(int n, const std::vector<double> &R, const std::vector<lon
             }
             if (fin && (!finite_box || inside(t))) probes.push_back(t);
         }
+    if (ls_ok) {
+        // where an ensemble sampler's walkers actually are: draws from the Gaussian posterior of the
+        // linear model, b = b_ls + R^-1 z with z ~ N(0, I) (and 3x wider).  On nearly collinear
+        // designs these spread far along the flat directions of chi^2 -- the rows of R (bhat - b)
+        // then cancel by many orders of magnitude although chi^2 stays within a few units of its minimum
+        bool solvable = true;
+        for (int i = 0; i < n; ++i) solvable = solvable && R[(size_t)i * n + i] != 0.0;
+        for (int k = 0; solvable && k < 64; ++k) {
+            const double sc = k < 32 ? 1.0 : 3.0;
+            std::vector<ld> z(n), db(n, 0.0L);
+            for (int j = 0; j < n; ++j) {   // sum of 12 uniforms - 6: unit variance, no libm
+                double a = 0.0;
+                for (int r = 0; r < 12; ++r) a += rng.uni();
+                z[j] = (ld)(sc * (a - 6.0));
+            }
+            for (int i = n - 1; i >= 0; --i) {
+                ld acc = z[i];
+                for (int j = i + 1; j < n; ++j) acc -= (ld)R[(size_t)i * n + j] * db[j];
+                db[i] = acc / (ld)R[(size_t)i * n + i];
+            }
+            std::vector<double> t(n);
+            const ld b0 = bhat_ls[0] + db[0];
+            t[0] = (double)b0;
+            bool fin = std::isfinite(t[0]) && t[0] != 0.0;
+            for (int j = 1; j < n; ++j) {
+                t[j] = (double)((bhat_ls[j] + db[j]) / b0);
+                fin = fin && std::isfinite(t[j]);
+            }
+            if (fin && (!finite_box || inside(t))) probes.push_back(t);
+        }
+    }
     // candidates for the expansion point
     std::vector<std::vector<double>> cand;
     {
@@ -252,11 +316,15 @@ double reduced_center(int n, const std::vector<double> &R, const std::vector<lon
     }
     cand.push_back(std::vector<double>(n, 0.0));
     double best = INFINITY;
-    std::vector<double> e(n);
+    std::vector<double> e(n), elo(n);
     if (probes.empty()) {
         // nothing to measure the kernel against (a non-finite box with no usable least-squares
         // solution): expand about zero and report "unknown", so AUTO takes the per-frequency form
-        for (int j = 0; j < n; ++j) { out_bhat[j] = 0.0; out_e[j] = (double)qty[j]; }
+        for (int j = 0; j < n; ++j) {
+            out_bhat[j] = 0.0;
+            out_e[j] = (double)qty[j];
+            out_elo[j] = (double)(qty[j] - (ld)out_e[j]);
+        }
         return INFINITY;
     }
     for (const auto &c : cand) {
@@ -264,11 +332,12 @@ double reduced_center(int n, const std::vector<double> &R, const std::vector<lon
             ld s = qty[i];
             for (int j = i; j < n; ++j) s -= (ld)R[(size_t)i * n + j] * (ld)c[j];
             e[i] = (double)s;
+            elo[i] = (double)(s - (ld)e[i]);
         }
         double worst = 0.0;
         for (const auto &t : probes) {
             const ld exact = reduced_chi2_exact(n, R, qty, rest, t.data());
-            const double got = reduced_chi2_double(n, R, c.data(), e.data(), rest, t.data());
+            const double got = reduced_chi2_double(n, R, c.data(), e.data(), elo.data(), rest, t.data(), comp);
             const ld lp = -0.5L * exact + (ld)lconst;
             const ld scale = fabsl(lp) > 1.0L ? fabsl(lp) : 1.0L;
             const double rel = (double)(fabsl(-0.5L * ((ld)got - exact)) / scale);
@@ -276,7 +345,7 @@ double reduced_center(int n, const std::vector<double> &R, const std::vector<lon
         }
         if (worst < best || best == INFINITY) {
             best = worst;
-            for (int j = 0; j < n; ++j) { out_bhat[j] = c[j]; out_e[j] = e[j]; }
+            for (int j = 0; j < n; ++j) { out_bhat[j] = c[j]; out_e[j] = e[j]; out_elo[j] = elo[j]; }
         }
     }
     return best;

@@ -36,14 +36,19 @@ void polydecomp_operands(int N, const double *w, int S, const double *taus, int 
 // bhat is O(1).  No single rule is best everywhere (measured: least squares 2e-10 .. 8.6e-3
 // when it lies far outside the prior box; box centre 2.5e-10 where zero gives 4e-14; zero 3x
 // worse than least squares around a well-determined mode), so this function EMULATES the
-// kernel's double arithmetic on the host for ~140 probe rows -- uniform in the prior box
-// [lo, hi] (theta space), clouds of small coefficients, clouds around the least-squares
-// solution -- against long double, for each candidate (least squares, centre of the box's
-// image, zero), keeps the best, and returns its worst relative log-probability error.
-// The caller (AUTO variant) falls back to the per-frequency form when that exceeds 1e-12.
+// kernel's double arithmetic on the host -- the plain form (comp = false) or the compensated
+// one (comp = true; kernels.h: logprob_row_reduced<P, COMP>) -- for ~200 probe rows: uniform in
+// the prior box [lo, hi] (theta space), clouds of small coefficients, clouds around the
+// least-squares solution, and draws from the Gaussian posterior b_ls + R^-1 z (where a
+// sampler's walkers sit: the flat valley of an ill-conditioned design) -- against long double,
+// for each candidate (least squares, centre of the box's image, zero), keeps the best, and
+// returns its worst relative log-probability error.  out_e + out_elo = Q^T y - R bhat to twice
+// the working precision.  The caller (AUTO variant) takes the plain kernel while its estimate
+// is <= 1e-12, else the compensated one, else the per-frequency form.
 double reduced_center(int n, const std::vector<double> &R, const std::vector<long double> &qty,
                       const std::vector<long double> &bhat_ls, double rest, double lconst,
-                      const double *lo, const double *hi, double *out_bhat, double *out_e);
+                      const double *lo, const double *hi, bool comp, double *out_bhat, double *out_e,
+                      double *out_elo);
 
 // -0.5 * sum_i 2*ln(zn_err_i^2), the walker-independent term of src/bisip/models.py:62
 double loglike_const(int n2, const double *zn_err);

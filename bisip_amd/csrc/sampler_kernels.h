@@ -53,7 +53,7 @@ struct GenericLP {
     }
 };
 
-template <int P>
+template <int P, bool COMP = false>
 struct ReducedLP {
     static constexpr int NDIM = P + 2;
     static constexpr int L = 1;
@@ -62,7 +62,7 @@ struct ReducedLP {
     Bounds b;
     __device__ __forceinline__ double operator()(const double (&th)[NDIM], int, int) const
     {
-        return logprob_row_reduced<P>(th, r, lconst, b);
+        return logprob_row_reduced<P, COMP>(th, r, lconst, b);
     }
 };
 
@@ -84,7 +84,7 @@ struct BatchGenericLP {
     }
 };
 
-template <int P, bool UNIFORM>
+template <int P, bool UNIFORM, bool COMP = false>
 struct BatchReducedLP {
     static constexpr int NDIM = P + 2;
     static constexpr int L = 1;
@@ -95,7 +95,7 @@ struct BatchReducedLP {
     __device__ __forceinline__ double operator()(const double (&th)[NDIM], int walker, int) const
     {
         const long long e = spectrum_of<UNIFORM>(walker, Wp);
-        return logprob_row_reduced<P>(th, red[e], lconst[e], b);
+        return logprob_row_reduced<P, COMP>(th, red[e], lconst[e], b);
     }
 };
 

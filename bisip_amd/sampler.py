@@ -738,7 +738,14 @@ class DeviceEnsembleSampler(_SamplerBase):
                     block = be.zeros((pad, ndim + 2), torch.float64)
                     be.eval(st, k, h, m, lo, hi, block)
                     gathered = be.empty((self._world * pad, ndim + 2), torch.float64)
-                    dist.all_gather_into_tensor(gathered, block, group=self._group)
+                    if block.is_cuda and dist.get_backend(self._group) == 'gloo':
+                        # rehearsal of the multi-rank path on a box whose ranks share one GPU
+                        # (RCCL refuses that): the exchange goes through host memory
+                        host = torch.empty(gathered.shape, dtype=torch.float64)
+                        dist.all_gather_into_tensor(host, block.cpu(), group=self._group)
+                        gathered.copy_(host)
+                    else:
+                        dist.all_gather_into_tensor(gathered, block, group=self._group)
                     be.apply(st, k, h, m, gathered, pad, self._world)
 
     def run_mcmc(self, initial_state, nsteps, progress=False, thin_by=1, **kwargs):

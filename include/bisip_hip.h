@@ -45,12 +45,15 @@ extern "C" {
 #define BISIP_MODEL_SHIN2015   3 /* Shin2015                -> Shin2015_cyth */
 
 /* kernel formulation for PolynomialDecomposition (other models have one) */
-#define BISIP_VARIANT_AUTO      0 /* fastest formulation that holds the parity tolerance (see bisip_ctx_reduced_error) */
+#define BISIP_VARIANT_AUTO      0 /* fastest formulation that holds the parity tolerance: REDUCED, else
+                                     REDUCED_COMP, else COLLAPSED (see bisip_ctx_reduced_error) */
 #define BISIP_VARIANT_FAITHFUL  1 /* sum_k M_k*K[j,k], the reference's loop structure     */
 #define BISIP_VARIANT_COLLAPSED 2 /* Z_j = R0*(1 - sum_p a_p*G[j,p])                       */
 #define BISIP_VARIANT_REDUCED   3 /* QR-reduced chi^2: (P+2)x(P+2) triangular form         */
 #define BISIP_VARIANT_WAVE      4 /* collapsed operands, one wave per walker, LDS-staged
                                      spectrum, wavefront-shuffle reduction (N <= 64)        */
+#define BISIP_VARIANT_REDUCED_COMP 5 /* the QR-reduced form in compensated (double-double row
+                                     sums) arithmetic: for nearly collinear designs        */
 
 /* status codes */
 #define BISIP_OK          0
@@ -290,8 +293,13 @@ double bisip_ctx_loglike_const(const bisip_ctx *ctx);
 const char *bisip_ctx_kernel_name(const bisip_ctx *ctx);
 /* PolynomialDecomposition: worst relative log-probability error of the QR-reduced kernel for the
  * current prior box, estimated by emulating its double arithmetic on the host against long
- * double on ~140 probe rows per spectrum (0 for other models).  BISIP_VARIANT_AUTO uses the
- * reduced form only while this is <= 1e-12 (and 2N >= poly_deg+2), else the collapsed form. */
+ * double on ~200 probe rows per spectrum -- uniform in the box, clouds of small coefficients,
+ * clouds around the least-squares solution and draws from the Gaussian posterior, the flat
+ * valley where a sampler's walkers sit -- (0 for other models).  BISIP_VARIANT_AUTO runs the plain
+ * reduced kernel while its estimate is <= 1e-12 (and 2N >= poly_deg+2), else the compensated one
+ * while ITS estimate is <= 1e-12, else the collapsed form.  The value returned is the estimate of
+ * the reduced kernel the current variant runs (or, when that is the collapsed form, of the better
+ * of the two). */
 double bisip_ctx_reduced_error(const bisip_ctx *ctx);
 
 /* Host-only inspection of the walker-independent PolynomialDecomposition operands the

@@ -30,7 +30,7 @@ def make_ctx(g, model, variant='auto'):
 def variants_for(g, model):
     if model != 'PolynomialDecomposition':
         return ['auto']
-    v = ['reduced', 'collapsed']
+    v = ['auto', 'reduced', 'reduced_comp', 'collapsed']
     if int(g['poly_deg']) <= 7:
         v.append('faithful')
     if g['w'].size <= 64:
@@ -71,6 +71,13 @@ def test_extended_shapes_match_reference_golden(path):
         ctx = make_ctx(g, model, variant)
         err = assert_logp_close(ctx.logprob(g['theta']), g['logp'])
         print(f'{case_id(path)} [{ctx.kernel_name}] max rel err {err:.2e}')
+        if variant == 'auto' and model == 'PolynomialDecomposition':
+            # AUTO runs a QR-reduced kernel -- plain, or compensated on the nearly collinear
+            # designs of degree 8-10 -- wherever the design has a triangle at all (2N >= P+2)
+            square = 2 * g['w'].size >= int(g['poly_deg']) + 2
+            assert ctx.kernel_name.startswith('k_logprob_pd_reduced') == square, ctx.kernel_name
+            if square:
+                assert ctx.reduced_error <= 1e-12
         ctx.close()
     ctx = make_ctx(g, model)
     rows = np.all(np.isfinite(g['theta']), axis=1)
@@ -477,44 +484,103 @@ def test_reduced_form_on_ill_conditioned_designs(n_freq, poly_deg, c_exp):
     ctx.close()
 
 
-def test_auto_variant_follows_the_reduced_kernels_error_estimate():
-    """AUTO = the QR-reduced kernel only where a host-side emulation of its double arithmetic
-    stays within 1e-12 of long double on probe rows (bisip_ctx_reduced_error), else the
-    per-frequency form; the estimate is refreshed when the prior box changes."""
+def _pd_context(n_freq, poly_deg, c_exp, idx=5, variant='auto'):
     from bisip_amd import _hip
+    d = _synthetic_problem(n_freq, idx)
+    per = np.log10(1. / d['w'])
+    lt = np.linspace(np.floor(per.min() - 1), np.floor(per.max() + 1), 2 * n_freq)
+    bounds = np.array([[0.9] + [-1.0] * (poly_deg + 1), [1.1] + [1.0] * (poly_deg + 1)])
+    taus, log_taus = 10 ** lt, np.array([lt ** i for i in range(poly_deg + 1)])
+    ctx = _hip.HipContext(0, d['w'], d['zn'], d['zn_err'], bounds, poly_deg=poly_deg, c_exp=c_exp,
+                          taus=taus, log_taus=log_taus, variant=variant)
+    return ctx, bounds, d, taus, log_taus
 
-    def ctx_for(n_freq, poly_deg, c_exp, idx=5):
-        d = _synthetic_problem(n_freq, idx)
-        per = np.log10(1. / d['w'])
-        lt = np.linspace(np.floor(per.min() - 1), np.floor(per.max() + 1), 2 * n_freq)
-        bounds = np.array([[0.9] + [-1.0] * (poly_deg + 1), [1.1] + [1.0] * (poly_deg + 1)])
-        return _hip.HipContext(0, d['w'], d['zn'], d['zn_err'], bounds, poly_deg=poly_deg, c_exp=c_exp,
-                               taus=10 ** lt, log_taus=np.array([lt ** i for i in range(poly_deg + 1)])), bounds
 
-    ctx, _ = ctx_for(32, 5, 1.0, 0)                  # the headline shape
+def test_auto_variant_follows_the_reduced_kernels_error_estimate():
+    """AUTO = the plain QR-reduced kernel where a host-side emulation of its double arithmetic
+    stays within 1e-12 of long double on probe rows (bisip_ctx_reduced_error), else the
+    compensated reduced kernel under the same test, else the per-frequency form; the estimates
+    are refreshed when the prior box changes."""
+    ctx, *_ = _pd_context(32, 5, 1.0, 0)             # the headline shape
     assert ctx.variant == 'reduced' and ctx.kernel_name == 'k_logprob_pd_reduced'
     assert ctx.reduced_error < 1e-13
     ctx.close()
     picked = []
-    for n_freq, poly_deg, c_exp in [(32, 8, 1.0), (48, 7, 0.5), (80, 10, 0.5), (21, 10, 0.5), (64, 9, 0.3), (32, 6, 1.0)]:
-        ctx, _ = ctx_for(n_freq, poly_deg, c_exp, 0)
-        est = ctx.reduced_error
-        assert ctx.variant == ('reduced' if est <= 1e-12 else 'collapsed'), (n_freq, poly_deg, c_exp, est)
+    for n_freq, poly_deg, c_exp in [(32, 8, 1.0), (48, 7, 0.5), (80, 10, 0.5), (21, 10, 0.5), (64, 9, 0.3),
+                                    (32, 6, 1.0), (20, 10, 1.0), (33, 10, 0.5)]:
+        ctx, *_ = _pd_context(n_freq, poly_deg, c_exp, 0)
+        assert ctx.variant in ('reduced', 'reduced_comp'), (n_freq, poly_deg, c_exp, ctx.variant)
+        assert ctx.reduced_error <= 1e-12
+        assert ctx.kernel_name == ('k_logprob_pd_reduced' if ctx.variant == 'reduced' else 'k_logprob_pd_reduced_comp')
         picked.append(ctx.variant)
-        if ctx.variant == 'collapsed':
-            ctx.set_variant('reduced')                # still available on request
-            assert ctx.variant == 'reduced' and ctx.kernel_name == 'k_logprob_pd_reduced'
+        est_auto = ctx.reduced_error
+        ctx.set_variant('reduced')                    # each tier is still available on request
+        est_plain = ctx.reduced_error
+        ctx.set_variant('reduced_comp')
+        est_comp = ctx.reduced_error
+        assert ctx.kernel_name == 'k_logprob_pd_reduced_comp'
+        assert est_auto == (est_plain if est_plain <= 1e-12 else est_comp)
+        assert est_comp <= 1e-12
         ctx.close()
-    assert 'collapsed' in picked                      # nearly collinear designs do fall back
-    ctx, bounds = ctx_for(3, 10, 1.0)                 # fewer data rows than unknowns
+    assert 'reduced_comp' in picked                   # nearly collinear designs need the compensated sums
+    ctx, bounds, *_ = _pd_context(3, 10, 1.0)         # fewer data rows than unknowns: no triangle
     assert ctx.variant == 'collapsed'
     ctx.close()
-    ctx, bounds = ctx_for(32, 8, 1.0, 0)
+    ctx, bounds, *_ = _pd_context(32, 8, 1.0, 0)
     before = ctx.reduced_error
     ctx.set_bounds(bounds * np.r_[1.0, np.full(9, 1e-4)])       # the estimate follows the prior box
     after = ctx.reduced_error
     assert np.isfinite(after) and after != before
-    assert ctx.variant == ('reduced' if after <= 1e-12 else 'collapsed')
+    assert ctx.variant in ('reduced', 'reduced_comp') and after <= 1e-12
+    ctx.close()
+
+
+@pytest.mark.parametrize('n_freq,poly_deg,c_exp,idx', [(32, 10, 0.5, 0), (33, 10, 0.5, 3), (20, 10, 0.5, 7), (80, 10, 0.5, 1),
+                                                         (32, 8, 0.5, 2), (64, 9, 1.0, 4), (48, 6, 0.3, 5)])
+def test_posterior_valley_walkers_on_nearly_collinear_designs(n_freq, poly_deg, c_exp, idx):
+    """Where an ensemble sampler's walkers actually sit on a design of degree 6-10: draws from the
+    Gaussian posterior of the linear model, spread along the flat valley of chi^2.  There every
+    row of R (bhat - b), and every per-frequency residual of the reference's own sum, cancels by
+    many orders of magnitude.  Every formulation must stay within the parity tolerance of the
+    oracle, and the compensated reduced kernel -- what AUTO runs when the plain one's estimate is
+    too large -- must agree with a 50-digit evaluation far better than that."""
+    import oracle
+    from bisip_amd import _hip
+    ctx, bounds, d, taus, log_taus = _pd_context(n_freq, poly_deg, c_exp, idx)
+    n = poly_deg + 2
+    ops = _hip.polydecomp_operands(d['w'], d['zn'], d['zn_err'], taus, log_taus, c_exp)
+    R, bls = ops['R'].astype(np.longdouble), ops['bhat'].astype(np.longdouble)
+    rng = np.random.RandomState(poly_deg * 100 + n_freq)
+    rows = []
+    for scale in (1.0, 3.0):
+        z = scale * rng.randn(400, n)
+        db = np.array([np.linalg.solve(ops['R'], zi) for zi in z])
+        b = bls[None, :] + db
+        t = np.concatenate([b[:, :1], b[:, 1:] / b[:, :1]], axis=1).astype(np.float64)
+        rows.append(t[np.all((bounds[0] < t) & (t < bounds[1]), axis=1)])
+    theta = np.concatenate(rows)
+    if len(theta) < 20:
+        pytest.skip('the posterior of this design lies outside the default prior box')
+    prob = oracle.OracleProblem('PolynomialDecomposition', d['w'], d['zn'], d['zn_err'], bounds,
+                                taus=taus, log_taus=log_taus, c_exp=c_exp)
+    want = oracle.logprob(prob, theta)
+    assert np.all(np.isfinite(want)) and np.ptp(want) < 1e4         # all near the mode
+    # chi^2 in long double from the same operands the kernels hold (the triangle R and Q^T y)
+    qty = ops['e'].astype(np.longdouble) + R @ bls
+    tl = theta.astype(np.longdouble)                  # b = R0 * (1, a): the products too in long double
+    bb = np.concatenate([tl[:, :1], tl[:, :1] * tl[:, 1:]], axis=1)
+    u = qty[None, :] - bb @ R.T
+    exact = (-0.5 * (np.longdouble(ops['rest']) + (u * u).sum(axis=1)) + np.longdouble(ops['lconst'])).astype(np.float64)
+    errs = {}
+    for variant in ('auto', 'reduced', 'reduced_comp', 'collapsed'):
+        ctx.set_variant(variant)
+        got = ctx.logprob(theta)
+        errs[variant] = (assert_logp_close(got, want),
+                         float(np.max(np.abs(got - exact) / np.maximum(1.0, np.abs(exact)))))
+    print(n_freq, poly_deg, c_exp, len(theta), {k: ('%.1e' % a, '%.1e' % b) for k, (a, b) in errs.items()})
+    assert errs['reduced_comp'][1] <= 1e-12
+    ctx.set_variant('auto')
+    assert ctx.variant in ('reduced', 'reduced_comp') and errs['auto'][1] <= 2e-12
     ctx.close()
 
 
@@ -739,4 +805,12 @@ def test_bench_two_ranks_on_one_device():
     assert rec['config']['global_walkers'] == 2 << 20 and rec['config']['kernel'] == 'k_logprob_pd_reduced'
     assert len(rec['roofline']['per_rank_kernel_ms']) == 2 and min(rec['roofline']['per_rank_kernel_ms']) > 0
     assert rec['value'] > 1e8 and 'cpu_baseline' not in rec       # rank-0-at-N=1 extras stay out
+    # after the result line the same two ranks ran BASELINE config 4's sharded stretch move (here
+    # over gloo through host memory, each rank evaluating its half of every half-step with the
+    # real kernels): every rank holds the same ensemble, and it is the single-GPU chain
+    extra = [json.loads(ln) for ln in r.stderr.splitlines() if ln.startswith('{"sampler_cfg4"')]
+    assert len(extra) == 1, r.stderr[-3000:]
+    sc = extra[0]['sampler_cfg4']
+    assert sc['n_gpus'] == 2 and sc['walkers'] == 32768 and sc['driver'] == 'sharded'
+    assert sc['state_identical_on_every_rank'] is True and sc['equals_single_gpu_fused_chain'] is True
 
