@@ -609,7 +609,7 @@ int bisip_stretch_persistent_dev(bisip_ctx *c, const bisip_persist_args *u, void
     if (E != c->E) return fail(BISIP_EINVAL, "n_walkers/walkers_per_ensemble=%lld but the context holds %d spectra", (long long)E, c->E);
     if (c->E > 1 && (Wp & 1)) return fail(BISIP_EINVAL, "batch context: walkers per spectrum must be even");
     if (u->thin_by < 1 || u->n_steps < 0 || u->n_steps % u->thin_by) return fail(BISIP_EINVAL, "n_steps must be a multiple of thin_by");
-    if ((size_t)Wp * (c->ndim + 1) * sizeof(double) > 65536 || (Wp + 1) / 2 > 1024)
+    if ((size_t)Wp * (c->ndim + 1) * sizeof(double) > 65536 || (Wp + 1) / 2 > 512)
         return fail(BISIP_EUNSUPPORTED, "ensemble of %lld walkers does not fit one workgroup", (long long)Wp);
     if (u->n_steps == 0) return BISIP_OK;
     HIP_TRY(hipSetDevice(c->device));

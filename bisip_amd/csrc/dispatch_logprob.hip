@@ -182,6 +182,7 @@ int dispatch_logprob(const bisip_ctx *c, const double *theta, int64_t W, double 
         return fail(BISIP_EINVAL, "W=%lld exceeds the launch grid limit", (long long)W);
     if (c->E > 1) {
         if (W % c->E) return fail(BISIP_EINVAL, "W=%lld is not a multiple of n_spectra=%d", (long long)W, c->E);
+        if (W > 0xffffffffLL) return fail(BISIP_EINVAL, "W=%lld: a batch context takes fewer than 2^32 rows per call", (long long)W);
         return dispatch_logprob_batch(c, theta, W, out, st);
     }
     switch (c->model_id) {

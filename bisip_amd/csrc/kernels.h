@@ -165,6 +165,44 @@ __device__ __forceinline__ double rcp_nr(double x)
     return fma(r, e, r);
 }
 
+// K independent values in lockstep: every Horner / Newton step is issued for all K before the
+// next step, so a wave has K independent dependency chains in flight.  One fp64 VALU op takes
+// ~8.3 cycles to its dependent successor but a SIMD can start one every ~4.5 cycles: with ONE
+// wave per SIMD -- every sampler half-step of <= 65,536 proposals, every emcee-sized call -- a
+// single chain runs at half the issue rate (benchmarks/micro/issue_latency.hip: 8.3 / 6.5 / 5.4
+// cycles per instruction at 1 / 2 / 4 chains).  Same operations per value, so the same bits.
+template <int K>
+__device__ __forceinline__ void exp2_finite_n(const double (&y)[K], double (&out)[K])
+{
+    double t[K], f[K], p[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) { t[k] = rint(y[k]); f[k] = y[k] - t[k]; p[k] = 0x1.e9bbe9e45e5a6p-32; }
+#define BISIP_HORNER(c) _Pragma("unroll") for (int k = 0; k < K; ++k) p[k] = fma(p[k], f[k], c);
+    BISIP_HORNER(0x1.e5ea03c5ae3ccp-28) BISIP_HORNER(0x1.b525087314718p-24) BISIP_HORNER(0x1.62bfe45ac08ccp-20)
+    BISIP_HORNER(0x1.ffcbfc61f8673p-17) BISIP_HORNER(0x1.4309130379f8bp-13) BISIP_HORNER(0x1.5d87fe78a5dc3p-10)
+    BISIP_HORNER(0x1.3b2ab6fba385bp-7) BISIP_HORNER(0x1.c6b08d704a0c0p-5) BISIP_HORNER(0x1.ebfbdff82c590p-3)
+    BISIP_HORNER(0x1.62e42fefa39efp-1) BISIP_HORNER(1.0)
+#undef BISIP_HORNER
+#pragma unroll
+    for (int k = 0; k < K; ++k) out[k] = ldexp(p[k], (int)t[k]);
+}
+
+template <int K>
+__device__ __forceinline__ void rcp_nr_n(const double (&x)[K], double (&r)[K])
+{
+    double e[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) r[k] = __builtin_amdgcn_rcp(x[k]);
+#pragma unroll
+    for (int k = 0; k < K; ++k) e[k] = fma(-x[k], r[k], 1.0);
+#pragma unroll
+    for (int k = 0; k < K; ++k) r[k] = fma(r[k], e[k], r[k]);
+#pragma unroll
+    for (int k = 0; k < K; ++k) e[k] = fma(-x[k], r[k], 1.0);
+#pragma unroll
+    for (int k = 0; k < K; ++k) r[k] = fma(r[k], e[k], r[k]);
+}
+
 // ---------------------------------------------------------------------------------
 // Forward models.  Each exposes
 //   NDIM, REC (doubles per frequency record; rec[0..3] = y_re, y_im, 1/s2_re, 1/s2_im)
@@ -173,6 +211,8 @@ __device__ __forceinline__ double rcp_nr(double x)
 //   residual(setup, rec, rr, ri)       y - Z at one frequency for the log-likelihood, with
 //                                      the walker-constant part of Z folded into per-walker
 //                                      constants (fewer instructions than y - eval())
+//   residual2(setup, recA, recB, ...)  the same for TWO frequencies with their dependency chains
+//                                      interleaved (see exp2_finite_n); identical values
 // ---------------------------------------------------------------------------------
 
 // PolynomialDecomposition, collapsed: Z_j = R0*(1 - sum_p a_p G[j,p]).
@@ -212,6 +252,20 @@ struct PDCollapsed {
         for (int p = 0; p <= P; ++p) {
             rr = fma(s.b[p], rec[4 + p], rr);
             ri = fma(s.b[p], rec[4 + P + 1 + p], ri);
+        }
+    }
+    __device__ static __forceinline__ void residual2(const Setup &s, const double *__restrict__ ra,
+                                                     const double *__restrict__ rb, double (&rr)[2],
+                                                     double (&ri)[2])
+    {
+        rr[0] = fma(s.r0, ra[2], ra[0]); rr[1] = fma(s.r0, rb[2], rb[0]);
+        ri[0] = ra[1]; ri[1] = rb[1];
+#pragma unroll
+        for (int p = 0; p <= P; ++p) {
+            rr[0] = fma(s.b[p], ra[4 + p], rr[0]);
+            rr[1] = fma(s.b[p], rb[4 + p], rr[1]);
+            ri[0] = fma(s.b[p], ra[4 + P + 1 + p], ri[0]);
+            ri[1] = fma(s.b[p], rb[4 + P + 1 + p], ri[1]);
         }
     }
     // Z = r0 - sum_p b_p G_p  (m = unweighted G_re[0..P], G_im[0..P])
@@ -275,6 +329,33 @@ struct ColeCole {
             ri = fma(t, di, ri);
         }
     }
+    __device__ static __forceinline__ void residual2(const Setup &s, const double *__restrict__ ra,
+                                                     const double *__restrict__ rb, double (&rr)[2],
+                                                     double (&ri)[2])
+    {
+        constexpr int K = 2 * D;     // value k = (frequency k / D, mode k % D)
+        const double lnw[2] = {ra[5], rb[5]};
+        double y[K], e[K], dr[K], di[K], den[K], inv[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) y[k] = fma(s.c2[k % D], lnw[k / D], s.clt2[k % D]);
+        exp2_finite_n<K>(y, e);
+#pragma unroll
+        for (int k = 0; k < K; ++k) { dr[k] = fma(e[k], s.cs[k % D], 1.0); di[k] = e[k] * s.sn[k % D]; }
+#pragma unroll
+        for (int k = 0; k < K; ++k) den[k] = fma(dr[k], dr[k], di[k] * di[k]);
+        rcp_nr_n<K>(den, inv);
+        rr[0] = ra[0] - s.C; rr[1] = rb[0] - s.C;
+        ri[0] = ra[1]; ri[1] = rb[1];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {          // per frequency: modes accumulate in ascending order
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                const double t = s.A[i] * inv[f * D + i];
+                rr[f] = fma(-t, dr[f * D + i], rr[f]);
+                ri[f] = fma(t, di[f * D + i], ri[f]);
+            }
+        }
+    }
     // Z = (r0 - sum A_i) + sum A_i conj(1+x_i)/|1+x_i|^2   (m = w, ln w, sqrt w)
     __device__ static __forceinline__ void eval(const Setup &s, const double *__restrict__ m,
                                                 double &zr, double &zi)
@@ -336,6 +417,35 @@ struct Dias {
         rr = fma(-t, dr, rec[0] - s.C);
         ri = fma(t, di, rec[1]);
     }
+    __device__ static __forceinline__ void residual2(const Setup &s, const double *__restrict__ ra,
+                                                     const double *__restrict__ rb, double (&rr)[2],
+                                                     double (&ri)[2])
+    {
+        const double *__restrict__ rec[2] = {ra, rb};
+        double mur[2], mui[2], den1[2], inv1[2], dr[2], di[2], den2[2], inv2[2];
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            mur[f] = rec[f][6] * s.teh;
+            mui[f] = fma(rec[f][4], s.tau, mur[f]);
+            den1[f] = fma(mur[f], mur[f], mui[f] * mui[f]);
+        }
+        rcp_nr_n<2>(den1, inv1);
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            const double tr = fma(mur[f], inv1[f], 1.0), nti = mui[f] * inv1[f];
+            const double a = rec[f][4] * s.taup;
+            dr[f] = fma(a, nti, 1.0);
+            di[f] = a * tr;
+            den2[f] = fma(dr[f], dr[f], di[f] * di[f]);
+        }
+        rcp_nr_n<2>(den2, inv2);
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            const double t = s.A * inv2[f];
+            rr[f] = fma(-t, dr[f], rec[f][0] - s.C);
+            ri[f] = fma(t, di[f], rec[f][1]);
+        }
+    }
     // Z = r0 (1-m) + r0 m conj(den)/|den|^2   (m = w, ln w, sqrt w)
     __device__ static __forceinline__ void eval(const Setup &s, const double *__restrict__ m,
                                                 double &zr, double &zi)
@@ -394,6 +504,33 @@ struct Shin {
             const double inv = rcp_nr(fma(yr, yr, yi * yi));
             rr = fma(-yr, inv, rr);
             ri = fma(yi, inv, ri);
+        }
+    }
+    __device__ static __forceinline__ void residual2(const Setup &s, const double *__restrict__ ra,
+                                                     const double *__restrict__ rb, double (&rr)[2],
+                                                     double (&ri)[2])
+    {
+        const double lnw[2] = {ra[5], rb[5]};
+        double y[4], p[4], yr[4], yi[4], den[4], inv[4];     // k = (frequency k / 2, element k % 2)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) y[k] = fma(s.n2[k % 2], lnw[k / 2], s.lq2[k % 2]);
+        exp2_finite_n<4>(y, p);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            yr[k] = fma(p[k], s.cs[k % 2], s.invR[k % 2]);
+            yi[k] = p[k] * s.sn[k % 2];
+            den[k] = fma(yr[k], yr[k], yi[k] * yi[k]);
+        }
+        rcp_nr_n<4>(den, inv);
+        rr[0] = ra[0]; rr[1] = rb[0];
+        ri[0] = ra[1]; ri[1] = rb[1];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                rr[f] = fma(-yr[f * 2 + i], inv[f * 2 + i], rr[f]);
+                ri[f] = fma(yi[f * 2 + i], inv[f * 2 + i], ri[f]);
+            }
         }
     }
     // Z = sum_i conj(y_i)/|y_i|^2,  y_i = Q (iw)^n + 1/R   (m = w, ln w, sqrt w)
@@ -469,7 +606,36 @@ __device__ __forceinline__ void rotate_sums(double rr, double ri, const double *
     }
 }
 
-template <class M, int L = 1>
+// Two 8-double frequency records (128 B) from LDS into registers, asynchronously: the ds_reads
+// are issued here, and lds_pair_wait() -- an s_waitcnt that names the same registers, so every
+// use is ordered after it -- is placed by the CALLER after the arithmetic of the current pair.
+// Written as inline assembly because the compiler, left to itself, sinks a load whose first use
+// is in the next loop iteration down to that use and waits there (and a volatile pointer loses
+// the LDS address space: flat loads, one wait each).
+// `tie` is an operand of the arithmetic that must come AFTER the reads are in flight (the
+// compiler may move ordinary arithmetic across a volatile asm it does not depend on).
+__device__ __forceinline__ void lds_pair_issue(const double *lds_ptr, dbl2 (&v)[8], double &tie)
+{
+    const unsigned a = (unsigned)(unsigned long long)(const __attribute__((address_space(3))) double *)lds_ptr;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v[0]) : "v"(a));
+    asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(v[1]) : "v"(a));
+    asm volatile("ds_read_b128 %0, %1 offset:32" : "=v"(v[2]) : "v"(a));
+    asm volatile("ds_read_b128 %0, %1 offset:48" : "=v"(v[3]) : "v"(a));
+    asm volatile("ds_read_b128 %0, %1 offset:64" : "=v"(v[4]) : "v"(a));
+    asm volatile("ds_read_b128 %0, %1 offset:80" : "=v"(v[5]) : "v"(a));
+    asm volatile("ds_read_b128 %0, %1 offset:96" : "=v"(v[6]) : "v"(a));
+    asm volatile("ds_read_b128 %0, %2 offset:112" : "=v"(v[7]), "+v"(tie) : "v"(a));
+}
+
+__device__ __forceinline__ void lds_pair_wait(dbl2 (&v)[8])
+{
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+}
+
+// LDSREC: o.cb points at records staged in LDS (16-byte aligned); the pipelined loop then
+// fetches the next pair with lds_pair_issue / lds_pair_wait around the current pair's arithmetic.
+template <class M, int L = 1, bool LDSREC = false>
 __device__ __forceinline__ double logprob_row(const double (&th)[M::NDIM], const ModelOperands &o,
                                               const Bounds &b, const int g = 0)
 {
@@ -478,9 +644,78 @@ __device__ __forceinline__ double logprob_row(const double (&th)[M::NDIM], const
     const typename M::Setup s = M::setup(th);
     double acc0 = 0.0, acc1 = 0.0;
     if constexpr (L == 1) {
+        // two frequencies at a time, their dependency chains interleaved (residual2); the sums
+        // still take their terms one by one in ascending frequency order
         const double *__restrict__ rec = o.cb;
-#pragma unroll 2
-        for (int j = 0; j < o.N; ++j, rec += M::REC) {
+        int j = 0;
+        if constexpr (!M::WEIGHTED && 2 * M::REC <= 16) {
+            // software pipeline: the records of the NEXT pair are requested before this pair is
+            // evaluated.  With one wave per SIMD nothing else hides a record load -- ~500 cycles
+            // from L2 when every wave reads its own spectrum (batch of spectra: the 16 KB scalar
+            // cache thrashes), ~100 from the scalar cache or LDS -- and the counters showed the
+            // half-step kernel waiting on them for 56 % of its time (profiles/r02_cfg5_pmc.txt).
+            constexpr int R2 = 2 * M::REC;
+            double cur[R2], nxt[R2];
+            if constexpr (LDSREC && M::REC == 8) {
+                dbl2 buf[8];
+                if (o.N >= 2) {
+                    lds_pair_issue(rec, buf, acc0);
+                    lds_pair_wait(buf);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { cur[2 * q] = buf[q].x; cur[2 * q + 1] = buf[q].y; }
+                }
+                for (; j + 1 < o.N; j += 2, rec += R2) {
+                    lds_pair_issue((j + 3 < o.N) ? rec + R2 : rec, buf, cur[5]);   // last pair: a harmless re-read
+                    double rr[2], ri[2];
+                    M::residual2(s, cur, cur + M::REC, rr, ri);
+#pragma unroll
+                    for (int f = 0; f < 2; ++f) {
+                        acc0 = fma(rr[f] * rr[f], cur[f * M::REC + 2], acc0);
+                        acc1 = fma(ri[f] * ri[f], cur[f * M::REC + 3], acc1);
+                    }
+                    // the compiler must not float the wait above the arithmetic: tie it to its results
+                    asm volatile("" : "+v"(acc0), "+v"(acc1));
+                    lds_pair_wait(buf);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { cur[2 * q] = buf[q].x; cur[2 * q + 1] = buf[q].y; }
+                }
+            } else {
+                if (o.N >= 2) {
+#pragma unroll
+                    for (int q = 0; q < R2; ++q) cur[q] = rec[q];
+                }
+                for (; j + 1 < o.N; j += 2, rec += R2) {
+                    const double *__restrict__ ahead = (j + 3 < o.N) ? rec + R2 : rec;   // last pair: a harmless re-read
+#pragma unroll
+                    for (int q = 0; q < R2; ++q) nxt[q] = ahead[q];
+                    double rr[2], ri[2];
+                    M::residual2(s, cur, cur + M::REC, rr, ri);
+#pragma unroll
+                    for (int f = 0; f < 2; ++f) {
+                        acc0 = fma(rr[f] * rr[f], cur[f * M::REC + 2], acc0);
+                        acc1 = fma(ri[f] * ri[f], cur[f * M::REC + 3], acc1);
+                    }
+#pragma unroll
+                    for (int q = 0; q < R2; ++q) cur[q] = nxt[q];
+                }
+            }
+        } else {
+            for (; j + 1 < o.N; j += 2, rec += 2 * M::REC) {
+                double rr[2], ri[2];
+                M::residual2(s, rec, rec + M::REC, rr, ri);
+#pragma unroll
+                for (int f = 0; f < 2; ++f) {
+                    if constexpr (M::WEIGHTED) {
+                        acc0 = fma(rr[f], rr[f], acc0);
+                        acc1 = fma(ri[f], ri[f], acc1);
+                    } else {
+                        acc0 = fma(rr[f] * rr[f], rec[f * M::REC + 2], acc0);
+                        acc1 = fma(ri[f] * ri[f], rec[f * M::REC + 3], acc1);
+                    }
+                }
+            }
+        }
+        if (j < o.N) {
             double rr, ri;
             M::residual(s, rec, rr, ri);
             if constexpr (M::WEIGHTED) {
@@ -860,7 +1095,9 @@ struct BatchArgs {
 template <bool UNIFORM>
 __device__ __forceinline__ long long spectrum_of(long long row, long long Wp)
 {
-    const int e = (int)(row / Wp);
+    // rows and Wp are below 2^31 (checked on the host): a 32-bit division, a third of the
+    // instructions of the 64-bit one
+    const int e = (int)((unsigned)row / (unsigned)Wp);
     return UNIFORM ? (long long)__builtin_amdgcn_readfirstlane(e) : (long long)e;
 }
 

@@ -40,16 +40,34 @@ struct StretchArgs {
     long long pad, base, extra;
 };
 
-// L = lanes per walker (see logprob_row); g = this lane's index inside its group
+// L = lanes per walker (see logprob_row); g = this lane's index inside its group.
+// Functors over per-frequency records (CAN_STAGE) also say where a walker's records live and
+// evaluate against a copy of them -- the persistent kernel keeps that copy in LDS.
 template <class M, int L_ = 1>
 struct GenericLP {
     static constexpr int NDIM = M::NDIM;
     static constexpr int L = L_;
+    static constexpr bool CAN_STAGE = true;
+    static constexpr int REC_DOUBLES = M::REC;
     ModelOperands o;
     Bounds b;
     __device__ __forceinline__ double operator()(const double (&th)[NDIM], int, int g) const
     {
         return logprob_row<M, L>(th, o, b, g);
+    }
+    // persistent kernel: the ensemble index e is known to the caller (no division per call);
+    // lds = that ensemble's records in LDS, or null to read them where they are
+    __device__ __forceinline__ const double *records(long long) const { return o.cb; }
+    __host__ __device__ __forceinline__ int n_freq() const { return o.N; }
+    template <bool STAGED>
+    __device__ __forceinline__ double eval_ens(const double (&th)[NDIM], long long, int g, const double *lds) const
+    {
+        if constexpr (STAGED) {
+            const ModelOperands oo{lds, o.N, o.lconst};
+            return logprob_row<M, L, true>(th, oo, b, g);
+        } else {
+            return logprob_row<M, L>(th, o, b, g);
+        }
     }
 };
 
@@ -57,10 +75,16 @@ template <int P, bool COMP = false>
 struct ReducedLP {
     static constexpr int NDIM = P + 2;
     static constexpr int L = 1;
+    static constexpr bool CAN_STAGE = false;
     ReducedArgs<P> r;
     double lconst;
     Bounds b;
     __device__ __forceinline__ double operator()(const double (&th)[NDIM], int, int) const
+    {
+        return logprob_row_reduced<P, COMP>(th, r, lconst, b);
+    }
+    template <bool STAGED>
+    __device__ __forceinline__ double eval_ens(const double (&th)[NDIM], long long, int, const double *) const
     {
         return logprob_row_reduced<P, COMP>(th, r, lconst, b);
     }
@@ -71,6 +95,8 @@ template <class M, bool UNIFORM, int L_ = 1>
 struct BatchGenericLP {
     static constexpr int NDIM = M::NDIM;
     static constexpr int L = L_;
+    static constexpr bool CAN_STAGE = true;
+    static constexpr int REC_DOUBLES = M::REC;
     const double *cb;
     long long cb_stride, Wp;
     const double *lconst;
@@ -82,12 +108,23 @@ struct BatchGenericLP {
         const ModelOperands o{cb + e * cb_stride, N, lconst[e]};
         return logprob_row<M, L>(th, o, b, g);
     }
+    __device__ __forceinline__ const double *records(long long e) const { return cb + e * cb_stride; }
+    __host__ __device__ __forceinline__ int n_freq() const { return N; }
+    template <bool STAGED>
+    __device__ __forceinline__ double eval_ens(const double (&th)[NDIM], long long e, int g, const double *lds) const
+    {
+        // e is the same for every lane of the wave (a wave never straddles two ensembles)
+        const long long eu = (long long)__builtin_amdgcn_readfirstlane((int)e);
+        const ModelOperands o{STAGED ? lds : cb + eu * cb_stride, N, lconst[eu]};
+        return logprob_row<M, L, STAGED>(th, o, b, g);
+    }
 };
 
 template <int P, bool UNIFORM, bool COMP = false>
 struct BatchReducedLP {
     static constexpr int NDIM = P + 2;
     static constexpr int L = 1;
+    static constexpr bool CAN_STAGE = false;
     const ReducedArgs<P> *red;
     long long Wp;
     const double *lconst;
@@ -97,16 +134,25 @@ struct BatchReducedLP {
         const long long e = spectrum_of<UNIFORM>(walker, Wp);
         return logprob_row_reduced<P, COMP>(th, red[e], lconst[e], b);
     }
+    template <bool STAGED>
+    __device__ __forceinline__ double eval_ens(const double (&th)[NDIM], long long e, int, const double *) const
+    {
+        const long long eu = (long long)__builtin_amdgcn_readfirstlane((int)e);
+        return logprob_row_reduced<P, COMP>(th, red[eu], lconst[eu], b);
+    }
 };
 
 // One stretch move: walker i (state row s, log-prob old_lp) along the line through row c.
 // `walker` is the global walker id handed to the log-prob functor (batch contexts pick
 // the spectrum from it).  Returns the row / log-prob AFTER the move.
-template <class LP>
+// ENS = 0: the functor finds the walker's spectrum itself; 1 / 2: the caller (persistent kernel)
+// names the ensemble, records where they are / staged in LDS at lds_records.
+template <int ENS = 0, class LP>
 __device__ __forceinline__ bool stretch_move(const double *s_row, const double *c_row, double old_lp,
                                              double z, double factor, double logu, const LP &lp,
                                              int walker, int g, int *status, double (&row)[LP::NDIM],
-                                             double &lp_row)
+                                             double &lp_row, long long ens = 0,
+                                             const double *lds_records = nullptr)
 {
     constexpr int NDIM = LP::NDIM;
     double s[NDIM], q[NDIM];
@@ -117,7 +163,10 @@ __device__ __forceinline__ bool stretch_move(const double *s_row, const double *
         const double d = c - s[k];
         q[k] = c - d * z;
     }
-    const double new_lp = lp(q, walker, g);
+    double new_lp;
+    if constexpr (ENS == 2) new_lp = lp.template eval_ens<true>(q, ens, g, lds_records);
+    else if constexpr (ENS == 1) new_lp = lp.template eval_ens<false>(q, ens, g, nullptr);
+    else new_lp = lp(q, walker, g);
     if (new_lp != new_lp) atomicOr(status, 1);
     const bool acc = (factor + new_lp) - old_lp > logu;
 #pragma unroll
@@ -161,11 +210,11 @@ __device__ __forceinline__ void commit_row(const StretchArgs &a, int i, const do
 // lanes still run (clamped to the last slot) so the wavefront exchanges stay uniform; only
 // lane 0 of a live slot commits.  All lanes of a wave read their rows before any commits
 // (same instruction stream), and no other wave touches them.
-template <class LP>
-__global__ __launch_bounds__(64) void k_stretch_half(const StretchArgs a, const LP lp)
+template <class LP, int BLK = 64>
+__global__ __launch_bounds__(BLK) void k_stretch_half(const StretchArgs a, const LP lp)
 {
     constexpr int L = LP::L;
-    const long long tid = (long long)blockIdx.x * 64 + threadIdx.x;
+    const long long tid = (long long)blockIdx.x * BLK + threadIdx.x;
     const long long slot = tid / L;
     const int g = (int)(tid % L);
     const bool live = slot < a.n_slots;
@@ -320,6 +369,10 @@ struct PersistArgs {
     double *logp_chain;  // (n_steps/thin_by, E*W) or null
     int *naccept;        // (E*W,) or null
     int *status;
+    // launch shape (dispatch_stretch.hip): a workgroup holds `epw` ensembles of `lanes_per_ens`
+    // lanes each (a multiple of 64, so no wave straddles two ensembles)
+    int lanes_per_ens, epw;
+    long long rec_stride;   // STAGED: doubles between two ensembles' record copies in LDS (even)
 };
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every
@@ -341,22 +394,45 @@ __device__ __forceinline__ SlotStream load_slot(const PersistArgs &a, long long 
     return d;
 }
 
-template <class LP>
-__global__ __launch_bounds__(1024) void k_stretch_persistent(const PersistArgs a, const LP lp)
+// Workgroup shape.  Many ensembles (a batch of spectra): workgroups of >= 256 lanes, i.e. several
+// ensembles each -- the dispatcher spreads four-wave workgroups one per CU with one wave per SIMD,
+// whereas 512 two-wave workgroups on 256 CUs land unevenly (measured 1.6x slower,
+// benchmarks/micro/issue_latency.hip).  The ensembles of a workgroup share nothing but the
+// barrier; lanes of a missing last ensemble shadow ensemble E-1 and never commit.
+// STAGED: the frequency records of each ensemble's spectrum are copied into LDS once per launch
+// and logprob_row reads them from there (software-pipelined, kernels.h): a scalar load costs
+// 250-500 cycles even on a scalar-cache hit, and with one wave per SIMD nothing hides it.
+// At most 512 lanes per workgroup: two waves per SIMD leave each lane 256 VGPRs (the pipelined
+// log-probability wants ~150; under a 1024-lane bound the compiler must stay below 128 and spills).
+template <class LP, bool STAGED>
+__global__ __launch_bounds__(512) void k_stretch_persistent(const PersistArgs a, const LP lp)
 {
     constexpr int NDIM = LP::NDIM;
     constexpr int L = LP::L;
-    extern __shared__ __attribute__((aligned(16))) double lds_state[];  // W*NDIM coords | W logp
-    double *xs = lds_state;
-    double *ls = lds_state + a.W * NDIM;
-    const long long e = blockIdx.x;
+    extern __shared__ __attribute__((aligned(16))) double lds_state[];  // per ensemble: W*NDIM coords | W logp
+    const int ens_local = threadIdx.x / a.lanes_per_ens;
+    const int lane = threadIdx.x - ens_local * a.lanes_per_ens;
+    const long long e_raw = (long long)blockIdx.x * a.epw + ens_local;
+    const bool ens_live = e_raw < a.E;
+    const long long e = ens_live ? e_raw : a.E - 1;
+    const long long state_doubles = a.W * (NDIM + 1);
+    double *xs = lds_state + ens_local * state_doubles;
+    double *ls = xs + a.W * NDIM;
     const long long base = e * a.W;           // first global walker of this ensemble
-    for (long long i = threadIdx.x; i < a.W * NDIM; i += blockDim.x) xs[i] = a.coords[base * NDIM + i];
-    for (long long i = threadIdx.x; i < a.W; i += blockDim.x) ls[i] = a.logp[base + i];
+    for (long long i = lane; i < a.W * NDIM; i += a.lanes_per_ens) xs[i] = a.coords[base * NDIM + i];
+    for (long long i = lane; i < a.W; i += a.lanes_per_ens) ls[i] = a.logp[base + i];
+    const double *recs = nullptr;
+    if constexpr (STAGED) {
+        double *mine = lds_state + ((a.epw * state_doubles + 1) & ~1LL) + ens_local * a.rec_stride;
+        const double *__restrict__ src = lp.records(e);
+        const int n = lp.n_freq() * LP::REC_DOUBLES;
+        for (int i = lane; i < n; i += a.lanes_per_ens) mine[i] = src[i];
+        recs = mine;
+    }
     __syncthreads();
     const long long nh = (a.W + 1) / 2;       // slots of half 0; half 1 has W/2
-    const long long slot = threadIdx.x / L;
-    const int g = threadIdx.x % L;
+    const long long slot = lane / L;
+    const int g = lane % L;
     // lanes past the last slot of a half run clamped to it (the wavefront exchanges of
     // L > 1 need whole groups) and never commit
     const long long t0 = slot < nh ? slot : nh - 1;
@@ -369,12 +445,13 @@ __global__ __launch_bounds__(1024) void k_stretch_persistent(const PersistArgs a
             // request the next half-step's entries now; they are consumed after the barrier
             const long long kn = h ? (k + 1 < a.n_steps ? k + 1 : k) : k;
             const SlotStream nxt = load_slot(a, ((kn * 2 + (1 - h)) * a.E + e) * nh + (h ? t0 : t1));
-            const bool live = slot < (h ? a.W / 2 : nh);
+            const bool live = ens_live && slot < (h ? a.W / 2 : nh);
             const int i = cur.active - (int)base, p = cur.partner - (int)base;
             double row[NDIM], lp_row;
             // every lane of a slot reads the rows before lane 0 writes (same wave, program order)
-            const bool acc = stretch_move(xs + (long long)i * NDIM, xs + (long long)p * NDIM, ls[i], cur.z,
-                                          cur.factor, cur.logu, lp, (int)(base + i), g, a.status, row, lp_row);
+            const bool acc = stretch_move<STAGED ? 2 : 1>(xs + (long long)i * NDIM, xs + (long long)p * NDIM, ls[i], cur.z,
+                                                          cur.factor, cur.logu, lp, (int)(base + i), g, a.status, row,
+                                                          lp_row, e, recs);
             if (live && g == 0) {
                 if (acc) {   // own row only; partners are never active in this half
 #pragma unroll
@@ -393,8 +470,10 @@ __global__ __launch_bounds__(1024) void k_stretch_persistent(const PersistArgs a
             lds_barrier();     // the other half reads the rows just written
         }
     }
-    for (long long i = threadIdx.x; i < a.W * NDIM; i += blockDim.x) a.coords[base * NDIM + i] = xs[i];
-    for (long long i = threadIdx.x; i < a.W; i += blockDim.x) a.logp[base + i] = ls[i];
+    if (ens_live) {
+        for (long long i = lane; i < a.W * NDIM; i += a.lanes_per_ens) a.coords[base * NDIM + i] = xs[i];
+        for (long long i = lane; i < a.W; i += a.lanes_per_ens) a.logp[base + i] = ls[i];
+    }
 }
 
 }  // namespace bisip

@@ -374,20 +374,34 @@ class HipStretchBackend:
         self.ctx = ctx
         self.device = torch.device('cuda', ctx.device)
 
-    def tensor(self, array, dtype=None):
+    def tensor(self, array, dtype=None, slot='a'):
+        """Host array -> device tensor WITHOUT waiting on the host: the data is staged in a
+        process-wide pinned scratch block and copied asynchronously on the compute stream (an
+        event guards the block's reuse).  A blocking copy here would also wait for the HIP
+        runtime to finish retiring the launch records of whatever ran before -- 20-35 ms after
+        a 2000-launch run (benchmarks/micro/upload_cost*.py) -- while an asynchronous one lets
+        that happen behind the new run's kernels.  ``slot`` names the scratch block: uploads
+        that follow each other within one run use different slots so that none waits for another."""
         torch = self.torch
         t = torch.as_tensor(np.ascontiguousarray(array), dtype=dtype)
-        if t.numel() * t.element_size() < (256 << 10):
-            return t.to(self.device)
-        # big uploads (the ensemble's start positions) go through a process-wide pinned scratch
-        # block: no per-call pinning of the caller's pageable pages by the HIP runtime, no fresh
-        # multi-MB allocation per run
         nbytes = t.numel() * t.element_size()
-        pinned = _pinned_scratch('upload', nbytes)[:nbytes].view(t.dtype).view(t.shape)
+        if nbytes == 0:
+            return torch.empty(t.shape, dtype=t.dtype, device=self.device)
+        ev = _PINNED.get('upload_event_' + slot)
+        if ev is not None:
+            ev.synchronize()             # the previous upload has left this scratch block
+        pinned = _pinned_scratch('upload_' + slot, nbytes)[:nbytes].view(t.dtype).view(t.shape)
         pinned.copy_(t)
         dev = pinned.to(self.device, non_blocking=True)
-        torch.cuda.current_stream(self.device).synchronize()   # the scratch block is free again
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        _PINNED['upload_event_' + slot] = ev
         return dev
+
+    def flag_nan(self, logp_t, status_t):
+        """status |= 2 when any of logp is NaN -- on the device, no host round trip."""
+        torch = self.torch
+        status_t.bitwise_or_(torch.isnan(logp_t).any().to(torch.int32) * 2)
 
     def empty(self, shape, dtype):
         return self.torch.empty(shape, dtype=dtype, device=self.device)
@@ -592,14 +606,20 @@ class DeviceEnsembleSampler(_SamplerBase):
             raise ValueError("sharded_loop must be 'rccl', 'rccl-own' or 'python'")
         self.sharded_loop = sharded_loop
         self._comm, self._comm_owned, self._comm_tried = None, False, False
-        # one rank and the ensemble fits a workgroup: ONE launch per chunk (workgroup per
-        # ensemble, state in LDS); bit-identical to the launch-per-half-step path, which is the
+        # one rank and the ensemble fits a workgroup: ONE launch per chunk (workgroups of whole
+        # ensembles, state in LDS); bit-identical to the launch-per-half-step path, which is the
         # automatic fallback for bigger ensembles.  A workgroup lives on ONE compute unit, so
-        # this wins while a half-ensemble x 4 lanes is at most one wave per SIMD (<= 128
-        # walkers: 2-3x fewer microseconds per iteration); above that, launches that spread a
-        # half-step over the whole chip are as fast or faster (measured at 256 and 512
-        # walkers).  None = that rule; True / False force it.
-        self.persistent = (int(nwalkers) <= 128) if persistent is None else bool(persistent)
+        # for a single ensemble this wins while a half-ensemble x 4 lanes is at most one wave
+        # per SIMD (<= 128 walkers: 2-3x fewer microseconds per iteration; at 512 walkers a
+        # launch that spreads the half-step over the whole chip is faster).  A big batch of
+        # ensembles fills the chip with whole-ensemble workgroups either way, and then the
+        # persistent kernel saves the launch, the gathers and the per-launch ramp of every
+        # half-step (512 spectra x 256 walkers: 8.1 vs 13.3 us per half-step).
+        # None = that rule; True / False force it.
+        if persistent is None:
+            persistent = int(nwalkers) <= 128 or (int(nwalkers) <= 1024 and
+                                                  int(nwalkers) * self.n_ensembles >= 65536)
+        self.persistent = bool(persistent)
         # keep the stored samples in HBM: nothing is copied to the host until get_chain() /
         # get_log_prob() ask for it, and param_moments() summarises the chain where it lies
         self.chain_on_device = bool(chain_on_device)
@@ -648,14 +668,13 @@ class DeviceEnsembleSampler(_SamplerBase):
         dev = dict(coords=be.tensor(coords, torch.float64),
                    naccept=be.zeros((W,), torch.int32), status=be.zeros((1,), torch.int32))
         if lp is None:
+            # initial log-probabilities: computed, and checked for NaN (status bit 1), on the
+            # device with no host synchronisation; run_mcmc reads the status word when it ends
             dev['logp'] = be.empty((W,), torch.float64)
             be.logprob(dev['coords'], dev['logp'])
-            be.synchronize()
-            lp0 = dev['logp'].cpu().numpy()
-            if np.any(np.isnan(lp0)):
-                raise ValueError('Probability function returned NaN')
+            be.flag_nan(dev['logp'], dev['status'])
         else:
-            dev['logp'] = be.tensor(lp, torch.float64)
+            dev['logp'] = be.tensor(lp, torch.float64, slot='b')
         self._dev = dev
 
     def _chunk_steps(self, nsteps):
@@ -771,7 +790,7 @@ class DeviceEnsembleSampler(_SamplerBase):
             # the per-step splits of the WHOLE run (12 B per iteration) go up in one copy: a
             # host->device copy per chunk would wait for the previous chunk's kernels
             perm_all = be.tensor(affine_splits(self.seed, self.walkers_per_ensemble,
-                                               self._iterations_run, nsteps * thin_by))
+                                               self._iterations_run, nsteps * thin_by), slot='c')
         # where a run spends its time
         self.timing = dict(setup_s=time.perf_counter() - t_start, stream_s=0.0, enqueue_s=0.0, alloc_s=0.0,
                            drain_s=0.0, finish_s=0.0, **setup_detail)
@@ -833,7 +852,8 @@ class DeviceEnsembleSampler(_SamplerBase):
         t_e = time.perf_counter()
         self.timing['drain_s'] = t_e - t_d
         self._iterations_run = it0
-        if int(self._dev['status'].cpu()[0]) & 1:
+        if int(self._dev['status'].cpu()[0]) & 3:     # bit 0: a proposal, bit 1: the initial state
+            self._dev = None                           # nothing of this run is kept
             raise ValueError('Probability function returned NaN')
         if dev_chain is not None:
             self._append(_DeviceSlabs([dev_chain]), _DeviceSlabs([dev_logp]))

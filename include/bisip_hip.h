@@ -221,7 +221,7 @@ int bisip_stretch_draw_dev(bisip_ctx *ctx, int64_t W, double a, uint64_t seed, i
  * bisip_stretch_run_dev -- arrays (n_steps, 2, E, nh), nh = (walkers_per_ensemble+1)/2,
  * global walker ids -- and produces bit-identical results.  Requires
  * walkers_per_ensemble*(ndim+1)*8 <= 65536 bytes of LDS and ceil(walkers_per_ensemble/2)
- * <= 1024; otherwise returns BISIP_EUNSUPPORTED (use bisip_stretch_run_dev).
+ * <= 512; otherwise returns BISIP_EUNSUPPORTED (use bisip_stretch_run_dev).
  * n_walkers = n_ensembles * walkers_per_ensemble. */
 typedef struct bisip_persist_args {
     double *coords;              /* (n_walkers, ndim) in/out */

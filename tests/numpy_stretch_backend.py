@@ -65,7 +65,7 @@ class NumpyStretchBackend:
         self.logprob_fn = logprob_fn
         self.n_ensembles = n_ensembles
 
-    def tensor(self, array, dtype=None):
+    def tensor(self, array, dtype=None, slot='a'):
         return torch.as_tensor(np.ascontiguousarray(array), dtype=dtype).clone()
 
     def empty(self, shape, dtype):
@@ -78,6 +78,10 @@ class NumpyStretchBackend:
 
     def synchronize(self):
         pass
+
+    def flag_nan(self, logp_t, status_t):
+        if torch.isnan(logp_t).any():
+            status_t[0] |= 2
 
     def _slot(self, st, k, h, n_slots, lo, hi):
         ndim = st['coords'].shape[1]
@@ -106,7 +110,7 @@ class NumpyStretchBackend:
         st['naccept'].numpy()[idx[acc]] += 1
 
     def run_persistent(self, st, wp, n_steps):
-        if wp * (st['coords'].shape[1] + 1) * 8 > 65536 or (wp + 1) // 2 > 1024:
+        if wp * (st['coords'].shape[1] + 1) * 8 > 65536 or (wp + 1) // 2 > 512:
             return False
         self.run(st, n_steps)
         return True
