@@ -15,8 +15,14 @@ int launch_forward(const bisip_ctx *c, const double *theta, int64_t W, double *Z
     // (a capped, looping grid measured 0-25 % slower depending on the box: benchmarks/micro/forward_variants.hip)
     const unsigned grid = (unsigned)((W + 63) / 64);
     const int N = c->N;
-    if (N % 16 != 0 && N <= 24) hipLaunchKernelGGL((k_forward_rows<M, 24>), dim3(grid), dim3(64), 0, st, a);
-    else if (N % 16 != 0 && N <= 32) hipLaunchKernelGGL((k_forward_rows<M, 32>), dim3(grid), dim3(64), 0, st, a);
+    const bool wide = (N % 2 == 0) && ((uintptr_t)Z % 16) == 0;   // 16-byte store pieces
+    if (N % 16 != 0 && N <= 24) {
+        if (wide) hipLaunchKernelGGL((k_forward_rows<M, 24, true>), dim3(grid), dim3(64), 0, st, a);
+        else hipLaunchKernelGGL((k_forward_rows<M, 24, false>), dim3(grid), dim3(64), 0, st, a);
+    } else if (N % 16 != 0 && N <= 32) {
+        if (wide) hipLaunchKernelGGL((k_forward_rows<M, 32, true>), dim3(grid), dim3(64), 0, st, a);
+        else hipLaunchKernelGGL((k_forward_rows<M, 32, false>), dim3(grid), dim3(64), 0, st, a);
+    } else if (N % 16 == 0 && wide) hipLaunchKernelGGL((k_forward_tiled16<M>), dim3(grid), dim3(64), 0, st, a);
     else if (((uintptr_t)theta % 16) == 0) hipLaunchKernelGGL((k_forward_tiled<M, true>), dim3(grid), dim3(64), 0, st, a);
     else hipLaunchKernelGGL((k_forward_tiled<M, false>), dim3(grid), dim3(64), 0, st, a);
     HIP_TRY(hipGetLastError());

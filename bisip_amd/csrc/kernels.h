@@ -211,8 +211,9 @@ __device__ __forceinline__ void rcp_nr_n(const double (&x)[K], double (&r)[K])
 //   residual(setup, rec, rr, ri)       y - Z at one frequency for the log-likelihood, with
 //                                      the walker-constant part of Z folded into per-walker
 //                                      constants (fewer instructions than y - eval())
-//   residual2(setup, recA, recB, ...)  the same for TWO frequencies with their dependency chains
-//                                      interleaved (see exp2_finite_n); identical values
+//   residual2(setup, recA, recB, ...)  (8-double-record models) the same for TWO frequencies with
+//                                      their dependency chains interleaved (exp2_finite_n);
+//                                      identical values; used where one wave per SIMD runs alone
 // ---------------------------------------------------------------------------------
 
 // PolynomialDecomposition, collapsed: Z_j = R0*(1 - sum_p a_p G[j,p]).
@@ -252,20 +253,6 @@ struct PDCollapsed {
         for (int p = 0; p <= P; ++p) {
             rr = fma(s.b[p], rec[4 + p], rr);
             ri = fma(s.b[p], rec[4 + P + 1 + p], ri);
-        }
-    }
-    __device__ static __forceinline__ void residual2(const Setup &s, const double *__restrict__ ra,
-                                                     const double *__restrict__ rb, double (&rr)[2],
-                                                     double (&ri)[2])
-    {
-        rr[0] = fma(s.r0, ra[2], ra[0]); rr[1] = fma(s.r0, rb[2], rb[0]);
-        ri[0] = ra[1]; ri[1] = rb[1];
-#pragma unroll
-        for (int p = 0; p <= P; ++p) {
-            rr[0] = fma(s.b[p], ra[4 + p], rr[0]);
-            rr[1] = fma(s.b[p], rb[4 + p], rr[1]);
-            ri[0] = fma(s.b[p], ra[4 + P + 1 + p], ri[0]);
-            ri[1] = fma(s.b[p], rb[4 + P + 1 + p], ri[1]);
         }
     }
     // Z = r0 - sum_p b_p G_p  (m = unweighted G_re[0..P], G_im[0..P])
@@ -643,79 +630,49 @@ __device__ __forceinline__ double logprob_row(const double (&th)[M::NDIM], const
     if (!in_prior<M::NDIM>(th, b)) return -__builtin_inf();  // never touches the forward model
     const typename M::Setup s = M::setup(th);
     double acc0 = 0.0, acc1 = 0.0;
-    if constexpr (L == 1) {
-        // two frequencies at a time, their dependency chains interleaved (residual2); the sums
-        // still take their terms one by one in ascending frequency order
+    if constexpr (L == 1 && LDSREC && M::REC == 8 && !M::WEIGHTED) {
+        // records staged in LDS (persistent sampler): two frequencies at a time, their dependency
+        // chains interleaved (residual2), and the NEXT pair's records in flight while this pair is
+        // evaluated.  With one wave per SIMD nothing else hides a record read, and a dependent
+        // fp64 instruction issues only every ~8 cycles (benchmarks/micro/issue_latency.hip,
+        // row_latency.hip: 15.8k -> 12.8k cycles per 32-frequency double-Cole-Cole row).  The sums
+        // still take their terms one by one in ascending frequency order: same bits as the loop below.
         const double *__restrict__ rec = o.cb;
+        constexpr int R2 = 2 * M::REC;
+        double cur[R2];
+        dbl2 buf[8];
         int j = 0;
-        if constexpr (!M::WEIGHTED && 2 * M::REC <= 16) {
-            // software pipeline: the records of the NEXT pair are requested before this pair is
-            // evaluated.  With one wave per SIMD nothing else hides a record load -- ~500 cycles
-            // from L2 when every wave reads its own spectrum (batch of spectra: the 16 KB scalar
-            // cache thrashes), ~100 from the scalar cache or LDS -- and the counters showed the
-            // half-step kernel waiting on them for 56 % of its time (profiles/r02_cfg5_pmc.txt).
-            constexpr int R2 = 2 * M::REC;
-            double cur[R2], nxt[R2];
-            if constexpr (LDSREC && M::REC == 8) {
-                dbl2 buf[8];
-                if (o.N >= 2) {
-                    lds_pair_issue(rec, buf, acc0);
-                    lds_pair_wait(buf);
+        if (o.N >= 2) {
+            lds_pair_issue(rec, buf, acc0);
+            lds_pair_wait(buf);
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) { cur[2 * q] = buf[q].x; cur[2 * q + 1] = buf[q].y; }
-                }
-                for (; j + 1 < o.N; j += 2, rec += R2) {
-                    lds_pair_issue((j + 3 < o.N) ? rec + R2 : rec, buf, cur[5]);   // last pair: a harmless re-read
-                    double rr[2], ri[2];
-                    M::residual2(s, cur, cur + M::REC, rr, ri);
+            for (int q = 0; q < 8; ++q) { cur[2 * q] = buf[q].x; cur[2 * q + 1] = buf[q].y; }
+        }
+        for (; j + 1 < o.N; j += 2, rec += R2) {
+            lds_pair_issue((j + 3 < o.N) ? rec + R2 : rec, buf, cur[5]);   // last pair: a harmless re-read
+            double rr[2], ri[2];
+            M::residual2(s, cur, cur + M::REC, rr, ri);
 #pragma unroll
-                    for (int f = 0; f < 2; ++f) {
-                        acc0 = fma(rr[f] * rr[f], cur[f * M::REC + 2], acc0);
-                        acc1 = fma(ri[f] * ri[f], cur[f * M::REC + 3], acc1);
-                    }
-                    // the compiler must not float the wait above the arithmetic: tie it to its results
-                    asm volatile("" : "+v"(acc0), "+v"(acc1));
-                    lds_pair_wait(buf);
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) { cur[2 * q] = buf[q].x; cur[2 * q + 1] = buf[q].y; }
-                }
-            } else {
-                if (o.N >= 2) {
-#pragma unroll
-                    for (int q = 0; q < R2; ++q) cur[q] = rec[q];
-                }
-                for (; j + 1 < o.N; j += 2, rec += R2) {
-                    const double *__restrict__ ahead = (j + 3 < o.N) ? rec + R2 : rec;   // last pair: a harmless re-read
-#pragma unroll
-                    for (int q = 0; q < R2; ++q) nxt[q] = ahead[q];
-                    double rr[2], ri[2];
-                    M::residual2(s, cur, cur + M::REC, rr, ri);
-#pragma unroll
-                    for (int f = 0; f < 2; ++f) {
-                        acc0 = fma(rr[f] * rr[f], cur[f * M::REC + 2], acc0);
-                        acc1 = fma(ri[f] * ri[f], cur[f * M::REC + 3], acc1);
-                    }
-#pragma unroll
-                    for (int q = 0; q < R2; ++q) cur[q] = nxt[q];
-                }
+            for (int f = 0; f < 2; ++f) {
+                acc0 = fma(rr[f] * rr[f], cur[f * M::REC + 2], acc0);
+                acc1 = fma(ri[f] * ri[f], cur[f * M::REC + 3], acc1);
             }
-        } else {
-            for (; j + 1 < o.N; j += 2, rec += 2 * M::REC) {
-                double rr[2], ri[2];
-                M::residual2(s, rec, rec + M::REC, rr, ri);
+            // the compiler must not float the wait above the arithmetic: tie it to its results
+            asm volatile("" : "+v"(acc0), "+v"(acc1));
+            lds_pair_wait(buf);
 #pragma unroll
-                for (int f = 0; f < 2; ++f) {
-                    if constexpr (M::WEIGHTED) {
-                        acc0 = fma(rr[f], rr[f], acc0);
-                        acc1 = fma(ri[f], ri[f], acc1);
-                    } else {
-                        acc0 = fma(rr[f] * rr[f], rec[f * M::REC + 2], acc0);
-                        acc1 = fma(ri[f] * ri[f], rec[f * M::REC + 3], acc1);
-                    }
-                }
-            }
+            for (int q = 0; q < 8; ++q) { cur[2 * q] = buf[q].x; cur[2 * q + 1] = buf[q].y; }
         }
         if (j < o.N) {
+            double rr, ri;
+            M::residual(s, rec, rr, ri);
+            acc0 = fma(rr * rr, rec[2], acc0);
+            acc1 = fma(ri * ri, rec[3], acc1);
+        }
+    } else if constexpr (L == 1) {
+        const double *__restrict__ rec = o.cb;
+#pragma unroll 2
+        for (int j = 0; j < o.N; ++j, rec += M::REC) {
             double rr, ri;
             M::residual(s, rec, rr, ri);
             if constexpr (M::WEIGHTED) {
@@ -1242,12 +1199,69 @@ __global__ __launch_bounds__(64) void k_forward_tiled(const LaunchArgs a)
     }
 }
 
+// k_forward_tiled for its common case, straight-line: N a multiple of 16 and Z 16-byte aligned --
+// one block of 64 walkers per workgroup, no grid-stride loop, store width fixed at compile time
+// (+3 % at N = 32 / 64, benchmarks/micro/forward_rows_variants.hip).  Same values.
+template <class M>
+__global__ __launch_bounds__(64) void k_forward_tiled16(const LaunchArgs a)
+{
+    constexpr int NDIM = M::NDIM;
+    constexpr int JC = 16;
+    constexpr int ROW = JC + 1;
+    __shared__ __attribute__((aligned(16))) double lds[64 * ROW];
+    const int lane = threadIdx.x;
+    const int N = a.N;
+    const long long row0 = (long long)blockIdx.x * 64;
+    const int rows_here = (int)((a.W - row0) < 64 ? (a.W - row0) : 64);
+    const long long row = row0 + lane < a.W ? row0 + lane : a.W - 1;
+    double th[NDIM];
+#pragma unroll
+    for (int q = 0; q < NDIM; ++q) th[q] = a.theta[row * NDIM + q];
+    const typename M::Setup s = M::setup(th);
+    const double *__restrict__ cb = a.cb + (a.Wp ? (row0 / a.Wp) * a.cb_stride : 0);
+    // lane l always writes columns c, c+1 of walkers (l>>3) + 8*it
+    auto stream_out = [&](int part, int j0) {
+        const int c = (lane & 7) << 1;
+        const double *src = lds + (lane >> 3) * ROW + c;
+        double *dst = a.out + (row0 + (lane >> 3)) * 2 * N + (long long)part * N + j0 + c;
+#pragma unroll 4
+        for (int w = lane >> 3; w < rows_here; w += 8, src += 8 * ROW, dst += 16 * (long long)N) {
+            dbl2 v;
+            v.x = src[0];
+            v.y = src[1];
+            __builtin_nontemporal_store(v, reinterpret_cast<dbl2 *>(dst));
+        }
+    };
+    for (int j0 = 0; j0 < N; j0 += JC) {
+        const double *__restrict__ rec = cb + (long long)j0 * M::REC;
+        double zim[JC];
+#pragma unroll
+        for (int jj = 0; jj < JC; ++jj) {
+            double zr, zi;
+            M::eval(s, rec + (long long)jj * M::REC + 4, zr, zi);
+            lds[lane * ROW + jj] = zr;
+            zim[jj] = zi;
+        }
+        wave_lds_fence();
+        stream_out(0, j0);
+        wave_lds_fence();
+#pragma unroll
+        for (int jj = 0; jj < JC; ++jj) lds[lane * ROW + jj] = zim[jj];
+        wave_lds_fence();
+        stream_out(1, j0);
+        wave_lds_fence();
+    }
+}
+
 // Batched forward(), N <= JC: whole rows.  Lane = walker computes all N frequencies (2N doubles in
 // registers); SUB walkers at a time go through LDS laid out exactly like Z ([re 0..N) [im 0..N)
 // per walker), so the SUB*2N doubles of a pass are ONE contiguous span of Z and every store
-// instruction writes 1 KB (16-byte pieces) or 512 B (odd N) of consecutive addresses:
-// no cache line is ever written in parts.
-template <class M, int JC>
+// instruction writes 1 KB (16-byte pieces, WIDE: N even and Z 16-byte aligned) or 512 B of
+// consecutive addresses: no cache line is ever written in parts.
+// One block of 64 walkers per single-wave workgroup, straight-line (a grid-stride loop around
+// this body and a run-time choice between the two store widths cost 30 % at N = 20:
+// 4.4 -> 6.2 TB/s, benchmarks/micro/forward_rows_variants.hip).
+template <class M, int JC, bool WIDE>
 __global__ __launch_bounds__(64) void k_forward_rows(const LaunchArgs a)
 {
     constexpr int NDIM = M::NDIM;
@@ -1257,58 +1271,54 @@ __global__ __launch_bounds__(64) void k_forward_rows(const LaunchArgs a)
     const int lane = threadIdx.x;
     const int N = a.N;
     const int rowlen = (2 * N) | 1;   // odd stride: conflict-free column writes
-    const bool wide = ((N & 1) == 0) && ((reinterpret_cast<unsigned long long>(a.out) & 15) == 0);
-    const long long nblocks = (a.W + 63) / 64;
-    for (long long blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
-        const long long row0 = blk * 64;
-        const int rows_here = (int)((a.W - row0) < 64 ? (a.W - row0) : 64);
-        const long long row = row0 + lane < a.W ? row0 + lane : a.W - 1;
-        double th[NDIM];
+    const long long row0 = (long long)blockIdx.x * 64;
+    const int rows_here = (int)((a.W - row0) < 64 ? (a.W - row0) : 64);
+    const long long row = row0 + lane < a.W ? row0 + lane : a.W - 1;
+    double th[NDIM];
 #pragma unroll
-        for (int q = 0; q < NDIM; ++q) th[q] = a.theta[row * NDIM + q];
-        const typename M::Setup s = M::setup(th);
-        const double *__restrict__ cb = a.cb + (a.Wp ? (row0 / a.Wp) * a.cb_stride : 0);
-        double zr[JC], zi[JC];
+    for (int q = 0; q < NDIM; ++q) th[q] = a.theta[row * NDIM + q];
+    const typename M::Setup s = M::setup(th);
+    const double *__restrict__ cb = a.cb + (a.Wp ? (row0 / a.Wp) * a.cb_stride : 0);
+    double zr[JC], zi[JC];
 #pragma unroll
-        for (int jj = 0; jj < JC; ++jj) {
-            zr[jj] = 0.0; zi[jj] = 0.0;
-            if (jj < N) M::eval(s, cb + (long long)jj * M::REC + 4, zr[jj], zi[jj]);
-        }
+    for (int jj = 0; jj < JC; ++jj) {
+        zr[jj] = 0.0; zi[jj] = 0.0;
+        if (jj < N) M::eval(s, cb + (long long)jj * M::REC + 4, zr[jj], zi[jj]);
+    }
 #pragma unroll 1
-        for (int sub = 0; sub * SUB < rows_here; ++sub) {
-            if ((lane / SUB) == sub) {
-                double *r = lds + (lane % SUB) * rowlen;
+    for (int sub = 0; sub * SUB < rows_here; ++sub) {
+        if ((lane / SUB) == sub) {
+            double *r = lds + (lane % SUB) * rowlen;
 #pragma unroll
-                for (int jj = 0; jj < JC; ++jj)
-                    if (jj < N) { r[jj] = zr[jj]; r[N + jj] = zi[jj]; }
-            }
-            wave_lds_fence();
-            const int wn = (rows_here - sub * SUB) < SUB ? (rows_here - sub * SUB) : SUB;
-            double *dst0 = a.out + (row0 + sub * SUB) * 2 * N;
-            if (wide) {
-                // 16-byte piece q of the pass = walker q / N, doubles 2*(q % N)..+1
-                const int total = wn * N, dw = 64 / N, de = 64 - dw * N;
-                int w = lane / N, e = lane - w * N;
-                for (int q = lane; q < total; q += 64) {
-                    const double *src = lds + w * rowlen + 2 * e;
-                    dbl2 v;
-                    v.x = src[0];
-                    v.y = src[1];
-                    __builtin_nontemporal_store(v, reinterpret_cast<dbl2 *>(dst0 + 2 * (long long)q));
-                    w += dw; e += de;
-                    if (e >= N) { e -= N; ++w; }
-                }
-            } else {
-                const int M2 = 2 * N, total = wn * M2, dw = 64 / M2, de = 64 - dw * M2;
-                int w = lane / M2, e = lane - w * M2;
-                for (int f = lane; f < total; f += 64) {
-                    dst0[f] = lds[w * rowlen + e];
-                    w += dw; e += de;
-                    if (e >= M2) { e -= M2; ++w; }
-                }
-            }
-            wave_lds_fence();
+            for (int jj = 0; jj < JC; ++jj)
+                if (jj < N) { r[jj] = zr[jj]; r[N + jj] = zi[jj]; }
         }
+        wave_lds_fence();
+        const int wn = (rows_here - sub * SUB) < SUB ? (rows_here - sub * SUB) : SUB;
+        double *dst0 = a.out + (row0 + sub * SUB) * 2 * N;
+        if constexpr (WIDE) {
+            // 16-byte piece q of the pass = walker q / N, doubles 2*(q % N)..+1
+            const int total = wn * N, dw = 64 / N, de = 64 - dw * N;
+            int w = lane / N, e = lane - w * N;
+            for (int q = lane; q < total; q += 64) {
+                const double *src = lds + w * rowlen + 2 * e;
+                dbl2 v;
+                v.x = src[0];
+                v.y = src[1];
+                __builtin_nontemporal_store(v, reinterpret_cast<dbl2 *>(dst0 + 2 * (long long)q));
+                w += dw; e += de;
+                if (e >= N) { e -= N; ++w; }
+            }
+        } else {
+            const int M2 = 2 * N, total = wn * M2, dw = 64 / M2, de = 64 - dw * M2;
+            int w = lane / M2, e = lane - w * M2;
+            for (int f = lane; f < total; f += 64) {
+                dst0[f] = lds[w * rowlen + e];
+                w += dw; e += de;
+                if (e >= M2) { e -= M2; ++w; }
+            }
+        }
+        wave_lds_fence();
     }
 }
 
