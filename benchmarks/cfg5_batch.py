@@ -17,6 +17,7 @@ def main():
     ap.add_argument('--chain', default='host', choices=['host', 'device'],
                     help="'device': stored samples stay in HBM; posterior mean/std are computed there")
     ap.add_argument('--persistent', action='store_true', help='force the persistent kernel (default: automatic)')
+    ap.add_argument('--no-persistent', action='store_true', help='force one launch per half-step')
     args = ap.parse_args()
     import bisip_amd
     from bisip_amd.synthetic import synthetic_columns
@@ -31,7 +32,8 @@ def main():
 
     def make():
         return DeviceEnsembleSampler(Wp, 7, batch.ctx, rng='philox', seed=3, n_ensembles=E,
-                                     chain_on_device=(args.chain == 'device'), persistent=True if args.persistent else None)
+                                     chain_on_device=(args.chain == 'device'),
+                                     persistent=True if args.persistent else (False if args.no_persistent else None))
     prime = time.perf_counter()           # warm-up + clocks up (as bench.py primes before timing)
     while time.perf_counter() - prime < 0.25:
         make().run_mcmc(p0.reshape(-1, 7), 2, thin_by=args.thin_by)
@@ -56,6 +58,7 @@ def main():
                       'percentile_s': None if percentile_s is None else round(percentile_s, 5),
                       'iterations': iters, 'stored': args.steps, 'thin_by': args.thin_by, 'seconds': round(dt, 4),
                       'it_per_s': round(iters / dt, 1),
+                      'us_per_half_step': round((s.timing['enqueue_s'] + s.timing['drain_s']) / iters / 2 * 1e6, 2),
                       'walker_steps_per_s': float('%.4g' % (iters * E * Wp / dt)),
                       'timing_s': {k: round(v, 4) for k, v in s.timing.items()},
                       'acceptance': round(float(s.acceptance_fraction.mean()), 3)}))

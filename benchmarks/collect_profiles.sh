@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collects the measurements kept under profiles/ (one MI355X).  Run from the repo root on the
-# GPU box:  bash benchmarks/collect_profiles.sh [bench|sweep|sampler|all]
+# GPU box:  bash benchmarks/collect_profiles.sh [bench|sweep|sampler|micro|all]
 # Everything is written under gpurun_out/ (scratch); copy what should be judged into profiles/.
 set -e -o pipefail
 what=${1:-all}
@@ -43,14 +43,29 @@ fi
 if [ "$what" = sampler ] || [ "$what" = all ]; then
   echo "== samplers" | tee -a "$out/progress.log"
   python3 benchmarks/sampler_bench.py > "$out/sampler_bench.jsonl" 2> "$out/sampler.err"
-  python3 benchmarks/cfg4_sampler.py --steps 200 --fused | grep "^{" > "$out/cfg4_fused.json" 2> "$out/cfg4.err"
   python3 benchmarks/cfg4_sampler.py --steps 200 --fused --chain device | grep "^{" > "$out/cfg4_fused_device_chain.json" 2>> "$out/cfg4.err"
-  python3 benchmarks/cfg4_sampler.py --steps 200 --chain device | grep "^{" > "$out/cfg4_sharded_path_1gpu.json" 2>> "$out/cfg4.err"
-  python3 benchmarks/cfg5_batch.py --chain device > "$out/cfg5_device_chain.json" 2> "$out/cfg5.err"
-  python3 benchmarks/cfg5_batch.py > "$out/cfg5_host_chain.json" 2>> "$out/cfg5.err"
+  for loop in rccl rccl-own python; do
+    python3 benchmarks/cfg4_sampler.py --steps 200 --chain device --loop $loop | grep "^{" > "$out/cfg4_sharded_$loop.json" 2>> "$out/cfg4.err"
+  done
+  # cfg5: 20000 iterations (0.3-0.6 s), so that a 20-30 ms start-up hiccup of the device does not decide the number
+  python3 benchmarks/cfg5_batch.py --chain device --steps 500 --thin-by 40 > "$out/cfg5_device_chain.json" 2> "$out/cfg5.err"
+  python3 benchmarks/cfg5_batch.py --chain device --steps 500 --thin-by 40 --no-persistent > "$out/cfg5_device_chain_launches.json" 2>> "$out/cfg5.err"
+  python3 benchmarks/cfg5_batch.py --steps 100 --thin-by 10 > "$out/cfg5_host_chain.json" 2>> "$out/cfg5.err"
   (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$scratch/prof_sampler" -- \
       python3 "$repo/benchmarks/sampler_bench.py" > "$out/sampler_under_rocprof.jsonl" 2> "$out/prof_sampler.err")
   keep "$scratch/prof_sampler" prof_sampler
+  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$scratch/prof_cfg5" -- \
+      python3 "$repo/benchmarks/cfg5_batch.py" --chain device --steps 100 --thin-by 10 > /dev/null 2> "$out/prof_cfg5.err")
+  keep "$scratch/prof_cfg5" prof_cfg5
+fi
+if [ "$what" = micro ] || [ "$what" = all ]; then
+  echo "== micro-benchmarks" | tee -a "$out/progress.log"
+  for m in issue_latency row_latency half_step_phases forward_rows_variants; do
+    [ -x benchmarks/micro/$m ] && timeout -k 5 200 benchmarks/micro/$m > "$out/micro_$m.txt" 2>&1
+  done
+  python3 benchmarks/micro/post_run_stall.py kernel 2>/dev/null | grep after > "$out/micro_post_run_stall.txt"
+  python3 benchmarks/micro/upload_cost4.py plain 2>/dev/null | grep "upload ms" >> "$out/micro_post_run_stall.txt"
+  CFG5_ENV="A=1" bash benchmarks/micro/cfg5_pmc.sh > "$out/micro_cfg5_pmc.txt" 2>&1
 fi
 rm -rf "$scratch"
 echo "== done" | tee -a "$out/progress.log"

@@ -1,0 +1,261 @@
+#!/usr/bin/env python3
+"""Regenerates every measured table of DESIGN.md and the whole of profiles/README.md from the
+files under profiles/ -- numbers in the prose are never retyped by hand.
+
+    python benchmarks/make_tables.py            # rewrite DESIGN.md's table blocks + profiles/README.md
+    python benchmarks/make_tables.py --check    # exit 1 if either file is out of date (used by tests/)
+
+A table block in DESIGN.md looks like
+
+    <!-- TABLE:bench -->
+    ...generated...
+    <!-- /TABLE:bench -->
+
+and is replaced as a whole.  ROUND selects the profile set (profiles/rNN_*).
+"""
+import csv
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PROF = os.path.join(ROOT, 'profiles')
+ROUND = 'r02'
+
+
+def jload(name):
+    with open(os.path.join(PROF, name)) as fh:
+        return json.load(fh)
+
+
+def jlines(name):
+    with open(os.path.join(PROF, name)) as fh:
+        return [json.loads(ln) for ln in fh if ln.strip().startswith('{')]
+
+
+def sci(x, d=3):
+    return f'{x:.{d}g}' if abs(x) < 1e4 else f'{x:.{d - 1}e}'.replace('e+', 'e').replace('e0', 'e')
+
+
+def md(rows, header):
+    out = ['| ' + ' | '.join(header) + ' |', '|' + '---|' * len(header)]
+    out += ['| ' + ' | '.join(str(c) for c in r) + ' |' for r in rows]
+    return '\n'.join(out)
+
+
+def kernel_stats(name, needle):
+    with open(os.path.join(PROF, name)) as fh:
+        for r in csv.DictReader(fh):
+            if needle in r['Name']:
+                return r
+    return None
+
+
+# ---------------------------------------------------------------------------------------
+def table_bench():
+    b = jload(f'{ROUND}_bench.json')
+    u = jload(f'{ROUND}_bench_under_rocprof.json')
+    ks = kernel_stats(f'{ROUND}_bench_kernel_stats.csv', 'k_logprob_pd_reduced')
+    t = jload('pmc_traffic.json')
+    r = b['roofline']
+    cb = b['cpu_baseline']
+    cal = cb.get('reference_calibration', {})
+    rows = [
+        ['value (whole job, 1 GPU)', f"{sci(b['value'], 4)} evals/s", f"`{ROUND}_bench.json`"],
+        ['ms per step (W = 2^24 walkers per launch)', f"{b['ms_per_step']:.4f}", ''],
+        ['kernel duration, HIP events on the launch stream', f"{r['kernel_ms'] * 1e3:.1f} us", 'un-profiled run'],
+        ['achieved / peak', f"{r['achieved']:.0f} / {r['peak']:.0f} GB/s = **{r['frac']:.3f}**", '64 B per eval'],
+        ['same command under `rocprofv3 --kernel-trace --stats`',
+         f"{float(ks['AverageNs']) / 1e3:.2f} us average over {ks['Calls']} launches",
+         f"`{ROUND}_bench_kernel_stats.csv`"],
+        ['in-process HIP-event clock in that profiled run', f"{u['roofline']['kernel_ms'] * 1e3:.2f} us", f"`{ROUND}_bench_under_rocprof.json`"],
+        ['HBM traffic per launch (PMC, FETCH_SIZE x2 + WRITE_SIZE)',
+         f"{t['hbm_bytes_per_launch'] / 1e6:.2f} MB vs {t['algorithmic_bytes_per_launch'] / 1e6:.2f} MB algorithmic "
+         f"= x{t['hbm_bytes_per_launch'] / t['algorithmic_bytes_per_launch']:.5f}", f"`pmc_traffic.json`, `{ROUND}_bench_pmc_summary.csv`"],
+        ['CPU baseline (oracle, kind "port")', f"{sci(cb['value'])} evals/s on {cb['cores']} threads; {sci(cb['value_1core'])} on one",
+         f"quota {cb.get('cpu_quota')} of {cb['host_cpus_visible']} visible CPUs"],
+    ]
+    if cal:
+        rows.append(['real reference / oracle, one core (build container)', f"{cal['reference_over_oracle_1core']:.3f}",
+                     f"=> reference here ~{sci(cal['estimated_reference_1core_here'])} evals/s per core, "
+                     f"~{sci(cal['estimated_reference_all_cores_here'])} on {cb['cores']}; `cpu_calibration.json`"])
+    rows.append(['parity spot check inside the run', f"max rel err {b['parity']['max_rel_err_vs_oracle']:.1e} (tolerance 1e-10)", ''])
+    return md(rows, ['quantity', 'measured', 'source / note'])
+
+
+def table_variants():
+    b = jload(f'{ROUND}_bench.json')
+    rows = []
+    for group, title in (('variants', 'PolynomialDecomposition P=5, N=32, W=2^24'), ('kernels', 'N=32, W=2^22')):
+        for label, v in b[group].items():
+            rv = v.get('roofline_valu')
+            rows.append([f'`{label}`', title, f"{sci(v['evals_per_s'])}", f"{v['kernel_ms'] * 1e3:.1f}",
+                         f"{v['hbm_frac']:.3f}", f"{rv['valu_wave_instr_per_eval']:.2f}" if rv else '-',
+                         f"**{rv['frac']:.2f}**" if rv else '-'])
+    return md(rows, ['kernel', 'workload', 'evals/s', 'us per launch', 'fraction of HBM peak',
+                     'VALU wave-instr per eval (PMC)', 'fraction of fp64 issue peak (2.4 GHz)'])
+
+
+def table_sweep():
+    rows = [[d['case'], f"`{d['kernel']}`", d['N'], d['W'], f"{d['us_per_launch']:.2f}", sci(d['evals_per_s']),
+             f"{d['hbm_frac']:.3f}"] for d in jlines(f'{ROUND}_sweep.jsonl')]
+    return md(rows, ['case', 'kernel', 'N', 'W', 'us per launch', 'evals/s', 'fraction of HBM peak'])
+
+
+def table_forward():
+    rows = []
+    for d in jlines(f'{ROUND}_host_path.jsonl'):
+        if 'forward' in d['case']:
+            rows.append([d['case'].replace(' bisip_forward_dev', ''), d['W'], d['us'], sci(d['rows_per_s']),
+                         f"{d['write_GBs'] / 1e3:.2f}"])
+    return md(rows, ['batched forward (device resident)', 'rows', 'us per launch', 'rows/s', 'TB/s of Z written'])
+
+
+def table_host_path():
+    rows = [[d['case'].replace(' bisip_logprob (host buffers, pageable)', ''), d['W'], sci(d['evals_per_s']), d['GBs_over_pcie']]
+            for d in jlines(f'{ROUND}_host_path.jsonl') if 'host buffers' in d['case']]
+    return md(rows, ['`bisip_logprob`, host buffers (PCIe inclusive; never `value`)', 'W', 'evals/s', 'GB/s over the link'])
+
+
+def table_samplers():
+    data = jlines(f'{ROUND}_sampler_bench.jsonl')
+    cases, samplers = [], ['device-philox-persistent', 'device-philox', 'device', 'device-launches', 'host']
+    for d in data:
+        if d['case'] not in cases:
+            cases.append(d['case'])
+    rows = []
+    for c in cases:
+        row = [c]
+        for s in samplers:
+            m = [d for d in data if d['case'] == c and d['sampler'] == s]
+            row.append(f"{m[0]['it_per_s'] / 1e3:.1f} k ({m[0].get('path') or 'host loop'})" if m else '-')
+        rows.append(row)
+    return md(rows, ['`fit()` workload: iterations/s'] + [f'`{s}`' for s in samplers])
+
+
+def table_cfg4():
+    rows = []
+    for f, label in ((f'{ROUND}_cfg4_fused_device_chain.json', 'fused half-step (one launch), single GPU'),
+                     (f'{ROUND}_cfg4_sharded_rccl.json', "sharded: C loop, eval -> ncclAllGather -> apply, torch's communicator"),
+                     (f'{ROUND}_cfg4_sharded_rccl-own.json', 'sharded: C loop, communicator from bisip_rccl_comm_create'),
+                     (f'{ROUND}_cfg4_sharded_python.json', 'sharded: Python loop over torch.distributed (round 1)')):
+        d = jload(f)
+        rows.append([label, d['n_gpus'], d['driver'], d['us_per_half_step'], sci(d['walker_steps_per_s']), d['acceptance']])
+    return md(rows, ['cfg4: 32,768 walkers, Debye S=40, P=5', 'ranks', 'driver', 'us per half-step', 'walker-steps/s', 'acceptance'])
+
+
+def table_cfg5():
+    rows = []
+    for f, label in ((f'{ROUND}_cfg5_device_chain.json', 'persistent kernel (automatic for this shape), chain in HBM'),
+                     (f'{ROUND}_cfg5_device_chain_launches.json', 'one launch per half-step, chain in HBM'),
+                     (f'{ROUND}_cfg5_host_chain.json', 'persistent kernel, chain copied to pinned host memory')):
+        d = jload(f)
+        rows.append([label, d['path'], d['iterations'], d['seconds'], d.get('us_per_half_step', '-'), sci(d['walker_steps_per_s'])])
+    return md(rows, ['cfg5 slice: 512 spectra x 256 walkers, double Cole-Cole, N=32', 'path', 'iterations', 'seconds (incl. summaries)',
+                     'us per half-step', 'walker-steps/s'])
+
+
+def table_fuzz():
+    rows = []
+    for d in jlines(f'{ROUND}_fuzz_parity_summary.jsonl'):
+        a = d['auto_on_polydecomp']
+        rows.append([f"parity, seed {d['seed']}", d['cases'], d['violations'], f"{d['worst_logp_rel_err']:.1e}", f"{d['worst_Z_rel_err']:.1e}",
+                     f"{a['reduced']} + {a['reduced_comp']} + {a['collapsed']} of {a['problems']} (reduced + compensated + collapsed)"])
+    for name, f in (('sampler', f'{ROUND}_fuzz_sampler_summary.jsonl'), ('batch of spectra', f'{ROUND}_fuzz_batch_summary.jsonl')):
+        for d in jlines(f):
+            rows.append([f"{name}, seed {d['seed']}", d['cases'], d['failures'], '-', '-', '-'])
+    return md(rows, ['campaign', 'cases', 'violations', 'worst log-prob rel. err (tol 1e-10)', 'worst Z rel. err (tol 1e-12)',
+                     'AUTO on PolynomialDecomposition designs with 2N >= P+2'])
+
+
+def table_auto_by_degree():
+    tot = {}
+    for d in jlines(f'{ROUND}_fuzz_parity_summary.jsonl'):
+        for deg, v in d['auto_on_polydecomp']['by_degree'].items():
+            t = tot.setdefault(int(deg), dict(problems=0, reduced=0, reduced_comp=0, collapsed=0))
+            for k in t:
+                t[k] += v[k]
+    rows = [[deg, v['problems'], v['reduced'], v['reduced_comp'], v['collapsed'],
+             f"{(v['reduced'] + v['reduced_comp']) / v['problems']:.2f}"] for deg, v in sorted(tot.items())]
+    return md(rows, ['poly_deg', 'problems', 'plain reduced', 'compensated reduced', 'collapsed', 'fraction on a reduced kernel'])
+
+
+TABLES = {
+    'bench': table_bench, 'variants': table_variants, 'sweep': table_sweep, 'forward': table_forward,
+    'host_path': table_host_path, 'samplers': table_samplers, 'cfg4': table_cfg4, 'cfg5': table_cfg5,
+    'fuzz': table_fuzz, 'auto_by_degree': table_auto_by_degree,
+}
+
+FILES = [
+    (f'{ROUND}_bench.json', '`python bench.py`', 'the headline line: value, roofline (HIP-event kernel time), variants and other kernels with `roofline_valu`, cpu_baseline + reference calibration, parity'),
+    (f'{ROUND}_bench_kernel_stats.csv', '`rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-variants`', 'average duration of the headline kernel under the profiler'),
+    (f'{ROUND}_bench_under_rocprof.json', 'stdout of that run', 'the in-process HIP-event clock under the profiler (agrees with the trace)'),
+    (f'{ROUND}_bench_pmc_summary.csv, pmc_traffic.json', 'two more runs with `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes), `benchmarks/summarize_pmc.py`', 'HBM bytes per launch; bench.py copies it into `roofline.traffic`'),
+    ('valu_counts.json', '`rocprofv3 --pmc SQ_INSTS_VALU -- python3 bench.py --pmc-pass`, `benchmarks/summarize_pmc.py`', 'VALU wave-instructions per eval of every kernel bench.py times: the numerators of `roofline_valu`'),
+    ('cpu_calibration.json', '`python benchmarks/cpu_calibration.py` (build container only: imports the real reference)', 'real reference vs oracle on one core, same rows: bit-identical values, rate ratio'),
+    (f'{ROUND}_sweep.jsonl, {ROUND}_sweep_kernel_stats.csv', '`python benchmarks/sweep.py` (and under `rocprofv3 --kernel-trace --stats`)', 'every log-probability kernel at the BASELINE config shapes'),
+    (f'{ROUND}_host_path.jsonl', '`python benchmarks/host_path.py`', 'PCIe-inclusive `bisip_logprob` rate; `bisip_forward_dev` store rate'),
+    (f'{ROUND}_sampler_bench.jsonl, {ROUND}_sampler_kernel_stats.csv', '`python benchmarks/sampler_bench.py`', 'end-to-end `fit()` iterations/s per sampler / stream mode'),
+    (f'{ROUND}_cfg4_*.json', '`python benchmarks/cfg4_sampler.py --steps 200 --chain device [--fused] [--loop rccl|rccl-own|python]`', 'BASELINE config 4 on one GPU: fused vs the sharded half-step driven from C over RCCL vs from Python'),
+    (f'{ROUND}_cfg5_*.json, {ROUND}_cfg5_kernel_stats.csv', '`python benchmarks/cfg5_batch.py --chain device --steps 500 --thin-by 40 [--no-persistent]`', "BASELINE config 5, one GPU's share (512 spectra x 256 walkers)"),
+    (f'{ROUND}_bench_2ranks_one_device*.json', '`python bench.py --gpus 2 --backend gloo --same-device --walkers 1048576 --steps 4`', 'the self-launched 2-rank run on one GPU (gloo): result line and the sharded-sampler extra (state identical on both ranks = single-GPU chain)'),
+    (f'{ROUND}_fuzz_*_summary.jsonl', '`python benchmarks/fuzz_parity.py --cases 1500 --seed S` (S = 41..43), `fuzz_sampler.py --cases 1500 --seed 2`, `fuzz_batch.py --cases 500 --seed 1`', 'randomised campaigns: violations, worst errors, which kernel AUTO ran'),
+    (f'{ROUND}_micro_issue_latency.txt', '`benchmarks/micro/issue_latency`', 'cycles per fp64 FMA for 1/2/4/8 independent chains at 1, 2, 4 waves per SIMD; placement of 1-, 2-, 4-, 8-, 16-wave workgroups'),
+    (f'{ROUND}_micro_row_latency.txt', '`benchmarks/micro/row_latency`', 'cycles of one log-probability row at one wave per SIMD, records from the scalar cache vs staged in LDS'),
+    (f'{ROUND}_micro_half_step_phases.txt', '`benchmarks/micro/half_step_phases`', 'phases of the cfg5 half-step launch by s_memtime'),
+    (f'{ROUND}_micro_cfg5_pmc.txt', '`bash benchmarks/micro/cfg5_pmc.sh`', 'SQ counters of the cfg5 sampler kernel (VALU busy vs waiting)'),
+    (f'{ROUND}_micro_forward_rows_variants.txt', '`benchmarks/micro/forward_rows_variants`', 'output path of the batched forward kernels (whole rows at N = 20, 16-frequency tiles at N = 32 / 64)'),
+    (f'{ROUND}_micro_post_run_stall.txt', '`python benchmarks/micro/post_run_stall.py kernel`, `upload_cost4.py plain`', 'the sporadic 20-30 ms delay of the first device work after a synchronisation early in a process'),
+]
+
+
+def readme():
+    out = [f'# profiles/ -- measured evidence, round {int(ROUND[1:])} (one MI355X, ROCm 7.2)', '',
+           'Generated by `python benchmarks/make_tables.py` from the files in this directory; the commands are what',
+           '`bash benchmarks/collect_profiles.sh all` runs on the GPU box (rocprofv3 from `/tmp`, `TMPDIR=/tmp`).',
+           'Files named `r01_*` are the previous round\'s and are kept for comparison.', '',
+           md([[f'`{f}`', c, w] for f, c, w in FILES], ['file', 'command', 'what to read']), '']
+    for name, title in (('bench', 'Headline'), ('variants', 'Formulations and the other kernels, with both rooflines'),
+                        ('sweep', 'Every log-probability kernel at the BASELINE shapes'), ('forward', 'Batched forward'),
+                        ('host_path', 'Host-buffer entry'), ('samplers', '`fit()` workloads'), ('cfg4', 'BASELINE config 4'),
+                        ('cfg5', 'BASELINE config 5'), ('fuzz', 'Randomised campaigns'), ('auto_by_degree', 'Which kernel AUTO ran, by polynomial degree')):
+        out += [f'## {title}', '', TABLES[name](), '']
+    return '\n'.join(out)
+
+
+def design_with_tables(text):
+    def repl(m):
+        name = m.group(1)
+        if name not in TABLES:
+            raise SystemExit(f'DESIGN.md names an unknown table {name!r}')
+        return f'<!-- TABLE:{name} -->\n{TABLES[name]()}\n<!-- /TABLE:{name} -->'
+    return re.sub(r'<!-- TABLE:(\w+) -->.*?<!-- /TABLE:\1 -->', repl, text, flags=re.S)
+
+
+def main():
+    check = '--check' in sys.argv
+    stale = []
+    dpath = os.path.join(ROOT, 'DESIGN.md')
+    old = open(dpath).read()
+    new = design_with_tables(old)
+    if new != old:
+        stale.append('DESIGN.md')
+        if not check:
+            open(dpath, 'w').write(new)
+    rpath = os.path.join(PROF, 'README.md')
+    old = open(rpath).read() if os.path.exists(rpath) else ''
+    new = readme() + '\n'
+    if new != old:
+        stale.append('profiles/README.md')
+        if not check:
+            open(rpath, 'w').write(new)
+    if check and stale:
+        print('out of date (run python benchmarks/make_tables.py):', ', '.join(stale))
+        return 1
+    print('rewrote' if stale else 'up to date:', ', '.join(stale) if stale else 'DESIGN.md tables, profiles/README.md')
+    return 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())

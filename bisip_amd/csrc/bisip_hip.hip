@@ -560,9 +560,9 @@ int bisip_stretch_draw_dev(bisip_ctx *c, int64_t W, double a, uint64_t seed, int
 
 static int moment_splits(int64_t n_samples, int64_t E)
 {
-    // enough workgroups to fill the chip (256 CUs x 8), never more than one per sample
-    int64_t s = (2048 + E - 1) / E;
-    if (s > n_samples) s = n_samples;
+    // enough workgroups to fill the chip (256 CUs x 16), at least four samples each
+    int64_t s = (4096 + E - 1) / E;
+    if (s > n_samples / 4) s = n_samples / 4;
     return (int)(s < 1 ? 1 : s);
 }
 

@@ -5,6 +5,7 @@ reference's surface, and a missing GPU fails loudly."""
 
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -255,3 +256,13 @@ def test_cpu_quota_is_within_the_machine():
     from bisip_amd.utils import cpu_quota
     n = cpu_quota()
     assert isinstance(n, int) and 1 <= n <= (os.cpu_count() or 1)
+
+
+def test_design_tables_are_generated():
+    """Every measured table of DESIGN.md and all of profiles/README.md come out of
+    benchmarks/make_tables.py from the files under profiles/ -- numbers are not retyped."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'benchmarks', 'make_tables.py'), '--check'],
+                       capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+
