@@ -95,6 +95,10 @@ SYMBOLS = {
     'bisip_chain_percentiles_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
                                                    ctypes.c_int64, ctypes.c_int, _dp, ctypes.c_int, ctypes.c_void_p,
                                                    ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
+    'bisip_column_percentiles_workspace': (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
+    'bisip_column_percentiles_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, _dp, ctypes.c_int,
+                                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
+    'bisip_forward_percentiles': (ctypes.c_int, [ctypes.c_void_p, _dp, ctypes.c_int64, _dp, ctypes.c_int, _dp]),
     'bisip_numpy_stretch_stream': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32), ctypes.c_int64,
                                                   ctypes.c_double, ctypes.c_int64] + [ctypes.c_void_p] * 4),
     'bisip_philox4x32': (None, [ctypes.POINTER(ctypes.c_uint32)] * 3),
@@ -301,6 +305,18 @@ class HipContext:
         theta = self._theta2d(theta)
         out = np.empty((theta.shape[0], 2, self.N), dtype=np.float64)
         _check(self._lib.bisip_forward(self._h, _p(theta), theta.shape[0], _p(out)))
+        return out
+
+    def forward_percentiles(self, theta, p):
+        """``np.percentile(forward(theta), p, axis=0)`` computed on the device: theta (W, ndim)
+        host -> (len(p), 2, N) host.  Raises NotImplementedError when W*2N exceeds one device sort."""
+        theta = self._theta2d(theta)
+        p = _c(np.atleast_1d(p)).ravel()
+        out = np.empty((p.size, 2, self.N), dtype=np.float64)
+        rc = self._lib.bisip_forward_percentiles(self._h, _p(theta), theta.shape[0], _p(p), p.size, _p(out))
+        if rc == -4:
+            raise NotImplementedError(self._lib.bisip_last_error().decode('utf-8', 'replace'))
+        _check(rc)
         return out
 
     def loglike_z(self, Z):

@@ -83,10 +83,9 @@ int sort_temp_bytes(long long items, long long columns, long long n, size_t *byt
 
 }  // namespace
 
-extern "C" {
+namespace {
 
-int64_t bisip_chain_percentiles_workspace(int64_t n_samples, int64_t n_ensembles,
-                                          int64_t walkers_per_ensemble, int ndim, int n_percentiles)
+int64_t percentiles_workspace(int64_t n_samples, int64_t n_ensembles, int64_t walkers_per_ensemble, int ndim, int n_percentiles)
 {
     if (n_samples < 1 || n_ensembles < 1 || walkers_per_ensemble < 1 || ndim < 1 || n_percentiles < 1) return 0;
     const long long n = n_samples * walkers_per_ensemble, columns = n_ensembles * ndim, items = n * columns;
@@ -96,13 +95,53 @@ int64_t bisip_chain_percentiles_workspace(int64_t n_samples, int64_t n_ensembles
     return (int64_t)(2 * align256((size_t)items * 8) + align256(temp) + align256((size_t)n_percentiles * 16));
 }
 
+int percentiles_impl(const double *d_chain, int64_t n_samples, int64_t sample_stride, int64_t n_ensembles,
+                     int64_t walkers_per_ensemble, int ndim, const double *percentiles, int n_percentiles,
+                     double *d_out, void *d_work, int64_t work_bytes, void *stream);
+
+}  // namespace
+
+extern "C" {
+
+int64_t bisip_chain_percentiles_workspace(int64_t n_samples, int64_t n_ensembles,
+                                          int64_t walkers_per_ensemble, int ndim, int n_percentiles)
+{
+    return percentiles_workspace(n_samples, n_ensembles, walkers_per_ensemble, ndim, n_percentiles);
+}
+
+int64_t bisip_column_percentiles_workspace(int64_t n_rows, int n_cols, int n_percentiles)
+{
+    return percentiles_workspace(1, 1, n_rows, n_cols, n_percentiles);
+}
+
+int bisip_column_percentiles_dev(const double *d_rows, int64_t n_rows, int n_cols, const double *percentiles,
+                                 int n_percentiles, double *d_out, void *d_work, int64_t work_bytes, void *stream)
+{
+    if (n_cols < 1 || n_cols > 65536) return fail(BISIP_EINVAL, "n_cols=%d out of range", n_cols);
+    // rows (n_rows, n_cols) = one sample of one ensemble of n_rows walkers with n_cols parameters
+    return percentiles_impl(d_rows, 1, n_rows * (int64_t)n_cols, 1, n_rows, n_cols, percentiles, n_percentiles, d_out,
+                            d_work, work_bytes, stream);
+}
+
 int bisip_chain_percentiles_dev(const double *d_chain, int64_t n_samples, int64_t sample_stride,
                                 int64_t n_ensembles, int64_t walkers_per_ensemble, int ndim,
                                 const double *percentiles, int n_percentiles, double *d_out,
                                 void *d_work, int64_t work_bytes, void *stream)
 {
-    if (!d_chain || !percentiles || !d_out || !d_work) return fail(BISIP_EINVAL, "null argument");
     if (ndim < 1 || ndim > BISIP_MAX_NDIM) return fail(BISIP_EINVAL, "ndim=%d out of range", ndim);
+    return percentiles_impl(d_chain, n_samples, sample_stride, n_ensembles, walkers_per_ensemble, ndim, percentiles,
+                            n_percentiles, d_out, d_work, work_bytes, stream);
+}
+
+}  // extern "C"
+
+namespace {
+
+int percentiles_impl(const double *d_chain, int64_t n_samples, int64_t sample_stride, int64_t n_ensembles,
+                     int64_t walkers_per_ensemble, int ndim, const double *percentiles, int n_percentiles,
+                     double *d_out, void *d_work, int64_t work_bytes, void *stream)
+{
+    if (!d_chain || !percentiles || !d_out || !d_work) return fail(BISIP_EINVAL, "null argument");
     if (n_samples < 1 || n_ensembles < 1 || walkers_per_ensemble < 1 || n_percentiles < 1 || n_percentiles > 1024)
         return fail(BISIP_EINVAL, "bad shape");
     if (sample_stride < n_ensembles * walkers_per_ensemble * ndim)
@@ -155,4 +194,4 @@ int bisip_chain_percentiles_dev(const double *d_chain, int64_t n_samples, int64_
     return BISIP_OK;
 }
 
-}  // extern "C"
+}  // namespace

@@ -101,9 +101,15 @@ class utils(object):
     def get_model_percentile(self, p=[2.5, 50, 97.5], chain=None, **kwargs):
         """Percentiles of the model response over a chain (src/bisip/utils.py:17-35);
         the forward pass over the whole chain is one batched kernel launch."""
-        chain = self.parse_chain(chain, **kwargs)
-        results = self.forward(np.ascontiguousarray(chain), self.data['w'])
-        return np.percentile(results, p, axis=0)
+        chain = np.ascontiguousarray(self.parse_chain(chain, **kwargs), dtype=np.float64)
+        try:
+            # forward over the chain and the percentiles over axis 0 both on the device: only the
+            # chain goes up and (len(p), 2, N) comes back (bisip_forward_percentiles)
+            out = self._context().forward_percentiles(chain, p)
+            return out if np.ndim(p) else out[0]
+        except NotImplementedError:      # more than 2^31 model values: reduce on the host
+            results = self.forward(chain, self.data['w'])
+            return np.percentile(results, p, axis=0)
 
     def get_param_percentile(self, p=[2.5, 50, 97.5], chain=None, **kwargs):
         """reference: src/bisip/utils.py:37-53"""

@@ -271,6 +271,22 @@ int bisip_chain_percentiles_dev(const double *d_chain, int64_t n_samples, int64_
                                 const double *percentiles, int n_percentiles, double *d_out,
                                 void *d_work, int64_t work_bytes, void *stream);
 
+/* np.percentile(rows, p, axis=0) for a device-resident (n_rows, n_cols) array (linear rule):
+ * d_out (n_percentiles, n_cols).  Workspace in BYTES (0: more than 2^31 values). */
+int64_t bisip_column_percentiles_workspace(int64_t n_rows, int n_cols, int n_percentiles);
+int bisip_column_percentiles_dev(const double *d_rows, int64_t n_rows, int n_cols,
+                                 const double *percentiles, int n_percentiles, double *d_out,
+                                 void *d_work, int64_t work_bytes, void *stream);
+
+/* Percentiles of the MODEL response over a chain -- utils.get_model_percentile
+ * (src/bisip/utils.py:17-35: a Python loop of forward() over the chain, then np.percentile
+ * over axis 0) in one call: theta (W, ndim) host -> forward on the device -> per-(part,
+ * frequency) percentiles on the device -> out (n_percentiles, 2, N) host.  Only theta goes up
+ * and n_percentiles*2N doubles come back.  BISIP_EUNSUPPORTED when W*2N exceeds 2^31 values
+ * (use bisip_forward and reduce on the host).  Single-spectrum contexts. */
+int bisip_forward_percentiles(bisip_ctx *ctx, const double *theta, int64_t W,
+                              const double *percentiles, int n_percentiles, double *out);
+
 /* Host: the stretch move's random stream in numpy.random.RandomState order for n_steps
  * iterations of a W-walker ensemble (the contract is bisip_amd/sampler.py:draw_step).
  * mt_key[624] / *mt_pos are RandomState.get_state()[1:3], advanced in place exactly as

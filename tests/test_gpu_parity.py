@@ -317,6 +317,32 @@ def test_foreign_model_callable():
     assert_logp_close(ctx.loglike_z(Z), m._log_likelihood(theta, m.forward, d['w'], d['zn'], d['zn_err']))
 
 
+def test_model_percentiles_on_the_device():
+    """get_model_percentile (src/bisip/utils.py:17-35: forward() over the chain, np.percentile over
+    axis 0) as ONE library call -- forward and the per-(part, frequency) percentiles both on the
+    device -- against NumPy's percentile of the batched forward, and of the oracle's forward."""
+    import bisip_amd
+    import oracle
+    path = bisip_amd.DataFiles()['SIP-K389175']
+    for cls, kw in ((bisip_amd.PolynomialDecomposition, {}), (bisip_amd.PeltonColeCole, dict(n_modes=2))):
+        m = cls(path, nwalkers=32, nsteps=10, **kw)
+        lo, hi = m.param_bounds
+        rng = np.random.RandomState(8)
+        chain = rng.uniform(lo, hi, (5003, lo.size))
+        p = [2.5, 50, 97.5, 0, 100, 33.3]
+        got = m.get_model_percentile(p, chain)
+        assert got.shape == (6, 2, 20)
+        Z = m.forward(chain, m.data['w'])
+        assert np.allclose(got, np.percentile(Z, p, axis=0), rtol=1e-13, atol=1e-15)
+        d = m.data
+        okw = dict(taus=m.taus, log_taus=m.log_taus, c_exp=m.c_exp) if cls is bisip_amd.PolynomialDecomposition else dict(n_modes=2)
+        prob = oracle.OracleProblem(cls.__name__, d['w'], d['zn'], d['zn_err'], m.param_bounds, **okw)
+        assert_Z_close(got, np.percentile(oracle.forward(prob, chain), p, axis=0))
+        # a scalar percentile gives (2, N), as np.percentile does
+        assert m.get_model_percentile(50, chain).shape == (2, 20)
+        assert np.array_equal(m.get_model_percentile(50, chain), got[1])
+
+
 def test_faithful_variant_fit_uses_the_host_loop():
     """The stretch-move kernels exist for the reduced / collapsed formulations; a model pinned
     to `faithful` samples through the host loop around that very kernel, and the C entry
