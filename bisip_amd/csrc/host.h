@@ -129,6 +129,7 @@ struct StretchWork {
 
 StretchArgs to_device_args(const bisip_stretch_args *u);
 int dispatch_stretch(const bisip_ctx *c, const StretchWork &a, long long Wp, hipStream_t st);
+int dispatch_stretch_batch(const bisip_ctx *c, const StretchWork &a, long long Wp, hipStream_t st);   // dispatch_stretch_batch.hip
 int dispatch_apply(const bisip_ctx *c, const StretchArgs &a, hipStream_t st);
 
 }  // namespace host
