@@ -18,7 +18,7 @@ int launch_persistent(const PersistArgs &p0, const LP &lp, hipStream_t st)
     const size_t state_bytes = (size_t)p.W * (LP::NDIM + 1) * sizeof(double);
     size_t rec_bytes = 0;
     if constexpr (LP::CAN_STAGE) {
-        static const bool off = std::getenv("BISIP_NO_LDS_STAGING") != nullptr;   // A/B runs
+        const bool off = std::getenv("BISIP_NO_LDS_STAGING") != nullptr;   // A/B runs (read per call)
         rec_bytes = off ? 0 : (((size_t)lp.n_freq() * LP::REC_DOUBLES + 1) & ~(size_t)1) * sizeof(double);
         if (state_bytes + rec_bytes + 16 > 65536) rec_bytes = 0;                  // does not fit: scalar-cache path
     }

@@ -270,6 +270,40 @@ def test_persistent_kernel_equals_launch_per_half_step(prefix, model, variant):
     ctx.close()
 
 
+@pytest.mark.parametrize('prefix,model', [('case15_', 'PeltonColeCole'), ('case17_', 'PeltonColeCole'),
+                                          ('case18_', 'Dias2000'), ('case19_', 'Shin2015')])
+def test_lanes_per_slot_and_record_staging_do_not_change_the_chain(prefix, model, monkeypatch):
+    """The tuning knobs of the sampler kernels -- lanes per slot (1 / 2 / 4), records read through
+    the scalar cache or staged in LDS with the pipelined two-frequency loop -- select different
+    instruction streams for the same arithmetic: every combination must give the same chain,
+    persistent kernel and launch path alike."""
+    from bisip_amd.sampler import DeviceEnsembleSampler
+    g = np.load(_case(prefix))
+    ctx = make_ctx(g, model)
+    ndim = g['bounds'].shape[1]
+    W = 96
+    p0 = _start(g, W, 41)
+
+    def run(persistent):
+        s = DeviceEnsembleSampler(W, ndim, ctx, rng='philox', seed=5, persistent=persistent)
+        s.run_mcmc(p0, 25)
+        return s.get_chain(), s.get_log_prob()
+
+    ref = run(False)
+    for lanes in ('1', '2', '4'):
+        monkeypatch.setenv('BISIP_STRETCH_LANES', lanes)
+        for staging_off in (False, True):
+            if staging_off:
+                monkeypatch.setenv('BISIP_NO_LDS_STAGING', '1')
+            else:
+                monkeypatch.delenv('BISIP_NO_LDS_STAGING', raising=False)
+            for persistent in (True, False):
+                chain, logp = run(persistent)
+                assert np.array_equal(chain, ref[0]), (lanes, staging_off, persistent)
+                assert np.array_equal(logp, ref[1]), (lanes, staging_off, persistent)
+    ctx.close()
+
+
 def test_persistent_falls_back_when_ensemble_too_large():
     from bisip_amd.sampler import DeviceEnsembleSampler
     g = np.load(_case('case15_'))
