@@ -110,6 +110,8 @@ SYMBOLS = {
     'bisip_ctx_reduced_error': (ctypes.c_double, [ctypes.c_void_p]),
     'bisip_polydecomp_operands': (ctypes.c_int, [ctypes.c_int, _dp, _dp, _dp, ctypes.POINTER(ModelDesc),
                                                  _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
+    'bisip_polydecomp_reduced_estimates': (ctypes.c_int, [ctypes.c_int, _dp, _dp, _dp, ctypes.POINTER(ModelDesc),
+                                                          _dp, _dp, _dp]),
     'bisip_abi_version': (ctypes.c_int, []),
     'bisip_device_count': (ctypes.c_int, []),
     'bisip_last_error': (ctypes.c_char_p, []),
@@ -187,6 +189,23 @@ def polydecomp_operands(w, zn, zn_err, taus, log_taus, c_exp):
     out['rest'] = float(out['rest'][0])
     out['lconst'] = float(out['lconst'][0])
     return out
+
+
+def polydecomp_reduced_estimates(w, zn, zn_err, taus, log_taus, c_exp, bounds):
+    """Host-side error estimates (plain, compensated) of the QR-reduced kernels for one spectrum
+    and prior box -- what BISIP_VARIANT_AUTO decides on.  No GPU needed."""
+    lib = load_library()
+    w, zn, zn_err = _c(w).ravel(), _c(zn).reshape(2, -1), _c(zn_err).reshape(2, -1)
+    taus = _c(taus).ravel()
+    log_taus = _c(log_taus).reshape(-1, taus.size)
+    b = _c(bounds).reshape(2, -1)
+    lo, hi = _c(b[0]), _c(b[1])
+    if lo.size != log_taus.shape[0] + 1:
+        raise ValueError('bounds must have shape (2, poly_deg + 2)')
+    desc = ModelDesc(0, log_taus.shape[0] - 1, taus.size, float(c_exp), _p(taus), _p(log_taus))
+    est = np.empty(2)
+    _check(lib.bisip_polydecomp_reduced_estimates(w.size, _p(w), _p(zn), _p(zn_err), ctypes.byref(desc), _p(lo), _p(hi), _p(est)))
+    return float(est[0]), float(est[1])
 
 
 def device_count():

@@ -208,6 +208,26 @@ int bisip_polydecomp_operands(int N, const double *w, const double *zn, const do
     });
 }
 
+int bisip_polydecomp_reduced_estimates(int N, const double *w, const double *zn, const double *zn_err,
+                                       const bisip_model_desc *desc, const double *lo, const double *hi,
+                                       double *est)
+{
+    if (!w || !zn || !zn_err || !desc || !desc->taus || !desc->log_taus || !lo || !hi || !est)
+        return fail(BISIP_EINVAL, "null argument");
+    if (N < 1 || desc->poly_deg < 0 || desc->poly_deg > BISIP_MAX_POLY_DEG || desc->n_taus < 1)
+        return fail(BISIP_EINVAL, "bad shape");
+    return guarded([&] {
+        PolyDecompOperands o;
+        const int D = desc->poly_deg + 1, n = D + 1;
+        polydecomp_operands(N, w, desc->n_taus, desc->taus, D, desc->log_taus, desc->c_exp, zn, zn_err, o);
+        const double lconst = loglike_const(2 * N, zn_err);
+        std::vector<double> bh(n), ev(n), el(n);
+        for (int tier = 0; tier < 2; ++tier)
+            est[tier] = reduced_center(n, o.R, o.qty, o.bhat_ls, o.rest, lconst, lo, hi, tier == 1, bh.data(), ev.data(), el.data());
+        return (int)BISIP_OK;
+    });
+}
+
 static int build_context(bisip_ctx **out, int device, int model_id, int E, int N, const double *w,
                          const double *zn, const double *zn_err, int ndim, const double *lo,
                          const double *hi, const bisip_model_desc *desc)

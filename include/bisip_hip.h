@@ -327,6 +327,14 @@ int bisip_polydecomp_operands(int N, const double *w, const double *zn, const do
                               double *R, double *bhat, double *e, double *rest,
                               double *lconst);
 
+/* Host-only: the error estimates behind BISIP_VARIANT_AUTO for one spectrum and prior box (what
+ * bisip_ctx_reduced_error reports for a context): worst relative log-probability error of the
+ * plain (est[0]) and the compensated (est[1]) QR-reduced kernel, from emulating their double
+ * arithmetic against long double on the probe rows.  No GPU needed. */
+int bisip_polydecomp_reduced_estimates(int N, const double *w, const double *zn, const double *zn_err,
+                                       const bisip_model_desc *desc, const double *lo,
+                                       const double *hi, double *est);
+
 int bisip_abi_version(void);
 int bisip_device_count(void);
 const char *bisip_last_error(void);

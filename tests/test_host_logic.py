@@ -258,6 +258,41 @@ def test_cpu_quota_is_within_the_machine():
     assert isinstance(n, int) and 1 <= n <= (os.cpu_count() or 1)
 
 
+def test_reduced_kernel_tiers_estimates_on_the_host():
+    """What BISIP_VARIANT_AUTO decides on, without a GPU: the host emulates the plain and the
+    compensated QR-reduced arithmetic against long double on probe rows (prior box, small
+    coefficients, least-squares clouds, posterior draws).  Well-conditioned designs -- the
+    headline shape, the bundled spectra -- pass with the plain form; nearly collinear ones
+    (degree 8-10) need, and pass with, the compensated one."""
+    import bisip_amd
+    from bench import make_problem
+    from bisip_amd import _hip
+    from bisip_amd.synthetic import synthetic_columns
+    from bisip_amd.utils import columns_to_data, load_data
+
+    def estimates(d, P, c_exp):
+        per = np.log10(1. / d['w'])
+        lt = np.linspace(np.floor(per.min() - 1), np.floor(per.max() + 1), 2 * d['N'])
+        bounds = np.array([[0.9] + [-1.0] * (P + 1), [1.1] + [1.0] * (P + 1)])
+        return _hip.polydecomp_reduced_estimates(d['w'], d['zn'], d['zn_err'], 10 ** lt,
+                                                 np.array([lt ** i for i in range(P + 1)]), c_exp, bounds)
+
+    data, taus, log_taus, bounds = make_problem()
+    plain, comp = _hip.polydecomp_reduced_estimates(data['w'], data['zn'], data['zn_err'], taus, log_taus, 1.0, bounds)
+    assert plain < 1e-13 and comp < 1e-13
+    for name, path in bisip_amd.DataFiles().items():
+        for P, c in ((5, 1.0), (4, 0.5)):
+            plain, comp = estimates(load_data(path), P, c)
+            assert plain <= 1e-12 and comp <= 1e-12, (name, P, c, plain, comp)
+    needs_comp = 0
+    for n_freq, P, c, idx in [(32, 10, 0.5, 0), (33, 10, 0.5, 3), (20, 10, 0.5, 7), (80, 10, 0.5, 1), (32, 8, 0.5, 2), (48, 9, 1.0, 4)]:
+        plain, comp = estimates(columns_to_data(synthetic_columns(n_freq, idx), 'mrad'), P, c)
+        assert comp <= 1e-12, (n_freq, P, c, comp)
+        assert comp <= plain
+        needs_comp += plain > 1e-12
+    assert needs_comp >= 3
+
+
 def test_design_tables_are_generated():
     """Every measured table of DESIGN.md and all of profiles/README.md come out of
     benchmarks/make_tables.py from the files under profiles/ -- numbers are not retyped."""
