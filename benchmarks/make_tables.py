@@ -160,7 +160,7 @@ def table_fuzz():
     rows = []
     for d in jlines(f'{ROUND}_fuzz_parity_summary.jsonl'):
         a = d['auto_on_polydecomp']
-        rows.append([f"parity, seed {d['seed']}", d['cases'], d['violations'], f"{d['worst_logp_rel_err']:.1e}", f"{d['worst_Z_rel_err']:.1e}",
+        rows.append([f"parity, seed {d['seed']}" + (f", prior boxes widened x{d['widen']}" if d.get('widen') else ''), d['cases'], d['violations'], f"{d['worst_logp_rel_err']:.1e}", f"{d['worst_Z_rel_err']:.1e}",
                      f"{a['reduced']} + {a['reduced_comp']} + {a['collapsed']} of {a['problems']} (reduced + compensated + collapsed)"])
     for name, f in (('sampler', f'{ROUND}_fuzz_sampler_summary.jsonl'), ('batch of spectra', f'{ROUND}_fuzz_batch_summary.jsonl')):
         for d in jlines(f):
