@@ -60,7 +60,7 @@ if [ "$what" = sampler ] || [ "$what" = all ]; then
 fi
 if [ "$what" = micro ] || [ "$what" = all ]; then
   echo "== micro-benchmarks" | tee -a "$out/progress.log"
-  for m in issue_latency row_latency half_step_phases forward_rows_variants; do
+  for m in issue_latency row_latency half_step_phases forward_rows_variants grid_barrier; do
     [ -x benchmarks/micro/$m ] && timeout -k 5 200 benchmarks/micro/$m > "$out/micro_$m.txt" 2>&1
   done
   python3 benchmarks/micro/post_run_stall.py kernel 2>/dev/null | grep after > "$out/micro_post_run_stall.txt"
