@@ -16,6 +16,8 @@
 // in as is); libbisip_hip.so itself does not link against it.
 #include <dlfcn.h>
 
+#include <mutex>
+
 #include <rccl/rccl.h>
 
 #include "host.h"
@@ -37,9 +39,11 @@ struct Rccl {
 };
 
 Rccl g_rccl;
+std::mutex g_rccl_mutex;
 
 int load_rccl()
 {
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);   // contexts of different threads may arrive together
     if (g_rccl.lib) return BISIP_OK;
     void *h = nullptr;
     for (const char *name : {"librccl.so.1", "librccl.so"}) {
