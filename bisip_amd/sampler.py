@@ -513,28 +513,29 @@ class HipStretchBackend:
         p.status = st['status'].data_ptr()
         return self.ctx.stretch_persistent_dev(p, self.stream())
 
-    def stream_staging(self, n, nh):
-        """Pinned host arrays (n, 2, nh) for one chunk of the NumPy-order stream, reused from
-        chunk to chunk once the previous upload has left them."""
+    def stream_staging(self, n, nh, slot=0):
+        """Pinned host arrays (n, 2, nh) for one chunk of the NumPy-order stream.  Two slots
+        alternate from chunk to chunk (one is being filled by the host while the other's upload
+        is in flight); a slot is reused once its previous upload has left it."""
         torch = self.torch
         need = int(n) * 2 * int(nh)
         kinds = (('active', torch.int32), ('partner', torch.int32), ('zz', torch.float64),
                  ('factor', torch.float64), ('logu', torch.float64))
-        ev = _PINNED.get('stream_event')
+        ev = _PINNED.get(f'stream_event_{slot}')
         if ev is not None:
             ev.synchronize()
         out = {}
         for name, dt in kinds:
-            blk = _pinned_scratch('stream_' + name, need * 8)
+            blk = _pinned_scratch(f'stream_{slot}_{name}', need * 8)
             out[name] = blk[:need * (4 if dt == torch.int32 else 8)].view(dt).view(int(n), 2, int(nh))
         return out
 
-    def upload_staged(self, stage):
+    def upload_staged(self, stage, slot=0):
         """Asynchronous host->device copies of the staged stream on the compute stream."""
         out = {name: t.to(self.device, non_blocking=True) for name, t in stage.items()}
         ev = self.torch.cuda.Event()
         ev.record(self.torch.cuda.current_stream(self.device))
-        _PINNED['stream_event'] = ev
+        _PINNED[f'stream_event_{slot}'] = ev
         return out
 
     def host_buffer(self, shape):
@@ -683,7 +684,13 @@ class DeviceEnsembleSampler(_SamplerBase):
         # bytes resident per iteration: chain row + log-prob + the five stream arrays.  2 GiB
         # per chunk is <1 % of the 288 GB of HBM and keeps the host work per chunk negligible
         per_step = self.nwalkers * (8 * self.ndim + 8 + 3 * 8 + 2 * 4)
-        return max(1, min(nsteps, (2 << 30) // per_step))
+        n = max(1, min(nsteps, (2 << 30) // per_step))
+        if self.rng == 'numpy':
+            # the NumPy-order stream is drawn on the host (MT19937 is sequential: ~20-60 ns per
+            # walker-step): chunks of ~250k walker-steps keep that to a few milliseconds, so the
+            # stream of chunk k+1 is drawn while the kernels of chunk k run instead of before them
+            n = min(n, max(16, 250_000 // self.nwalkers))
+        return n
 
     # -- run_mcmc and its stages ---------------------------------------------------------
     def _start_from(self, initial_state):
@@ -713,14 +720,14 @@ class DeviceEnsembleSampler(_SamplerBase):
         self._upload_state(p0)
         return dict(check_s=t1 - t0, upload_s=time.perf_counter() - t1)
 
-    def _numpy_stream(self, st, n, nh):
-        """Chunk of the NumPy-order stream: generated in C from the RandomState's MT19937 state
-        (bit-identical to calling draw_step n times, ~30x cheaper) straight into pinned staging
-        memory; the logs are NumPy's so they match the host sampler's.  Pinned staging keeps the
-        upload asynchronous: the next chunk's stream is generated while this chunk's kernels run."""
+    def _numpy_stream_host(self, n, nh, slot):
+        """Chunk of the NumPy-order stream, host part: generated in C from the RandomState's
+        MT19937 state (bit-identical to calling draw_step n times, ~30x cheaper) straight into
+        pinned staging memory; the logs are NumPy's so they match the host sampler's.  Runs on a
+        worker thread for every chunk but the first (the C generator and NumPy's log release the
+        GIL), so chunk k+1 is drawn while the main thread enqueues chunk k's kernels."""
         from ._hip import numpy_stretch_stream
-        be = self.backend
-        stage = be.stream_staging(n, nh)
+        stage = self.backend.stream_staging(n, nh, slot)
         _, _, zz, u = numpy_stretch_stream(
             self._random, self.nwalkers, self.a, n,
             out=tuple(stage[name].numpy() for name in ('active', 'partner', 'zz', 'logu')))
@@ -729,7 +736,7 @@ class DeviceEnsembleSampler(_SamplerBase):
             np.log(zz, out=factor)
             factor *= self.ndim - 1.0
             np.log(u, out=u)             # 'logu' staging held u
-        st.update(be.upload_staged(stage))
+        return stage
 
     def _advance(self, st, n, nh, it0):
         """Enqueue the n iterations of a chunk: persistent kernel, fused launches, or (several
@@ -796,55 +803,84 @@ class DeviceEnsembleSampler(_SamplerBase):
                            drain_s=0.0, finish_s=0.0, **setup_detail)
         done = 0                                 # stored samples so far
         it0 = self._iterations_run
-        while done < nsteps:
-            t_a = time.perf_counter()
-            ns = min(max(1, self._chunk_steps(nsteps * thin_by) // thin_by), nsteps - done)
-            n = ns * thin_by                     # iterations in this chunk
-            st = dict(self._dev)
-            st['nh'] = nh
-            st['thin'] = thin_by
-            if self.n_ensembles > 1:
-                st['wp'] = self.walkers_per_ensemble
-            if self.rng == 'numpy':
-                self._numpy_stream(st, n, nh)
-            else:
-                # only the per-step split is drawn on the host; the stream is generated on
-                # the device from (seed, step, half, slot) counters
-                off = it0 - self._iterations_run
-                st['perm'] = perm_all[off:off + n]
-            if self.chain_on_device:
-                if dev_chain is None:
-                    dev_chain = be.empty((nsteps, W, ndim), torch.float64)
-                    dev_logp = be.empty((nsteps, W), torch.float64)
-                st['chain'], st['logp_chain'] = dev_chain[done:done + ns], dev_logp[done:done + ns]
-            else:
-                st['chain'] = be.empty((ns, W, ndim), torch.float64)
-                st['logp_chain'] = be.empty((ns, W), torch.float64)
-            t_b = time.perf_counter()
-            if self.rng == 'philox':
-                if stream_bufs is None:          # the first chunk is the largest; later ones reuse it
-                    stream_bufs = {name: be.empty((n, 2, nh), dt) for name, dt in (
-                        ('active', torch.int32), ('partner', torch.int32), ('zz', torch.float64),
-                        ('factor', torch.float64), ('logu', torch.float64))}
-                for name, buf in stream_bufs.items():
-                    st[name] = buf[:n]
-                be.draw(st, self.walkers_per_ensemble, self.a, self.seed, it0, n)
-            self._advance(st, n, nh, it0)
-            t_alloc = 0.0
-            if not self.chain_on_device:
-                if chain_host is None:
-                    # pinning a big host chain takes tens of ms: do it while the first chunk runs
-                    t_h = time.perf_counter()
-                    chain_host = be.host_buffer((nsteps, W, ndim))
-                    logp_host = be.host_buffer((nsteps, W))
-                    t_alloc = time.perf_counter() - t_h
-                    self.timing['alloc_s'] = t_alloc
-                be.copy_out(chain_host[done:done + ns], st['chain'])
-                be.copy_out(logp_host[done:done + ns], st['logp_chain'])
-            done += ns
-            it0 += n
-            self.timing['stream_s'] += t_b - t_a
-            self.timing['enqueue_s'] += time.perf_counter() - t_b - t_alloc
+        # stored samples per chunk, known up front so that the next chunk's stream can be drawn ahead
+        sizes, left = [], nsteps
+        while left > 0:
+            sizes.append(min(max(1, self._chunk_steps(nsteps * thin_by) // thin_by), left))
+            left -= sizes[-1]
+        ahead = None                             # (worker thread, its result holder) for the next chunk
+        try:
+            for k, ns in enumerate(sizes):
+                t_a = time.perf_counter()
+                n = ns * thin_by                     # iterations in this chunk
+                st = dict(self._dev)
+                st['nh'] = nh
+                st['thin'] = thin_by
+                if self.n_ensembles > 1:
+                    st['wp'] = self.walkers_per_ensemble
+                if self.rng == 'numpy':
+                    if ahead is None:
+                        stage = self._numpy_stream_host(n, nh, k % 2)
+                    else:
+                        ahead[0].join()
+                        if 'error' in ahead[1]:
+                            raise ahead[1]['error']
+                        stage = ahead[1]['stage']
+                    st.update(be.upload_staged(stage, k % 2))
+                    ahead = None
+                    if k + 1 < len(sizes):           # draw the next chunk while this one is enqueued
+                        import threading
+                        box = {}
+
+                        def draw(n_next=sizes[k + 1] * thin_by, slot=(k + 1) % 2, box=box):
+                            try:
+                                box['stage'] = self._numpy_stream_host(n_next, nh, slot)
+                            except BaseException as exc:     # re-raised on the main thread
+                                box['error'] = exc
+                        worker = threading.Thread(target=draw, daemon=True)
+                        worker.start()
+                        ahead = (worker, box)
+                else:
+                    # only the per-step split is drawn on the host; the stream is generated on
+                    # the device from (seed, step, half, slot) counters
+                    off = it0 - self._iterations_run
+                    st['perm'] = perm_all[off:off + n]
+                if self.chain_on_device:
+                    if dev_chain is None:
+                        dev_chain = be.empty((nsteps, W, ndim), torch.float64)
+                        dev_logp = be.empty((nsteps, W), torch.float64)
+                    st['chain'], st['logp_chain'] = dev_chain[done:done + ns], dev_logp[done:done + ns]
+                else:
+                    st['chain'] = be.empty((ns, W, ndim), torch.float64)
+                    st['logp_chain'] = be.empty((ns, W), torch.float64)
+                t_b = time.perf_counter()
+                if self.rng == 'philox':
+                    if stream_bufs is None:          # the first chunk is the largest; later ones reuse it
+                        stream_bufs = {name: be.empty((n, 2, nh), dt) for name, dt in (
+                            ('active', torch.int32), ('partner', torch.int32), ('zz', torch.float64),
+                            ('factor', torch.float64), ('logu', torch.float64))}
+                    for name, buf in stream_bufs.items():
+                        st[name] = buf[:n]
+                    be.draw(st, self.walkers_per_ensemble, self.a, self.seed, it0, n)
+                self._advance(st, n, nh, it0)
+                t_alloc = 0.0
+                if not self.chain_on_device:
+                    if chain_host is None:
+                        # pinning a big host chain takes tens of ms: do it while the first chunk runs
+                        t_h = time.perf_counter()
+                        chain_host = be.host_buffer((nsteps, W, ndim))
+                        logp_host = be.host_buffer((nsteps, W))
+                        t_alloc = time.perf_counter() - t_h
+                        self.timing['alloc_s'] = t_alloc
+                    be.copy_out(chain_host[done:done + ns], st['chain'])
+                    be.copy_out(logp_host[done:done + ns], st['logp_chain'])
+                done += ns
+                it0 += n
+                self.timing['stream_s'] += t_b - t_a
+                self.timing['enqueue_s'] += time.perf_counter() - t_b - t_alloc
+        finally:
+            if ahead is not None:        # an error above: let the worker finish with the RandomState first
+                ahead[0].join()
         if chain_host is None and dev_chain is None:  # nsteps == 0
             chain_host, logp_host = be.host_buffer((0, W, ndim)), be.host_buffer((0, W))
         t_d = time.perf_counter()

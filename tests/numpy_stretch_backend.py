@@ -115,12 +115,12 @@ class NumpyStretchBackend:
         self.run(st, n_steps)
         return True
 
-    def stream_staging(self, n, nh):
+    def stream_staging(self, n, nh, slot=0):
         kinds = (('active', torch.int32), ('partner', torch.int32), ('zz', torch.float64),
                  ('factor', torch.float64), ('logu', torch.float64))
         return {name: torch.zeros((n, 2, nh), dtype=dt) for name, dt in kinds}
 
-    def upload_staged(self, stage):
+    def upload_staged(self, stage, slot=0):
         return dict(stage)
 
     def host_buffer(self, shape):
