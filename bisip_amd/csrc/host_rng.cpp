@@ -18,6 +18,8 @@ namespace {
 struct MT {
     uint32_t *key;  // 624 words
     int pos;
+    uint32_t out[624];   // tempered words of the current state block, valid from `pos` on
+    bool fresh = false;  // out[] matches key[]
     void gen()
     {
         const int N = 624, M = 397;
@@ -35,28 +37,43 @@ struct MT {
         y = (key[N - 1] & UP) | (key[0] & LO);
         key[N - 1] = key[M - 1] ^ (y >> 1) ^ (-(int32_t)(y & 1) & A);
         pos = 0;
+        fresh = false;
     }
-    uint32_t next32()
+    // tempering of the whole block in one vectorisable loop (the state words themselves stay
+    // untempered in key[], as NumPy keeps them)
+    void temper_block()
+    {
+        for (int i = 0; i < 624; i++) {
+            uint32_t y = key[i];
+            y ^= (y >> 11);
+            y ^= (y << 7) & 0x9d2c5680u;
+            y ^= (y << 15) & 0xefc60000u;
+            y ^= (y >> 18);
+            out[i] = y;
+        }
+        fresh = true;
+    }
+    inline uint32_t next32()
     {
         if (pos == 624) gen();
-        uint32_t y = key[pos++];
-        y ^= (y >> 11);
-        y ^= (y << 7) & 0x9d2c5680u;
-        y ^= (y << 15) & 0xefc60000u;
-        y ^= (y >> 18);
-        return y;
+        if (!fresh) temper_block();
+        return out[pos++];
     }
-    double next_double()
+    inline double next_double()
     {
         const int32_t a = next32() >> 5, b = next32() >> 6;
         return (a * 67108864.0 + b) / 9007199254740992.0;
     }
-    // masked rejection on [0, max], max < 2^32 (random_interval / bounded_masked_uint32)
-    uint32_t bounded(uint32_t max)
+    static inline uint32_t mask_for(uint32_t max)
     {
-        if (max == 0) return 0;
         uint32_t mask = max;
         mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+        return mask;
+    }
+    // masked rejection on [0, max], max < 2^32 (random_interval / bounded_masked_uint32)
+    inline uint32_t bounded(uint32_t max, uint32_t mask)
+    {
+        if (max == 0) return 0;
         uint32_t v;
         while ((v = (next32() & mask)) > max) {}
         return v;
@@ -73,15 +90,19 @@ extern "C" int bisip_numpy_stretch_stream(uint32_t *mt_key, int32_t *mt_pos, int
         return BISIP_EINVAL;
     if (n_steps == 0) return BISIP_OK;   // nothing to draw: the output arrays may be empty
     if (!active || !partner || !zz || !u) return BISIP_EINVAL;
-    MT mt{mt_key, *mt_pos};
+    MT mt;
+    mt.key = mt_key;
+    mt.pos = *mt_pos;
     const int64_t nh = (W + 1) / 2;
     std::vector<int32_t> inds(W), half[2];
     half[0].reserve(nh); half[1].reserve(nh);
     for (int64_t k = 0; k < n_steps; ++k) {
         (void)mt.next_double();   // the weighted choice over the move list: one uniform double
         for (int64_t i = 0; i < W; ++i) inds[i] = (int32_t)(i & 1);
+        uint32_t smask = MT::mask_for((uint32_t)(W - 1));
         for (int64_t i = W - 1; i >= 1; --i) {  // rng.shuffle(inds)
-            const uint32_t j = mt.bounded((uint32_t)i);
+            if (((uint32_t)i & ((smask >> 1) + 1)) == 0) smask >>= 1;   // i dropped below a power of two
+            const uint32_t j = mt.bounded((uint32_t)i, smask);
             const int32_t tmp = inds[i]; inds[i] = inds[j]; inds[j] = tmp;
         }
         half[0].clear(); half[1].clear();
@@ -95,8 +116,9 @@ extern "C" int bisip_numpy_stretch_stream(uint32_t *mt_key, int32_t *mt_pos, int
                 zz[off + t] = (v * v) / a;
                 active[off + t] = act[t];
             }
+            const uint32_t pmask = MT::mask_for((uint32_t)(Nc - 1));
             for (int64_t t = 0; t < Ns; ++t)        // randint(Nc, size=Ns)
-                partner[off + t] = comp[mt.bounded((uint32_t)(Nc - 1))];
+                partner[off + t] = comp[mt.bounded((uint32_t)(Nc - 1), pmask)];
             for (int64_t t = 0; t < Ns; ++t) u[off + t] = mt.next_double();   // rand(Ns)
             for (int64_t t = Ns; t < nh; ++t) {      // padding slot of the smaller half
                 active[off + t] = 0; partner[off + t] = 0; zz[off + t] = 1.0; u[off + t] = 1.0;
