@@ -16,7 +16,8 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize('script,extra', [('fuzz_parity.py', ['--cases', '200', '--seed', '21']),
                                           ('fuzz_parity.py', ['--cases', '100', '--seed', '22', '--widen', '2']),
                                           ('fuzz_sampler.py', ['--cases', '60', '--seed', '21']),
-                                          ('fuzz_batch.py', ['--cases', '40', '--seed', '21'])])
+                                          ('fuzz_batch.py', ['--cases', '40', '--seed', '21']),
+                                          ('extreme_shapes.py', ['--sizes', '100,1024,4096'])])
 def test_randomised_campaign(script, extra):
     run = subprocess.run([sys.executable, os.path.join(ROOT, 'benchmarks', script)] + extra,
                          capture_output=True, text=True, timeout=600)
