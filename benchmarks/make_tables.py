@@ -152,7 +152,12 @@ def table_cfg5():
                      (f'{ROUND}_cfg5_host_chain.json', 'persistent kernel, chain copied to pinned host memory')):
         d = jload(f)
         rows.append([label, d['path'], d['iterations'], d['seconds'], d.get('us_per_half_step', '-'), sci(d['walker_steps_per_s'])])
-    return md(rows, ['cfg5 slice: 512 spectra x 256 walkers, double Cole-Cole, N=32', 'path', 'iterations', 'seconds (incl. summaries)',
+    for f, label in ((f'{ROUND}_cfg5_4096_spectra.json', 'ALL 4096 spectra (1,048,576 walkers) on one GPU, persistent kernel'),
+                     (f'{ROUND}_cfg5_4096_spectra_launches.json', 'ALL 4096 spectra on one GPU, one launch per half-step')):
+        if os.path.exists(os.path.join(PROF, f)):
+            d = jload(f)
+            rows.append([label, d['path'], d['iterations'], d['seconds'], d.get('us_per_half_step', '-'), sci(d['walker_steps_per_s'])])
+    return md(rows, ['cfg5: 512 spectra (one GPU's share) x 256 walkers unless stated, double Cole-Cole, N=32', 'path', 'iterations', 'seconds (incl. summaries)',
                      'us per half-step', 'walker-steps/s'])
 
 
