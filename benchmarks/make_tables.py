@@ -157,7 +157,7 @@ def table_cfg5():
         if os.path.exists(os.path.join(PROF, f)):
             d = jload(f)
             rows.append([label, d['path'], d['iterations'], d['seconds'], d.get('us_per_half_step', '-'), sci(d['walker_steps_per_s'])])
-    return md(rows, ['cfg5: 512 spectra (one GPU's share) x 256 walkers unless stated, double Cole-Cole, N=32', 'path', 'iterations', 'seconds (incl. summaries)',
+    return md(rows, ["cfg5: 512 spectra (one GPU's share) x 256 walkers unless stated, double Cole-Cole, N=32", 'path', 'iterations', 'seconds (incl. summaries)',
                      'us per half-step', 'walker-steps/s'])
 
 
