@@ -10,7 +10,7 @@
 #include "../../bisip_amd/csrc/sampler_kernels.h"
 using namespace bisip;
 
-template <class LP>
+template <class LP, bool STAGED>
 __global__ __launch_bounds__(64) void k_half_timed(const StretchArgs a, const LP lp, long long *stamps)
 {
     constexpr int NDIM = LP::NDIM;
@@ -25,9 +25,12 @@ __global__ __launch_bounds__(64) void k_half_timed(const StretchArgs a, const LP
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     const long long T1 = __builtin_amdgcn_s_memtime();
     const double *staged = nullptr;
-    if constexpr (lp_stages<LP>::value) {
+    const long long e = (long long)__builtin_amdgcn_readfirstlane(i / (int)lp.Wp);   // one spectrum per wave
+    if constexpr (STAGED) {
         extern __shared__ __attribute__((aligned(16))) double lds_records[];
-        lp.stage(lds_records, i);
+        const double *__restrict__ src = lp.records(e);
+        for (int k = threadIdx.x; k < lp.n_freq() * LP::REC_DOUBLES; k += 64) lds_records[k] = src[k];
+        __syncthreads();
         staged = lds_records;
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -35,9 +38,7 @@ __global__ __launch_bounds__(64) void k_half_timed(const StretchArgs a, const LP
     double q[NDIM];
 #pragma unroll
     for (int k = 0; k < NDIM; ++k) { const double d = c[k] - s[k]; q[k] = c[k] - d * z; }
-    double new_lp;
-    if constexpr (lp_stages<LP>::value) new_lp = lp.staged(q, i, 0, staged);
-    else new_lp = lp(q, i, 0);
+    const double new_lp = lp.template eval_ens<STAGED>(q, e, 0, staged);
     asm volatile("" :: "v"(new_lp));
     const long long T3 = __builtin_amdgcn_s_memtime();
     const bool acc = (fac + new_lp) - old_lp > lu;
@@ -83,15 +84,15 @@ int main()
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     float ms;
     {
-        BatchGenericLP<ColeCole<2>, true, 1, false> lp; lp.cb = d_cb; lp.cb_stride = (long long)N * REC; lp.Wp = Wp; lp.lconst = d_lconst; lp.N = N; lp.b = b;
-        for (int r = 0; r < 300; ++r) k_half_timed<<<slots / 64, 64>>>(a, lp, d_st);
-        hipEventRecord(e0); for (int r = 0; r < 100; ++r) k_half_timed<<<slots / 64, 64>>>(a, lp, d_st); hipEventRecord(e1); hipDeviceSynchronize();
+        BatchGenericLP<ColeCole<2>, true, 1> lp; lp.cb = d_cb; lp.cb_stride = (long long)N * REC; lp.Wp = Wp; lp.lconst = d_lconst; lp.N = N; lp.b = b;
+        for (int r = 0; r < 300; ++r) k_half_timed<decltype(lp), false><<<slots / 64, 64>>>(a, lp, d_st);
+        hipEventRecord(e0); for (int r = 0; r < 100; ++r) k_half_timed<decltype(lp), false><<<slots / 64, 64>>>(a, lp, d_st); hipEventRecord(e1); hipDeviceSynchronize();
         hipEventElapsedTime(&ms, e0, e1); report("scalar-cache records", ms * 10);
     }
     {
-        BatchGenericLP<ColeCole<2>, true, 1, true> lp; lp.cb = d_cb; lp.cb_stride = (long long)N * REC; lp.Wp = Wp; lp.lconst = d_lconst; lp.N = N; lp.b = b;
-        for (int r = 0; r < 300; ++r) k_half_timed<<<slots / 64, 64, N * REC * 8>>>(a, lp, d_st);
-        hipEventRecord(e0); for (int r = 0; r < 100; ++r) k_half_timed<<<slots / 64, 64, N * REC * 8>>>(a, lp, d_st); hipEventRecord(e1); hipDeviceSynchronize();
+        BatchGenericLP<ColeCole<2>, true, 1> lp; lp.cb = d_cb; lp.cb_stride = (long long)N * REC; lp.Wp = Wp; lp.lconst = d_lconst; lp.N = N; lp.b = b;
+        for (int r = 0; r < 300; ++r) k_half_timed<decltype(lp), true><<<slots / 64, 64, N * REC * 8>>>(a, lp, d_st);
+        hipEventRecord(e0); for (int r = 0; r < 100; ++r) k_half_timed<decltype(lp), true><<<slots / 64, 64, N * REC * 8>>>(a, lp, d_st); hipEventRecord(e1); hipDeviceSynchronize();
         hipEventElapsedTime(&ms, e0, e1); report("LDS-staged records  ", ms * 10);
     }
     return 0;
