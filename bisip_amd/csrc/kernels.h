@@ -635,7 +635,7 @@ __device__ __forceinline__ double logprob_row(const double (&th)[M::NDIM], const
         // chains interleaved (residual2), and the NEXT pair's records in flight while this pair is
         // evaluated.  With one wave per SIMD nothing else hides a record read, and a dependent
         // fp64 instruction issues only every ~8 cycles (benchmarks/micro/issue_latency.hip,
-        // row_latency.hip: 15.8k -> 12.8k cycles per 32-frequency double-Cole-Cole row).  The sums
+        // row_latency.hip: 15.8-16.9k -> 12.8k cycles per 32-frequency double-Cole-Cole row).  The sums
         // still take their terms one by one in ascending frequency order: same bits as the loop below.
         const double *__restrict__ rec = o.cb;
         constexpr int R2 = 2 * M::REC;
