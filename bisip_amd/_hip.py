@@ -260,6 +260,8 @@ class HipContext:
         self.N = N
         self.n_spectra = E
         self.device = int(device)
+        self.model_id = int(model_id)
+        self.n_modes = int(n_modes)
         if variant != 'auto':
             self.set_variant(variant)
 
@@ -295,6 +297,21 @@ class HipContext:
     @property
     def kernel_name(self):
         return self._lib.bisip_ctx_kernel_name(self._h).decode()
+
+    @property
+    def persistent_walkers(self):
+        """Largest single ensemble for which the persistent sampler kernel (one workgroup holds the
+        ensemble) beats one launch per half-step with this context's log-probability kernel --
+        measured crossovers, benchmarks/micro/persistent_crossover.py: the cheaper the kernel per
+        walker, the longer one CU keeps up with launches that spread over the chip."""
+        name = self.kernel_name
+        if 'reduced' in name:
+            return 1024
+        if 'Dias' in name:
+            return 768
+        if 'ColeCole' in name:
+            return {1: 768, 2: 512}.get(self.n_modes, 256)
+        return 512          # Shin, per-frequency PolynomialDecomposition
 
     @property
     def reduced_error(self):

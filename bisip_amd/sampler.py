@@ -610,16 +610,19 @@ class DeviceEnsembleSampler(_SamplerBase):
         # one rank and the ensemble fits a workgroup: ONE launch per chunk (workgroups of whole
         # ensembles, state in LDS); bit-identical to the launch-per-half-step path, which is the
         # automatic fallback for bigger ensembles.  A workgroup lives on ONE compute unit, so
-        # for a single ensemble this wins while a half-ensemble x 4 lanes is at most one wave
-        # per SIMD (<= 128 walkers: 2-3x fewer microseconds per iteration; at 512 walkers a
-        # launch that spreads the half-step over the whole chip is faster).  A big batch of
+        # for a single ensemble this wins up to a few hundred walkers: 2-3x fewer microseconds per
+        # iteration at <= 128, until one CU no longer keeps up with launches that spread the
+        # half-step over the chip
+        # (the crossover depends on the kernel: HipContext.persistent_walkers, 256 ... 1024 walkers
+        # after round 2's rework of the kernel).  A big batch of
         # ensembles fills the chip with whole-ensemble workgroups either way, and then the
         # persistent kernel saves the launch, the gathers and the per-launch ramp of every
         # half-step (512 spectra x 256 walkers: 8.1 vs 13.3 us per half-step).
         # None = that rule; True / False force it.
         if persistent is None:
-            persistent = int(nwalkers) <= 128 or (int(nwalkers) <= 1024 and
-                                                  int(nwalkers) * self.n_ensembles >= 65536)
+            limit = getattr(getattr(self.backend, 'ctx', None), 'persistent_walkers', 128)
+            persistent = int(nwalkers) <= limit or (int(nwalkers) <= 1024 and
+                                                    int(nwalkers) * self.n_ensembles >= 65536)
         self.persistent = bool(persistent)
         # keep the stored samples in HBM: nothing is copied to the host until get_chain() /
         # get_log_prob() ask for it, and param_moments() summarises the chain where it lies
