@@ -172,7 +172,7 @@ class Inversion(_utils.utils):
                                  'dataset before attempting to plot results.')
 
     def fit(self, p0=None, pool=None, moves=None, sampler='device', rng='numpy', thin_by=1,
-            persistent=None):
+            persistent=None, chain='host'):
         """Sample the posterior with the stretch-move ensemble sampler.
 
         Args:
@@ -192,6 +192,10 @@ class Inversion(_utils.utils):
                 run); 'philox' generates it on the device (2-3x faster for small
                 ensembles, its own reproducible stream).  Device sampler only.
             thin_by (int): store one sample every ``thin_by`` iterations.
+            chain (str): device sampler: 'host' (default) copies the stored samples to host memory
+                as the run proceeds; 'device' keeps them in HBM -- get_param_mean / get_param_std /
+                get_param_percentile (called without a chain) then summarise them on the device
+                and get_chain() copies on demand.  For big ensembles the copy costs more than the run.
             persistent (bool or None): device sampler: run all iterations of a chunk inside
                 one kernel launch (one workgroup holds the ensemble) instead of one launch per
                 half-step.  Same chain, bit for bit.  None (default): when the ensemble has at
@@ -213,8 +217,10 @@ class Inversion(_utils.utils):
             # the vectorised log-probability of exactly that formulation (same chain contract)
             self._sampler = EnsembleSampler(self.nwalkers, self.ndim, ctx.logprob)
         elif sampler == 'device':
+            if chain not in ('host', 'device'):
+                raise ValueError("chain must be 'host' or 'device'")
             self._sampler = DeviceEnsembleSampler(self.nwalkers, self.ndim, ctx, rng=rng,
-                                                  persistent=persistent)
+                                                  persistent=persistent, chain_on_device=(chain == 'device'))
         elif sampler == 'host':
             self._sampler = EnsembleSampler(self.nwalkers, self.ndim, ctx.logprob)
         else:

@@ -111,16 +111,42 @@ class utils(object):
             results = self.forward(chain, self.data['w'])
             return np.percentile(results, p, axis=0)
 
+    def _device_chain_sampler(self, chain, kwargs):
+        """The sampler, when its chain lives in HBM (fit(chain='device')) and the caller asked for a
+        summary of the fitted chain rather than of an array of its own; else None."""
+        s = getattr(self, '_sampler', None)
+        if chain is not None or not getattr(s, 'chain_on_device', False):
+            return None
+        self._check_if_fitted()
+        extra = set(kwargs) - {'discard', 'thin', 'flat'}
+        if extra:
+            raise TypeError(f'unexpected keyword(s) {sorted(extra)}')
+        if 'discard' not in kwargs and 'thin' not in kwargs:      # same advice as parse_chain
+            warnings.warn('No samples were discarded from the chain.\n'
+                          'Pass discard and thin keywords to remove '
+                          'burn-in samples and reduce autocorrelation.', UserWarning)
+        return s
+
     def get_param_percentile(self, p=[2.5, 50, 97.5], chain=None, **kwargs):
         """reference: src/bisip/utils.py:37-53"""
+        s = self._device_chain_sampler(chain, kwargs)
+        if s is not None:      # sorted and interpolated where the chain lies
+            out = s.param_percentiles(p, discard=kwargs.get('discard', 0), thin=kwargs.get('thin', 1))[:, 0, :]
+            return out if np.ndim(p) else out[0]
         return np.percentile(self.parse_chain(chain, **kwargs), p, axis=0)
 
     def get_param_mean(self, chain=None, **kwargs):
         """reference: src/bisip/utils.py:55-69"""
+        s = self._device_chain_sampler(chain, kwargs)
+        if s is not None:
+            return s.param_moments(discard=kwargs.get('discard', 0), thin=kwargs.get('thin', 1))[0][0]
         return np.mean(self.parse_chain(chain, **kwargs), axis=0)
 
     def get_param_std(self, chain=None, **kwargs):
         """reference: src/bisip/utils.py:71-85"""
+        s = self._device_chain_sampler(chain, kwargs)
+        if s is not None:
+            return s.param_moments(discard=kwargs.get('discard', 0), thin=kwargs.get('thin', 1))[1][0]
         return np.std(self.parse_chain(chain, **kwargs), axis=0)
 
 

@@ -317,6 +317,37 @@ def test_foreign_model_callable():
     assert_logp_close(ctx.loglike_z(Z), m._log_likelihood(theta, m.forward, d['w'], d['zn'], d['zn_err']))
 
 
+def test_fit_with_the_chain_kept_on_the_device():
+    """fit(chain='device'): the stored samples stay in HBM; the reference's summary calls
+    (get_param_mean / _std / _percentile, src/bisip/utils.py:37-85) are answered there and agree
+    with NumPy on the chain that get_chain() copies out; the chain itself is the host-chain run's."""
+    import bisip_amd
+    path = bisip_amd.DataFiles()['SIP-K389175']
+    runs = {}
+    for chain in ('host', 'device'):
+        m = bisip_amd.PeltonColeCole(path, nwalkers=300, nsteps=120, n_modes=1)
+        np.random.seed(21)
+        m.fit(rng='philox', chain=chain)
+        runs[chain] = m
+    dev, host = runs['device'], runs['host']
+    assert dev.sampler.chain_on_device and not host.sampler.chain_on_device
+    with pytest.warns(UserWarning):
+        dev.get_param_mean()
+    mean, std = dev.get_param_mean(discard=40, thin=2), dev.get_param_std(discard=40, thin=2)
+    pct = dev.get_param_percentile([2.5, 50, 97.5], discard=40, thin=2)
+    med = dev.get_param_percentile(50, discard=40)
+    flat = dev.get_chain(discard=40, thin=2, flat=True)                 # copied out now
+    assert np.array_equal(flat, host.get_chain(discard=40, thin=2, flat=True))
+    assert np.allclose(mean, flat.mean(axis=0), rtol=1e-12, atol=1e-14)
+    assert np.allclose(std, flat.std(axis=0), rtol=1e-9, atol=1e-14)
+    assert np.allclose(pct, np.percentile(flat, [2.5, 50, 97.5], axis=0), rtol=1e-13, atol=1e-15)
+    assert med.shape == (4,) and np.allclose(med, np.percentile(dev.get_chain(discard=40, flat=True), 50, axis=0), rtol=1e-13)
+    # a caller's own array still goes through NumPy
+    assert np.array_equal(dev.get_param_mean(flat), flat.mean(axis=0))
+    with pytest.raises(ValueError):
+        dev.fit(chain='somewhere')
+
+
 def test_model_percentiles_on_the_device():
     """get_model_percentile (src/bisip/utils.py:17-35: forward() over the chain, np.percentile over
     axis 0) as ONE library call -- forward and the per-(part, frequency) percentiles both on the
