@@ -353,7 +353,10 @@ _PINNED = {}
 
 
 def _pinned_scratch(key, nbytes):
-    """Grow-only pinned host blocks shared by every sampler of the process (uint8 tensors)."""
+    """Grow-only pinned host blocks (uint8 tensors) that outlive a sampler: pinning costs more than
+    a short run.  Keys carry the owning thread and device (HipStretchBackend._key), so samplers
+    that follow each other on one thread share blocks -- an event guards each reuse -- and samplers
+    on different threads or GPUs never see each other's."""
     import torch
     blk = _PINNED.get(key)
     if blk is None or blk.numel() < nbytes:
@@ -373,6 +376,8 @@ class HipStretchBackend:
         self.torch = torch
         self.ctx = ctx
         self.device = torch.device('cuda', ctx.device)
+        import threading
+        self._key = f'{threading.get_ident()}:{ctx.device}:'     # the prefetch worker inherits it
 
     def tensor(self, array, dtype=None, slot='a'):
         """Host array -> device tensor WITHOUT waiting on the host: the data is staged in a
@@ -387,15 +392,15 @@ class HipStretchBackend:
         nbytes = t.numel() * t.element_size()
         if nbytes == 0:
             return torch.empty(t.shape, dtype=t.dtype, device=self.device)
-        ev = _PINNED.get('upload_event_' + slot)
+        ev = _PINNED.get(self._key + 'upload_event_' + slot)
         if ev is not None:
             ev.synchronize()             # the previous upload has left this scratch block
-        pinned = _pinned_scratch('upload_' + slot, nbytes)[:nbytes].view(t.dtype).view(t.shape)
+        pinned = _pinned_scratch(self._key + 'upload_' + slot, nbytes)[:nbytes].view(t.dtype).view(t.shape)
         pinned.copy_(t)
         dev = pinned.to(self.device, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))
-        _PINNED['upload_event_' + slot] = ev
+        _PINNED[self._key + 'upload_event_' + slot] = ev
         return dev
 
     def flag_nan(self, logp_t, status_t):
@@ -521,12 +526,12 @@ class HipStretchBackend:
         need = int(n) * 2 * int(nh)
         kinds = (('active', torch.int32), ('partner', torch.int32), ('zz', torch.float64),
                  ('factor', torch.float64), ('logu', torch.float64))
-        ev = _PINNED.get(f'stream_event_{slot}')
+        ev = _PINNED.get(f'{self._key}stream_event_{slot}')
         if ev is not None:
             ev.synchronize()
         out = {}
         for name, dt in kinds:
-            blk = _pinned_scratch(f'stream_{slot}_{name}', need * 8)
+            blk = _pinned_scratch(f'{self._key}stream_{slot}_{name}', need * 8)
             out[name] = blk[:need * (4 if dt == torch.int32 else 8)].view(dt).view(int(n), 2, int(nh))
         return out
 
@@ -535,7 +540,7 @@ class HipStretchBackend:
         out = {name: t.to(self.device, non_blocking=True) for name, t in stage.items()}
         ev = self.torch.cuda.Event()
         ev.record(self.torch.cuda.current_stream(self.device))
-        _PINNED[f'stream_event_{slot}'] = ev
+        _PINNED[f'{self._key}stream_event_{slot}'] = ev
         return out
 
     def host_buffer(self, shape):
@@ -881,6 +886,9 @@ class DeviceEnsembleSampler(_SamplerBase):
                 it0 += n
                 self.timing['stream_s'] += t_b - t_a
                 self.timing['enqueue_s'] += time.perf_counter() - t_b - t_alloc
+        except BaseException:
+            self._dev = None             # the device ensemble is part-way through a chunk: nothing to continue from
+            raise
         finally:
             if ahead is not None:        # an error above: let the worker finish with the RandomState first
                 ahead[0].join()

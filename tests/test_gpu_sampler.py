@@ -315,3 +315,40 @@ def test_persistent_falls_back_when_ensemble_too_large():
     s.run_mcmc(p0, 3)
     assert s.last_path == 'launch-per-half-step'
     ctx.close()
+
+
+def test_samplers_on_two_threads_do_not_share_staging():
+    """Two samplers run at the same time on two threads (own contexts, NumPy-order stream drawn on
+    the host and staged in pinned memory, several chunks each so that the prefetch workers run
+    too): each chain equals the chain of the same sampler run alone."""
+    import threading
+    from bisip_amd.sampler import DeviceEnsembleSampler
+    g = np.load(_case('case15_'))
+
+    def one(seed, W, nsteps, out):
+        try:
+            ctx = make_ctx(g, 'PeltonColeCole')
+            p0 = _start(g, W, seed)
+            s = DeviceEnsembleSampler(W, 4, ctx, rng='numpy', chunk=7)
+            s._random.seed(seed)
+            s.run_mcmc(p0, nsteps)
+            out[seed] = (s.get_chain().copy(), s.get_log_prob().copy())
+            ctx.close()
+        except BaseException as exc:      # surfaced by the assertions below
+            out[seed] = exc
+
+    alone = {}
+    one(3, 64, 60, alone)
+    one(4, 256, 45, alone)
+    for _ in range(3):
+        both = {}
+        threads = [threading.Thread(target=one, args=(3, 64, 60, both)),
+                   threading.Thread(target=one, args=(4, 256, 45, both))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        for seed in (3, 4):
+            assert not isinstance(both[seed], BaseException), both[seed]
+            assert np.array_equal(both[seed][0], alone[seed][0])
+            assert np.array_equal(both[seed][1], alone[seed][1])
