@@ -61,6 +61,7 @@ SYMBOLS = {
     'bisip_ctx_nspectra': (ctypes.c_int, [ctypes.c_void_p]),
     'bisip_ctx_destroy': (None, [ctypes.c_void_p]),
     'bisip_ctx_set_bounds': (ctypes.c_int, [ctypes.c_void_p, _dp, _dp]),
+    'bisip_ctx_set_spectrum_offset': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64]),
     'bisip_ctx_set_variant': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     'bisip_ctx_get_variant': (ctypes.c_int, [ctypes.c_void_p]),
     'bisip_logprob': (ctypes.c_int, [ctypes.c_void_p, _dp, ctypes.c_int64, _dp]),
@@ -278,6 +279,11 @@ class HipContext:
             pass
 
     # -- configuration ----------------------------------------------------------------
+    def set_spectrum_offset(self, first_spectrum):
+        """This batch context holds spectra [first_spectrum, first_spectrum + E) of a survey: the
+        Philox stream of each is keyed by its survey index."""
+        _check(self._lib.bisip_ctx_set_spectrum_offset(self._h, int(first_spectrum)))
+
     def set_bounds(self, bounds):
         b = _c(bounds).reshape(2, -1)
         if b.shape[1] != self.ndim:

@@ -63,6 +63,7 @@ class SpectraBatch:
         self.model = 'PeltonColeCole' if model == 'ColeCole' else model
         lo, hi = shard_range(len(spectra), world, rank)
         self.spectrum_range = (lo, hi)
+        self.n_spectra_total = len(spectra)
         if hi <= lo:
             raise ValueError('no spectra for this rank')
         batch = load_data_batch(spectra[lo:hi], headers, ph_units)
@@ -86,6 +87,7 @@ class SpectraBatch:
             kw = dict(n_modes=n_modes)
         self.ctx = _hip.HipContext(_MODELS[self.model], self.w, self.zn, self.zn_err,
                                    self.param_bounds, device=device, **kw)
+        self.ctx.set_spectrum_offset(lo)     # chains do not depend on how the survey is split over ranks
         self._sampler = None
 
     @property
@@ -121,12 +123,16 @@ class SpectraBatch:
         stored).  ``chain='device'`` keeps the stored samples in HBM: ``get_param_mean`` /
         ``get_param_std`` then summarise them on the device and ``get_chain`` copies them to
         the host only when called.  ``persistent``: one workgroup per spectrum runs all
-        iterations of a chunk in one launch (same chain; default: ensembles of <= 128 walkers)."""
+        iterations of a chunk in one launch (same chain; default: when the ensembles fit a
+        workgroup and the batch fills the chip, see DeviceEnsembleSampler)."""
         if chain not in ('host', 'device'):
             raise ValueError("chain must be 'host' or 'device'")
         E, Wp, ndim = self.n_spectra, self.nwalkers, self.ndim
         if p0 is None:
-            p0 = np.random.uniform(*self.param_bounds, (E, Wp, ndim))
+            # the whole survey's starts from the global RNG, this rank's block kept: with the same
+            # np.random.seed on every rank a spectrum starts (and runs) the same on any number of GPUs
+            first, last = self.spectrum_range
+            p0 = np.random.uniform(*self.param_bounds, (self.n_spectra_total, Wp, ndim))[first:last]
         self.ctx.set_bounds(self.param_bounds)
         self._sampler = DeviceEnsembleSampler(Wp, ndim, self.ctx, rng='philox', seed=seed,
                                               n_ensembles=E, chain_on_device=(chain == 'device'),
@@ -172,9 +178,30 @@ class SpectraBatch:
         return ch
 
     def get_log_prob(self, discard=0, thin=1):
+        if self._sampler is None:
+            raise AssertionError('Model is not fitted!')
         lp = self._sampler.get_log_prob(discard=discard, thin=thin)
         return lp.reshape(lp.shape[0], self.n_spectra, self.nwalkers)
 
     @property
     def acceptance_fraction(self):
+        if self._sampler is None:
+            raise AssertionError('Model is not fitted!')
         return self._sampler.acceptance_fraction.reshape(self.n_spectra, self.nwalkers)
+
+    def gather(self, per_spectrum, group=None):
+        """The end of a multi-GPU survey: every rank passes a per-spectrum result of ITS block --
+        ``(n_spectra, ...)``, e.g. ``get_param_mean()`` -- and gets the whole survey's
+        ``(n_spectra_total, ...)`` in spectrum order.  The only collective of the batch path (the
+        ensembles never exchange anything while they run); a single process gets its input back.
+        A leading percentile axis is the caller's to move: ``gather(np.moveaxis(pct, 1, 0))``."""
+        from .dist import all_gather_rows
+        a = np.ascontiguousarray(per_spectrum, dtype=np.float64)
+        if a.ndim < 1 or a.shape[0] != self.n_spectra:
+            raise ValueError(f'expected {self.n_spectra} rows (one per spectrum of this rank), got {a.shape}')
+        flat = all_gather_rows(a.reshape(self.n_spectra, -1), self.n_spectra_total, group)
+        return flat.reshape((flat.shape[0],) + a.shape[1:])
+
+    def close(self):
+        """Release the device context."""
+        self.ctx.close()

@@ -553,6 +553,15 @@ int bisip_stretch_run_dev(bisip_ctx *c, const bisip_stretch_args *first, int64_t
     return BISIP_OK;
 }
 
+int bisip_ctx_set_spectrum_offset(bisip_ctx *c, int64_t first_spectrum)
+{
+    if (!c) return fail(BISIP_EINVAL, "null argument");
+    if (first_spectrum < 0 || first_spectrum + c->E > 0x7fffffffLL)     // 31 bits of the Philox counter
+        return fail(BISIP_EINVAL, "first_spectrum=%lld out of range", (long long)first_spectrum);
+    c->spectrum_offset = first_spectrum;
+    return BISIP_OK;
+}
+
 int bisip_stretch_draw_dev(bisip_ctx *c, int64_t W, double a, uint64_t seed, int64_t step0,
                            int64_t n_steps, const int32_t *d_perm, int32_t *d_active,
                            int32_t *d_partner, double *d_zz, double *d_factor, double *d_logu,
@@ -565,7 +574,7 @@ int bisip_stretch_draw_dev(bisip_ctx *c, int64_t W, double a, uint64_t seed, int
     if (n_steps == 0) return BISIP_OK;
     HIP_TRY(hipSetDevice(c->device));
     DrawArgs d;
-    d.W = W; d.nh = (W + 1) / 2; d.n_steps = n_steps; d.step0 = step0; d.E = c->E;
+    d.W = W; d.nh = (W + 1) / 2; d.n_steps = n_steps; d.step0 = step0; d.E = c->E; d.e0 = c->spectrum_offset;
     if (c->E > 1 && (W & 1)) return fail(BISIP_EINVAL, "batch context: walkers per spectrum must be even");
     d.a = a; d.ndim_m1 = (double)(c->ndim - 1);
     d.seed_lo = (unsigned int)(seed & 0xffffffffu); d.seed_hi = (unsigned int)(seed >> 32);

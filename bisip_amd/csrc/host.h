@@ -75,6 +75,7 @@ struct bisip_ctx {
     size_t ws_bytes = 0;
     double *d_gather = nullptr;    // sharded sampler: world slabs of ceil(slots/world) x (ndim+2)
     size_t gather_bytes = 0;
+    int64_t spectrum_offset = 0;   // batch: survey index of spectrum 0 (keys the Philox stream)
     char *h_pin = nullptr;         // pinned, device-mapped staging for small host-buffer calls
     char *d_pin = nullptr;         // its device-side address
     static constexpr size_t PIN_BYTES = 1 << 20;

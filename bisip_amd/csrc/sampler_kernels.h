@@ -283,6 +283,7 @@ __global__ __launch_bounds__(64) void k_stretch_apply(const StretchArgs a)
 struct DrawArgs {
     long long W, nh, n_steps, step0;  // W = walkers per ensemble
     long long E;                      // ensembles (E > 1 requires W even)
+    long long e0;                     // index of the context's first spectrum in the whole survey
     double a, ndim_m1;
     unsigned int seed_lo, seed_hi;
     const int *perm;  // (n_steps, 3): A, Ainv, B
@@ -338,7 +339,7 @@ static __global__ __launch_bounds__(256) void k_stretch_draw(const DrawArgs d)
         return;
     }
     const SlotDraw s = draw_slot(d.W, d.a, d.ndim_m1, d.seed_lo, d.seed_hi, (unsigned)(d.step0 + k), h,
-                                 (unsigned)e, t, d.perm[3 * k + 1], d.perm[3 * k + 2]);
+                                 (unsigned)(d.e0 + e), t, d.perm[3 * k + 1], d.perm[3 * k + 2]);
     d.active[idx] = (int)(e * d.W) + s.active;
     d.partner[idx] = (int)(e * d.W) + s.partner;
     d.zz[idx] = s.z;

@@ -160,10 +160,18 @@ class _DeviceSlabs:
         return self.tensors[0]
 
     def materialize(self):
-        return self.tensor().cpu().numpy()
+        """Host copy, made once; the samples also stay on the device for the summaries."""
+        if getattr(self, '_host', None) is None:
+            self._host = self.tensor().cpu().numpy()
+        return self._host
 
 
 def _host_parts(parts):
+    """Chain parts as host arrays.  Device-resident parts are first merged into one (on the
+    device) and stay what they are: get_chain() must not take the chain away from
+    param_moments() / param_percentiles()."""
+    if len(parts) > 1 and all(isinstance(p, _DeviceSlabs) for p in parts):
+        parts[:] = [_DeviceSlabs(t for p in parts for t in p.tensors)]
     return [p.materialize() if isinstance(p, _DeviceSlabs) else p for p in parts]
 
 
@@ -199,19 +207,20 @@ class _SamplerBase:
         self._coords = None
         self._lp = None
 
+    @staticmethod
+    def _joined(parts, empty_shape):
+        host = _host_parts(parts)
+        if len(host) > 1:                 # host-resident parts of several runs: keep the joined array
+            parts[:] = host = [np.concatenate(host, axis=0)]
+        return host[0] if host else np.empty(empty_shape)
+
     @property
     def _chain(self):
-        self._chain_parts = _host_parts(self._chain_parts)
-        if len(self._chain_parts) > 1:
-            self._chain_parts = [np.concatenate(self._chain_parts, axis=0)]
-        return self._chain_parts[0] if self._chain_parts else np.empty((0, self.nwalkers, self.ndim))
+        return self._joined(self._chain_parts, (0, self.nwalkers, self.ndim))
 
     @property
     def _log_prob(self):
-        self._log_prob_parts = _host_parts(self._log_prob_parts)
-        if len(self._log_prob_parts) > 1:
-            self._log_prob_parts = [np.concatenate(self._log_prob_parts, axis=0)]
-        return self._log_prob_parts[0] if self._log_prob_parts else np.empty((0, self.nwalkers))
+        return self._joined(self._log_prob_parts, (0, self.nwalkers))
 
     def _check_initial(self, initial_state):
         p0 = np.array(initial_state, dtype=np.float64, copy=True)
@@ -922,7 +931,7 @@ class DeviceEnsembleSampler(_SamplerBase):
             raise AttributeError('the chain is not resident on the device '
                                  '(run with chain_on_device=True)')
         if len(parts) > 1:
-            self._chain_parts = parts = [_DeviceSlabs(t for p in parts for t in p.tensors)]
+            parts[:] = [_DeviceSlabs(t for p in parts for t in p.tensors)]
         return parts[0].tensor()
 
     def param_moments(self, discard=0, thin=1):

@@ -206,6 +206,13 @@ int bisip_rccl_unique_id(void *id);
 int bisip_rccl_comm_create(void **comm, int world, int rank, const void *id, int device);
 int bisip_rccl_comm_destroy(void *comm);
 
+/* A batch context that holds spectra [first_spectrum, first_spectrum + E) of a larger survey
+ * (one block per GPU): bisip_stretch_draw_dev then keys spectrum e's stream by its index in the
+ * SURVEY, so every spectrum's chain is the same however the survey is split over GPUs.
+ * Default 0.  (The reference has no batch object: a survey is a loop over Inversion objects,
+ * src/bisip/models.py:41-57.) */
+int bisip_ctx_set_spectrum_offset(bisip_ctx *ctx, int64_t first_spectrum);
+
 /* Fill the random-stream arrays on the device (counter-based Philox4x32-10; the contract
  * is documented in bisip_amd/csrc/sampler_kernels.h and bisip_amd/sampler.py).
  * d_perm (n_steps,3) = per-step affine split (A, A^-1 mod W, B).  W = walkers per ensemble;

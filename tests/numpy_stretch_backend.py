@@ -28,10 +28,10 @@ def u53(a, b):
     return (((a >> np.uint64(5)) << np.uint64(26)) | (b >> np.uint64(6))).astype(np.float64) / 9007199254740992.0
 
 
-def philox_stream(W, ndim, a, seed, step0, perm, E=1):
+def philox_stream(W, ndim, a, seed, step0, perm, E=1, e0=0):
     """NumPy statement of the rng='philox' contract (bisip_amd/csrc/sampler_kernels.h):
     returns active, partner, zz, factor, logu of shape (n, 2, E*nh); W = walkers per
-    ensemble, walker ids are global (e*W + i)."""
+    ensemble, walker ids are global (e*W + i); e0 = survey index of ensemble 0 (keys the counter)."""
     n = perm.shape[0]
     nh = (W + 1) // 2
     out = dict(active=np.zeros((n, 2, E, nh), np.int32), partner=np.zeros((n, 2, E, nh), np.int32),
@@ -45,7 +45,7 @@ def philox_stream(W, ndim, a, seed, step0, perm, E=1):
             t = np.arange(Ns, dtype=np.uint64)
             ti = t.astype(np.int64)
             for e in range(E):
-                c2 = h | (e << 1)
+                c2 = h | ((e0 + e) << 1)
                 x0, x1, x2, _ = philox4x32_10(t, step0 + k, c2, 0, k0, k1)
                 y0, y1, _, _ = philox4x32_10(t, step0 + k, c2, 1, k0, k1)
                 r = ((x2 * np.uint64(Nc)) >> np.uint64(32)).astype(np.int64)

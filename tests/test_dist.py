@@ -50,9 +50,18 @@ def _worker(rank, world, port, case, outdir):
     np.random.seed(12)
     s = EnsembleSampler(18, lo.size, fn, distributed=True)
     s.run_mcmc(p0, 25)
+    # (4) a survey's per-spectrum summaries, gathered in spectrum order (SpectraBatch.gather;
+    #     the batch object itself needs a GPU, its gather does not)
+    from bisip_amd.batch import SpectraBatch
+    sb = object.__new__(SpectraBatch)
+    sb.n_spectra_total = 11
+    lo_s, hi_s = shard_range(11, world, rank)
+    sb.n_spectra = hi_s - lo_s
+    mine = np.arange(lo_s, hi_s, dtype=float)[:, None, None] * 100 + np.arange(6.0).reshape(2, 3)
+    survey = sb.gather(mine)
     np.savez(os.path.join(outdir, f'rank{rank}.npz'), full=full, local=local, a=a, b=b,
              gathered=gathered, chain=s.get_chain(), logp=s.get_log_prob(),
-             acc=s.acceptance_fraction)
+             acc=s.acceptance_fraction, survey=survey)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -96,6 +105,8 @@ def test_two_rank_gloo(tmp_path):
         assert np.array_equal(r[i]['chain'], s.get_chain())
         assert np.array_equal(r[i]['logp'], s.get_log_prob())
         assert np.array_equal(r[i]['acc'], s.acceptance_fraction)
+        # every rank ends with the whole survey's summaries, spectrum e in row e
+        assert np.array_equal(r[i]['survey'], np.arange(11.0)[:, None, None] * 100 + np.arange(6.0).reshape(2, 3))
 
 
 def _device_driver_worker(rank, world, port, case, outdir):

@@ -299,3 +299,40 @@ def test_batch_percentiles_from_the_device_chain():
         assert got.shape == (3, E, 7)
         _close(got, want, 1e-14)
     _close(runs['device'].get_param_percentile([16, 84], discard=5), runs['host'].get_param_percentile([16, 84], discard=5), 1e-14)
+
+
+def test_a_survey_split_over_ranks_gives_the_same_chains():
+    """Whole-replica sharding: spectrum e's chain, summaries and acceptance
+    are the same whether the survey runs as one batch or as blocks of spectra on several ranks --
+    the Philox stream is keyed by the spectrum's index in the SURVEY (bisip_ctx_set_spectrum_offset)
+    and the default starts are drawn for the whole survey.  The ranks run one after the other here
+    (one GPU); they never exchange anything while sampling."""
+    import bisip_amd
+    E, Wp = 7, 64
+    tables = _tables(E)
+
+    def run(rank, world, p0=None):
+        b = bisip_amd.SpectraBatch('PeltonColeCole', tables, nwalkers=Wp, nsteps=30, n_modes=2,
+                                   rank=rank, world=world)
+        np.random.seed(5)
+        first, last = b.spectrum_range
+        b.fit(p0=None if p0 is None else p0[first:last], seed=None if p0 is None else 9, chain='device')
+        out = (b.get_chain(), b.get_param_mean(discard=10), b.acceptance_fraction)
+        b.close()
+        return out
+
+    centre = np.array([1.0, 0.15, 0.5, -1.5, -12.0, 0.45, 0.6])
+    for p0 in (None, centre + 1e-3 * np.random.RandomState(0).randn(E, Wp, 7)):
+        whole = run(0, 1, p0)
+        for world in (2, 3):
+            parts = [run(r, world, p0) for r in range(world)]
+            assert np.array_equal(np.concatenate([p[0] for p in parts], axis=1), whole[0])
+            assert np.array_equal(np.concatenate([p[1] for p in parts], axis=0), whole[1])
+            assert np.array_equal(np.concatenate([p[2] for p in parts], axis=0), whole[2])
+    # the offset is validated
+    b = bisip_amd.SpectraBatch('PeltonColeCole', tables[:2], nwalkers=Wp, nsteps=1, n_modes=2)
+    with pytest.raises(ValueError):
+        b.ctx.set_spectrum_offset(-1)
+    with pytest.raises(ValueError):
+        b.ctx.set_spectrum_offset(2 ** 31 - 2)
+    b.close()

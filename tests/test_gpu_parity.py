@@ -344,6 +344,12 @@ def test_fit_with_the_chain_kept_on_the_device():
     assert med.shape == (4,) and np.allclose(med, np.percentile(dev.get_chain(discard=40, flat=True), 50, axis=0), rtol=1e-13)
     # a caller's own array still goes through NumPy
     assert np.array_equal(dev.get_param_mean(flat), flat.mean(axis=0))
+    # get_chain() copied the samples out; they are still on the device for the summaries,
+    # also after the run is continued
+    assert np.array_equal(dev.get_param_mean(discard=40, thin=2), mean)
+    dev.sampler.run_mcmc(None, 30)
+    assert dev.get_chain().shape == (150, 300, 4) and np.array_equal(dev.get_chain()[:120], host.get_chain())
+    assert np.allclose(dev.get_param_std(discard=100), dev.get_chain(discard=100, flat=True).std(axis=0), rtol=1e-9)
     with pytest.raises(ValueError):
         dev.fit(chain='somewhere')
 
