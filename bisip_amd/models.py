@@ -84,7 +84,7 @@ class Inversion(_utils.utils):
                 bounds = np.array([np.full(bounds.shape[1], -np.inf), np.full(bounds.shape[1], np.inf)])
                 # no box to centre the QR-reduced form in: the per-frequency kernel is accurate
                 # for any theta
-                if desc.get('variant') == 'auto':
+                if desc.get('variant') in ('auto', 'reduced', 'reduced_comp'):
                     desc = dict(desc, variant='collapsed')
             ctx = _hip.HipContext(self._model_id, x, y, yerr, bounds, device=self.device, **desc)
             if len(self._ctx_cache) >= 8:
@@ -198,8 +198,9 @@ class Inversion(_utils.utils):
                 and get_chain() copies on demand.  For big ensembles the copy costs more than the run.
             persistent (bool or None): device sampler: run all iterations of a chunk inside
                 one kernel launch (one workgroup holds the ensemble) instead of one launch per
-                half-step.  Same chain, bit for bit.  None (default): when the ensemble has at
-                most 128 walkers, where it is 2-3x faster.
+                half-step.  Same chain, bit for bit.  None (default): up to the ensemble size where
+                one compute unit still beats launches spread over the chip (256-1024 walkers
+                depending on the model, HipContext.persistent_walkers).
         """
         self._p0 = p0
         self.ndim = self.param_bounds.shape[1]

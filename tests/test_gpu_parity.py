@@ -265,6 +265,11 @@ def test_model_classes_drop_in():
     # the likelihood never touches the box of the context fit() / _log_probability use
     assert np.array_equal(m._context().logprob(g['theta']), m.log_prob(g['theta']))
     assert m._context().variant == 'reduced' and m._context(prior=False).variant == 'collapsed'
+    # a model pinned to a reduced formulation: the likelihood alone has no box to centre it in
+    mr = bisip_amd.PolynomialDecomposition(path, variant='reduced_comp')
+    assert mr._context().variant == 'reduced_comp' and mr._context(prior=False).variant == 'collapsed'
+    assert abs(mr._log_likelihood(outside, mr.forward, d['w'], d['zn'], d['zn_err'])
+               - m._log_likelihood(outside, m.forward, d['w'], d['zn'], d['zn_err'])) <= 1e-9
 
 
 def test_foreign_model_callable():
