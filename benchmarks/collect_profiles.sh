@@ -39,6 +39,7 @@ if [ "$what" = sweep ] || [ "$what" = all ]; then
       python3 "$repo/benchmarks/sweep.py" > "$out/sweep_under_rocprof.jsonl" 2> "$out/prof_sweep.err")
   keep "$scratch/prof_sweep" prof_sweep
   python3 benchmarks/host_path.py > "$out/host_path.jsonl" 2> "$out/host_path.err"
+  python3 benchmarks/ingest.py > "$out/ingest.json" 2> "$out/ingest.err"
 fi
 if [ "$what" = sampler ] || [ "$what" = all ]; then
   echo "== samplers" | tee -a "$out/progress.log"

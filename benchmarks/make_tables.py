@@ -161,6 +161,15 @@ def table_cfg5():
                      'us per half-step', 'walker-steps/s'])
 
 
+def table_ingest():
+    d = jload(f'{ROUND}_ingest.json')
+    th = max(int(k.split('_')[1]) for k in d if k.startswith('batch_') and k.endswith('_threads_s'))
+    rows = [['np.loadtxt + per-file arithmetic, file after file (the reference\'s way)', d['per_file_numpy_s'], round(1e6 * d['per_file_numpy_s'] / d['spectra'], 1), '1'],
+            ['`load_data_batch`, 1 thread', d['batch_1_threads_s'], round(1e6 * d['batch_1_threads_s'] / d['spectra'], 1), d['batch_1_threads_speedup']],
+            [f'`load_data_batch`, {th} threads', d[f'batch_{th}_threads_s'], round(1e6 * d[f'batch_{th}_threads_s'] / d['spectra'], 1), d[f'batch_{th}_threads_speedup']]]
+    return md(rows, [f"ingest of {d['spectra']} spectrum files (N = {d['n_freq']}), GPU box host ({d['cpus']} CPUs); bit-identical: {str(d['bit_identical']).lower()}", 'seconds', 'us per file', 'speed-up'])
+
+
 def table_fuzz():
     rows = []
     for d in jlines(f'{ROUND}_fuzz_parity_summary.jsonl'):
@@ -189,7 +198,7 @@ def table_auto_by_degree():
 TABLES = {
     'bench': table_bench, 'variants': table_variants, 'sweep': table_sweep, 'forward': table_forward,
     'host_path': table_host_path, 'samplers': table_samplers, 'cfg4': table_cfg4, 'cfg5': table_cfg5,
-    'fuzz': table_fuzz, 'auto_by_degree': table_auto_by_degree,
+    'fuzz': table_fuzz, 'auto_by_degree': table_auto_by_degree, 'ingest': table_ingest,
 }
 
 FILES = [
@@ -205,7 +214,8 @@ FILES = [
     (f'{ROUND}_cfg4_*.json', '`python benchmarks/cfg4_sampler.py --steps 200 --chain device [--fused] [--loop rccl|rccl-own|python]`', 'BASELINE config 4 on one GPU: fused vs the sharded half-step driven from C over RCCL vs from Python'),
     (f'{ROUND}_cfg5_*.json, {ROUND}_cfg5_kernel_stats.csv', '`python benchmarks/cfg5_batch.py --chain device --steps 500 --thin-by 40 [--no-persistent]`', "BASELINE config 5, one GPU's share (512 spectra x 256 walkers)"),
     (f'{ROUND}_bench_2ranks_one_device*.json', '`python bench.py --gpus 2 --backend gloo --same-device --walkers 1048576 --steps 4`', 'the self-launched 2-rank run on one GPU (gloo): result line and the sharded-sampler extra (state identical on both ranks = single-GPU chain)'),
-    (f'{ROUND}_fuzz_*_summary.jsonl', '`python benchmarks/fuzz_parity.py --cases 1500 --seed S` (S = 41..43), `fuzz_sampler.py --cases 1500 --seed 2`, `fuzz_batch.py --cases 500 --seed 1`', 'randomised campaigns: violations, worst errors, which kernel AUTO ran'),
+    (f'{ROUND}_ingest.json', '`python benchmarks/ingest.py` (host only)', 'survey ingest: the C parser + batched arithmetic against np.loadtxt file after file, same bits'),
+    (f'{ROUND}_fuzz_*_summary.jsonl', '`python benchmarks/fuzz_parity.py --cases 1500 --seed S` (S = 41..43; 3000 cases at S = 4242), `fuzz_sampler.py --cases 1500 --seed 2`, `fuzz_batch.py --cases 500 --seed 1`', 'randomised campaigns: violations, worst errors, which kernel AUTO ran'),
     (f'{ROUND}_micro_issue_latency.txt', '`benchmarks/micro/issue_latency`', 'cycles per fp64 FMA for 1/2/4/8 independent chains at 1, 2, 4 waves per SIMD; placement of 1-, 2-, 4-, 8-, 16-wave workgroups'),
     (f'{ROUND}_micro_row_latency.txt', '`benchmarks/micro/row_latency`', 'cycles of one log-probability row at one wave per SIMD, records from the scalar cache vs staged in LDS'),
     (f'{ROUND}_micro_half_step_phases.txt', '`benchmarks/micro/half_step_phases`', 'phases of the cfg5 half-step launch by s_memtime'),
@@ -226,7 +236,7 @@ def readme():
     for name, title in (('bench', 'Headline'), ('variants', 'Formulations and the other kernels, with both rooflines'),
                         ('sweep', 'Every log-probability kernel at the BASELINE shapes'), ('forward', 'Batched forward'),
                         ('host_path', 'Host-buffer entry'), ('samplers', '`fit()` workloads'), ('cfg4', 'BASELINE config 4'),
-                        ('cfg5', 'BASELINE config 5'), ('fuzz', 'Randomised campaigns'), ('auto_by_degree', 'Which kernel AUTO ran, by polynomial degree')):
+                        ('cfg5', 'BASELINE config 5'), ('ingest', 'Survey ingest'), ('fuzz', 'Randomised campaigns'), ('auto_by_degree', 'Which kernel AUTO ran, by polynomial degree')):
         out += [f'## {title}', '', TABLES[name](), '']
     return '\n'.join(out)
 

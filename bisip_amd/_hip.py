@@ -102,6 +102,8 @@ SYMBOLS = {
     'bisip_forward_percentiles': (ctypes.c_int, [ctypes.c_void_p, _dp, ctypes.c_int64, _dp, ctypes.c_int, _dp]),
     'bisip_numpy_stretch_stream': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32), ctypes.c_int64,
                                                   ctypes.c_double, ctypes.c_int64] + [ctypes.c_void_p] * 4),
+    'bisip_read_tables': (ctypes.c_int, [ctypes.POINTER(ctypes.c_char_p), ctypes.c_int64, ctypes.c_int, ctypes.c_int64,
+                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
     'bisip_philox4x32': (None, [ctypes.POINTER(ctypes.c_uint32)] * 3),
     'bisip_ctx_ndim': (ctypes.c_int, [ctypes.c_void_p]),
     'bisip_ctx_nfreq': (ctypes.c_int, [ctypes.c_void_p]),
@@ -489,6 +491,21 @@ def numpy_stretch_stream(rng, W, a, n_steps, out=None):
                                           zz.ctypes.data, u.ctypes.data))
     rng.set_state((name, key, int(cpos.value), has_gauss, cached))
     return active, partner, zz, u
+
+
+def read_tables(paths, headers, n_rows, threads=1):
+    """Parse many 5-column spectrum files on `threads` host threads (bisip_read_tables).
+    Returns ``tables (n_files, n_rows, 5)`` and ``status (n_files,)``: 0 = filled with what
+    np.loadtxt yields, 1 = read this file with np.loadtxt instead (see include/bisip_hip.h)."""
+    import os
+    lib = load_library()
+    enc = [os.fsencode(p) for p in paths]
+    arr = (ctypes.c_char_p * len(enc))(*enc)
+    tables = np.empty((len(enc), int(n_rows), 5), dtype=np.float64)
+    status = np.ones(len(enc), dtype=np.int32)
+    _check(lib.bisip_read_tables(arr, len(enc), int(headers), int(n_rows), tables.ctypes.data,
+                                 status.ctypes.data, int(threads)))
+    return tables, status
 
 
 def philox4x32(counter, key):

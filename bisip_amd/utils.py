@@ -54,24 +54,103 @@ def load_data(filename, headers=1, ph_units='mrad'):
     return columns_to_data(np.atleast_2d(table), ph_units)
 
 
-def load_data_batch(spectra, headers=1, ph_units='mrad'):
+def _is_path(sp):
+    return isinstance(sp, (str, bytes)) or hasattr(sp, '__fspath__')
+
+
+def tables_to_operands(tables, ph_units='mrad'):
+    """(E,N,5) stacked tables -> the stacked operands of a batch context, each spectrum exactly what
+    ``columns_to_data`` (the reference's per-file arithmetic, src/bisip/utils.py:124-144) gives.
+    Everything that rounds the same for any array shape -- products, quotients, square roots --
+    is done once over the whole batch; cos / sin / |Z| stay one call per spectrum on arrays laid out
+    as in the per-file path (NumPy picks SIMD or scalar code for those by layout and length, and
+    the two need not agree in the last bit)."""
+    T = np.ascontiguousarray(tables, dtype=np.float64)
+    if T.ndim != 3 or T.shape[2] != 5:
+        raise ValueError('expected stacked (E, N, 5) tables')
+    E, N = T.shape[:2]
+    freq, amp, pha, amp_err, pha_err = (T[:, :, i] for i in range(5))
+    if ph_units == 'mrad':
+        pha, pha_err = pha / 1000, pha_err / 1000
+    if ph_units == 'deg':
+        pha, pha_err = np.radians(pha), np.radians(pha_err)
+    cos_p, sin_p = np.empty((E, N)), np.empty((E, N))
+    for e in range(E):
+        np.cos(pha[e], out=cos_p[e])
+        np.sin(pha[e], out=sin_p[e])
+    Z = amp * (cos_p + 1j * sin_p)
+    err_im = np.sqrt((amp * cos_p * pha_err) ** 2 + (sin_p * amp_err) ** 2)
+    err_re = np.sqrt((amp * sin_p * pha_err) ** 2 + (cos_p * amp_err) ** 2)
+    Z_err = err_re + 1j * err_im
+    mod = np.empty((E, N))
+    for e in range(E):
+        np.abs(Z[e], out=mod[e])
+    norm = mod.max(axis=1)
+    for e in np.flatnonzero(np.isnan(norm)):     # the reference's Python max() skips NaNs its own way
+        norm[e] = max(mod[e])
+    zn = Z / norm[:, None]
+    zn_err = Z_err / norm[:, None]
+    return {'w': 2 * np.pi * freq,
+            'zn': np.ascontiguousarray(np.stack([zn.real, zn.imag], axis=1)),
+            'zn_err': np.ascontiguousarray(np.stack([zn_err.real, zn_err.imag], axis=1)),
+            'norm_factor': norm, 'N': N}
+
+
+def load_data_batch(spectra, headers=1, ph_units='mrad', threads=None):
     """Ingest many spectra that share one frequency count (BASELINE config 5):
     every item is a file path (read as ``load_data`` reads it) or a raw (N,5) table
     [freq, amp, pha, amp_err, pha_err].  Returns the stacked operands of a batch context --
     ``w (E,N)``, ``zn (E,2,N)``, ``zn_err (E,2,N)``, ``norm_factor (E,)``, ``N`` -- each row
-    exactly what the reference's per-file ``load_data`` yields (src/bisip/utils.py:108-146)."""
-    items = [load_data(sp, headers, ph_units) if isinstance(sp, (str, bytes)) or hasattr(sp, '__fspath__')
-             else columns_to_data(sp, ph_units) for sp in spectra]
-    if not items:
+    exactly what the reference's per-file ``load_data`` yields (src/bisip/utils.py:108-146).
+
+    Files are parsed by the library on ``threads`` host threads (default: the CPUs this process may
+    use, at most 16) -- ``bisip_read_tables``, ~40x np.loadtxt on a survey of thousands of small files
+    (benchmarks/ingest.py); a file it does not recognise as plain 5-column text is read with
+    np.loadtxt itself, so it behaves, or fails, as in the reference."""
+    import os
+    spectra = list(spectra)
+    if not spectra:
         raise ValueError('no spectra')
-    n = {d['N'] for d in items}
-    if len(n) != 1:
-        raise ValueError(f'spectra have different frequency counts: {sorted(n)}')
-    return {'w': np.stack([d['w'] for d in items]),
-            'zn': np.stack([d['zn'] for d in items]),
-            'zn_err': np.stack([d['zn_err'] for d in items]),
-            'norm_factor': np.array([d['norm_factor'] for d in items]),
-            'N': items[0]['N']}
+    files = [i for i, sp in enumerate(spectra) if _is_path(sp)]
+
+    def checked(table):
+        table = np.asarray(table, dtype=np.float64)
+        if table.ndim != 2 or table.shape[1] < 5:
+            raise ValueError('expected 5 comma-separated columns: freq, amp, pha, amp_err, pha_err')
+        return table
+
+    def loadtxt(i):
+        return checked(np.atleast_2d(np.loadtxt(f'{spectra[i]}', skiprows=headers, delimiter=',')))
+
+    first = loadtxt(files[0]) if files else checked(spectra[0])      # fixes the row count of the batch
+    N = first.shape[0]
+    T = np.empty((len(spectra), N, 5))
+    counts = {N}
+
+    def place(i, table):
+        counts.add(table.shape[0])
+        if table.shape[0] == N:
+            T[i] = table[:, :5]
+
+    if files:
+        place(files[0], first)
+        rest = [i for i in files[1:] if not isinstance(spectra[i], bytes)]
+        status = np.zeros(0, dtype=np.int32)
+        if rest:
+            from . import _hip
+            if threads is None:
+                threads = min(cpu_quota(), 16)
+            got, status = _hip.read_tables([os.fspath(spectra[i]) for i in rest], headers, N, threads)
+            T[rest] = got
+        todo = set(files[1:]) - {i for i, st in zip(rest, status) if st == 0}
+        for i in sorted(todo):
+            place(i, loadtxt(i))
+    for i, sp in enumerate(spectra):
+        if not _is_path(sp):
+            place(i, checked(sp))
+    if len(counts) != 1:
+        raise ValueError(f'spectra have different frequency counts: {sorted(counts)}')
+    return tables_to_operands(T, ph_units)
 
 
 class utils(object):
