@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""What a survey costs before and after the sampling run: ingest, batch context creation (host
+precompute of every spectrum's operands + upload), first launch, summaries.  One GPU.
+
+    python benchmarks/batch_setup.py [--spectra 512]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--spectra', type=int, default=512)
+ap.add_argument('--walkers', type=int, default=256)
+args = ap.parse_args()
+
+import bisip_amd
+from bisip_amd.synthetic import synthetic_columns
+
+E, Wp = args.spectra, args.walkers
+tables = [synthetic_columns(32, i) for i in range(E)]
+import torch
+torch.zeros(1, device='cuda')                     # HIP runtime up before anything is timed
+for model, kw, centre in (('PeltonColeCole', dict(n_modes=2), [1.0, 0.15, 0.5, -1.5, -12.0, 0.45, 0.6]),
+                          ('PolynomialDecomposition', dict(poly_deg=5), [1.0, 0.005, -0.003, -0.001, 0.0005, 0.0002, 0.00001]),
+                          ('Dias2000', {}, [1.0, 0.5, -8.0, 10.0, 0.5])):
+    out = {'model': model, 'spectra': E, 'walkers_per_spectrum': Wp}
+    for rep in range(2):                           # second pass: library and allocator warm
+        t0 = time.perf_counter()
+        b = bisip_amd.SpectraBatch(model, tables, nwalkers=Wp, nsteps=100, **kw)
+        t1 = time.perf_counter()
+        p0 = np.asarray(centre) + 1e-4 * np.random.RandomState(0).randn(E, Wp, len(centre))
+        t2 = time.perf_counter()
+        b.fit(p0, seed=3, chain='device')
+        t3 = time.perf_counter()
+        b.get_param_mean(discard=50); b.get_param_percentile([2.5, 50, 97.5], discard=50)
+        t4 = time.perf_counter()
+        out.update(create_s=round(t1 - t0, 4), fit_100_iterations_s=round(t3 - t2, 4), summaries_s=round(t4 - t3, 4),
+                   kernel=b.ctx.kernel_name)
+        b.close()
+    print(json.dumps(out), flush=True)

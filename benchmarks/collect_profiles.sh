@@ -40,6 +40,7 @@ if [ "$what" = sweep ] || [ "$what" = all ]; then
   keep "$scratch/prof_sweep" prof_sweep
   python3 benchmarks/host_path.py > "$out/host_path.jsonl" 2> "$out/host_path.err"
   python3 benchmarks/ingest.py > "$out/ingest.json" 2> "$out/ingest.err"
+  python3 benchmarks/batch_setup.py > "$out/batch_setup.jsonl" 2> "$out/batch_setup.err"
 fi
 if [ "$what" = sampler ] || [ "$what" = all ]; then
   echo "== samplers" | tee -a "$out/progress.log"

@@ -127,25 +127,33 @@ static int recenter_reduced(bisip_ctx *c)
     const size_t red_doubles = (size_t)n * (n + 1) / 2 + 3 * (size_t)n + 1;  // == sizeof(ReducedArgs<P>)/8
     for (int tier = 0; tier < 2; ++tier) {
         bisip_ctx::ReducedTier &T = c->red[tier];
-        std::vector<double> red, bh(n), ev(n), el(n);
-        T.err = 0.0;
-        for (size_t e = 0; e < c->reduced.size(); ++e) {
-            const bisip_ctx::ReducedHost &rh = c->reduced[e];
-            const double est = reduced_center(n, rh.R, rh.qty, rh.bhat_ls, rh.rest, rh.lconst, c->bounds.lo,
-                                              c->bounds.hi, tier == 1, bh.data(), ev.data(), el.data());
-            if (!(est <= T.err)) T.err = est;
-            std::vector<double> Rp;
-            for (int i = 0; i < n; ++i)
-                for (int j = i; j < n; ++j) Rp.push_back(rh.R[(size_t)i * n + j]);
-            if (e == 0) { c->Rpacked = Rp; T.bhat = bh; T.evec = ev; T.elo = el; c->rest = rh.rest; }
-            if (c->E > 1) {  // ReducedArgs<P> image: R | bhat | e | elo | rest
-                red.insert(red.end(), Rp.begin(), Rp.end());
-                red.insert(red.end(), bh.begin(), bh.end());
-                red.insert(red.end(), ev.begin(), ev.end());
-                red.insert(red.end(), el.begin(), el.end());
-                red.push_back(rh.rest);
+        const size_t E = c->reduced.size();
+        std::vector<double> red(c->E > 1 ? red_doubles * E : 0), est(E);
+        // the probing of every spectrum (reduced_center emulates the kernel on ~200 rows per
+        // candidate) is independent of the others: blocks of spectra on host threads
+        parallel_blocks((int64_t)E, 4, [&](int64_t e_lo, int64_t e_hi) {
+            std::vector<double> bh(n), ev(n), el(n), Rp;
+            for (int64_t e = e_lo; e < e_hi; ++e) {
+                const bisip_ctx::ReducedHost &rh = c->reduced[(size_t)e];
+                est[(size_t)e] = reduced_center(n, rh.R, rh.qty, rh.bhat_ls, rh.rest, rh.lconst, c->bounds.lo,
+                                                c->bounds.hi, tier == 1, bh.data(), ev.data(), el.data());
+                Rp.clear();
+                for (int i = 0; i < n; ++i)
+                    for (int j = i; j < n; ++j) Rp.push_back(rh.R[(size_t)i * n + j]);
+                if (e == 0) { c->Rpacked = Rp; T.bhat = bh; T.evec = ev; T.elo = el; c->rest = rh.rest; }
+                if (c->E > 1) {  // ReducedArgs<P> image: R | bhat | e | elo | rest
+                    double *dst = &red[red_doubles * (size_t)e];
+                    dst = std::copy(Rp.begin(), Rp.end(), dst);
+                    dst = std::copy(bh.begin(), bh.end(), dst);
+                    dst = std::copy(ev.begin(), ev.end(), dst);
+                    dst = std::copy(el.begin(), el.end(), dst);
+                    *dst = rh.rest;
+                }
             }
-        }
+        });
+        T.err = 0.0;
+        for (double v : est)
+            if (!(v <= T.err)) T.err = v;
         if (c->E > 1) {
             if (red.size() != red_doubles * (size_t)c->E) return fail(BISIP_EHIP, "internal: reduced operand size mismatch");
             HIP_TRY(hipSetDevice(c->device));
@@ -284,21 +292,31 @@ static int build_context(bisip_ctx **out, int device, int model_id, int E, int N
     std::vector<double> cb((size_t)E * N * rec, 0.0), lconsts(E), cb_lp;
     if (model_id == BISIP_MODEL_POLYDECOMP) cb_lp.assign((size_t)E * N * rec, 0.0);
     int rc = BISIP_OK;
-    for (int e = 0; e < E; ++e) {
-        const double *we = w + (size_t)e * N, *zne = zn + (size_t)e * 2 * N, *erre = zn_err + (size_t)e * 2 * N;
-        lconsts[e] = loglike_const(2 * N, erre);
-        std::vector<double> lnw, iv;
-        common_operands(N, we, erre, lnw, iv);
-        double *base = &cb[(size_t)e * N * rec];
-        for (int j = 0; j < N; ++j) {
-            double *r = base + (size_t)j * rec;
-            r[0] = zne[j]; r[1] = zne[N + j]; r[2] = iv[j]; r[3] = iv[N + j];
-            if (model_id != BISIP_MODEL_POLYDECOMP) { r[4] = we[j]; r[5] = lnw[j]; r[6] = (double)sqrtl((long double)we[j]); }
-        }
-        if (model_id == BISIP_MODEL_POLYDECOMP) {
-            c->c_exp = desc->c_exp;
-            PolyDecompOperands o;
-            polydecomp_operands(N, we, S, desc->taus, P + 1, desc->log_taus, desc->c_exp, zne, erre, o);
+    if (model_id == BISIP_MODEL_POLYDECOMP) { c->c_exp = desc->c_exp; c->reduced.resize((size_t)E); }
+    std::vector<double> fb;       // E == 1: loop-faithful records (see k_logprob_pd_faithful)
+    // per-spectrum operands, blocks of spectra on host threads (each writes its own slots).  The
+    // kernel sums K, G depend on the frequencies only: a block reuses them while consecutive
+    // spectra share their frequency list, as the spectra of a survey usually do.
+    parallel_blocks(E, 8, [&](int64_t e_lo, int64_t e_hi) {
+        PolyDecompOperands o;
+        const double *w_of_o = nullptr;
+        for (int64_t e = e_lo; e < e_hi; ++e) {
+            const double *we = w + (size_t)e * N, *zne = zn + (size_t)e * 2 * N, *erre = zn_err + (size_t)e * 2 * N;
+            lconsts[e] = loglike_const(2 * N, erre);
+            std::vector<double> lnw, iv;
+            common_operands(N, we, erre, lnw, iv);
+            double *base = &cb[(size_t)e * N * rec];
+            for (int j = 0; j < N; ++j) {
+                double *r = base + (size_t)j * rec;
+                r[0] = zne[j]; r[1] = zne[N + j]; r[2] = iv[j]; r[3] = iv[N + j];
+                if (model_id != BISIP_MODEL_POLYDECOMP) { r[4] = we[j]; r[5] = lnw[j]; r[6] = (double)sqrtl((long double)we[j]); }
+            }
+            if (model_id != BISIP_MODEL_POLYDECOMP) continue;
+            if (!w_of_o || std::memcmp(w_of_o, we, sizeof(double) * (size_t)N) != 0) {
+                polydecomp_kernel_sums(N, we, S, desc->taus, P + 1, desc->log_taus, desc->c_exp, o);
+                w_of_o = we;
+            }
+            polydecomp_reduce(zne, erre, o);
             for (int j = 0; j < N; ++j) {
                 double *r = base + (size_t)j * rec;
                 for (int p = 0; p <= P; ++p) {
@@ -316,13 +334,12 @@ static int build_context(bisip_ctx **out, int device, int model_id, int E, int N
                     r[4 + P + 1 + p] = (double)(si * (long double)o.G_im[(size_t)j * (P + 1) + p]);
                 }
             }
-            bisip_ctx::ReducedHost rh;
+            bisip_ctx::ReducedHost &rh = c->reduced[(size_t)e];
             rh.R = o.R; rh.qty = o.qty; rh.bhat_ls = o.bhat_ls; rh.rest = o.rest; rh.lconst = lconsts[e];
-            c->reduced.push_back(std::move(rh));
-            if (E == 1) {  // loop-faithful records (see k_logprob_pd_faithful)
+            if (E == 1) {
                 const int JB = 16, nb = (N + JB - 1) / JB;
                 const size_t blk_stride = 4 * (size_t)JB + (size_t)S * 2 * JB;
-                std::vector<double> fb((size_t)S * 8 + (size_t)nb * blk_stride, 0.0);
+                fb.assign((size_t)S * 8 + (size_t)nb * blk_stride, 0.0);
                 for (int k = 0; k < S; ++k)
                     for (int p = 0; p <= P && p < 8; ++p) fb[(size_t)k * 8 + p] = desc->log_taus[(size_t)p * S + k];
                 for (int j = 0; j < N; ++j) {
@@ -335,10 +352,10 @@ static int build_context(bisip_ctx **out, int device, int model_id, int E, int N
                         blk[4 * JB + (size_t)k * 2 * JB + JB + jj] = o.K_im[(size_t)j * S + k];
                     }
                 }
-                if (P < 8) rc = upload(&c->d_cb_faithful, fb);
             }
         }
-    }
+    });
+    if (!fb.empty() && P < 8) rc = upload(&c->d_cb_faithful, fb);
     c->lconst = lconsts[0];
     if (rc == BISIP_OK) rc = upload(&c->d_cb, cb);
     if (rc == BISIP_OK && !cb_lp.empty()) rc = upload(&c->d_cb_lp, cb_lp);

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "../../include/bisip_hip.h"
+#include "host_precompute.h"
 
 namespace {
 
@@ -100,7 +101,7 @@ extern "C" int bisip_read_tables(const char *const *paths, int64_t n_files, int 
                                  double *tables, int32_t *status, int threads)
 {
     if (!paths || !tables || !status || n_files < 0 || n_rows < 1 || headers < 0) return BISIP_EINVAL;
-    if (threads < 1) threads = 1;
+    if (threads < 1) threads = bisip::host_threads();
     if (threads > n_files) threads = (int)(n_files > 0 ? n_files : 1);
     std::atomic<int64_t> next{0};
     auto work = [&]() {

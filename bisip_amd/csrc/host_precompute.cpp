@@ -2,8 +2,14 @@
 // context, never per walker.
 #include "host_precompute.h"
 
+#include <sched.h>
+
 #include <cmath>
 #include <cstddef>
+#include <cstdio>
+#include <cstdlib>
+#include <exception>
+#include <thread>
 
 namespace bisip {
 
@@ -36,6 +42,13 @@ void common_operands(int N, const double *w, const double *zn_err, std::vector<d
 void polydecomp_operands(int N, const double *w, int S, const double *taus, int D,
                          const double *log_taus, double c_exp, const double *zn,
                          const double *zn_err, PolyDecompOperands &o)
+{
+    polydecomp_kernel_sums(N, w, S, taus, D, log_taus, c_exp, o);
+    polydecomp_reduce(zn, zn_err, o);
+}
+
+void polydecomp_kernel_sums(int N, const double *w, int S, const double *taus, int D,
+                            const double *log_taus, double c_exp, PolyDecompOperands &o)
 {
     o.N = N; o.S = S; o.D = D;
     std::vector<ld> Kr((size_t)N * S), Ki((size_t)N * S);
@@ -70,7 +83,11 @@ void polydecomp_operands(int N, const double *w, int S, const double *taus, int 
         }
     o.G_re.resize((size_t)N * D); o.G_im.resize((size_t)N * D);
     for (size_t i = 0; i < (size_t)N * D; ++i) { o.G_re[i] = (double)Gr[i]; o.G_im[i] = (double)Gi[i]; }
+}
 
+void polydecomp_reduce(const double *zn, const double *zn_err, PolyDecompOperands &o)
+{
+    const int N = o.N, D = o.D;
     // Weighted design matrix of the linear model Z = R0 - sum_p (R0 a_p) G_p, built from
     // the ROUNDED G (what the collapsed kernel uses), rows = (real j..., imag j...).
     const int n = D + 1, m = 2 * N;
@@ -349,6 +366,55 @@ double reduced_center(int n, const std::vector<double> &R, const std::vector<lon
         }
     }
     return best;
+}
+
+int host_threads()
+{
+    if (const char *env = std::getenv("BISIP_HOST_THREADS")) {
+        const long v = std::strtol(env, nullptr, 10);
+        if (v >= 1) return (int)(v > 256 ? 256 : v);
+    }
+    long n = 1;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = CPU_COUNT(&set);
+    if (n < 1) n = 1;
+    // cgroup v2 "quota period" (or "max"), then v1: a container is throttled, not helped, by more
+    // runnable threads than its quota
+    if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        long long quota = 0, period = 0;
+        if (std::fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0 && quota / period < n)
+            n = (long)(quota / period < 1 ? 1 : quota / period);
+        std::fclose(f);
+    } else {
+        long long quota = -1, period = 0;
+        if (FILE *q = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (std::fscanf(q, "%lld", &quota) != 1) quota = -1; std::fclose(q); }
+        if (FILE *q = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (std::fscanf(q, "%lld", &period) != 1) period = 0; std::fclose(q); }
+        if (quota > 0 && period > 0 && quota / period < n) n = (long)(quota / period < 1 ? 1 : quota / period);
+    }
+    return (int)(n > 16 ? 16 : n);
+}
+
+void parallel_blocks(int64_t n, int64_t min_per_thread, const std::function<void(int64_t, int64_t)> &fn)
+{
+    if (n <= 0) return;
+    if (min_per_thread < 1) min_per_thread = 1;
+    int64_t threads = host_threads();
+    if (threads > n / min_per_thread) threads = n / min_per_thread;
+    if (threads <= 1) { fn(0, n); return; }
+    std::vector<std::exception_ptr> errors((size_t)threads);
+    auto block = [&](int64_t t) {
+        try {
+            fn(n * t / threads, n * (t + 1) / threads);
+        } catch (...) {
+            errors[(size_t)t] = std::current_exception();
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int64_t t = 1; t < threads; ++t) pool.emplace_back(block, t);
+    block(0);
+    for (auto &th : pool) th.join();
+    for (auto &e : errors)
+        if (e) std::rethrow_exception(e);
 }
 
 }  // namespace bisip

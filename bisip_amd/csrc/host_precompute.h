@@ -1,6 +1,8 @@
 // host_precompute.h -- walker-independent operands, computed once per context in
 // x87 80-bit long double and rounded once to binary64.
 #pragma once
+#include <cstdint>
+#include <functional>
 #include <vector>
 
 namespace bisip {
@@ -49,6 +51,21 @@ double reduced_center(int n, const std::vector<double> &R, const std::vector<lon
                       const std::vector<long double> &bhat_ls, double rest, double lconst,
                       const double *lo, const double *hi, bool comp, double *out_bhat, double *out_e,
                       double *out_elo);
+
+// The part of polydecomp_operands that depends on the frequencies and the tau grid only (K, G):
+// the spectra of a survey usually share one frequency list, and the N*S long-double powers are
+// most of the cost of a spectrum's operands.
+void polydecomp_kernel_sums(int N, const double *w, int S, const double *taus, int D,
+                            const double *log_taus, double c_exp, PolyDecompOperands &out);
+// The rest (weighted design matrix from out's rounded G, Householder QR, least squares).
+void polydecomp_reduce(const double *zn, const double *zn_err, PolyDecompOperands &out);
+
+// Host threads for per-spectrum work (batch contexts, file ingest): BISIP_HOST_THREADS, else the
+// CPUs this process may use -- affinity mask and cgroup CPU quota -- capped at 16.
+int host_threads();
+// fn(begin, end) over contiguous blocks of [0, n) on host_threads() threads (the caller's included);
+// serial when n is small.  An exception in any block is rethrown on the caller's thread.
+void parallel_blocks(int64_t n, int64_t min_per_thread, const std::function<void(int64_t, int64_t)> &fn);
 
 // -0.5 * sum_i 2*ln(zn_err_i^2), the walker-independent term of src/bisip/models.py:62
 double loglike_const(int n2, const double *zn_err);

@@ -306,7 +306,8 @@ int bisip_numpy_stretch_stream(uint32_t *mt_key, int32_t *mt_pos, int64_t W, dou
 /* Host: read n_files 5-column spectrum files (freq, amp, pha, amp_err, pha_err; comma separated,
  * `headers` lines skipped, '#' comments and blank lines ignored -- what the reference reads one
  * at a time with np.loadtxt(skiprows=headers, delimiter=','), src/bisip/utils.py:121-123) on
- * `threads` host threads into tables (n_files, n_rows, 5).  status[i] = 0: table i is filled
+ * `threads` host threads (<= 0: as many as the process may use, at most 16) into tables
+ * (n_files, n_rows, 5).  status[i] = 0: table i is filled
  * with exactly the doubles np.loadtxt yields; 1: file i is not in the plain format, cannot be
  * read, or does not hold n_rows rows -- read that one the reference's way (the Python host does,
  * so such files behave and fail as in the reference).  No GPU involved. */

@@ -336,3 +336,45 @@ def test_a_survey_split_over_ranks_gives_the_same_chains():
     with pytest.raises(ValueError):
         b.ctx.set_spectrum_offset(2 ** 31 - 2)
     b.close()
+
+
+def test_batch_operands_do_not_depend_on_threads_or_on_shared_frequencies(monkeypatch):
+    """A batch context's per-spectrum operands are computed in blocks of spectra on host threads, and
+    the kernel sums are reused while consecutive spectra share their frequency list: spectrum e must
+    get exactly the operands a context of its own gets -- with one thread or many, and when the
+    frequency lists differ from spectrum to spectrum or alternate (reuse, recompute, reuse ...)."""
+    import bisip_amd
+    from bisip_amd import _hip
+    E, Wp = 37, 16
+    tables = _tables(E)
+    for e in range(E):
+        if e % 5 in (2, 3):                       # runs of equal and of different frequency lists
+            tables[e] = tables[e].copy()
+            tables[e][:, 0] *= 1.0 + 0.01 * (e // 5)
+    rng = np.random.RandomState(8)
+    got = {}
+    for threads in ('1', '3', None):
+        if threads is None:
+            monkeypatch.delenv('BISIP_HOST_THREADS', raising=False)
+        else:
+            monkeypatch.setenv('BISIP_HOST_THREADS', threads)
+        batch = bisip_amd.SpectraBatch('PolynomialDecomposition', tables, nwalkers=Wp, poly_deg=4, c_exp=0.7)
+        lo, hi = batch.param_bounds
+        theta = np.random.RandomState(8).uniform(lo, hi, (E, Wp, lo.size))
+        got[threads] = batch.log_prob(theta)
+        # a wider box re-centres every spectrum's reduced form (the other threaded loop)
+        wide = batch.param_bounds.copy()
+        wide[:, 1:] *= 1.5
+        batch.ctx.set_bounds(wide)
+        got[threads, 'wide'] = batch.ctx.logprob(theta.reshape(-1, lo.size)).reshape(E, Wp)
+        if threads is None:
+            assert_logp_close(got[threads], _oracle_logp(batch, theta))
+            for e in (0, 2, 3, 4, 12, 13, 36):
+                for bounds, key in ((batch.param_bounds, None), (wide, (None, 'wide'))):
+                    single = _hip.HipContext(0, batch.w[e], batch.zn[e], batch.zn_err[e], bounds, poly_deg=4,
+                                             c_exp=0.7, taus=batch.taus, log_taus=batch.log_taus)
+                    assert np.array_equal(single.logprob(theta[e]), got[key][e])
+                    single.close()
+        batch.close()
+    for key in ('1', '3'):
+        assert np.array_equal(got[key], got[None]) and np.array_equal(got[key, 'wide'], got[None, 'wide'])
