@@ -30,7 +30,8 @@ for model, kw, centre in (('PeltonColeCole', dict(n_modes=2), [1.0, 0.15, 0.5, -
                           ('PolynomialDecomposition', dict(poly_deg=5), [1.0, 0.005, -0.003, -0.001, 0.0005, 0.0002, 0.00001]),
                           ('Dias2000', {}, [1.0, 0.5, -8.0, 10.0, 0.5])):
     out = {'model': model, 'spectra': E, 'walkers_per_spectrum': Wp}
-    for rep in range(2):                           # second pass: library and allocator warm
+    best = {}
+    for rep in range(4):                           # first pass: library and allocator cold; then the best of three
         t0 = time.perf_counter()
         b = bisip_amd.SpectraBatch(model, tables, nwalkers=Wp, nsteps=100, **kw)
         t1 = time.perf_counter()
@@ -40,7 +41,10 @@ for model, kw, centre in (('PeltonColeCole', dict(n_modes=2), [1.0, 0.15, 0.5, -
         t3 = time.perf_counter()
         b.get_param_mean(discard=50); b.get_param_percentile([2.5, 50, 97.5], discard=50)
         t4 = time.perf_counter()
-        out.update(create_s=round(t1 - t0, 4), fit_100_iterations_s=round(t3 - t2, 4), summaries_s=round(t4 - t3, 4),
-                   kernel=b.ctx.kernel_name)
+        if rep:
+            for key, v in (('create_s', t1 - t0), ('fit_100_iterations_s', t3 - t2), ('summaries_s', t4 - t3)):
+                best[key] = min(best.get(key, 1e9), v)
+        out['kernel'] = b.ctx.kernel_name
         b.close()
+    out.update({k: round(v, 4) for k, v in best.items()})
     print(json.dumps(out), flush=True)

@@ -236,10 +236,11 @@ class _SamplerBase:
 
     @staticmethod
     def _check_coords(coords):
+        if np.isfinite(coords).all():      # one pass in the usual case
+            return
         if np.any(np.isinf(coords)):
             raise ValueError('At least one parameter value was infinite')
-        if np.any(np.isnan(coords)):
-            raise ValueError('At least one parameter value was NaN')
+        raise ValueError('At least one parameter value was NaN')
 
     def _append(self, chain, logp):
         self._chain_parts.append(chain)
