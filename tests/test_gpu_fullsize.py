@@ -116,3 +116,62 @@ def test_cfg5_full_size_batch_of_spectra():
     # and the batch log-probability entry on the final positions agrees with the chain's
     last = np.ascontiguousarray(chain[-1])
     assert np.array_equal(b.log_prob(last), logp[-1])
+
+
+def test_headline_full_size_properties():
+    """The bench metric's own shape and size -- PolynomialDecomposition P = 5, 32 frequencies, 64
+    relaxation times, W = 2^24 walkers resident in HBM (BASELINE.json `metric`) -- through
+    properties that need no oracle at that size, plus the oracle on a sample:
+    -inf exactly on the rows outside the prior; walker index preserved under a permutation of
+    the rows, bit for bit; a launch over any split of the batch gives the same bits; the
+    per-frequency formulation agrees to 1e-11; 8192 rows spread over the batch match the oracle."""
+    import glob
+    import os
+    import torch
+    import oracle
+    from conftest import GOLDEN
+    from test_gpu_parity import make_ctx, _oracle_problem
+    from bisip_amd.synthetic import synthetic_theta
+    g = np.load(glob.glob(os.path.join(GOLDEN, 'case10_*'))[0])
+    assert g['w'].size == 32 and int(g['poly_deg']) == 5 and g['taus'].size == 64
+    W = 1 << 24
+    lo, hi = g['bounds']
+    theta = synthetic_theta(lo, hi, W)                     # the bench's rows (seed 2024)
+    rng = np.random.RandomState(5)
+    bad = rng.rand(W) < 0.01
+    theta[bad, 3] = np.where(rng.rand(int(bad.sum())) < 0.5, hi[3], lo[3] - 1.0)   # on a bound / outside
+    ctx = make_ctx(g, 'PolynomialDecomposition')
+    assert ctx.variant == 'reduced'
+    dev = torch.device('cuda', 0)
+    th = torch.from_numpy(theta).to(dev)
+    out = torch.empty(W, dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    ctx.logprob_dev(th.data_ptr(), W, out.data_ptr(), stream)
+    torch.cuda.synchronize()
+    a = out.cpu().numpy()
+    assert np.array_equal(np.isneginf(a), bad) and not np.isnan(a).any()
+    # permutation equivariance, on the device
+    perm = torch.randperm(W, device=dev)
+    th_p = th[perm].contiguous()
+    out_p = torch.empty_like(out)
+    ctx.logprob_dev(th_p.data_ptr(), W, out_p.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert torch.equal(out_p, out[perm])
+    del th_p, out_p, perm
+    # any split of the batch: same bits (ragged pieces, one smaller than a workgroup)
+    cuts = [0, 100, 5_000_001, 5_000_064, W]
+    out_s = torch.empty_like(out)
+    for lo_i, hi_i in zip(cuts[:-1], cuts[1:]):
+        ctx.logprob_dev(th.data_ptr() + 8 * 7 * lo_i, hi_i - lo_i, out_s.data_ptr() + 8 * lo_i, stream)
+    torch.cuda.synchronize()
+    assert torch.equal(out_s, out)
+    # the per-frequency formulation
+    ctx.set_variant('collapsed')
+    ctx.logprob_dev(th.data_ptr(), W, out_s.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert_logp_close(out_s.cpu().numpy(), a, 1e-11)
+    # the oracle on rows spread over the whole batch
+    pick = np.unique(np.concatenate([np.arange(0, W, W // 8000), [W - 1], np.flatnonzero(bad)[:64]]))
+    want = oracle.logprob(_oracle_problem(g, 'PolynomialDecomposition'), theta[pick], n_threads=8)
+    assert_logp_close(a[pick], want)
+    ctx.close()
