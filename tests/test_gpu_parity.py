@@ -780,6 +780,29 @@ def test_plain_c_consumer(tmp_path):
     assert abs(got[0] - vals['const']) < 1e-6
 
 
+@pytest.mark.parametrize('script,expect', [
+    ('quickstart.py', ['parameters', 'acceptance']),
+    ('batch_of_spectra.py', ['spectrum   0', 'acceptance']),
+    ('multi_gpu_logprob.py', ['1 rank(s): 1048576 log-probabilities']),
+    ('multi_gpu_sampler.py', ['1 rank(s), driver sharded-rccl', 'posterior mean']),
+])
+def test_python_examples_run(script, expect):
+    """examples/*.py as a user would start them on one GPU (the multi-GPU ones with a single rank:
+    the same code path -- RCCL communicator, C half-step loop -- as under torch.distributed.run)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(29500 + os.getpid() % 2000))
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'examples', script)], env=env, text=True,
+                       capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for needle in expect:
+        assert needle in r.stdout, r.stdout[-2000:]
+
+
 def test_polydecomp_random_spectra_fuzz():
     """Random problems (frequencies, spectrum, errors over four decades, degree, exponent):
     every formulation against the oracle, on walkers clustered at the least-squares optimum
