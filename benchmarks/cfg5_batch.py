@@ -16,6 +16,9 @@ def main():
     ap.add_argument('--thin-by', type=int, default=10)
     ap.add_argument('--chain', default='host', choices=['host', 'device'],
                     help="'device': stored samples stay in HBM; posterior mean/std are computed there")
+    ap.add_argument('--repeat', type=int, default=3,
+                    help='timed runs (fresh sampler each); the fastest is reported, all are listed: a box now and '
+                         'then delays the first work after a synchronisation by tens of milliseconds')
     ap.add_argument('--persistent', action='store_true', help='force the persistent kernel (default: automatic)')
     ap.add_argument('--no-persistent', action='store_true', help='force one launch per half-step')
     args = ap.parse_args()
@@ -37,26 +40,31 @@ def main():
     prime = time.perf_counter()           # warm-up + clocks up (as bench.py primes before timing)
     while time.perf_counter() - prime < 0.25:
         make().run_mcmc(p0.reshape(-1, 7), 2, thin_by=args.thin_by)
-    s = make()
-    t0 = time.perf_counter()
-    s.run_mcmc(p0.reshape(-1, 7), args.steps, thin_by=args.thin_by)
-    dt = time.perf_counter() - t0
-    summary_s = percentile_s = None
-    if args.chain == 'device':        # posterior mean / std of every spectrum, second half of the chain
-        t1 = time.perf_counter()
-        mean, std = s.param_moments(discard=args.steps // 2)
-        summary_s = time.perf_counter() - t1
-        dt += summary_s
-        t2 = time.perf_counter()
-        pct = s.param_percentiles((2.5, 50, 97.5), discard=args.steps // 2)     # not part of `seconds`
-        percentile_s = time.perf_counter() - t2
-        assert pct.shape == (3, E, 7) and np.all(pct[0] <= pct[1]) and np.all(pct[1] <= pct[2])
-        assert mean.shape == (E, 7) and np.all(np.isfinite(std))
+    runs = []
+    for _ in range(max(1, args.repeat)):
+        s = make()
+        t0 = time.perf_counter()
+        s.run_mcmc(p0.reshape(-1, 7), args.steps, thin_by=args.thin_by)
+        dt = time.perf_counter() - t0
+        summary_s = percentile_s = None
+        if args.chain == 'device':        # posterior mean / std of every spectrum, second half of the chain
+            t1 = time.perf_counter()
+            mean, std = s.param_moments(discard=args.steps // 2)
+            summary_s = time.perf_counter() - t1
+            dt += summary_s
+            t2 = time.perf_counter()
+            pct = s.param_percentiles((2.5, 50, 97.5), discard=args.steps // 2)     # not part of `seconds`
+            percentile_s = time.perf_counter() - t2
+            assert pct.shape == (3, E, 7) and np.all(pct[0] <= pct[1]) and np.all(pct[1] <= pct[2])
+            assert mean.shape == (E, 7) and np.all(np.isfinite(std))
+        runs.append((dt, summary_s, percentile_s, s))
+    dt, summary_s, percentile_s, s = min(runs, key=lambda r: r[0])
     iters = args.steps * args.thin_by
     print(json.dumps({'config': 'cfg5 slice: double Cole-Cole, 32 frequencies', 'spectra': E, 'walkers_per_spectrum': Wp,
                       'chain': args.chain, 'path': s.last_path, 'summary_s': None if summary_s is None else round(summary_s, 5),
                       'percentile_s': None if percentile_s is None else round(percentile_s, 5),
                       'iterations': iters, 'stored': args.steps, 'thin_by': args.thin_by, 'seconds': round(dt, 4),
+                      'seconds_all_runs': [round(r[0], 4) for r in runs],
                       'it_per_s': round(iters / dt, 1),
                       'us_per_half_step': round((s.timing['enqueue_s'] + s.timing['drain_s']) / iters / 2 * 1e6, 2),
                       'walker_steps_per_s': float('%.4g' % (iters * E * Wp / dt)),

@@ -1,0 +1,30 @@
+#!/bin/bash
+# Copies what `collect_profiles.sh all` left under gpurun_out/ into profiles/<round>_* (the tracked
+# evidence), summarises the PMC passes and regenerates the tables.  Run from the repo root:
+#   bash benchmarks/import_profiles.sh r02
+set -e -o pipefail
+tag=${1:?round tag, e.g. r02}
+src=gpurun_out
+dst=profiles
+newest() { ls -t "$1"/*"$2" 2>/dev/null | head -1; }   # earlier calls leave their PID-named files behind
+cpy() { [ -s "$1" ] && cp "$1" "$2" || echo "missing or empty: $1" >&2; }
+cpy $src/bench.json                    $dst/${tag}_bench.json
+cpy $src/bench_under_rocprof.json      $dst/${tag}_bench_under_rocprof.json
+cpy "$(newest $src/prof_bench/runc kernel_stats.csv)"   $dst/${tag}_bench_kernel_stats.csv
+cpy $src/sweep.jsonl                   $dst/${tag}_sweep.jsonl
+cpy "$(newest $src/prof_sweep/runc kernel_stats.csv)"   $dst/${tag}_sweep_kernel_stats.csv
+cpy $src/host_path.jsonl               $dst/${tag}_host_path.jsonl
+cpy $src/ingest.json                   $dst/${tag}_ingest.json
+cpy $src/batch_setup.jsonl             $dst/${tag}_batch_setup.jsonl
+cpy $src/sampler_bench.jsonl           $dst/${tag}_sampler_bench.jsonl
+cpy "$(newest $src/prof_sampler/runc kernel_stats.csv)" $dst/${tag}_sampler_kernel_stats.csv
+for f in cfg4_fused_device_chain cfg4_sharded_python cfg4_sharded_rccl-own cfg4_sharded_rccl \
+         cfg5_device_chain cfg5_device_chain_launches cfg5_host_chain; do
+  cpy $src/$f.json $dst/${tag}_$f.json
+done
+cpy "$(newest $src/prof_cfg5/runc kernel_stats.csv)"    $dst/${tag}_cfg5_kernel_stats.csv
+for m in issue_latency row_latency half_step_phases forward_rows_variants grid_barrier post_run_stall cfg5_pmc persistent_crossover; do
+  cpy $src/micro_$m.txt $dst/${tag}_micro_$m.txt
+done
+python3 benchmarks/summarize_pmc.py $src $dst $tag
+python3 benchmarks/make_tables.py

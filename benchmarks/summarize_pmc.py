@@ -21,12 +21,21 @@ import os
 import sys
 
 src, dst, tag = sys.argv[1:4]
+
+
+def newest_run(pattern):
+    """The counter CSV of the LAST run only: gpurun merges every call's files into the same local
+    directory under PID-derived names, so earlier runs' files sit next to the new one."""
+    files = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return files[-1:]
+
+
 KERNEL = 'k_logprob_pd_reduced'
 rows = []
 mean = {}
 grid = None
 for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
-    files = glob.glob(os.path.join(src, f'pmc_{counter}', '*', '*counter_collection.csv'))
+    files = newest_run(os.path.join(src, f'pmc_{counter}', '*', '*counter_collection.csv'))
     if not files:
         sys.exit(f'no counter_collection.csv for {counter} under {src}')
     vals, name = [], None
@@ -59,7 +68,7 @@ print(json.dumps(rec))
 
 def valu_counts():
     order_file = os.path.join(src, 'pmc_valu.json')
-    files = glob.glob(os.path.join(src, 'pmc_valu', '*', '*counter_collection.csv'))
+    files = newest_run(os.path.join(src, 'pmc_valu', '*', '*counter_collection.csv'))
     if not files or not os.path.exists(order_file):
         return
     order = None

@@ -467,6 +467,18 @@ def chain_percentiles_dev(d_chain_ptr, n_samples, sample_stride, n_ensembles, wa
                                                       d_work_ptr, work_bytes, stream))
 
 
+def column_percentiles_workspace(n_rows, n_cols, n_percentiles):
+    """BYTES of device workspace for column_percentiles_dev (0: more than 2^31 values)."""
+    return int(load_library().bisip_column_percentiles_workspace(int(n_rows), int(n_cols), int(n_percentiles)))
+
+
+def column_percentiles_dev(d_rows_ptr, n_rows, n_cols, percentiles, d_out_ptr, d_work_ptr, work_bytes, stream=0):
+    """np.percentile(rows, p, axis=0) of a device-resident (n_rows, n_cols) array; device pointers (ints)."""
+    p = _c(percentiles).ravel()
+    _check(load_library().bisip_column_percentiles_dev(d_rows_ptr, int(n_rows), int(n_cols), _p(p), p.size,
+                                                       d_out_ptr, d_work_ptr, int(work_bytes), stream))
+
+
 def numpy_stretch_stream(rng, W, a, n_steps, out=None):
     """n_steps iterations of the stretch move's RandomState stream, generated in C; ``rng``
     (a numpy.random.RandomState) is advanced exactly as draw_step would advance it.

@@ -960,6 +960,36 @@ class DeviceEnsembleSampler(_SamplerBase):
         be.synchronize()
         return mean.cpu().numpy(), std.cpu().numpy()
 
+    def model_percentiles(self, p=(2.5, 50, 97.5), discard=0, thin=1):
+        """``np.percentile(forward(get_chain(discard, thin, flat=True)), p, axis=0)`` -- the
+        reference's get_model_percentile (src/bisip/utils.py:17-35) -- without the chain leaving
+        the device: batched forward over the stored samples, then a column sort.  One ensemble
+        only; returns ``(len(p), 2, N)``.  NotImplementedError when the responses exceed one device
+        sort (2^31 values): the caller then reduces on the host."""
+        import torch
+        from . import _hip
+        if self.n_ensembles != 1:
+            raise NotImplementedError('model percentiles of a batch of spectra: one spectrum at a time')
+        t = self.device_chain()
+        n_total = int(t.shape[0])
+        discard, thin = int(discard), int(thin)
+        if thin < 1 or discard < 0 or len(range(discard + thin - 1, n_total, thin)) < 1:
+            raise ValueError(f'no samples left with discard={discard}, thin={thin} of {n_total} stored')
+        rows = t[discard + thin - 1::thin].reshape(-1, self.ndim).contiguous()
+        be, ctx = self.backend, self.backend.ctx
+        p = np.atleast_1d(np.asarray(p, dtype=np.float64))
+        n, cols = int(rows.shape[0]), 2 * ctx.N
+        nbytes = _hip.column_percentiles_workspace(n, cols, p.size)
+        if nbytes <= 0:
+            raise NotImplementedError('more than 2^31 model values: reduce on the host')
+        Z = be.empty((n, cols), torch.float64)
+        ctx.forward_dev(rows.data_ptr(), n, Z.data_ptr(), be.stream())
+        work = be.empty((nbytes,), torch.uint8)
+        out = be.empty((p.size, cols), torch.float64)
+        _hip.column_percentiles_dev(Z.data_ptr(), n, cols, p, out.data_ptr(), work.data_ptr(), nbytes, be.stream())
+        be.synchronize()
+        return out.cpu().numpy().reshape(p.size, 2, ctx.N)
+
     def param_percentiles(self, p=(2.5, 50, 97.5), discard=0, thin=1):
         """``np.percentile(get_chain(discard, thin, flat=True), p, axis=0)`` per ensemble
         (reference: src/bisip/utils.py:37-53), sorted and interpolated on the device; returns

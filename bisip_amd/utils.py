@@ -180,6 +180,13 @@ class utils(object):
     def get_model_percentile(self, p=[2.5, 50, 97.5], chain=None, **kwargs):
         """Percentiles of the model response over a chain (src/bisip/utils.py:17-35);
         the forward pass over the whole chain is one batched kernel launch."""
+        s = self._device_chain_sampler(chain, kwargs)
+        if s is not None:       # fit(chain='device'): forward and percentiles where the chain lies
+            try:
+                out = s.model_percentiles(p, discard=kwargs.get('discard', 0), thin=kwargs.get('thin', 1))
+                return out if np.ndim(p) else out[0]
+            except NotImplementedError:
+                pass
         chain = np.ascontiguousarray(self.parse_chain(chain, **kwargs), dtype=np.float64)
         try:
             # forward over the chain and the percentiles over axis 0 both on the device: only the

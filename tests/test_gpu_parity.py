@@ -347,6 +347,11 @@ def test_fit_with_the_chain_kept_on_the_device():
     assert np.allclose(std, flat.std(axis=0), rtol=1e-9, atol=1e-14)
     assert np.allclose(pct, np.percentile(flat, [2.5, 50, 97.5], axis=0), rtol=1e-13, atol=1e-15)
     assert med.shape == (4,) and np.allclose(med, np.percentile(dev.get_chain(discard=40, flat=True), 50, axis=0), rtol=1e-13)
+    # model-space percentiles: forward + column sort where the chain lies == the same kernels fed from the host
+    mp = dev.get_model_percentile([2.5, 50, 97.5], discard=40, thin=2)
+    assert mp.shape == (3, 2, 20) and np.array_equal(mp, host.get_model_percentile([2.5, 50, 97.5], chain=flat))
+    assert np.allclose(mp, np.percentile(dev.forward(flat, dev.data['w']), [2.5, 50, 97.5], axis=0), rtol=1e-13, atol=1e-15)
+    assert dev.get_model_percentile(50, discard=40, thin=2).shape == (2, 20)
     # a caller's own array still goes through NumPy
     assert np.array_equal(dev.get_param_mean(flat), flat.mean(axis=0))
     # get_chain() copied the samples out; they are still on the device for the summaries,
