@@ -65,6 +65,7 @@ def main():
                       'percentile_s': None if percentile_s is None else round(percentile_s, 5),
                       'iterations': iters, 'stored': args.steps, 'thin_by': args.thin_by, 'seconds': round(dt, 4),
                       'seconds_all_runs': [round(r[0], 4) for r in runs],
+                      'summary_s_all_runs': [None if r[1] is None else round(r[1], 5) for r in runs],
                       'it_per_s': round(iters / dt, 1),
                       'us_per_half_step': round((s.timing['enqueue_s'] + s.timing['drain_s']) / iters / 2 * 1e6, 2),
                       'walker_steps_per_s': float('%.4g' % (iters * E * Wp / dt)),
