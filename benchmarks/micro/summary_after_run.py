@@ -15,7 +15,8 @@ from bisip_amd.synthetic import synthetic_columns
 
 E, Wp = 512, 256
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 500
-mode = sys.argv[2] if len(sys.argv) > 2 else ''      # letters: k = keep samplers alive, p = percentiles too, t = trivial kernel first
+mode = sys.argv[2] if len(sys.argv) > 2 else ''      # letters: k = keep samplers alive, p = percentiles too, t = trivial kernel first,
+                                                     # l = one launch per half-step instead of the persistent kernel
 alive = []
 
 
@@ -43,8 +44,9 @@ def delta(a, b):
 tiny = torch.zeros(64, device='cuda')
 batch = bisip_amd.SpectraBatch('PeltonColeCole', [synthetic_columns(32, i) for i in range(E)], nwalkers=Wp, nsteps=steps, n_modes=2)
 p0 = np.array([1.0, 0.15, 0.5, -1.5, -12.0, 0.45, 0.6]) + 1e-3 * np.random.RandomState(0).randn(E * Wp, 7)
-for rep in range(4):
-    s = DeviceEnsembleSampler(Wp, 7, batch.ctx, rng='philox', seed=3, n_ensembles=E, chain_on_device=True)
+for rep in range(8):
+    s = DeviceEnsembleSampler(Wp, 7, batch.ctx, rng='philox', seed=3, n_ensembles=E, chain_on_device=True,
+                              persistent=False if 'l' in mode else None)     # l = one launch per half-step
     c0 = cpu_stat()
     s.run_mcmc(p0, steps, thin_by=40)
     c1 = cpu_stat()
