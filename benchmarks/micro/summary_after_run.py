@@ -16,7 +16,8 @@ from bisip_amd.synthetic import synthetic_columns
 E, Wp = 512, 256
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 500
 mode = sys.argv[2] if len(sys.argv) > 2 else ''      # letters: k = keep samplers alive, p = percentiles too, t = trivial kernel first,
-                                                     # l = one launch per half-step instead of the persistent kernel
+                                                     # l = one launch per half-step instead of the persistent kernel,
+                                                     # s / S = stream synchronisation for the summary / everywhere
 alive = []
 
 
@@ -44,6 +45,9 @@ def delta(a, b):
 tiny = torch.zeros(64, device='cuda')
 batch = bisip_amd.SpectraBatch('PeltonColeCole', [synthetic_columns(32, i) for i in range(E)], nwalkers=Wp, nsteps=steps, n_modes=2)
 p0 = np.array([1.0, 0.15, 0.5, -1.5, -12.0, 0.45, 0.6]) + 1e-3 * np.random.RandomState(0).randn(E * Wp, 7)
+if 'S' in mode:        # every synchronisation of the sampler too
+    from bisip_amd.sampler import HipStretchBackend
+    HipStretchBackend.synchronize = lambda self: torch.cuda.current_stream(self.device).synchronize()
 for rep in range(8):
     s = DeviceEnsembleSampler(Wp, 7, batch.ctx, rng='philox', seed=3, n_ensembles=E, chain_on_device=True,
                               persistent=False if 'l' in mode else None)     # l = one launch per half-step
@@ -61,10 +65,17 @@ for rep in range(8):
     mean = be.empty((E, nd), torch.float64); std = be.empty((E, nd), torch.float64)
     work = be.empty((max(1, _hip.chain_moments_workspace(n, E, nd)),), torch.float64)
     T.append(time.perf_counter())
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev[0].record()
     _hip.chain_moments_dev(t.data_ptr() + 8 * first * W * nd, n, W * nd, E, Wp, nd, mean.data_ptr(), std.data_ptr(), work.data_ptr(), be.stream())
+    ev[1].record()
     T.append(time.perf_counter())
-    be.synchronize()
+    if 's' in mode or 'S' in mode:
+        torch.cuda.current_stream().synchronize()      # hipStreamSynchronize instead of hipDeviceSynchronize
+    else:
+        be.synchronize()
     T.append(time.perf_counter())
+    on_device_ms = ev[0].elapsed_time(ev[1])      # the device's own clock between the two markers
     m = mean.cpu().numpy()
     T.append(time.perf_counter())
     _hip.chain_moments_dev(t.data_ptr() + 8 * first * W * nd, n, W * nd, E, Wp, nd, mean.data_ptr(), std.data_ptr(), work.data_ptr(), be.stream())
@@ -72,7 +83,7 @@ for rep in range(8):
     T.append(time.perf_counter())
     c2 = cpu_stat()
     print('   cgroup/process over the run:', delta(c0, c1), ' over the summary:', delta(c1, c2))
-    print(f'run {rep}: alloc {1e3*(T[1]-T[0]):.3f}  launch {1e3*(T[2]-T[1]):.3f}  sync {1e3*(T[3]-T[2]):.3f}  copy {1e3*(T[4]-T[3]):.3f}  second call+sync {1e3*(T[5]-T[4]):.3f} ms', flush=True)
+    print(f'run {rep}: alloc {1e3*(T[1]-T[0]):.3f}  launch {1e3*(T[2]-T[1]):.3f}  sync {1e3*(T[3]-T[2]):.3f} (markers on the device {on_device_ms:.3f})  copy {1e3*(T[4]-T[3]):.3f}  second call+sync {1e3*(T[5]-T[4]):.3f} ms', flush=True)
     if 'p' in mode:
         t0 = time.perf_counter(); s.param_percentiles((2.5, 50, 97.5), discard=first); print(f'   percentiles {1e3*(time.perf_counter()-t0):.3f} ms')
     if 'k' in mode:
