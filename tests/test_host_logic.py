@@ -301,3 +301,19 @@ def test_design_tables_are_generated():
                        capture_output=True, text=True, cwd=ROOT)
     assert r.returncode == 0, r.stdout + r.stderr
 
+
+
+def test_no_built_artefacts_are_tracked():
+    """History stays source-only: nothing git tracks is an ELF object, library or executable."""
+    import subprocess
+    if not os.path.isdir(os.path.join(ROOT, '.git')):
+        pytest.skip('not a git checkout (the GPU box gets a snapshot)')
+    files = subprocess.check_output(['git', 'ls-files'], cwd=ROOT, text=True).split()
+    elf = []
+    for f in files:
+        path = os.path.join(ROOT, f)
+        if os.path.isfile(path):
+            with open(path, 'rb') as fh:
+                if fh.read(4) == b'\x7fELF':
+                    elf.append(f)
+    assert not elf, elf
