@@ -570,6 +570,15 @@ int bisip_stretch_run_dev(bisip_ctx *c, const bisip_stretch_args *first, int64_t
     return BISIP_OK;
 }
 
+int bisip_read_tables(const char *const *paths, int64_t n_files, int headers, int64_t n_rows,
+                      double *tables, int32_t *status, int threads)
+{
+    if (!paths || !tables || !status) return fail(BISIP_EINVAL, "null argument");
+    if (n_files < 0 || n_rows < 1 || headers < 0)
+        return fail(BISIP_EINVAL, "bad n_files=%lld, n_rows=%lld or headers=%d", (long long)n_files, (long long)n_rows, headers);
+    return guarded([&] { read_tables(paths, n_files, headers, n_rows, tables, status, threads); return (int)BISIP_OK; });
+}
+
 int bisip_ctx_set_spectrum_offset(bisip_ctx *c, int64_t first_spectrum)
 {
     if (!c) return fail(BISIP_EINVAL, "null argument");

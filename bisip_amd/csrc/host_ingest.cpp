@@ -19,7 +19,6 @@
 #include <thread>
 #include <vector>
 
-#include "../../include/bisip_hip.h"
 #include "host_precompute.h"
 
 namespace {
@@ -97,10 +96,10 @@ int read_one(const char *path, int headers, int64_t n_rows, double *out /* (n_ro
 
 }  // namespace
 
-extern "C" int bisip_read_tables(const char *const *paths, int64_t n_files, int headers, int64_t n_rows,
-                                 double *tables, int32_t *status, int threads)
+// bisip_read_tables (bisip_hip.hip checks the arguments)
+void bisip::read_tables(const char *const *paths, int64_t n_files, int headers, int64_t n_rows,
+                        double *tables, int32_t *status, int threads)
 {
-    if (!paths || !tables || !status || n_files < 0 || n_rows < 1 || headers < 0) return BISIP_EINVAL;
     if (threads < 1) threads = bisip::host_threads();
     if (threads > n_files) threads = (int)(n_files > 0 ? n_files : 1);
     std::atomic<int64_t> next{0};
@@ -115,5 +114,4 @@ extern "C" int bisip_read_tables(const char *const *paths, int64_t n_files, int 
     for (int t = 1; t < threads; ++t) pool.emplace_back(work);
     work();
     for (auto &t : pool) t.join();
-    return BISIP_OK;
 }

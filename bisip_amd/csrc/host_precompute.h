@@ -67,6 +67,10 @@ int host_threads();
 // serial when n is small.  An exception in any block is rethrown on the caller's thread.
 void parallel_blocks(int64_t n, int64_t min_per_thread, const std::function<void(int64_t, int64_t)> &fn);
 
+// host_ingest.cpp: the body of bisip_read_tables (include/bisip_hip.h)
+void read_tables(const char *const *paths, int64_t n_files, int headers, int64_t n_rows, double *tables,
+                 int32_t *status, int threads);
+
 // -0.5 * sum_i 2*ln(zn_err_i^2), the walker-independent term of src/bisip/models.py:62
 double loglike_const(int n2, const double *zn_err);
 
