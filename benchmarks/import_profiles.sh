@@ -17,6 +17,7 @@ cpy $src/host_path.jsonl               $dst/${tag}_host_path.jsonl
 cpy $src/ingest.json                   $dst/${tag}_ingest.json
 cpy $src/batch_setup.jsonl             $dst/${tag}_batch_setup.jsonl
 cpy $src/sampler_bench.jsonl           $dst/${tag}_sampler_bench.jsonl
+cpy $src/batch_models.jsonl            $dst/${tag}_batch_models.jsonl
 cpy "$(newest $src/prof_sampler/runc kernel_stats.csv)" $dst/${tag}_sampler_kernel_stats.csv
 for f in cfg4_fused_device_chain cfg4_sharded_python cfg4_sharded_rccl-own cfg4_sharded_rccl \
          cfg5_device_chain cfg5_device_chain_launches cfg5_host_chain; do

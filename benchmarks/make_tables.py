@@ -170,6 +170,16 @@ def table_ingest():
     return md(rows, [f"ingest of {d['spectra']} spectrum files (N = {d['n_freq']}), GPU box host ({d['cpus']} CPUs); bit-identical: {str(d['bit_identical']).lower()}", 'seconds', 'us per file', 'speed-up'])
 
 
+def table_batch_models():
+    rows = []
+    for d in jlines(f'{ROUND}_batch_models.jsonl'):
+        a, b = d['persistent'], d['launch_per_half_step']
+        rows.append([d['model'], a['us_per_half_step'], sci(a['walker_steps_per_s']), b['us_per_half_step'], sci(b['walker_steps_per_s']), a['acceptance']])
+    d0 = jlines(f'{ROUND}_batch_models.jsonl')[0]
+    return md(rows, [f"{d0['spectra']} spectra x {d0['walkers_per_spectrum']} walkers, 32 frequencies, {d0['iterations']} iterations, chain in HBM: model",
+                     'persistent kernel: us per half-step', 'walker-steps/s', 'launch per half-step: us per half-step', 'walker-steps/s', 'acceptance'])
+
+
 def table_batch_setup():
     rows = [[d['model'], d['kernel'], d['create_s'], d['fit_100_iterations_s'], d['summaries_s']] for d in jlines(f'{ROUND}_batch_setup.jsonl')]
     return md(rows, ['512 spectra x 256 walkers: model', 'kernel', 'batch context creation, s', '`fit()` of 100 iterations, s', 'mean + std + 3 percentiles on the device, s'])
@@ -204,7 +214,7 @@ TABLES = {
     'bench': table_bench, 'variants': table_variants, 'sweep': table_sweep, 'forward': table_forward,
     'host_path': table_host_path, 'samplers': table_samplers, 'cfg4': table_cfg4, 'cfg5': table_cfg5,
     'fuzz': table_fuzz, 'auto_by_degree': table_auto_by_degree, 'ingest': table_ingest,
-    'batch_setup': table_batch_setup,
+    'batch_setup': table_batch_setup, 'batch_models': table_batch_models,
 }
 
 FILES = [
@@ -221,6 +231,7 @@ FILES = [
     (f'{ROUND}_cfg5_*.json, {ROUND}_cfg5_kernel_stats.csv', '`python benchmarks/cfg5_batch.py --chain device --steps 500 --thin-by 40 [--no-persistent]`', "BASELINE config 5, one GPU's share (512 spectra x 256 walkers)"),
     (f'{ROUND}_bench_2ranks_one_device*.json', '`python bench.py --gpus 2 --backend gloo --same-device --walkers 1048576 --steps 4`', 'the self-launched 2-rank run on one GPU (gloo): result line and the sharded-sampler extra (state identical on both ranks = single-GPU chain)'),
     (f'{ROUND}_ingest.json', '`python benchmarks/ingest.py` (host only)', 'survey ingest: the C parser + batched arithmetic against np.loadtxt file after file, same bits'),
+    (f'{ROUND}_batch_models.jsonl', '`python benchmarks/batch_models.py`', 'the batch-of-spectra sampler for every model at the cfg5 shape'),
     (f'{ROUND}_batch_setup.jsonl', '`python benchmarks/batch_setup.py`', 'what surrounds a survey run: batch context creation (host precompute on threads), a short fit, the summaries'),
     (f'{ROUND}_fuzz_*_summary.jsonl', '`python benchmarks/fuzz_parity.py --cases 1500 --seed S` (S = 41..43; 3000 cases at S = 4242), `fuzz_sampler.py --cases 1500 --seed 2`, `fuzz_batch.py --cases 500 --seed 1`', 'randomised campaigns: violations, worst errors, which kernel AUTO ran'),
     (f'{ROUND}_micro_issue_latency.txt', '`benchmarks/micro/issue_latency`', 'cycles per fp64 FMA for 1/2/4/8 independent chains at 1, 2, 4 waves per SIMD; placement of 1-, 2-, 4-, 8-, 16-wave workgroups'),
@@ -243,7 +254,7 @@ def readme():
     for name, title in (('bench', 'Headline'), ('variants', 'Formulations and the other kernels, with both rooflines'),
                         ('sweep', 'Every log-probability kernel at the BASELINE shapes'), ('forward', 'Batched forward'),
                         ('host_path', 'Host-buffer entry'), ('samplers', '`fit()` workloads'), ('cfg4', 'BASELINE config 4'),
-                        ('cfg5', 'BASELINE config 5'), ('ingest', 'Survey ingest'), ('batch_setup', 'Survey set-up'), ('fuzz', 'Randomised campaigns'), ('auto_by_degree', 'Which kernel AUTO ran, by polynomial degree')):
+                        ('cfg5', 'BASELINE config 5'), ('batch_models', 'Batch of spectra, every model'), ('ingest', 'Survey ingest'), ('batch_setup', 'Survey set-up'), ('fuzz', 'Randomised campaigns'), ('auto_by_degree', 'Which kernel AUTO ran, by polynomial degree')):
         out += [f'## {title}', '', TABLES[name](), '']
     return '\n'.join(out)
 

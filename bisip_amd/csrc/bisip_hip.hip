@@ -606,8 +606,19 @@ int bisip_stretch_draw_dev(bisip_ctx *c, int64_t W, double a, uint64_t seed, int
     d.seed_lo = (unsigned int)(seed & 0xffffffffu); d.seed_hi = (unsigned int)(seed >> 32);
     d.perm = d_perm; d.active = d_active; d.partner = d_partner;
     d.zz = d_zz; d.factor = d_factor; d.logu = d_logu;
-    const long long total = n_steps * 2 * d.E * d.nh;
-    hipLaunchKernelGGL(k_stretch_draw, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+    const long long per_half = d.E * d.nh, halves = 2 * n_steps;
+    d.flat = per_half < 256 && per_half * halves + 256 <= 0xffffffffLL;
+    if (d.flat) {
+        hipLaunchKernelGGL(k_stretch_draw, dim3((unsigned)((per_half * halves + 255) / 256)), dim3(256), 0,
+                           (hipStream_t)stream, d);
+        HIP_TRY(hipGetLastError());
+        return BISIP_OK;
+    }
+    if ((per_half + 255) / 256 > 0x7fffffffLL) return fail(BISIP_EINVAL, "too many slots per half-step");
+    const unsigned gy = (unsigned)(halves < 32768 ? halves : 32768);
+    const long long gz = (halves + gy - 1) / gy;
+    if (gz > 65535) return fail(BISIP_EINVAL, "n_steps=%lld too large for one draw (chunk the run)", (long long)n_steps);
+    hipLaunchKernelGGL(k_stretch_draw, dim3((unsigned)((per_half + 255) / 256), gy, (unsigned)gz), dim3(256), 0,
                        (hipStream_t)stream, d);
     HIP_TRY(hipGetLastError());
     return BISIP_OK;

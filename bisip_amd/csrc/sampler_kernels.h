@@ -284,6 +284,7 @@ struct DrawArgs {
     long long W, nh, n_steps, step0;  // W = walkers per ensemble
     long long E;                      // ensembles (E > 1 requires W even)
     long long e0;                     // index of the context's first spectrum in the whole survey
+    int flat;                         // launch shape, see k_stretch_draw
     double a, ndim_m1;
     unsigned int seed_lo, seed_hi;
     const int *perm;  // (n_steps, 3): A, Ainv, B
@@ -291,10 +292,15 @@ struct DrawArgs {
     double *zz, *factor, *logu;
 };
 
+// pi^-1(y) = Ainv * (y - B) mod W for y, B in [0, W), Ainv in [1, W).  A 64-bit division is ~100
+// instructions and the draw kernel had four per slot -- more than its two Philox blocks: y - B needs
+// no division at all, and for W <= 65536 (every ensemble that is not one huge one) the product fits
+// 32 bits.  Same integers either way.
 __device__ __forceinline__ int perm_inverse(long long y, long long W, long long Ainv, long long B)
 {
-    long long v = (y - B) % W;
+    long long v = y - B;
     if (v < 0) v += W;
+    if (W <= 65536) return (int)(((unsigned)Ainv * (unsigned)v) % (unsigned)W);
     return (int)((Ainv * v) % W);
 }
 
@@ -324,15 +330,32 @@ __device__ __forceinline__ SlotDraw draw_slot(long long W, double a, double ndim
     return d;
 }
 
+// Grid: x covers the E*nh slots of one half-step, (y, z) the 2*n_steps half-steps -- the index
+// arithmetic of a flat 64-bit grid was four 64-bit divisions per slot.  `flat`: one 32-bit index over
+// everything (two 32-bit divisions), for ensembles too small to fill a workgroup per half-step.
 static __global__ __launch_bounds__(256) void k_stretch_draw(const DrawArgs d)
 {
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long total = d.n_steps * 2 * d.E * d.nh;
-    if (idx >= total) return;
-    const long long t = idx % d.nh;
-    const long long e = (idx / d.nh) % d.E;
-    const int h = (int)((idx / (d.nh * d.E)) & 1);
-    const long long k = idx / (2 * d.E * d.nh);
+    const long long per_half = d.E * d.nh;
+    long long kh, slot;                     // iteration * 2 + half; (ensemble, t)
+    if (d.flat) {                           // small ensembles: a half-step would not fill a workgroup
+        const unsigned idx32 = blockIdx.x * 256u + threadIdx.x;
+        const unsigned q = idx32 / (unsigned)per_half;
+        kh = q; slot = idx32 - q * (unsigned)per_half;
+    } else {
+        kh = (long long)blockIdx.y + (long long)gridDim.y * blockIdx.z;
+        slot = (long long)blockIdx.x * 256 + threadIdx.x;
+    }
+    if (kh >= 2 * d.n_steps || slot >= per_half) return;
+    const long long k = kh >> 1;
+    const int h = (int)(kh & 1);
+    long long e, t;
+    if (per_half <= 0xffffffffLL) {
+        const unsigned q = (unsigned)slot / (unsigned)d.nh;
+        e = q; t = (long long)((unsigned)slot - q * (unsigned)d.nh);
+    } else {
+        e = slot / d.nh; t = slot % d.nh;
+    }
+    const long long idx = kh * per_half + slot;
     const long long Ns = h ? d.W / 2 : (d.W + 1) / 2;
     if (t >= Ns) {  // padding slot of the smaller half
         d.active[idx] = 0; d.partner[idx] = 0; d.zz[idx] = 1.0; d.factor[idx] = 0.0; d.logu[idx] = 0.0;

@@ -572,11 +572,35 @@ class HipStretchBackend:
             dst_host.copy_(src_dev, non_blocking=True)
         src_dev.record_stream(self._copy_stream)
 
-    def draw(self, st, W, a, seed, step0, n_steps):
+    def draw(self, st, W, a, seed, step0, n_steps, after=None):
+        """Fill a chunk's stream arrays (Philox).  ``after`` = events the draw must wait for (its
+        inputs uploaded, its output buffers no longer read): the draw then runs on a side stream,
+        next to the kernels of the previous chunk -- a persistent sampler kernel keeps one wave per
+        SIMD busy and leaves the rest of the chip to it -- and the compute stream waits for it.
+        ``after=None``: on the compute stream, as any other kernel."""
+        stream = self.stream()
+        if after is not None:
+            torch = self.torch
+            if not hasattr(self, '_draw_stream'):
+                self._draw_stream = torch.cuda.Stream(self.device)
+            for ev in after:
+                if ev is not None:
+                    self._draw_stream.wait_event(ev)
+            stream = self._draw_stream.cuda_stream
         self.ctx.stretch_draw_dev(W, a, seed, step0, n_steps, st['perm'].data_ptr(),
                                   st['active'].data_ptr(), st['partner'].data_ptr(),
                                   st['zz'].data_ptr(), st['factor'].data_ptr(),
-                                  st['logu'].data_ptr(), self.stream())
+                                  st['logu'].data_ptr(), stream)
+        if after is not None:
+            done = self.torch.cuda.Event()
+            done.record(self._draw_stream)
+            self.torch.cuda.current_stream(self.device).wait_event(done)
+
+    def mark(self):
+        """An event at the current end of the compute stream."""
+        ev = self.torch.cuda.Event()
+        ev.record(self.torch.cuda.current_stream(self.device))
+        return ev
 
     def synchronize(self):
         self.torch.cuda.synchronize(self.device)
@@ -632,7 +656,7 @@ class DeviceEnsembleSampler(_SamplerBase):
         # after round 2's rework of the kernel).  A big batch of
         # ensembles fills the chip with whole-ensemble workgroups either way, and then the
         # persistent kernel saves the launch, the gathers and the per-launch ramp of every
-        # half-step (512 spectra x 256 walkers: 8.1 vs 13.3 us per half-step).
+        # half-step (512 spectra x 256 walkers: 6.5 vs 12.4 us per half-step).
         # None = that rule; True / False force it.
         if persistent is None:
             limit = getattr(getattr(self.backend, 'ctx', None), 'persistent_walkers', 128)
@@ -701,7 +725,8 @@ class DeviceEnsembleSampler(_SamplerBase):
             return max(1, int(self.chunk))
         # bytes resident per iteration: chain row + log-prob + the five stream arrays.  2 GiB
         # per chunk is <1 % of the 288 GB of HBM and keeps the host work per chunk negligible
-        per_step = self.nwalkers * (8 * self.ndim + 8 + 3 * 8 + 2 * 4)
+        # (the Philox stream is double-buffered: the next chunk's is drawn while this one runs)
+        per_step = self.nwalkers * (8 * self.ndim + 8 + (2 if self.rng == 'philox' else 1) * (3 * 8 + 2 * 4))
         n = max(1, min(nsteps, (2 << 30) // per_step))
         if self.rng == 'numpy':
             # the NumPy-order stream is drawn on the host (MT19937 is sequential: ~20-60 ns per
@@ -809,13 +834,16 @@ class DeviceEnsembleSampler(_SamplerBase):
         nh = (W + 1) // 2                       # slots per half (the first half gets the odd one)
         chain_host = logp_host = None
         dev_chain = dev_logp = None              # chain_on_device: the whole run's samples, one block
-        stream_bufs = None                       # philox stream arrays, allocated once per run
+        stream_bufs = [None, None]               # philox stream arrays: two sets, one being drawn while the other is read
+        free_ev = [None, None]                   # ... and the event after which each set may be overwritten
+        perm_ev = None
         perm_all = None
         if self.rng == 'philox' and nsteps > 0:
             # the per-step splits of the WHOLE run (12 B per iteration) go up in one copy: a
             # host->device copy per chunk would wait for the previous chunk's kernels
             perm_all = be.tensor(affine_splits(self.seed, self.walkers_per_ensemble,
                                                self._iterations_run, nsteps * thin_by), slot='c')
+            perm_ev = be.mark() if hasattr(be, 'mark') else None
         # where a run spends its time
         self.timing = dict(setup_s=time.perf_counter() - t_start, stream_s=0.0, enqueue_s=0.0, alloc_s=0.0,
                            drain_s=0.0, finish_s=0.0, **setup_detail)
@@ -873,14 +901,24 @@ class DeviceEnsembleSampler(_SamplerBase):
                     st['logp_chain'] = be.empty((ns, W), torch.float64)
                 t_b = time.perf_counter()
                 if self.rng == 'philox':
-                    if stream_bufs is None:          # the first chunk is the largest; later ones reuse it
-                        stream_bufs = {name: be.empty((n, 2, nh), dt) for name, dt in (
-                            ('active', torch.int32), ('partner', torch.int32), ('zz', torch.float64),
-                            ('factor', torch.float64), ('logu', torch.float64))}
-                    for name, buf in stream_bufs.items():
+                    b = k % 2
+                    if k == 0:                       # chunks never grow: later ones reuse these two sets
+                        for i, rows in enumerate([n] + ([sizes[1] * thin_by] if len(sizes) > 1 else [])):
+                            stream_bufs[i] = {name: be.empty((rows, 2, nh), dt) for name, dt in (
+                                ('active', torch.int32), ('partner', torch.int32), ('zz', torch.float64),
+                                ('factor', torch.float64), ('logu', torch.float64))}
+                        if perm_ev is not None:      # the side stream starts after the split upload AND these
+                            perm_ev = be.mark()      # allocations (the allocator may hand out memory still in use upstream)
+                    for name, buf in stream_bufs[b].items():
                         st[name] = buf[:n]
-                    be.draw(st, self.walkers_per_ensemble, self.a, self.seed, it0, n)
+                    if len(sizes) > 1 and perm_ev is not None:
+                        # beside the previous chunk's kernels; this set was last read two chunks ago
+                        be.draw(st, self.walkers_per_ensemble, self.a, self.seed, it0, n, after=(perm_ev, free_ev[b]))
+                    else:
+                        be.draw(st, self.walkers_per_ensemble, self.a, self.seed, it0, n)
                 self._advance(st, n, nh, it0)
+                if self.rng == 'philox' and len(sizes) > 1 and perm_ev is not None:
+                    free_ev[k % 2] = be.mark()
                 t_alloc = 0.0
                 if not self.chain_on_device:
                     if chain_host is None:
