@@ -462,9 +462,12 @@ __global__ __launch_bounds__(512) void k_stretch_persistent(const PersistArgs a,
     const long long t0 = slot < nh ? slot : nh - 1;
     const long long t1 = slot < a.W / 2 ? slot : a.W / 2 - 1;
     SlotStream cur = load_slot(a, (0 * a.E + e) * nh + t0);
+    // which iterations are stored, by counting: (k + 1) % thin_by and k / thin_by are two 64-bit
+    // divisions per iteration, a few hundred instructions on a path where one wave per SIMD waits
+    // for every one of them
+    long long srow = 0, until_store = a.thin_by;
     for (long long k = 0; k < a.n_steps; ++k) {
-        const bool store = ((k + 1) % a.thin_by) == 0;
-        const long long srow = k / a.thin_by;
+        const bool store = --until_store == 0;
         for (int h = 0; h < 2; ++h) {
             // request the next half-step's entries now; they are consumed after the barrier
             const long long kn = h ? (k + 1 < a.n_steps ? k + 1 : k) : k;
@@ -493,6 +496,7 @@ __global__ __launch_bounds__(512) void k_stretch_persistent(const PersistArgs a,
             cur = nxt;
             lds_barrier();     // the other half reads the rows just written
         }
+        if (store) { ++srow; until_store = a.thin_by; }
     }
     if (ens_live) {
         for (long long i = lane; i < a.W * NDIM; i += a.lanes_per_ens) a.coords[base * NDIM + i] = xs[i];
