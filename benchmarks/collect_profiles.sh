@@ -60,6 +60,9 @@ if [ "$what" = sampler ] || [ "$what" = all ]; then
   (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$scratch/prof_cfg5" -- \
       python3 "$repo/benchmarks/cfg5_batch.py" --chain device --steps 100 --thin-by 10 > /dev/null 2> "$out/prof_cfg5.err")
   keep "$scratch/prof_cfg5" prof_cfg5
+  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$scratch/prof_batch_models" -- \
+      python3 "$repo/benchmarks/batch_models.py" --only Polynomial > /dev/null 2> "$out/prof_batch_models.err")
+  keep "$scratch/prof_batch_models" prof_batch_models
 fi
 if [ "$what" = micro ] || [ "$what" = all ]; then
   echo "== micro-benchmarks" | tee -a "$out/progress.log"

@@ -231,7 +231,7 @@ FILES = [
     (f'{ROUND}_cfg5_*.json, {ROUND}_cfg5_kernel_stats.csv', '`python benchmarks/cfg5_batch.py --chain device --steps 500 --thin-by 40 [--no-persistent]`', "BASELINE config 5, one GPU's share (512 spectra x 256 walkers)"),
     (f'{ROUND}_bench_2ranks_one_device*.json', '`python bench.py --gpus 2 --backend gloo --same-device --walkers 1048576 --steps 4`', 'the self-launched 2-rank run on one GPU (gloo): result line and the sharded-sampler extra (state identical on both ranks = single-GPU chain)'),
     (f'{ROUND}_ingest.json', '`python benchmarks/ingest.py` (host only)', 'survey ingest: the C parser + batched arithmetic against np.loadtxt file after file, same bits'),
-    (f'{ROUND}_batch_models.jsonl', '`python benchmarks/batch_models.py`', 'the batch-of-spectra sampler for every model at the cfg5 shape'),
+    (f'{ROUND}_batch_models.jsonl, {ROUND}_batch_models_kernel_stats.csv', '`python benchmarks/batch_models.py` (and `--only Polynomial` under `rocprofv3 --kernel-trace --stats`)', 'the batch-of-spectra sampler for every model at the cfg5 shape; the trace shows the stream draw next to the sampler kernel'),
     (f'{ROUND}_batch_setup.jsonl', '`python benchmarks/batch_setup.py`', 'what surrounds a survey run: batch context creation (host precompute on threads), a short fit, the summaries'),
     (f'{ROUND}_fuzz_*_summary.jsonl', '`python benchmarks/fuzz_parity.py --cases 1500 --seed S` (S = 41..43; 3000 cases at S = 4242), `fuzz_sampler.py --cases 1500 --seed 2`, `fuzz_batch.py --cases 500 --seed 1`', 'randomised campaigns: violations, worst errors, which kernel AUTO ran'),
     (f'{ROUND}_micro_issue_latency.txt', '`benchmarks/micro/issue_latency`', 'cycles per fp64 FMA for 1/2/4/8 independent chains at 1, 2, 4 waves per SIMD; placement of 1-, 2-, 4-, 8-, 16-wave workgroups'),
