@@ -170,7 +170,10 @@ def test_philox_draw_kernel_matches_contract():
     from numpy_stretch_backend import philox_stream
     g = np.load(_case('case16_'))
     ctx = make_ctx(g, 'PeltonColeCole')
-    for W, n, step0, seed in [(32, 9, 0, 1), (33, 5, 1000, 0xdeadbeefcafe), (4096, 3, 7, 42)]:
+    # 32 / 33: the flat launch shape of small ensembles; 4096 and 65536: 32-bit modular products;
+    # 65537 and 70001: past 2^16 walkers the products need 64 bits
+    for W, n, step0, seed in [(32, 9, 0, 1), (33, 5, 1000, 0xdeadbeefcafe), (4096, 3, 7, 42), (65536, 2, 3, 9),
+                              (65537, 2, 11, 5), (70001, 2, 0, 77)]:
         perm = affine_splits(seed, W, step0, n)
         nh = (W + 1) // 2
         dperm = torch.from_numpy(perm).cuda()
