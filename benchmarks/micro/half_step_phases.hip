@@ -38,7 +38,8 @@ __global__ __launch_bounds__(64) void k_half_timed(const StretchArgs a, const LP
     double q[NDIM];
 #pragma unroll
     for (int k = 0; k < NDIM; ++k) { const double d = c[k] - s[k]; q[k] = c[k] - d * z; }
-    const double new_lp = lp.template eval_ens<STAGED>(q, e, 0, staged);
+    const auto loc = lp.local(e);
+    const double new_lp = lp.template eval_ens<STAGED>(q, loc, 0, staged);
     asm volatile("" :: "v"(new_lp));
     const long long T3 = __builtin_amdgcn_s_memtime();
     const bool acc = (fac + new_lp) - old_lp > lu;

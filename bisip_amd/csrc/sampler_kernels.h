@@ -59,8 +59,12 @@ struct GenericLP {
     // lds = that ensemble's records in LDS, or null to read them where they are
     __device__ __forceinline__ const double *records(long long) const { return o.cb; }
     __host__ __device__ __forceinline__ int n_freq() const { return o.N; }
+    // what the persistent kernel fetches ONCE per launch for its ensemble (nothing here: the
+    // operands travel in the kernarg segment)
+    struct Local {};
+    __device__ __forceinline__ Local local(long long) const { return {}; }
     template <bool STAGED>
-    __device__ __forceinline__ double eval_ens(const double (&th)[NDIM], long long, int g, const double *lds) const
+    __device__ __forceinline__ double eval_ens(const double (&th)[NDIM], const Local &, int g, const double *lds) const
     {
         if constexpr (STAGED) {
             const ModelOperands oo{lds, o.N, o.lconst};
@@ -83,10 +87,21 @@ struct ReducedLP {
     {
         return logprob_row_reduced<P, COMP>(th, r, lconst, b);
     }
-    template <bool STAGED>
-    __device__ __forceinline__ double eval_ens(const double (&th)[NDIM], long long, int, const double *) const
+    // a copy of the kernarg operands in VECTOR registers (see BatchReducedLP::Local: as scalars
+    // they do not fit and return lane by lane in every half-step)
+    struct Local { ReducedArgs<P> r; };
+    __device__ __forceinline__ Local local(long long) const
     {
-        return logprob_row_reduced<P, COMP>(th, r, lconst, b);
+        Local loc{r};
+        double *v = reinterpret_cast<double *>(&loc.r);
+#pragma unroll
+        for (int i = 0; i < (int)(sizeof(ReducedArgs<P>) / sizeof(double)); ++i) asm volatile("" : "+v"(v[i]));
+        return loc;
+    }
+    template <bool STAGED>
+    __device__ __forceinline__ double eval_ens(const double (&th)[NDIM], const Local &loc, int, const double *) const
+    {
+        return logprob_row_reduced<P, COMP>(th, loc.r, lconst, b);
     }
 };
 
@@ -110,12 +125,17 @@ struct BatchGenericLP {
     }
     __device__ __forceinline__ const double *records(long long e) const { return cb + e * cb_stride; }
     __host__ __device__ __forceinline__ int n_freq() const { return N; }
-    template <bool STAGED>
-    __device__ __forceinline__ double eval_ens(const double (&th)[NDIM], long long e, int g, const double *lds) const
+    // the ensemble is the same for every lane of a wave (a wave never straddles two ensembles)
+    struct Local { const double *rec; double lconst; };
+    __device__ __forceinline__ Local local(long long e) const
     {
-        // e is the same for every lane of the wave (a wave never straddles two ensembles)
         const long long eu = (long long)__builtin_amdgcn_readfirstlane((int)e);
-        const ModelOperands o{STAGED ? lds : cb + eu * cb_stride, N, lconst[eu]};
+        return {cb + eu * cb_stride, lconst[eu]};
+    }
+    template <bool STAGED>
+    __device__ __forceinline__ double eval_ens(const double (&th)[NDIM], const Local &loc, int g, const double *lds) const
+    {
+        const ModelOperands o{STAGED ? lds : loc.rec, N, loc.lconst};
         return logprob_row<M, L, STAGED>(th, o, b, g);
     }
 };
@@ -134,11 +154,21 @@ struct BatchReducedLP {
         const long long e = spectrum_of<UNIFORM>(walker, Wp);
         return logprob_row_reduced<P, COMP>(th, red[e], lconst[e], b);
     }
-    template <bool STAGED>
-    __device__ __forceinline__ double eval_ens(const double (&th)[NDIM], long long e, int, const double *) const
+    // The spectrum's triangle, expansion point and residual vector (50 doubles at P = 5) are read
+    // ONCE per launch into registers: read where they lie they were ~25 vector loads per half-step,
+    // each a trip to memory that the 130 instructions of a half-step cannot hide (SQ counters of the
+    // 512 x 256 batch: 4,300 cycles per half-step, 1,900 of them waiting; benchmarks/micro/batch_pd_pmc.sh).
+    struct Local { ReducedArgs<P> r; double lconst; };
+    __device__ __forceinline__ Local local(long long e) const
     {
-        const long long eu = (long long)__builtin_amdgcn_readfirstlane((int)e);
-        return logprob_row_reduced<P, COMP>(th, red[eu], lconst[eu], b);
+        // through the vector path on purpose: as wave-uniform values the 100 dwords would overflow the
+        // scalar registers and come back lane by lane (v_readlane) in every half-step
+        return {red[e], lconst[e]};
+    }
+    template <bool STAGED>
+    __device__ __forceinline__ double eval_ens(const double (&th)[NDIM], const Local &loc, int, const double *) const
+    {
+        return logprob_row_reduced<P, COMP>(th, loc.r, loc.lconst, b);
     }
 };
 
@@ -146,12 +176,12 @@ struct BatchReducedLP {
 // `walker` is the global walker id handed to the log-prob functor (batch contexts pick
 // the spectrum from it).  Returns the row / log-prob AFTER the move.
 // ENS = 0: the functor finds the walker's spectrum itself; 1 / 2: the caller (persistent kernel)
-// names the ensemble, records where they are / staged in LDS at lds_records.
+// hands over what it fetched for its ensemble (LP::Local), records where they are / staged in LDS.
 template <int ENS = 0, class LP>
 __device__ __forceinline__ bool stretch_move(const double *s_row, const double *c_row, double old_lp,
                                              double z, double factor, double logu, const LP &lp,
                                              int walker, int g, int *status, double (&row)[LP::NDIM],
-                                             double &lp_row, long long ens = 0,
+                                             double &lp_row, const typename LP::Local *loc = nullptr,
                                              const double *lds_records = nullptr)
 {
     constexpr int NDIM = LP::NDIM;
@@ -164,8 +194,8 @@ __device__ __forceinline__ bool stretch_move(const double *s_row, const double *
         q[k] = c - d * z;
     }
     double new_lp;
-    if constexpr (ENS == 2) new_lp = lp.template eval_ens<true>(q, ens, g, lds_records);
-    else if constexpr (ENS == 1) new_lp = lp.template eval_ens<false>(q, ens, g, nullptr);
+    if constexpr (ENS == 2) new_lp = lp.template eval_ens<true>(q, *loc, g, lds_records);
+    else if constexpr (ENS == 1) new_lp = lp.template eval_ens<false>(q, *loc, g, nullptr);
     else new_lp = lp(q, walker, g);
     if (new_lp != new_lp) atomicOr(status, 1);
     const bool acc = (factor + new_lp) - old_lp > logu;
@@ -461,6 +491,7 @@ __global__ __launch_bounds__(512) void k_stretch_persistent(const PersistArgs a,
     // L > 1 need whole groups) and never commit
     const long long t0 = slot < nh ? slot : nh - 1;
     const long long t1 = slot < a.W / 2 ? slot : a.W / 2 - 1;
+    const typename LP::Local loc = lp.local(e);
     SlotStream cur = load_slot(a, (0 * a.E + e) * nh + t0);
     // which iterations are stored, by counting: (k + 1) % thin_by and k / thin_by are two 64-bit
     // divisions per iteration, a few hundred instructions on a path where one wave per SIMD waits
@@ -478,7 +509,7 @@ __global__ __launch_bounds__(512) void k_stretch_persistent(const PersistArgs a,
             // every lane of a slot reads the rows before lane 0 writes (same wave, program order)
             const bool acc = stretch_move<STAGED ? 2 : 1>(xs + (long long)i * NDIM, xs + (long long)p * NDIM, ls[i], cur.z,
                                                           cur.factor, cur.logu, lp, (int)(base + i), g, a.status, row,
-                                                          lp_row, e, recs);
+                                                          lp_row, &loc, recs);
             if (live && g == 0) {
                 if (acc) {   // own row only; partners are never active in this half
 #pragma unroll
