@@ -102,6 +102,7 @@ SYMBOLS = {
     'bisip_forward_percentiles': (ctypes.c_int, [ctypes.c_void_p, _dp, ctypes.c_int64, _dp, ctypes.c_int, _dp]),
     'bisip_numpy_stretch_stream': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32), ctypes.c_int64,
                                                   ctypes.c_double, ctypes.c_int64] + [ctypes.c_void_p] * 4),
+    'bisip_ctx_reduced_check': (ctypes.c_int, [ctypes.c_void_p, _dp, ctypes.c_int64, _dp, _dp]),
     'bisip_read_tables': (ctypes.c_int, [ctypes.POINTER(ctypes.c_char_p), ctypes.c_int64, ctypes.c_int, ctypes.c_int64,
                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
     'bisip_philox4x32': (None, [ctypes.POINTER(ctypes.c_uint32)] * 3),
@@ -325,6 +326,18 @@ class HipContext:
     def reduced_error(self):
         """Estimated worst relative log-prob error of the QR-reduced kernel for the current box."""
         return float(self._lib.bisip_ctx_reduced_error(self._h))
+
+    def reduced_check(self, theta, logp):
+        """Worst |logp - reference| / max(1, |reference|) of log-probabilities a QR-reduced kernel
+        gave for the rows of ``theta``, against the reduced form in long double from the unrounded
+        operands (host; bisip_ctx_reduced_check).  PolynomialDecomposition contexts only."""
+        theta = self._theta2d(theta)
+        logp = _c(logp).ravel()
+        if logp.size != theta.shape[0]:
+            raise ValueError('one log-probability per row of theta')
+        out = np.empty(1)
+        _check(self._lib.bisip_ctx_reduced_check(self._h, _p(theta), theta.shape[0], _p(logp), _p(out)))
+        return float(out[0])
 
     @property
     def loglike_const(self):

@@ -138,6 +138,15 @@ class SpectraBatch:
                                               n_ensembles=E, chain_on_device=(chain == 'device'),
                                               persistent=persistent)
         self._sampler.run_mcmc(np.asarray(p0).reshape(E * Wp, ndim), self.nsteps, thin_by=thin_by)
+        # PolynomialDecomposition: the reduced kernels were chosen from an estimate; measure them on
+        # the final ensembles against long double (see Inversion._check_reduced_kernel)
+        self.reduced_check_ = None
+        if self.ctx.variant in ('reduced', 'reduced_comp'):
+            self.reduced_check_ = self.ctx.reduced_check(self._sampler._coords, self._sampler._lp)
+            if not self.reduced_check_ <= 1e-10:
+                import warnings
+                warnings.warn(f'the {self.ctx.variant!r} kernel is {self.reduced_check_:.1e} (relative) away from the '
+                              'exact log-probability on the final ensembles (tolerance 1e-10)', RuntimeWarning)
         return self
 
     def _moments(self, discard, thin):

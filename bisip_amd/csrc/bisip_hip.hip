@@ -5,6 +5,7 @@
 #include "host_precompute.h"
 #include "chain_kernels.h"
 
+#include <atomic>
 #include <exception>
 
 using namespace bisip;
@@ -120,6 +121,14 @@ const char *name_for(const bisip_ctx *c)
 // PolynomialDecomposition, reduced form: (re)choose the expansion point bhat for the current
 // prior box (host_precompute.h:reduced_center), record the kernel's estimated rounding error,
 // refresh the kernarg copy of spectrum 0 and the device copies of a batch.
+// the open-box prior of SURVEY.md §8 a2 on the host (rows outside it never reach a formulation)
+static bool in_prior_host(const double *th, const bisip_ctx *c)
+{
+    for (int q = 0; q < c->ndim; ++q)
+        if (!(c->bounds.lo[q] < th[q] && th[q] < c->bounds.hi[q])) return false;
+    return true;
+}
+
 static int recenter_reduced(bisip_ctx *c)
 {
     if (c->model_id != BISIP_MODEL_POLYDECOMP || c->reduced.empty()) return BISIP_OK;
@@ -568,6 +577,38 @@ int bisip_stretch_run_dev(bisip_ctx *c, const bisip_stretch_args *first, int64_t
         }
     }
     return BISIP_OK;
+}
+
+int bisip_ctx_reduced_check(bisip_ctx *c, const double *theta, int64_t W, const double *logp, double *worst_rel)
+{
+    if (!c || !theta || !logp || !worst_rel) return fail(BISIP_EINVAL, "null argument");
+    if (c->model_id != BISIP_MODEL_POLYDECOMP || c->reduced.empty())
+        return fail(BISIP_EUNSUPPORTED, "only PolynomialDecomposition contexts have a QR-reduced form");
+    if (W < 0 || (c->E > 1 && W % c->E)) return fail(BISIP_EINVAL, "W=%lld is not a multiple of the %d spectra", (long long)W, c->E);
+    const int n = c->P + 2;
+    const int64_t per = c->E > 1 ? W / c->E : W;
+    std::vector<double> worst((size_t)host_threads() + 1, 0.0);
+    return guarded([&] {
+        std::atomic<int> slot{0};
+        parallel_blocks(W, 4096, [&](int64_t lo, int64_t hi) {
+            double w = 0.0;
+            for (int64_t i = lo; i < hi; ++i) {
+                const double *th = theta + i * c->ndim;
+                if (!in_prior_host(th, c)) continue;                  // the prior decides those rows, exactly
+                const bisip_ctx::ReducedHost &rh = c->reduced[(size_t)(per ? i / per : 0)];
+                const double want = reduced_logp_reference(n, rh.R, rh.qty, rh.rest, rh.lconst, th);
+                const double scale = std::fabs(want) > 1.0 ? std::fabs(want) : 1.0;
+                const double rel = std::fabs(logp[i] - want) / scale;
+                if (!(rel <= w)) w = rel;                              // NaN counts as worst
+            }
+            worst[(size_t)slot.fetch_add(1)] = w;
+        });
+        double all = 0.0;
+        for (double w : worst)
+            if (!(w <= all)) all = w;
+        *worst_rel = all;
+        return (int)BISIP_OK;
+    });
 }
 
 int bisip_read_tables(const char *const *paths, int64_t n_files, int headers, int64_t n_rows,

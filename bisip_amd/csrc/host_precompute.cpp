@@ -368,6 +368,12 @@ double reduced_center(int n, const std::vector<double> &R, const std::vector<lon
     return best;
 }
 
+double reduced_logp_reference(int n, const std::vector<double> &R, const std::vector<long double> &qty,
+                              double rest, double lconst, const double *theta)
+{
+    return (double)(-0.5L * reduced_chi2_exact(n, R, qty, rest, theta) + (ld)lconst);
+}
+
 int host_threads()
 {
     if (const char *env = std::getenv("BISIP_HOST_THREADS")) {

@@ -71,6 +71,11 @@ void parallel_blocks(int64_t n, int64_t min_per_thread, const std::function<void
 void read_tables(const char *const *paths, int64_t n_files, int headers, int64_t n_rows, double *tables,
                  int32_t *status, int threads);
 
+// The reduced form's log-likelihood of one theta row from the unrounded operands, in long double:
+// what the reduced kernels compute, without their rounding (reduced_center's yardstick).
+double reduced_logp_reference(int n, const std::vector<double> &R, const std::vector<long double> &qty,
+                              double rest, double lconst, const double *theta);
+
 // -0.5 * sum_i 2*ln(zn_err_i^2), the walker-independent term of src/bisip/models.py:62
 double loglike_const(int n2, const double *zn_err);
 

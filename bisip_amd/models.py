@@ -12,11 +12,18 @@ There is no CPU fallback: without the HIP library or without a GPU these methods
 raise ``RuntimeError``.
 """
 
+import warnings
+
 import numpy as np
 
 from . import _hip
 from . import utils as _utils
 from .sampler import DeviceEnsembleSampler, EnsembleSampler
+
+
+def moves_sampler(sampler):
+    """True for a real emcee sampler (fit(moves=...)): it has no device state to check."""
+    return not isinstance(sampler, (DeviceEnsembleSampler, EnsembleSampler))
 
 
 class Inversion(_utils.utils):
@@ -233,6 +240,28 @@ class Inversion(_utils.utils):
         else:
             self._sampler.run_mcmc(self._p0, self.nsteps, progress=True, thin_by=thin_by)
         self.__fitted = True
+        self._check_reduced_kernel(ctx)
+
+    # the tolerance the kernels are held to against the reference
+    _LOGP_TOL = 1e-10
+
+    def _check_reduced_kernel(self, ctx):
+        """PolynomialDecomposition runs on a QR-reduced kernel chosen from an error ESTIMATE on probe
+        rows (HipContext.reduced_error).  After a fit, measure: the final ensemble's log-probabilities
+        against the reduced form in long double (host, microseconds for a few thousand rows).  The
+        result stays in ``reduced_check_``; beyond the parity tolerance it warns and names the way out."""
+        self.reduced_check_ = None
+        if ctx.variant not in ('reduced', 'reduced_comp') or moves_sampler(self._sampler):
+            return
+        coords, lp = self._sampler._coords, self._sampler._lp
+        if coords is None or lp is None:
+            return
+        step = max(1, len(coords) // 4096)
+        self.reduced_check_ = ctx.reduced_check(coords[::step], lp[::step])
+        if not self.reduced_check_ <= self._LOGP_TOL:
+            warnings.warn(f'the {ctx.variant!r} kernel is {self.reduced_check_:.1e} (relative) away from the exact '
+                          f'log-probability on the final ensemble (tolerance {self._LOGP_TOL:.0e}); '
+                          "refit with variant='reduced_comp' (or 'collapsed')", RuntimeWarning)
 
     def get_chain(self, **kwargs):
         """MCMC chain; kwargs ``discard``, ``thin``, ``flat`` as in emcee."""

@@ -303,6 +303,15 @@ int bisip_numpy_stretch_stream(uint32_t *mt_key, int32_t *mt_pos, int64_t W, dou
                                int64_t n_steps, int32_t *active, int32_t *partner, double *zz,
                                double *u);
 
+/* Host, after the fact: how far are log-probabilities that a QR-reduced kernel produced from the
+ * reduced form evaluated in long double from the unrounded operands?  theta (W, ndim) and logp (W,)
+ * are host arrays -- typically a sampler's final ensemble and its log-probabilities (batch context:
+ * the (E*Wp, ndim) layout of bisip_logprob).  *worst_rel = max |logp - reference| / max(1, |reference|)
+ * over the rows inside the prior.  BISIP_VARIANT_AUTO picks a formulation from an ESTIMATE made on
+ * probe rows when the context is created; this measures the same quantity where the walkers ended
+ * up.  PolynomialDecomposition contexts only (BISIP_EUNSUPPORTED otherwise). */
+int bisip_ctx_reduced_check(bisip_ctx *ctx, const double *theta, int64_t W, const double *logp, double *worst_rel);
+
 /* Host: read n_files 5-column spectrum files (freq, amp, pha, amp_err, pha_err; comma separated,
  * `headers` lines skipped, '#' comments and blank lines ignored -- what the reference reads one
  * at a time with np.loadtxt(skiprows=headers, delimiter=','), src/bisip/utils.py:121-123) on

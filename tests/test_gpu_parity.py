@@ -364,6 +364,44 @@ def test_fit_with_the_chain_kept_on_the_device():
         dev.fit(chain='somewhere')
 
 
+def test_fit_measures_its_reduced_kernel_on_the_final_ensemble(monkeypatch):
+    """AUTO picks a QR-reduced kernel from an estimate on probe rows; fit() then measures that kernel on
+    the ensemble it ends with, against long double, keeps the result in reduced_check_ and warns past
+    the parity tolerance (forced here by a tolerance no double arithmetic meets)."""
+    import warnings
+    import bisip_amd
+    path = bisip_amd.DataFiles()['SIP-K389175']
+    m = bisip_amd.PolynomialDecomposition(path, nwalkers=64, nsteps=200)
+    np.random.seed(3)
+    with warnings.catch_warnings():
+        warnings.simplefilter('error', RuntimeWarning)
+        m.fit()
+    assert m._context().variant == 'reduced' and 0.0 <= m.reduced_check_ <= 1e-12
+    # rows outside the prior are the prior's business; a wrong log-probability is found
+    ctx = m._context()
+    coords, lp = m.sampler._coords.copy(), m.sampler._lp.copy()
+    assert ctx.reduced_check(coords, lp) == m.reduced_check_
+    lp[5] += 1e-6 * abs(lp[5])
+    assert 0.5e-6 < ctx.reduced_check(coords, lp) < 2e-6
+    coords[5, 0] = 2.0                               # now outside the box: not looked at
+    assert ctx.reduced_check(coords, lp) == m.reduced_check_ or ctx.reduced_check(coords, lp) <= 1e-12
+    monkeypatch.setattr(bisip_amd.PolynomialDecomposition, '_LOGP_TOL', 1e-30)
+    with pytest.warns(RuntimeWarning, match="variant='reduced_comp'"):
+        m.fit()
+    # models without a reduced form: nothing to check, nothing raised
+    cc = bisip_amd.PeltonColeCole(path, nwalkers=32, nsteps=20)
+    cc.fit()
+    assert cc.reduced_check_ is None
+    with pytest.raises(RuntimeError):
+        cc._context().reduced_check(cc.sampler._coords, cc.sampler._lp)
+    # a batch of spectra measures every ensemble
+    from bisip_amd.synthetic import synthetic_columns
+    b = bisip_amd.SpectraBatch('PolynomialDecomposition', [synthetic_columns(32, i) for i in range(5)], nwalkers=32, nsteps=50)
+    b.fit(seed=1)
+    assert 0.0 <= b.reduced_check_ <= 1e-11
+    b.close()
+
+
 def test_model_percentiles_on_the_device():
     """get_model_percentile (src/bisip/utils.py:17-35: forward() over the chain, np.percentile over
     axis 0) as ONE library call -- forward and the per-(part, frequency) percentiles both on the
@@ -650,6 +688,10 @@ def test_posterior_valley_walkers_on_nearly_collinear_designs(n_freq, poly_deg, 
         got = ctx.logprob(theta)
         errs[variant] = (assert_logp_close(got, want),
                          float(np.max(np.abs(got - exact) / np.maximum(1.0, np.abs(exact)))))
+        # the library's own after-the-fact check (bisip_ctx_reduced_check: the reduced form in long double
+        # from the unrounded operands) measures the same distance as the 80-bit evaluation above
+        mine = ctx.reduced_check(theta, got)
+        assert abs(mine - errs[variant][1]) <= 0.5 * errs[variant][1] + 2e-15, (variant, mine, errs[variant][1])
     print(n_freq, poly_deg, c_exp, len(theta), {k: ('%.1e' % a, '%.1e' % b) for k, (a, b) in errs.items()})
     assert errs['reduced_comp'][1] <= 1e-12
     ctx.set_variant('auto')
