@@ -117,6 +117,14 @@ template <int P, bool COMP>
 int launch_reduced_batch(const bisip_ctx *c, const double *theta, int64_t W, double *out, hipStream_t st)
 {
     const BatchArgs a = make_batch_args(c, theta, out, W);
+    constexpr int BLK = COMP ? BLK_LARGE : BLK_STREAM;
+    if (W >= SMALL_W && a.Wp % BLK == 0) {      // bulk evaluation: stream like the single-spectrum kernel
+        const unsigned sgrid = (unsigned)((W + BLK - 1) / BLK);
+        if (((uintptr_t)theta % 16) == 0) hipLaunchKernelGGL((k_logprob_batch_reduced_stream<P, BLK, true, COMP>), dim3(sgrid), dim3(BLK), 0, st, a);
+        else hipLaunchKernelGGL((k_logprob_batch_reduced_stream<P, BLK, false, COMP>), dim3(sgrid), dim3(BLK), 0, st, a);
+        HIP_TRY(hipGetLastError());
+        return BISIP_OK;
+    }
     const unsigned grid = (unsigned)((W + 63) / 64);
     if (a.Wp % 64 == 0) hipLaunchKernelGGL((k_logprob_batch_reduced<P, true, COMP>), dim3(grid), dim3(64), 0, st, a);
     else hipLaunchKernelGGL((k_logprob_batch_reduced<P, false, COMP>), dim3(grid), dim3(64), 0, st, a);

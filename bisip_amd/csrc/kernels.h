@@ -1086,6 +1086,27 @@ __global__ __launch_bounds__(64) void k_logprob_batch_reduced(const BatchArgs a)
     a.out[row] = logprob_row_reduced<P, COMP>(th, *r, a.lconst[e], a.b);
 }
 
+// The same for big batches whose spectra hold a multiple of BLK walkers: the headline kernel's streaming
+// structure (theta rows through the LDS transposition, non-temporal loads, 128-lane workgroups), the
+// workgroup's spectrum known from blockIdx alone so that its operands come through the scalar path.
+template <int P, int BLK, bool VEC, bool COMP = false>
+__global__ __launch_bounds__(BLK) void k_logprob_batch_reduced_stream(const BatchArgs a)
+{
+    constexpr int NDIM = P + 2;
+    __shared__ __attribute__((aligned(16))) double lds[BLK * NDIM];
+    const long long row0 = (long long)blockIdx.x * BLK;
+    stage_theta<NDIM, BLK, VEC>(a.theta, a.W, row0, lds);
+    __syncthreads();
+    const long long row = row0 + threadIdx.x;
+    if (row >= a.W) return;
+    double th[NDIM];
+#pragma unroll
+    for (int q = 0; q < NDIM; ++q) th[q] = lds[threadIdx.x * NDIM + q];
+    const unsigned e = (unsigned)row0 / (unsigned)a.Wp;          // one spectrum per workgroup (Wp % BLK == 0)
+    const ReducedArgs<P> *__restrict__ r = reinterpret_cast<const ReducedArgs<P> *>(a.red) + e;
+    a.out[row] = logprob_row_reduced<P, COMP>(th, *r, a.lconst[e], a.b);
+}
+
 template <class M>
 __global__ __launch_bounds__(256) void k_forward_batch(const BatchArgs a)
 {

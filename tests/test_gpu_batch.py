@@ -378,3 +378,33 @@ def test_batch_operands_do_not_depend_on_threads_or_on_shared_frequencies(monkey
         batch.close()
     for key in ('1', '3'):
         assert np.array_equal(got[key], got[None]) and np.array_equal(got[key, 'wide'], got[None, 'wide'])
+
+
+@pytest.mark.parametrize('variant', ['reduced', 'reduced_comp'])
+def test_bulk_batch_logprob_streams_like_the_single_spectrum_kernel(variant):
+    """E x Wp >= 131072 rows with Wp a multiple of the workgroup: the batch takes the headline kernel's
+    streaming structure (k_logprob_batch_reduced_stream).  Spectrum e's block must equal, bit for bit,
+    what a context of that spectrum alone returns, and agree with the oracle on a sample; a ragged
+    batch of the same spectra (Wp not a multiple) takes the general kernel and gives the same bits."""
+    import torch
+    from bisip_amd import _hip
+    import bisip_amd
+    E, Wp = 3, 65536
+    batch = bisip_amd.SpectraBatch('PolynomialDecomposition', _tables(E), nwalkers=64, poly_deg=5)
+    batch.ctx.set_variant(variant)
+    lo, hi = batch.param_bounds
+    rng = np.random.RandomState(17)
+    theta = rng.uniform(lo, hi, (E, Wp, lo.size))
+    theta[1, 5, 2] = hi[2]                                   # on a bound
+    got = batch.log_prob(theta)
+    assert got.shape == (E, Wp) and np.isneginf(got[1, 5]) and np.isfinite(np.delete(got.ravel(), Wp + 5)).all()
+    pick = rng.choice(Wp, 300, replace=False)
+    assert_logp_close(got[:, pick], _oracle_logp(batch, theta[:, pick]))
+    for e in range(E):
+        single = _hip.HipContext(0, batch.w[e], batch.zn[e], batch.zn_err[e], batch.param_bounds, poly_deg=5,
+                                 c_exp=batch.c_exp, taus=batch.taus, log_taus=batch.log_taus, variant=variant)
+        assert np.array_equal(single.logprob(theta[e]), got[e])
+        single.close()
+    ragged = batch.log_prob(theta[:, :Wp - 3])               # Wp - 3 walkers per spectrum: the general kernel
+    assert np.array_equal(ragged, got[:, :Wp - 3])
+    batch.close()
