@@ -181,8 +181,9 @@ def table_batch_models():
 
 
 def table_batch_setup():
-    rows = [[d['model'], d['kernel'], d['create_s'], d['fit_100_iterations_s'], d['summaries_s']] for d in jlines(f'{ROUND}_batch_setup.jsonl')]
-    return md(rows, ['512 spectra x 256 walkers: model', 'kernel', 'batch context creation, s', '`fit()` of 100 iterations, s', 'mean + std + 3 percentiles on the device, s'])
+    rows = [[d['model'], d['kernel'], d['create_s'], d['fit_100_iterations_s'], d['summaries_s'], d.get('model_percentiles_s', '-')] for d in jlines(f'{ROUND}_batch_setup.jsonl')]
+    return md(rows, ['512 spectra x 256 walkers: model', 'kernel', 'batch context creation, s', '`fit()` of 100 iterations, s', 'mean + std + 3 percentiles on the device, s',
+                     'model-space percentile bands of every spectrum (50 x 256 samples each), s'])
 
 
 def table_fuzz():

@@ -99,9 +99,14 @@ SYMBOLS = {
     'bisip_column_percentiles_workspace': (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
     'bisip_column_percentiles_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, _dp, ctypes.c_int,
                                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
+    'bisip_grouped_percentiles_workspace': (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
+    'bisip_grouped_percentiles_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, _dp, ctypes.c_int,
+                                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
     'bisip_forward_percentiles': (ctypes.c_int, [ctypes.c_void_p, _dp, ctypes.c_int64, _dp, ctypes.c_int, _dp]),
     'bisip_numpy_stretch_stream': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32), ctypes.c_int64,
                                                   ctypes.c_double, ctypes.c_int64] + [ctypes.c_void_p] * 4),
+    'bisip_forward_spectrum_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
+                                                  ctypes.c_void_p, ctypes.c_void_p]),
     'bisip_ctx_reduced_check': (ctypes.c_int, [ctypes.c_void_p, _dp, ctypes.c_int64, _dp, _dp]),
     'bisip_read_tables': (ctypes.c_int, [ctypes.POINTER(ctypes.c_char_p), ctypes.c_int64, ctypes.c_int, ctypes.c_int64,
                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
@@ -394,6 +399,11 @@ class HipContext:
         _check(self._lib.bisip_forward_dev(self._h, ctypes.c_void_p(d_theta_ptr), int(W),
                                            ctypes.c_void_p(d_Z_ptr), ctypes.c_void_p(stream)))
 
+    def forward_spectrum_dev(self, spectrum, d_theta_ptr, W, d_Z_ptr, stream=0):
+        """Batch context: forward of W rows that all belong to one spectrum (device pointers)."""
+        _check(self._lib.bisip_forward_spectrum_dev(self._h, int(spectrum), ctypes.c_void_p(d_theta_ptr), int(W),
+                                                    ctypes.c_void_p(d_Z_ptr), ctypes.c_void_p(stream)))
+
     # -- device-resident stretch move ---------------------------------------------------
     def stretch_half_dev(self, args, stream=0):
         _check(self._lib.bisip_stretch_half_dev(self._h, ctypes.byref(args), ctypes.c_void_p(stream)))
@@ -490,6 +500,19 @@ def column_percentiles_dev(d_rows_ptr, n_rows, n_cols, percentiles, d_out_ptr, d
     p = _c(percentiles).ravel()
     _check(load_library().bisip_column_percentiles_dev(d_rows_ptr, int(n_rows), int(n_cols), _p(p), p.size,
                                                        d_out_ptr, d_work_ptr, int(work_bytes), stream))
+
+
+def grouped_percentiles_workspace(n_groups, n_rows, n_cols, n_percentiles):
+    """BYTES of device workspace for grouped_percentiles_dev (0: more than 2^31 values in one sort)."""
+    return int(load_library().bisip_grouped_percentiles_workspace(int(n_groups), int(n_rows), int(n_cols), int(n_percentiles)))
+
+
+def grouped_percentiles_dev(d_rows_ptr, n_groups, n_rows, n_cols, percentiles, d_out_ptr, d_work_ptr, work_bytes, stream=0):
+    """np.percentile(rows[g], p, axis=0) for every g of a device-resident (n_groups, n_rows, n_cols) array in
+    one segmented sort; d_out (len(p), n_groups, n_cols).  Device pointers (ints)."""
+    p = _c(percentiles).ravel()
+    _check(load_library().bisip_grouped_percentiles_dev(d_rows_ptr, int(n_groups), int(n_rows), int(n_cols), _p(p), p.size,
+                                                        d_out_ptr, d_work_ptr, int(work_bytes), stream))
 
 
 def numpy_stretch_stream(rng, W, a, n_steps, out=None):

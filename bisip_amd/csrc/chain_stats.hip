@@ -123,6 +123,22 @@ int bisip_column_percentiles_dev(const double *d_rows, int64_t n_rows, int n_col
                             d_work, work_bytes, stream);
 }
 
+int64_t bisip_grouped_percentiles_workspace(int64_t n_groups, int64_t n_rows, int n_cols, int n_percentiles)
+{
+    return percentiles_workspace(1, n_groups, n_rows, n_cols, n_percentiles);
+}
+
+int bisip_grouped_percentiles_dev(const double *d_rows, int64_t n_groups, int64_t n_rows, int n_cols,
+                                  const double *percentiles, int n_percentiles, double *d_out, void *d_work,
+                                  int64_t work_bytes, void *stream)
+{
+    if (n_cols < 1 || n_cols > 65536) return fail(BISIP_EINVAL, "n_cols=%d out of range", n_cols);
+    if (n_groups < 1) return fail(BISIP_EINVAL, "n_groups=%lld", (long long)n_groups);
+    // (n_groups, n_rows, n_cols) = one sample of n_groups ensembles of n_rows walkers with n_cols parameters
+    return percentiles_impl(d_rows, 1, n_groups * n_rows * (int64_t)n_cols, n_groups, n_rows, n_cols, percentiles,
+                            n_percentiles, d_out, d_work, work_bytes, stream);
+}
+
 int bisip_chain_percentiles_dev(const double *d_chain, int64_t n_samples, int64_t sample_stride,
                                 int64_t n_ensembles, int64_t walkers_per_ensemble, int ndim,
                                 const double *percentiles, int n_percentiles, double *d_out,

@@ -40,12 +40,14 @@ mean = batch.gather(batch.get_param_mean(discard=100))         # (E, ndim): comp
 std = batch.gather(batch.get_param_std(discard=100))
 pct = batch.get_param_percentile([16, 50, 84], discard=100)    # (3, E_rank, ndim)
 p16, p50, p84 = np.moveaxis(batch.gather(np.moveaxis(pct, 1, 0)), 1, 0)
+band = batch.get_model_percentile([2.5, 50, 97.5], discard=100)         # (3, E_rank, 2, N): the band a fit is plotted with
 accept = batch.gather(batch.acceptance_fraction.mean(axis=1))
 if rank == 0:
     print('parameters', batch.param_names)
     for e in (0, 1, E - 1):
         print(f'spectrum {e:3d}  mean {np.round(mean[e], 3)}  median {np.round(p50[e], 3)}')
     print('acceptance', round(float(accept.mean()), 3))
+    print('95 % band of Re Z at the lowest frequency, first spectrum of this rank:', np.round(band[[0, 2], 0, 0, -1], 4))
 batch.close()
 if world > 1:
     dist.barrier()

@@ -116,6 +116,10 @@ int bisip_logprob_dev(bisip_ctx *ctx, const double *d_theta, int64_t W, double *
 int bisip_forward(bisip_ctx *ctx, const double *theta, int64_t W, double *Z);
 int bisip_forward_dev(bisip_ctx *ctx, const double *d_theta, int64_t W, double *d_Z,
                       void *stream);
+/* Batch context: forward of rows that ALL belong to spectrum `spectrum` (the model response over one
+ * spectrum's chain: utils.get_model_percentile per spectrum of a survey, src/bisip/utils.py:17-35). */
+int bisip_forward_spectrum_dev(bisip_ctx *ctx, int64_t spectrum, const double *d_theta, int64_t W,
+                               double *d_Z, void *stream);
 
 /* Gaussian log-likelihood of a model response the caller evaluated itself: Z (W,2,N)
  * [row 0 real, row 1 imaginary per walker] -> (W,)  =  -0.5*sum((zn - Z)^2/zn_err^2 +
@@ -284,6 +288,13 @@ int64_t bisip_column_percentiles_workspace(int64_t n_rows, int n_cols, int n_per
 int bisip_column_percentiles_dev(const double *d_rows, int64_t n_rows, int n_cols,
                                  const double *percentiles, int n_percentiles, double *d_out,
                                  void *d_work, int64_t work_bytes, void *stream);
+
+/* The same for n_groups stacked arrays (n_groups, n_rows, n_cols) in one sort: d_out
+ * (n_percentiles, n_groups, n_cols) -- the model responses of many spectra's chains at once. */
+int64_t bisip_grouped_percentiles_workspace(int64_t n_groups, int64_t n_rows, int n_cols, int n_percentiles);
+int bisip_grouped_percentiles_dev(const double *d_rows, int64_t n_groups, int64_t n_rows, int n_cols,
+                                  const double *percentiles, int n_percentiles, double *d_out,
+                                  void *d_work, int64_t work_bytes, void *stream);
 
 /* Percentiles of the MODEL response over a chain -- utils.get_model_percentile
  * (src/bisip/utils.py:17-35: a Python loop of forward() over the chain, then np.percentile

@@ -408,3 +408,41 @@ def test_bulk_batch_logprob_streams_like_the_single_spectrum_kernel(variant):
     ragged = batch.log_prob(theta[:, :Wp - 3])               # Wp - 3 walkers per spectrum: the general kernel
     assert np.array_equal(ragged, got[:, :Wp - 3])
     batch.close()
+
+
+@pytest.mark.parametrize('model,kw,centre', [
+    ('PeltonColeCole', dict(n_modes=2), [1.0, 0.15, 0.5, -1.5, -12.0, 0.45, 0.6]),
+    ('PolynomialDecomposition', dict(poly_deg=4), [1.0, 0.005, -0.003, -0.001, 0.0005, 0.0002]),
+])
+def test_batch_model_percentiles_per_spectrum(model, kw, centre):
+    """SpectraBatch.get_model_percentile: per spectrum, np.percentile over axis 0 of the model response
+    over that spectrum's flattened chain (the reference's get_model_percentile, src/bisip/utils.py:17-35,
+    which a survey would call file by file) -- computed spectrum by spectrum on the device, the same
+    from a chain kept in HBM and from one copied to the host."""
+    import bisip_amd
+    from bisip_amd import _hip
+    E, Wp = 5, 48
+    tables = _tables(E)
+    p0 = np.asarray(centre) + 1e-4 * np.random.RandomState(1).randn(E, Wp, len(centre))
+    got = {}
+    for chain in ('device', 'host'):
+        b = bisip_amd.SpectraBatch(model, tables, nwalkers=Wp, nsteps=40, **kw)
+        b.fit(p0, seed=6, chain=chain)
+        got[chain] = b.get_model_percentile([2.5, 50, 97.5], discard=10, thin=3)
+        assert got[chain].shape == (3, E, 2, 32)
+        if chain == 'host':
+            flat = b.get_chain(discard=10, thin=3, flat=True)            # (E, n*Wp, ndim)
+            okw = dict(kw)
+            if model == 'PolynomialDecomposition':
+                okw = dict(poly_deg=b.poly_deg, c_exp=b.c_exp, taus=b.taus, log_taus=b.log_taus)
+            mid = {'PolynomialDecomposition': 0, 'PeltonColeCole': 1}[model]
+            for e in range(E):
+                single = _hip.HipContext(mid, b.w[e], b.zn[e], b.zn_err[e], b.param_bounds, **okw)
+                want = np.percentile(single.forward(flat[e]), [2.5, 50, 97.5], axis=0)
+                np.testing.assert_allclose(got[chain][:, e], want, rtol=1e-13, atol=1e-15)
+                single.close()
+            with pytest.raises(ValueError):
+                b.get_model_percentile(50, discard=40)
+            assert b.get_model_percentile(50, discard=10).shape == (1, E, 2, 32)
+        b.close()
+    assert np.array_equal(got['device'], got['host'])
