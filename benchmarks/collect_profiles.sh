@@ -41,6 +41,8 @@ if [ "$what" = sweep ] || [ "$what" = all ]; then
   python3 benchmarks/host_path.py > "$out/host_path.jsonl" 2> "$out/host_path.err"
   python3 benchmarks/ingest.py > "$out/ingest.json" 2> "$out/ingest.err"
   python3 benchmarks/batch_setup.py > "$out/batch_setup.jsonl" 2> "$out/batch_setup.err"
+  python3 benchmarks/survey.py > "$out/survey.jsonl" 2> "$out/survey.err"
+  python3 benchmarks/survey.py --model PeltonColeCole >> "$out/survey.jsonl" 2>> "$out/survey.err"
 fi
 if [ "$what" = sampler ] || [ "$what" = all ]; then
   echo "== samplers" | tee -a "$out/progress.log"

@@ -16,6 +16,7 @@ cpy "$(newest $src/prof_sweep/runc kernel_stats.csv)"   $dst/${tag}_sweep_kernel
 cpy $src/host_path.jsonl               $dst/${tag}_host_path.jsonl
 cpy $src/ingest.json                   $dst/${tag}_ingest.json
 cpy $src/batch_setup.jsonl             $dst/${tag}_batch_setup.jsonl
+cpy $src/survey.jsonl                  $dst/${tag}_survey.jsonl
 cpy $src/sampler_bench.jsonl           $dst/${tag}_sampler_bench.jsonl
 cpy $src/batch_models.jsonl            $dst/${tag}_batch_models.jsonl
 cpy "$(newest $src/prof_sampler/runc kernel_stats.csv)" $dst/${tag}_sampler_kernel_stats.csv

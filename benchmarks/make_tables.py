@@ -180,6 +180,14 @@ def table_batch_models():
                      'persistent kernel: us per half-step', 'walker-steps/s', 'launch per half-step: us per half-step', 'walker-steps/s', 'acceptance'])
 
 
+def table_survey():
+    rows = [[d['model'], d['ingest_and_context_s'], d['fit_s'], d['parameter_summaries_s'], d['model_bands_s'], d['total_s'], sci(d['walker_steps_per_s_end_to_end'])]
+            for d in jlines(f'{ROUND}_survey.jsonl')]
+    d0 = jlines(f'{ROUND}_survey.jsonl')[0]
+    return md(rows, [f"a survey end to end on one GPU: {d0['spectra']} spectrum files, {d0['walkers_per_spectrum']} walkers x {d0['iterations']} iterations each; model",
+                     'ingest + batch context, s', '`fit()`, s', 'mean, std, 3 percentiles of every parameter, s', 'model-space bands of every spectrum, s', 'total, s', 'walker-steps/s end to end'])
+
+
 def table_batch_setup():
     rows = [[d['model'], d['kernel'], d['create_s'], d['fit_100_iterations_s'], d['summaries_s'], d.get('model_percentiles_s', '-')] for d in jlines(f'{ROUND}_batch_setup.jsonl')]
     return md(rows, ['512 spectra x 256 walkers: model', 'kernel', 'batch context creation, s', '`fit()` of 100 iterations, s', 'mean + std + 3 percentiles on the device, s',
@@ -215,7 +223,7 @@ TABLES = {
     'bench': table_bench, 'variants': table_variants, 'sweep': table_sweep, 'forward': table_forward,
     'host_path': table_host_path, 'samplers': table_samplers, 'cfg4': table_cfg4, 'cfg5': table_cfg5,
     'fuzz': table_fuzz, 'auto_by_degree': table_auto_by_degree, 'ingest': table_ingest,
-    'batch_setup': table_batch_setup, 'batch_models': table_batch_models,
+    'batch_setup': table_batch_setup, 'batch_models': table_batch_models, 'survey': table_survey,
 }
 
 FILES = [
@@ -233,6 +241,7 @@ FILES = [
     (f'{ROUND}_bench_2ranks_one_device*.json', '`python bench.py --gpus 2 --backend gloo --same-device --walkers 1048576 --steps 4`', 'the self-launched 2-rank run on one GPU (gloo): result line and the sharded-sampler extra (state identical on both ranks = single-GPU chain)'),
     (f'{ROUND}_ingest.json', '`python benchmarks/ingest.py` (host only)', 'survey ingest: the C parser + batched arithmetic against np.loadtxt file after file, same bits'),
     (f'{ROUND}_batch_models.jsonl, {ROUND}_batch_models_kernel_stats.csv', '`python benchmarks/batch_models.py` (and `--only Polynomial` under `rocprofv3 --kernel-trace --stats`)', 'the batch-of-spectra sampler for every model at the cfg5 shape; the trace shows the stream draw next to the sampler kernel'),
+    (f'{ROUND}_survey.jsonl', '`python benchmarks/survey.py [--model PeltonColeCole]`', 'a 4096-spectrum survey end to end: files to posterior summaries and model bands'),
     (f'{ROUND}_batch_setup.jsonl', '`python benchmarks/batch_setup.py`', 'what surrounds a survey run: batch context creation (host precompute on threads), a short fit, the summaries'),
     (f'{ROUND}_fuzz_*_summary.jsonl', '`python benchmarks/fuzz_parity.py --cases 1500 --seed S` (S = 41..43; 3000 cases each at S = 4242, 101..103; 2000 at S = 104 with boxes widened x2), `fuzz_sampler.py --cases 1500 --seed 2` (and 5), `fuzz_batch.py --cases 500 --seed 1` (and 4)', 'randomised campaigns: violations, worst errors, which kernel AUTO ran'),
     (f'{ROUND}_micro_issue_latency.txt', '`benchmarks/micro/issue_latency`', 'cycles per fp64 FMA for 1/2/4/8 independent chains at 1, 2, 4 waves per SIMD; placement of 1-, 2-, 4-, 8-, 16-wave workgroups'),
@@ -257,7 +266,7 @@ def readme():
     for name, title in (('bench', 'Headline'), ('variants', 'Formulations and the other kernels, with both rooflines'),
                         ('sweep', 'Every log-probability kernel at the BASELINE shapes'), ('forward', 'Batched forward'),
                         ('host_path', 'Host-buffer entry'), ('samplers', '`fit()` workloads'), ('cfg4', 'BASELINE config 4'),
-                        ('cfg5', 'BASELINE config 5'), ('batch_models', 'Batch of spectra, every model'), ('ingest', 'Survey ingest'), ('batch_setup', 'Survey set-up'), ('fuzz', 'Randomised campaigns'), ('auto_by_degree', 'Which kernel AUTO ran, by polynomial degree')):
+                        ('cfg5', 'BASELINE config 5'), ('batch_models', 'Batch of spectra, every model'), ('survey', 'A survey end to end'), ('ingest', 'Survey ingest'), ('batch_setup', 'Survey set-up'), ('fuzz', 'Randomised campaigns'), ('auto_by_degree', 'Which kernel AUTO ran, by polynomial degree')):
         out += [f'## {title}', '', TABLES[name](), '']
     return '\n'.join(out)
 

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""A whole survey, end to end on one GPU: E spectrum files -> ingest -> batch context -> stretch-move fit of
+every spectrum (Wp walkers, n iterations) -> posterior summaries and model-space bands of every spectrum.
+The reference's way is a Python loop over Inversion objects (load_data, fit, get_param_*, get_model_percentile
+per file: src/bisip/models.py:41-57, 84-119; src/bisip/utils.py:17-106).
+
+    python benchmarks/survey.py [--spectra 4096] [--walkers 256] [--iterations 1000] [--model PolynomialDecomposition]
+"""
+import argparse
+import json
+import os
+import shutil
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--spectra', type=int, default=4096)
+ap.add_argument('--walkers', type=int, default=256)
+ap.add_argument('--iterations', type=int, default=1000)
+ap.add_argument('--thin-by', type=int, default=10)
+ap.add_argument('--model', default='PolynomialDecomposition', choices=['PolynomialDecomposition', 'PeltonColeCole'])
+args = ap.parse_args()
+
+import torch
+import bisip_amd
+from bisip_amd.synthetic import synthetic_columns
+
+E, Wp = args.spectra, args.walkers
+kw, centre = (dict(poly_deg=5), [1.0, 0.005, -0.003, -0.001, 0.0005, 0.0002, 0.00001]) if args.model == 'PolynomialDecomposition' \
+    else (dict(n_modes=2), [1.0, 0.15, 0.5, -1.5, -12.0, 0.45, 0.6])
+d = tempfile.mkdtemp(prefix='bisip_survey_')
+try:
+    paths = []
+    for i in range(E):
+        p = os.path.join(d, f'spectrum{i:05d}.csv')
+        np.savetxt(p, synthetic_columns(32, i), delimiter=',', header='freq,amp,pha,amp_err,pha_err')
+        paths.append(p)
+    torch.zeros(1, device='cuda')                            # the HIP runtime is up before the clock starts
+    p0 = np.asarray(centre) + 1e-4 * np.random.RandomState(0).randn(E, Wp, len(centre))
+    stored = args.iterations // args.thin_by
+    out = {'model': args.model, 'spectra': E, 'walkers_per_spectrum': Wp, 'iterations': stored * args.thin_by, 'stored': stored}
+    for rep in range(2):                                     # the second pass is the warm one
+        t = [time.perf_counter()]
+        b = bisip_amd.SpectraBatch(args.model, paths, nwalkers=Wp, nsteps=stored, **kw)      # ingest + context
+        t.append(time.perf_counter())
+        b.fit(p0, seed=1, thin_by=args.thin_by, chain='device')
+        t.append(time.perf_counter())
+        mean, std = b.get_param_mean(discard=stored // 2), b.get_param_std(discard=stored // 2)
+        pct = b.get_param_percentile([2.5, 50, 97.5], discard=stored // 2)
+        t.append(time.perf_counter())
+        band = b.get_model_percentile([2.5, 50, 97.5], discard=stored // 2)
+        t.append(time.perf_counter())
+        assert mean.shape == (E, len(centre)) and pct.shape == (3, E, len(centre)) and band.shape == (3, E, 2, 32)
+        assert np.isfinite(band).all() and (band[0] <= band[2]).all()
+        out.update(ingest_and_context_s=round(t[1] - t[0], 4), fit_s=round(t[2] - t[1], 4),
+                   parameter_summaries_s=round(t[3] - t[2], 4), model_bands_s=round(t[4] - t[3], 4),
+                   total_s=round(t[4] - t[0], 4), walker_steps=E * Wp * stored * args.thin_by,
+                   acceptance=round(float(b.acceptance_fraction.mean()), 3), path=b._sampler.last_path,
+                   reduced_check=b.reduced_check_)
+        b.close()
+    out['walker_steps_per_s_end_to_end'] = float('%.4g' % (out['walker_steps'] / out['total_s']))
+    print(json.dumps(out))
+finally:
+    shutil.rmtree(d, ignore_errors=True)
