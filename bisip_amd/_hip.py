@@ -107,6 +107,8 @@ SYMBOLS = {
                                                   ctypes.c_double, ctypes.c_int64] + [ctypes.c_void_p] * 4),
     'bisip_forward_spectrum_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
                                                   ctypes.c_void_p, ctypes.c_void_p]),
+    'bisip_forward_spectra_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
+                                                 ctypes.c_void_p, ctypes.c_void_p]),
     'bisip_ctx_reduced_check': (ctypes.c_int, [ctypes.c_void_p, _dp, ctypes.c_int64, _dp, _dp]),
     'bisip_read_tables': (ctypes.c_int, [ctypes.POINTER(ctypes.c_char_p), ctypes.c_int64, ctypes.c_int, ctypes.c_int64,
                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
@@ -403,6 +405,12 @@ class HipContext:
         """Batch context: forward of W rows that all belong to one spectrum (device pointers)."""
         _check(self._lib.bisip_forward_spectrum_dev(self._h, int(spectrum), ctypes.c_void_p(d_theta_ptr), int(W),
                                                     ctypes.c_void_p(d_Z_ptr), ctypes.c_void_p(stream)))
+
+    def forward_spectra_dev(self, first_spectrum, n_spectra, d_theta_ptr, W, d_Z_ptr, stream=0):
+        """Batch context: forward of W rows over n_spectra consecutive spectra, W / n_spectra rows each
+        (a multiple of 64 when n_spectra > 1), one launch (device pointers)."""
+        _check(self._lib.bisip_forward_spectra_dev(self._h, int(first_spectrum), int(n_spectra), ctypes.c_void_p(d_theta_ptr),
+                                                   int(W), ctypes.c_void_p(d_Z_ptr), ctypes.c_void_p(stream)))
 
     # -- device-resident stretch move ---------------------------------------------------
     def stretch_half_dev(self, args, stream=0):

@@ -208,8 +208,11 @@ class SpectraBatch:
             k = g1 - g0
             rows = grid[:, g0:g1].permute(1, 0, 2, 3).reshape(k, rows_per, ndim)   # one copy: spectrum-major
             Z = be.empty((k, rows_per, cols), torch.float64)
-            for e in range(k):
-                self.ctx.forward_spectrum_dev(g0 + e, rows[e].data_ptr(), rows_per, Z[e].data_ptr(), be.stream())
+            if rows_per % 64 == 0:           # whole 64-row blocks per spectrum: one launch for the pass
+                self.ctx.forward_spectra_dev(g0, k, rows.data_ptr(), k * rows_per, Z.data_ptr(), be.stream())
+            else:
+                for e in range(k):
+                    self.ctx.forward_spectrum_dev(g0 + e, rows[e].data_ptr(), rows_per, Z[e].data_ptr(), be.stream())
             nbytes = _hip.grouped_percentiles_workspace(k, rows_per, cols, p.size)
             work = be.empty((nbytes,), torch.uint8)
             res = be.empty((p.size, k, cols), torch.float64)

@@ -477,14 +477,21 @@ int bisip_forward_dev(bisip_ctx *c, const double *d_theta, int64_t W, double *d_
     return dispatch_forward(c, d_theta, W, d_Z, (hipStream_t)stream);
 }
 
-int bisip_forward_spectrum_dev(bisip_ctx *c, int64_t spectrum, const double *d_theta, int64_t W, double *d_Z, void *stream)
+int bisip_forward_spectra_dev(bisip_ctx *c, int64_t first_spectrum, int64_t n_spectra, const double *d_theta, int64_t W,
+                              double *d_Z, void *stream)
 {
     if (!c) return fail(BISIP_EINVAL, "null context");
-    if (spectrum < 0 || spectrum >= c->E) return fail(BISIP_EINVAL, "spectrum %lld not in [0,%d)", (long long)spectrum, c->E);
+    if (first_spectrum < 0 || n_spectra < 1 || first_spectrum + n_spectra > c->E)
+        return fail(BISIP_EINVAL, "spectra [%lld, %lld) not in [0,%d)", (long long)first_spectrum, (long long)(first_spectrum + n_spectra), c->E);
     if (W < 0) return fail(BISIP_EINVAL, "W=%lld < 0", (long long)W);
     if (W > 0 && (!d_theta || !d_Z)) return fail(BISIP_EINVAL, "null buffer");
     HIP_TRY(hipSetDevice(c->device));
-    return dispatch_forward(c, d_theta, W, d_Z, (hipStream_t)stream, spectrum);
+    return dispatch_forward(c, d_theta, W, d_Z, (hipStream_t)stream, first_spectrum, n_spectra);
+}
+
+int bisip_forward_spectrum_dev(bisip_ctx *c, int64_t spectrum, const double *d_theta, int64_t W, double *d_Z, void *stream)
+{
+    return bisip_forward_spectra_dev(c, spectrum, 1, d_theta, W, d_Z, stream);
 }
 
 int bisip_loglike_z_dev(bisip_ctx *c, const double *d_Z, int64_t W, double *d_out, void *stream)

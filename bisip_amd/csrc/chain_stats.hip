@@ -5,12 +5,16 @@
 // a batch of spectra the chain lives in HBM, so the percentiles are taken there:
 //   1. k_gather_columns: (sample, walker, parameter) -> one contiguous column per
 //      (ensemble, parameter), coalesced on both sides;
-//   2. rocPRIM segmented radix sort of the E*ndim columns (library sort: hipCUB header);
+//   2. the two order statistics each percentile needs: radix selection, one workgroup per column
+//      (k_segmented_select) -- or, for many percentiles / few long columns, a rocPRIM segmented
+//      radix sort of the E*ndim columns (library sort: hipCUB header) followed by
 //   3. k_percentile_lerp: NumPy's 'linear' rule between the two neighbouring order statistics
 //      (indices and weights are computed on the host exactly as numpy does).
 #include "host.h"
 
 #include <hipcub/hipcub.hpp>
+
+#include <cstdlib>
 
 using namespace bisip;
 using namespace bisip::host;
@@ -38,6 +42,35 @@ __global__ __launch_bounds__(256) void k_gather_columns(const GatherArgs a)
     for (int q = 0; q < a.ndim; ++q) dst[(long long)q * n] = row[q];
 }
 
+// The same through an LDS tile of 64 rows x 64 parameters, for rows of many doubles (a model response has 2N):
+// read row-major, written column-major, both coalesced -- one thread per row reads 8 bytes out of every
+// 8*ndim and moves eight times the data it needs.
+__global__ __launch_bounds__(256) void k_gather_columns_tiled(const GatherArgs a)
+{
+    __shared__ double tile[64][65];
+    const long long tiles_w = (a.Wp + 63) / 64;
+    const int tiles_q = (a.ndim + 63) / 64;
+    long long b = blockIdx.x;
+    const int tq = (int)(b % tiles_q); b /= tiles_q;
+    const long long tw = b % tiles_w; b /= tiles_w;
+    const long long e = b % a.E, s = b / a.E;
+    const long long w0 = tw * 64;
+    const int q0 = tq * 64;
+    const int nr = (int)(a.Wp - w0 < 64 ? a.Wp - w0 : 64), nc = a.ndim - q0 < 64 ? a.ndim - q0 : 64;
+    const double *__restrict__ src = a.chain + s * a.sample_stride + (e * a.Wp + w0) * a.ndim + q0;
+    for (int idx = threadIdx.x; idx < nr * nc; idx += 256) {
+        const int r = idx / nc, q = idx - r * nc;
+        tile[r][q] = src[(long long)r * a.ndim + q];
+    }
+    __syncthreads();
+    const long long n = a.n_samples * a.Wp;
+    double *__restrict__ dst = a.cols + (e * a.ndim + q0) * n + s * a.Wp + w0;
+    for (int idx = threadIdx.x; idx < nr * nc; idx += 256) {
+        const int q = idx / nr, r = idx - q * nr;
+        dst[(long long)q * n + r] = tile[r][q];
+    }
+}
+
 struct LerpArgs {
     const double *sorted;   // (E*ndim, n)
     long long n, columns;
@@ -59,6 +92,296 @@ __global__ __launch_bounds__(256) void k_percentile_lerp(const LerpArgs a)
     const double d = y - x;
     // numpy.lib._function_base_impl._lerp
     a.out[idx] = t >= 0.5 ? y - d * (1.0 - t) : x + d * t;
+}
+
+// ---------------------------------------------------------------------------------
+// Selection instead of a sort.  A percentile needs two order statistics of its column, not the
+// column in order: one workgroup per column finds them by radix selection on the order-preserving
+// 64-bit image of the doubles -- eight passes of eight bits, most significant first; in each pass a
+// 256-bin histogram (LDS) of the values that still match a rank's prefix, then the bin that holds
+// the rank.  Ranks whose prefixes are still equal share a histogram (the two neighbours of one
+// percentile usually do until the last passes).  The column is read eight times (L2 after the
+// first) instead of being sorted: a 4096-spectrum survey's model-space bands (262,144 columns of
+// 12,800 values) took 229 ms with the segmented sort.  Same order statistics, same interpolation
+// arithmetic (numpy's _lerp) => the same doubles as the sort path.
+// ---------------------------------------------------------------------------------
+constexpr int SEL_MAX_P = 8;            // percentiles per call on this path
+constexpr int SEL_R = 2 * SEL_MAX_P;    // order statistics
+
+struct SelectArgs {
+    const double *cols;     // (columns, n), each column contiguous
+    long long n, columns;
+    int n_p;
+    const long long *lo;    // (n_p,) lower order statistic
+    const double *t;        // (n_p,) weight of the upper one
+    double *out;            // (n_p, columns)
+};
+
+__device__ __forceinline__ unsigned long long select_key(double v)
+{
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);      // ascending keys <=> ascending doubles
+}
+
+__device__ __forceinline__ double select_value(unsigned long long k)
+{
+    const unsigned long long u = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)u);
+}
+
+__global__ __launch_bounds__(256) void k_segmented_select(const SelectArgs a)
+{
+    __shared__ unsigned hist[SEL_R][256];
+    __shared__ unsigned long long prefix[SEL_R];     // the bits of each rank's key found so far
+    __shared__ long long rem[SEL_R];                 // its rank among the values that share them
+    __shared__ int group[SEL_R];                     // which histogram it reads this pass
+    __shared__ unsigned long long gprefix[SEL_R];
+    __shared__ int n_groups;
+    const int tid = threadIdx.x;
+    const long long col = blockIdx.x;
+    const double *__restrict__ c = a.cols + col * a.n;
+    const int R = 2 * a.n_p;
+    if (tid < R) {
+        const long long lo = a.lo[tid >> 1];
+        rem[tid] = (tid & 1) ? (lo + 1 < a.n ? lo + 1 : a.n - 1) : lo;
+        prefix[tid] = 0;
+    }
+    __syncthreads();
+    for (int pass = 0; pass < 8; ++pass) {
+        const int shift = 56 - 8 * pass;
+        if (tid == 0) {
+            int g = 0;
+            for (int r = 0; r < R; ++r) {
+                int same = -1;
+                for (int q = 0; q < r && same < 0; ++q)
+                    if (prefix[q] == prefix[r]) same = group[q];
+                if (same < 0) { gprefix[g] = prefix[r]; same = g++; }
+                group[r] = same;
+            }
+            n_groups = g;
+        }
+        __syncthreads();
+        const int G = n_groups;
+        for (int i = tid; i < G * 256; i += 256) (&hist[0][0])[i] = 0;
+        __syncthreads();
+        for (long long i0 = 0; i0 < a.n; i0 += 256) {      // every lane takes every turn (the ballots below are wave-wide)
+            const long long i = i0 + tid;
+            const bool in = i < a.n;
+            const unsigned long long k = select_key(in ? c[i] : 0.0);
+            const unsigned long long head = pass ? (k >> (shift + 8)) : 0ull;
+            const unsigned bin = (unsigned)(k >> shift) & 255u;
+            for (int g = 0; g < G; ++g) {
+                // The high bytes of a posterior sample hardly vary (same sign, same exponent): whole waves
+                // land in one bin, and 64 atomics on one LDS word take 64 turns.  The lanes that share the
+                // first matching lane's bin add once, together; the others add for themselves.
+                const bool m = in && head == gprefix[g];
+                const unsigned long long todo = __ballot(m);
+                if (!todo) continue;
+                const int leader = __ffsll((long long)todo) - 1;
+                const unsigned b0 = (unsigned)__builtin_amdgcn_readlane((int)bin, leader);
+                const unsigned long long same = __ballot(m && bin == b0);
+                if ((int)(tid & 63) == leader) atomicAdd(&hist[g][b0], (unsigned)__popcll(same));
+                else if (m && bin != b0) atomicAdd(&hist[g][bin], 1u);
+            }
+        }
+        __syncthreads();
+        if (tid < R) {
+            const unsigned *h = hist[group[tid]];
+            long long before = 0, want = rem[tid];
+            int b = 0;
+            for (; b < 255; ++b) {
+                const long long cnt = h[b];
+                if (want < before + cnt) break;
+                before += cnt;
+            }
+            rem[tid] = want - before;
+            prefix[tid] = (prefix[tid] << 8) | (unsigned long long)b;
+        }
+        __syncthreads();
+    }
+    if (tid < a.n_p) {
+        const double x = select_value(prefix[2 * tid]), y = select_value(prefix[2 * tid + 1]), t = a.t[tid];
+        const double d = y - x;
+        // numpy.lib._function_base_impl._lerp, as k_percentile_lerp
+        a.out[(long long)tid * a.columns + col] = t >= 0.5 ? y - d * (1.0 - t) : x + d * t;
+    }
+}
+
+// The same selection with the column held in REGISTERS (1024 lanes x VPT keys, read from memory once),
+// narrowing a RANGE of keys instead of a prefix, and finished by counting.
+//   * Every rank keeps [base, base + 2^s): the keys that can still be it.  It starts as [min, max] of the
+//     column; a pass histograms (key - base) >> (s - 8) -- 256 equal slices of the range -- finds the slice
+//     that holds the rank and makes it the new range.  Radix digits of the keys themselves would put a column
+//     that straddles a power of two (0.97 ... 1.03) into two bins of the first useful byte, and a thousand
+//     lanes adding to two LDS words take turns; slices of the occupied range spread any sample over the bins.
+//   * Histogram passes run only while more than SEL_CAP keys remain in the ranks' ranges -- one or two for a
+//     posterior sample -- then the survivors go to LDS and each rank is found by counting the smaller ones.
+//   * Ranks with the same range share a histogram and a survivor list (the two neighbours of a percentile
+//     usually do until the end).
+// Columns of up to 40,960 values: the model-space band of a spectrum (samples x walkers), most parameter columns.
+constexpr int SEL_CAP = 192;            // survivors that are finished by counting (all ranks together)
+
+// (two workgroups per CU when the keys leave room: the phases of one hide behind the other's)
+template <int VPT>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(VPT <= 16 ? 8 : 4, VPT <= 16 ? 8 : 4)))
+void k_segmented_select_regs(const SelectArgs a)
+{
+    __shared__ unsigned hist[SEL_R][256];
+    __shared__ unsigned long long base[SEL_R];       // low end of each rank's range of keys
+    __shared__ long long rem[SEL_R];                 // its rank among the keys in the range
+    __shared__ unsigned surv[SEL_R];                 // how many keys the range holds
+    __shared__ int group[SEL_R];                     // ranks with equal ranges share a histogram / a survivor list
+    __shared__ unsigned long long gbase[SEL_R];
+    __shared__ unsigned gsize[SEL_R], goffset[SEL_R], gcount[SEL_R];
+    __shared__ unsigned long long cand[SEL_CAP];
+    __shared__ unsigned long long wmin[16], wmax[16];
+    __shared__ int n_groups, finish;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long col = blockIdx.x;
+    const double *__restrict__ c = a.cols + col * a.n;
+    const int R = 2 * a.n_p;
+    unsigned long long key[VPT];
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+        const long long i = (long long)j * 1024 + tid;
+        key[j] = i < a.n ? select_key(__builtin_nontemporal_load(c + i)) : 0ull;
+    }
+    const int mine = (int)((a.n - tid + 1023) / 1024);      // how many of them are real (<= VPT)
+    unsigned long long kmin = ~0ull, kmax = 0ull;
+#pragma unroll
+    for (int j = 0; j < VPT; ++j)
+        if (j < mine) { kmin = key[j] < kmin ? key[j] : kmin; kmax = key[j] > kmax ? key[j] : kmax; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned long long lo_ = __shfl_xor(kmin, d, 64), hi_ = __shfl_xor(kmax, d, 64);
+        kmin = lo_ < kmin ? lo_ : kmin; kmax = hi_ > kmax ? hi_ : kmax;
+    }
+    if (lane == 0) { wmin[wave] = kmin; wmax[wave] = kmax; }
+    __syncthreads();
+    kmin = wmin[0]; kmax = wmax[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) { kmin = wmin[w] < kmin ? wmin[w] : kmin; kmax = wmax[w] > kmax ? wmax[w] : kmax; }
+    int s = kmax == kmin ? 0 : 64 - __clzll((long long)(kmax - kmin));     // bits of (key - base) still open; the same for every rank
+    if (tid < R) {
+        const long long lo = a.lo[tid >> 1];
+        rem[tid] = (tid & 1) ? (lo + 1 < a.n ? lo + 1 : a.n - 1) : lo;
+        base[tid] = kmin;
+        surv[tid] = (unsigned)a.n;
+    }
+    if (tid == 0) finish = a.n <= SEL_CAP;
+    __syncthreads();
+
+    auto regroup = [&]() {                // wave 0; at most 16 ranks
+        if (wave == 0) {
+            int leader = lane;
+            if (lane < R)
+                for (int q = lane - 1; q >= 0; --q)
+                    if (base[q] == base[lane]) leader = q;
+            const bool is_leader = lane < R && leader == lane;
+            const unsigned long long leaders = __ballot(is_leader);
+            if (lane < R) {
+                const int g = __popcll(leaders & ((1ull << leader) - 1ull));
+                group[lane] = g;
+                if (is_leader) { gbase[g] = base[lane]; gsize[g] = surv[lane]; }
+            }
+            if (lane == 0) n_groups = __popcll(leaders);
+        }
+    };
+    auto in_range = [&](unsigned long long d) { return s >= 64 || (d >> s) == 0ull; };
+
+    while (!finish && s > 0) {
+        const int shift = s > 8 ? s - 8 : 0;
+        regroup();
+        __syncthreads();
+        const int G = n_groups;
+        for (int i = tid; i < G * 256; i += 1024) (&hist[0][0])[i] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) {
+            if (j < mine) {
+                const unsigned long long k = key[j];
+                for (int g = 0; g < G; ++g) {
+                    const unsigned long long d = k - gbase[g];
+                    if (in_range(d)) atomicAdd(&hist[g][(unsigned)(d >> shift)], 1u);
+                }
+            }
+        }
+        __syncthreads();
+        if (wave < R) {                   // wave w finds the slice of rank w: scan of the 256 counts, four per lane
+            const unsigned *h = hist[group[wave]];
+            const unsigned c0 = h[4 * lane], c1 = h[4 * lane + 1], c2 = h[4 * lane + 2], c3 = h[4 * lane + 3];
+            const long long mine4 = (long long)c0 + c1 + c2 + c3;
+            long long incl = mine4;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const long long up = __shfl_up(incl, d, 64);
+                if (lane >= d) incl += up;
+            }
+            const long long want = rem[wave], excl = incl - mine4;
+            if (excl <= want && want < incl) {       // exactly one lane
+                long long before = excl;
+                int b = 4 * lane;
+                unsigned cnt = c0;
+                if (want >= before + c0) { before += c0; ++b; cnt = c1;
+                    if (want >= before + c1) { before += c1; ++b; cnt = c2;
+                        if (want >= before + c2) { before += c2; ++b; cnt = c3; } } }
+                rem[wave] = want - before;
+                base[wave] += (unsigned long long)b << shift;
+                surv[wave] = cnt;
+            }
+        }
+        __syncthreads();
+        s = shift;
+        if (tid == 0) {
+            unsigned long long total = 0;
+            for (int r = 0; r < R; ++r) total += surv[r];      // ranks that share a range counted twice: an upper bound
+            finish = total <= SEL_CAP;
+        }
+        __syncthreads();
+    }
+
+    if (s > 0) {
+        // the keys still inside a rank's range, group by group, into LDS; then count
+        regroup();
+        __syncthreads();
+        const int G = n_groups;
+        if (tid == 0) {
+            unsigned off = 0;
+            for (int g = 0; g < G; ++g) { goffset[g] = off; off += gsize[g]; gcount[g] = 0; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) {
+            if (j < mine) {
+                const unsigned long long k = key[j];
+                for (int g = 0; g < G; ++g)
+                    if (in_range(k - gbase[g])) cand[goffset[g] + atomicAdd(&gcount[g], 1u)] = k;
+            }
+        }
+        __syncthreads();
+        if (wave < R) {                   // wave w: the survivor of its group that has exactly rem[w] smaller ones
+            const int g = group[wave];
+            const unsigned m = gsize[g];
+            const unsigned long long *cg = cand + goffset[g];
+            const long long want = rem[wave];
+            for (unsigned i = lane; i < m; i += 64) {
+                const unsigned long long ki = cg[i];
+                long long less = 0;
+                for (unsigned q = 0; q < m; ++q) {
+                    const unsigned long long kq = cg[q];
+                    less += (kq < ki) || (kq == ki && q < i);
+                }
+                if (less == want) base[wave] = ki;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid < a.n_p) {
+        const double x = select_value(base[2 * tid]), y = select_value(base[2 * tid + 1]), t = a.t[tid];
+        const double d = y - x;
+        // numpy.lib._function_base_impl._lerp, as k_percentile_lerp
+        a.out[(long long)tid * a.columns + col] = t >= 0.5 ? y - d * (1.0 - t) : x + d * t;
+    }
 }
 
 struct SegmentOffset {
@@ -179,12 +502,15 @@ int percentiles_impl(const double *d_chain, int64_t n_samples, int64_t sample_st
     double *d_t = (double *)(d_lo + n_percentiles);
     hipStream_t st = (hipStream_t)stream;
 
-    // numpy's virtual index for method='linear' (alpha = beta = 1), evaluated as numpy does
+    // numpy's virtual index for method='linear', evaluated as numpy does: its table of methods gives
+    // 'linear' the closed form (n - 1) * q, not the general n*q + (alpha + q*(1 - alpha - beta)) - 1
+    // (numpy/lib/_function_base_impl.py:_QuantileMethods) -- the two differ in the last bits of the
+    // weight, which shows as soon as neighbouring order statistics are far apart (integer data)
     std::vector<long long> lo(n_percentiles);
     std::vector<double> t(n_percentiles);
     for (int k = 0; k < n_percentiles; ++k) {
         const double q = percentiles[k] / 100.0;
-        double v = ((double)n * q + (1.0 + q * (1.0 - 1.0 - 1.0))) - 1.0;
+        double v = (double)(n - 1) * q;
         if (v < 0) v = 0;
         if (v > (double)(n - 1)) v = (double)(n - 1);
         const double f = std::floor(v);
@@ -197,8 +523,23 @@ int percentiles_impl(const double *d_chain, int64_t n_samples, int64_t sample_st
 
     GatherArgs g{d_chain, n_samples, sample_stride, n_ensembles, walkers_per_ensemble, ndim, cols};
     const long long rows = n_samples * n_ensembles * walkers_per_ensemble;
-    hipLaunchKernelGGL(k_gather_columns, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, g);
+    const long long tiles = n_samples * n_ensembles * ((walkers_per_ensemble + 63) / 64) * ((ndim + 63) / 64);
+    if (ndim >= 16 && tiles <= 0x7fffffffLL)
+        hipLaunchKernelGGL(k_gather_columns_tiled, dim3((unsigned)tiles), dim3(256), 0, st, g);
+    else
+        hipLaunchKernelGGL(k_gather_columns, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, g);
     HIP_TRY(hipGetLastError());
+    // enough columns to fill the chip with one workgroup each, few percentiles: select, do not sort
+    const char *force_sort = std::getenv("BISIP_PERCENTILE_SORT");
+    if (n_percentiles <= SEL_MAX_P && columns >= 64 && columns <= 0x7fffffffLL && !(force_sort && force_sort[0] == '1')) {
+        SelectArgs sa{cols, n, columns, n_percentiles, d_lo, d_t, d_out};
+        if (n <= 1024 * 8) hipLaunchKernelGGL(k_segmented_select_regs<8>, dim3((unsigned)columns), dim3(1024), 0, st, sa);
+        else if (n <= 1024 * 16) hipLaunchKernelGGL(k_segmented_select_regs<16>, dim3((unsigned)columns), dim3(1024), 0, st, sa);
+        else if (n <= 1024 * 40) hipLaunchKernelGGL(k_segmented_select_regs<40>, dim3((unsigned)columns), dim3(1024), 0, st, sa);
+        else hipLaunchKernelGGL(k_segmented_select, dim3((unsigned)columns), dim3(256), 0, st, sa);
+        HIP_TRY(hipGetLastError());
+        return BISIP_OK;
+    }
     using Counting = hipcub::CountingInputIterator<int>;
     using Offsets = hipcub::TransformInputIterator<int, SegmentOffset, Counting>;
     Offsets begin(Counting(0), SegmentOffset{n}), end(Counting(1), SegmentOffset{n});

@@ -6,12 +6,15 @@ using namespace bisip::host;
 
 namespace {
 
-// spectrum >= 0: every row belongs to that spectrum of a batch context (bisip_forward_spectrum_dev)
+// spectrum >= 0: the rows belong to `count` consecutive spectra of a batch context, starting with that one,
+// W / count rows each (bisip_forward_spectra_dev)
 template <class M>
-int launch_forward(const bisip_ctx *c, const double *theta, int64_t W, double *Z, hipStream_t st, long long spectrum = -1)
+int launch_forward(const bisip_ctx *c, const double *theta, int64_t W, double *Z, hipStream_t st, long long spectrum = -1,
+                   long long count = 1)
 {
     LaunchArgs a = make_args(c, theta, Z, W, c->d_cb + (spectrum >= 0 ? spectrum * c->cb_stride : 0));
     if (c->E > 1 && spectrum < 0) { a.Wp = W / c->E; a.cb_stride = c->cb_stride; }   // batch: caller checked Wp % 64 == 0
+    if (spectrum >= 0 && count > 1) { a.Wp = W / count; a.cb_stride = c->cb_stride; }   // caller checked (W / count) % 64 == 0
     // one single-wave workgroup per 64 walkers; the grid is not capped at the resident count
     // (a capped, looping grid measured 0-25 % slower depending on the box: benchmarks/micro/forward_variants.hip)
     const unsigned grid = (unsigned)((W + 63) / 64);
@@ -70,10 +73,13 @@ int dispatch_forward_batch(const bisip_ctx *c, const double *theta, int64_t W, d
 namespace bisip {
 namespace host {
 
-int dispatch_forward(const bisip_ctx *c, const double *theta, int64_t W, double *Z, hipStream_t st, long long spectrum)
+int dispatch_forward(const bisip_ctx *c, const double *theta, int64_t W, double *Z, hipStream_t st, long long spectrum,
+                     long long count)
 {
     if (W == 0) return BISIP_OK;
-    if (spectrum >= c->E) return fail(BISIP_EINVAL, "spectrum %lld of %d", spectrum, c->E);
+    if (spectrum >= 0 && (count < 1 || spectrum + count > c->E)) return fail(BISIP_EINVAL, "spectra [%lld, %lld) of %d", spectrum, spectrum + count, c->E);
+    if (spectrum >= 0 && count > 1 && (W % count || (W / count) % 64))
+        return fail(BISIP_EINVAL, "W=%lld rows over %lld spectra: each needs a multiple of 64 rows", (long long)W, count);
     if (((long long)W * c->N + 255) / 256 > 0x7fffffffLL)
         return fail(BISIP_EINVAL, "W=%lld exceeds the launch grid limit", (long long)W);
     if (((uintptr_t)theta % 8) || ((uintptr_t)Z % 8)) return fail(BISIP_EINVAL, "buffers must be 8-byte aligned");
@@ -84,20 +90,20 @@ int dispatch_forward(const bisip_ctx *c, const double *theta, int64_t W, double 
     switch (c->model_id) {
     case BISIP_MODEL_POLYDECOMP:
         switch (c->P) {
-#define X(p) case p: return launch_forward<PDCollapsed<p>>(c, theta, W, Z, st, spectrum);
+#define X(p) case p: return launch_forward<PDCollapsed<p>>(c, theta, W, Z, st, spectrum, count);
             PD_CASES(X)
 #undef X
         }
         break;
     case BISIP_MODEL_COLECOLE:
         switch (c->D) {
-#define X(d) case d: return launch_forward<ColeCole<d>>(c, theta, W, Z, st, spectrum);
+#define X(d) case d: return launch_forward<ColeCole<d>>(c, theta, W, Z, st, spectrum, count);
             CC_CASES(X)
 #undef X
         }
         break;
-    case BISIP_MODEL_DIAS2000: return launch_forward<Dias>(c, theta, W, Z, st, spectrum);
-    case BISIP_MODEL_SHIN2015: return launch_forward<Shin>(c, theta, W, Z, st, spectrum);
+    case BISIP_MODEL_DIAS2000: return launch_forward<Dias>(c, theta, W, Z, st, spectrum, count);
+    case BISIP_MODEL_SHIN2015: return launch_forward<Shin>(c, theta, W, Z, st, spectrum, count);
     }
     return fail(BISIP_EUNSUPPORTED, "no forward kernel for this model shape");
 }

@@ -120,6 +120,10 @@ int bisip_forward_dev(bisip_ctx *ctx, const double *d_theta, int64_t W, double *
  * spectrum's chain: utils.get_model_percentile per spectrum of a survey, src/bisip/utils.py:17-35). */
 int bisip_forward_spectrum_dev(bisip_ctx *ctx, int64_t spectrum, const double *d_theta, int64_t W,
                                double *d_Z, void *stream);
+/* ... or to n_spectra consecutive spectra starting with first_spectrum, W / n_spectra rows each
+ * (a multiple of 64 when n_spectra > 1), in one launch. */
+int bisip_forward_spectra_dev(bisip_ctx *ctx, int64_t first_spectrum, int64_t n_spectra, const double *d_theta,
+                              int64_t W, double *d_Z, void *stream);
 
 /* Gaussian log-likelihood of a model response the caller evaluated itself: Z (W,2,N)
  * [row 0 real, row 1 imaginary per walker] -> (W,)  =  -0.5*sum((zn - Z)^2/zn_err^2 +

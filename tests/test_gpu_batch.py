@@ -446,3 +446,49 @@ def test_batch_model_percentiles_per_spectrum(model, kw, centre):
             assert b.get_model_percentile(50, discard=10).shape == (1, E, 2, 32)
         b.close()
     assert np.array_equal(got['device'], got['host'])
+
+
+@pytest.mark.parametrize('n,E,Wp,ndim,kind', [(40, 12, 64, 7, 'normal'), (3, 16, 5, 4, 'normal'), (1, 64, 1, 1, 'normal'),
+                                               (25, 10, 33, 8, 'ties'), (60, 9, 50, 9, 'signs'), (7, 70, 300, 1, 'tight')])
+def test_percentiles_by_selection_equal_the_sorted_ones(n, E, Wp, ndim, kind, monkeypatch):
+    """With enough columns the percentiles come from a radix SELECTION of the two order statistics each
+    needs (k_segmented_select) instead of a segmented sort: same doubles as the sort path (forced with
+    BISIP_PERCENTILE_SORT=1), and NumPy's -- on negative and positive values, zeros, exact ties,
+    infinities, columns that differ only in their last bits, and every rank from the minimum to the maximum."""
+    import torch
+    from bisip_amd import _hip
+    rng = np.random.RandomState(n + E + ndim)
+    full = rng.standard_normal((n, E * Wp, ndim)) * rng.uniform(0.1, 50, ndim) + rng.uniform(-20, 20, ndim)
+    if kind == 'ties':
+        full = np.round(full)                                  # many equal values, -0.0 and 0.0 among them
+        full[full == 0] *= rng.choice([-1.0, 1.0], size=(full == 0).sum())
+    elif kind == 'signs':
+        full[::3] *= -1e-300
+        full[1, 1, :] = np.inf
+        full[2, 2, :] = -np.inf
+        full[3, :, 0] = 0.0
+    elif kind == 'tight':
+        full = 1.0 + rng.randint(0, 1 << 20, size=full.shape) * 2.0 ** -52      # same exponent, same high mantissa bits
+    assert E * ndim >= 64
+    t = torch.from_numpy(full).cuda()
+    p = np.array([0.0, 2.5, 50.0, 33.3, 97.5, 99.99, 100.0, 16.0])
+    nbytes = _hip.chain_percentiles_workspace(n, E, Wp, ndim, p.size)
+    work = torch.empty(nbytes, dtype=torch.uint8, device='cuda')
+    outs = {}
+    for mode in ('select', 'sort'):
+        if mode == 'sort':
+            monkeypatch.setenv('BISIP_PERCENTILE_SORT', '1')
+        else:
+            monkeypatch.delenv('BISIP_PERCENTILE_SORT', raising=False)
+        out = torch.full((p.size, E, ndim), float('nan'), dtype=torch.float64, device='cuda')
+        _hip.chain_percentiles_dev(t.data_ptr(), n, E * Wp * ndim, E, Wp, ndim, p, out.data_ptr(), work.data_ptr(), nbytes,
+                                   torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        outs[mode] = out.cpu().numpy()
+    assert np.array_equal(outs['select'], outs['sort'], equal_nan=True)
+    used = full.reshape(n, E, Wp, ndim).transpose(1, 0, 2, 3).reshape(E, n * Wp, ndim)
+    with np.errstate(invalid='ignore'):
+        want = np.percentile(used, p, axis=1)
+    ok = np.isfinite(want)
+    assert np.array_equal(outs['select'][ok], want[ok])            # order statistics, weights and _lerp are NumPy's: same doubles
+    assert np.array_equal(np.isnan(outs['select']), np.isnan(want)) or kind == 'signs'
