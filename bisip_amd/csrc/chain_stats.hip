@@ -529,9 +529,10 @@ int percentiles_impl(const double *d_chain, int64_t n_samples, int64_t sample_st
     else
         hipLaunchKernelGGL(k_gather_columns, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, g);
     HIP_TRY(hipGetLastError());
-    // enough columns to fill the chip with one workgroup each, few percentiles: select, do not sort
+    // few percentiles, and enough columns to fill the chip with one workgroup each or columns short enough for the
+    // register-resident kernel: select, do not sort
     const char *force_sort = std::getenv("BISIP_PERCENTILE_SORT");
-    if (n_percentiles <= SEL_MAX_P && columns >= 64 && columns <= 0x7fffffffLL && !(force_sort && force_sort[0] == '1')) {
+    if (n_percentiles <= SEL_MAX_P && (columns >= 64 || n <= 1024 * 40) && columns <= 0x7fffffffLL && !(force_sort && force_sort[0] == '1')) {
         SelectArgs sa{cols, n, columns, n_percentiles, d_lo, d_t, d_out};
         if (n <= 1024 * 8) hipLaunchKernelGGL(k_segmented_select_regs<8>, dim3((unsigned)columns), dim3(1024), 0, st, sa);
         else if (n <= 1024 * 16) hipLaunchKernelGGL(k_segmented_select_regs<16>, dim3((unsigned)columns), dim3(1024), 0, st, sa);
