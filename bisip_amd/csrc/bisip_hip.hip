@@ -129,6 +129,11 @@ static bool in_prior_host(const double *th, const bisip_ctx *c)
     return true;
 }
 
+// Only the tiers the current variant can run are (re)computed -- the probing is most of what a batch
+// context costs to build, and on well-conditioned designs (every bundled spectrum, the headline shape)
+// the plain tier passes and the compensated one is never looked at: AUTO / REDUCED need tier 0, and
+// tier 1 when tier 0's estimate is too large; REDUCED_COMP needs tier 1.  set_variant and set_bounds come
+// back here.
 static int recenter_reduced(bisip_ctx *c)
 {
     if (c->model_id != BISIP_MODEL_POLYDECOMP || c->reduced.empty()) return BISIP_OK;
@@ -136,6 +141,10 @@ static int recenter_reduced(bisip_ctx *c)
     const size_t red_doubles = (size_t)n * (n + 1) / 2 + 3 * (size_t)n + 1;  // == sizeof(ReducedArgs<P>)/8
     for (int tier = 0; tier < 2; ++tier) {
         bisip_ctx::ReducedTier &T = c->red[tier];
+        const bool wanted = tier == 0 ? (c->variant == BISIP_VARIANT_AUTO || c->variant == BISIP_VARIANT_REDUCED)
+                                      : (c->variant == BISIP_VARIANT_REDUCED_COMP ||
+                                         (c->variant == BISIP_VARIANT_AUTO && !(c->red[0].err <= BISIP_REDUCED_ERR_MAX)));
+        if (T.valid || !wanted) continue;
         const size_t E = c->reduced.size();
         std::vector<double> red(c->E > 1 ? red_doubles * E : 0), est(E);
         // the probing of every spectrum (reduced_center emulates the kernel on ~200 rows per
@@ -163,6 +172,7 @@ static int recenter_reduced(bisip_ctx *c)
         T.err = 0.0;
         for (double v : est)
             if (!(v <= T.err)) T.err = v;
+        T.valid = true;
         if (c->E > 1) {
             if (red.size() != red_doubles * (size_t)c->E) return fail(BISIP_EHIP, "internal: reduced operand size mismatch");
             HIP_TRY(hipSetDevice(c->device));
@@ -419,6 +429,7 @@ int bisip_ctx_set_bounds(bisip_ctx *c, const double *lo, const double *hi)
     for (int q = 0; q < c->ndim; ++q) same = same && c->bounds.lo[q] == lo[q] && c->bounds.hi[q] == hi[q];
     if (same) return BISIP_OK;
     for (int q = 0; q < c->ndim; ++q) { c->bounds.lo[q] = lo[q]; c->bounds.hi[q] = hi[q]; }
+    for (auto &t : c->red) { t.valid = false; t.err = INFINITY; }     // estimates and expansion points belong to the old box
     const int rc = guarded([&] { return recenter_reduced(c); });   // the reduced form expands about a point of the box
     c->kernel_name = name_for(c);                                  // AUTO may change formulation with the box
     return rc;
@@ -439,8 +450,9 @@ int bisip_ctx_set_variant(bisip_ctx *c, int variant)
     if (variant == BISIP_VARIANT_FAITHFUL && !c->d_cb_faithful)
         return fail(BISIP_EUNSUPPORTED, "faithful variant needs poly_deg <= 7");
     c->variant = variant;
+    const int rc = guarded([&] { return recenter_reduced(c); });   // a tier this variant needs may not have been estimated yet
     c->kernel_name = name_for(c);
-    return BISIP_OK;
+    return rc;
 }
 
 int bisip_ctx_get_variant(const bisip_ctx *c) { return c ? effective_variant(c) : BISIP_EINVAL; }

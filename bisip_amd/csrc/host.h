@@ -57,7 +57,8 @@ struct bisip_ctx {
     // logprob_row_reduced<P, COMP>); each has its own expansion point
     struct ReducedTier {
         std::vector<double> bhat, evec, elo;   // spectrum 0, for the kernarg segment
-        double err = 0.0;                       // worst estimated relative log-prob error (all spectra)
+        double err = INFINITY;                  // worst estimated relative log-prob error (all spectra); INFINITY: not estimated
+        bool valid = false;                     // estimated for the current prior box
         void *d_red = nullptr;                  // (E,) ReducedArgs<P>  batch only
     };
     ReducedTier red[2];
