@@ -410,18 +410,20 @@ def test_bulk_batch_logprob_streams_like_the_single_spectrum_kernel(variant):
     batch.close()
 
 
-@pytest.mark.parametrize('model,kw,centre', [
-    ('PeltonColeCole', dict(n_modes=2), [1.0, 0.15, 0.5, -1.5, -12.0, 0.45, 0.6]),
-    ('PolynomialDecomposition', dict(poly_deg=4), [1.0, 0.005, -0.003, -0.001, 0.0005, 0.0002]),
+@pytest.mark.parametrize('model,kw,centre,Wp', [
+    ('PeltonColeCole', dict(n_modes=2), [1.0, 0.15, 0.5, -1.5, -12.0, 0.45, 0.6], 48),       # one forward launch per spectrum
+    ('PolynomialDecomposition', dict(poly_deg=4), [1.0, 0.005, -0.003, -0.001, 0.0005, 0.0002], 48),
+    ('PeltonColeCole', dict(n_modes=2), [1.0, 0.15, 0.5, -1.5, -12.0, 0.45, 0.6], 64),       # whole 64-row blocks: one launch per pass
+    ('Dias2000', {}, [1.0, 0.5, -8.0, 10.0, 0.5], 128),
 ])
-def test_batch_model_percentiles_per_spectrum(model, kw, centre):
+def test_batch_model_percentiles_per_spectrum(model, kw, centre, Wp):
     """SpectraBatch.get_model_percentile: per spectrum, np.percentile over axis 0 of the model response
     over that spectrum's flattened chain (the reference's get_model_percentile, src/bisip/utils.py:17-35,
     which a survey would call file by file) -- computed spectrum by spectrum on the device, the same
     from a chain kept in HBM and from one copied to the host."""
     import bisip_amd
     from bisip_amd import _hip
-    E, Wp = 5, 48
+    E = 5
     tables = _tables(E)
     p0 = np.asarray(centre) + 1e-4 * np.random.RandomState(1).randn(E, Wp, len(centre))
     got = {}
@@ -435,7 +437,7 @@ def test_batch_model_percentiles_per_spectrum(model, kw, centre):
             okw = dict(kw)
             if model == 'PolynomialDecomposition':
                 okw = dict(poly_deg=b.poly_deg, c_exp=b.c_exp, taus=b.taus, log_taus=b.log_taus)
-            mid = {'PolynomialDecomposition': 0, 'PeltonColeCole': 1}[model]
+            mid = {'PolynomialDecomposition': 0, 'PeltonColeCole': 1, 'Dias2000': 2}[model]
             for e in range(E):
                 single = _hip.HipContext(mid, b.w[e], b.zn[e], b.zn_err[e], b.param_bounds, **okw)
                 want = np.percentile(single.forward(flat[e]), [2.5, 50, 97.5], axis=0)
@@ -446,6 +448,32 @@ def test_batch_model_percentiles_per_spectrum(model, kw, centre):
             assert b.get_model_percentile(50, discard=10).shape == (1, E, 2, 32)
         b.close()
     assert np.array_equal(got['device'], got['host'])
+
+
+def test_forward_over_a_range_of_spectra():
+    """bisip_forward_spectra_dev: rows of n consecutive spectra of a batch context in one launch -- each spectrum's
+    block is what a context of that spectrum alone computes; ranges and ragged row counts are checked."""
+    import torch
+    import bisip_amd
+    from bisip_amd import _hip
+    E, rows = 6, 128
+    b = bisip_amd.SpectraBatch('PeltonColeCole', _tables(E), nwalkers=64, n_modes=1)
+    lo, hi = b.param_bounds
+    th = torch.from_numpy(np.random.RandomState(2).uniform(lo, hi, (3, rows, lo.size))).cuda()
+    Z = torch.empty((3, rows, 2, 32), dtype=torch.float64, device='cuda')
+    st = torch.cuda.current_stream().cuda_stream
+    b.ctx.forward_spectra_dev(2, 3, th.data_ptr(), 3 * rows, Z.data_ptr(), st)          # spectra 2, 3, 4
+    torch.cuda.synchronize()
+    for k, e in enumerate((2, 3, 4)):
+        single = _hip.HipContext(1, b.w[e], b.zn[e], b.zn_err[e], b.param_bounds, n_modes=1)
+        assert np.array_equal(single.forward(th[k].cpu().numpy()), Z[k].cpu().numpy())
+        single.close()
+    for first, count, W in ((4, 3, 3 * rows), (-1, 1, rows), (0, 0, rows), (0, 2, 2 * rows - 2), (0, 2, 2 * 100)):
+        with pytest.raises(ValueError):
+            b.ctx.forward_spectra_dev(first, count, th.data_ptr(), W, Z.data_ptr(), st)
+    b.ctx.forward_spectrum_dev(5, th.data_ptr(), 100, Z.data_ptr(), st)                  # one spectrum: any row count
+    torch.cuda.synchronize()
+    b.close()
 
 
 @pytest.mark.parametrize('n,E,Wp,ndim,kind', [(40, 12, 64, 7, 'normal'), (3, 16, 5, 4, 'normal'), (1, 64, 1, 1, 'normal'),
