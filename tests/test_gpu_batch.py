@@ -477,7 +477,9 @@ def test_forward_over_a_range_of_spectra():
 
 
 @pytest.mark.parametrize('n,E,Wp,ndim,kind', [(40, 12, 64, 7, 'normal'), (3, 16, 5, 4, 'normal'), (1, 64, 1, 1, 'normal'),
-                                               (25, 10, 33, 8, 'ties'), (60, 9, 50, 9, 'signs'), (7, 70, 300, 1, 'tight')])
+                                               (25, 10, 33, 8, 'ties'), (60, 9, 50, 9, 'signs'), (7, 70, 300, 1, 'tight'),
+                                               # columns of more than 40,960 values select from memory, not from registers
+                                               (700, 10, 64, 7, 'normal'), (650, 64, 70, 1, 'tight'), (41, 8, 1000, 8, 'signs')])
 def test_percentiles_by_selection_equal_the_sorted_ones(n, E, Wp, ndim, kind, monkeypatch):
     """With enough columns the percentiles come from a radix SELECTION of the two order statistics each
     needs (k_segmented_select) instead of a segmented sort: same doubles as the sort path (forced with
