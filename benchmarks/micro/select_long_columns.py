@@ -4,7 +4,7 @@ segmented sort: parameter percentiles of a 512 x 256 x 250-sample chain, and 448
 import os, sys, time, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from bisip_amd import _hip
-for (G, n, cols, centre) in ((512, 64000, 7, 1.0), (512, 64000, 7, 0.3), (64, 500000, 7, 1.0)):
+for (G, n, cols, centre) in ((512, 64000, 7, 1.0), (512, 64000, 7, 0.3), (64, 500000, 7, 1.0), (1, 4000000, 7, 1.0), (1, 30000000, 7, 1.0), (1, 2000000, 40, 1.0)):
     x = centre + 0.01 * torch.randn(G, n, cols, dtype=torch.float64, device='cuda')
     p = np.array([2.5, 50, 97.5])
     nb = _hip.grouped_percentiles_workspace(G, n, cols, 3)

@@ -96,13 +96,9 @@ __global__ __launch_bounds__(256) void k_percentile_lerp(const LerpArgs a)
 
 // ---------------------------------------------------------------------------------
 // Selection instead of a sort.  A percentile needs two order statistics of its column, not the
-// column in order: one workgroup per column finds them by radix selection on the order-preserving
-// 64-bit image of the doubles -- eight passes of eight bits, most significant first; in each pass a
-// 256-bin histogram (LDS) of the values that still match a rank's prefix, then the bin that holds
-// the rank.  Ranks whose prefixes are still equal share a histogram (the two neighbours of one
-// percentile usually do until the last passes).  The column is read eight times (L2 after the
-// first) instead of being sorted: a 4096-spectrum survey's model-space bands (262,144 columns of
-// 12,800 values) took 229 ms with the segmented sort.  Same order statistics, same interpolation
+// column in order: one workgroup per column finds them on the order-preserving 64-bit image of the
+// doubles (k_segmented_select below).  A 4096-spectrum survey's model-space bands (262,144 columns
+// of 12,800 values) took 229 ms with the segmented sort.  Same order statistics, same interpolation
 // arithmetic (numpy's _lerp) => the same doubles as the sort path.
 // ---------------------------------------------------------------------------------
 constexpr int SEL_MAX_P = 8;            // percentiles per call on this path
@@ -129,86 +125,9 @@ __device__ __forceinline__ double select_value(unsigned long long k)
     return __longlong_as_double((long long)u);
 }
 
-__global__ __launch_bounds__(256) void k_segmented_select(const SelectArgs a)
-{
-    __shared__ unsigned hist[SEL_R][256];
-    __shared__ unsigned long long prefix[SEL_R];     // the bits of each rank's key found so far
-    __shared__ long long rem[SEL_R];                 // its rank among the values that share them
-    __shared__ int group[SEL_R];                     // which histogram it reads this pass
-    __shared__ unsigned long long gprefix[SEL_R];
-    __shared__ int n_groups;
-    const int tid = threadIdx.x;
-    const long long col = blockIdx.x;
-    const double *__restrict__ c = a.cols + col * a.n;
-    const int R = 2 * a.n_p;
-    if (tid < R) {
-        const long long lo = a.lo[tid >> 1];
-        rem[tid] = (tid & 1) ? (lo + 1 < a.n ? lo + 1 : a.n - 1) : lo;
-        prefix[tid] = 0;
-    }
-    __syncthreads();
-    for (int pass = 0; pass < 8; ++pass) {
-        const int shift = 56 - 8 * pass;
-        if (tid == 0) {
-            int g = 0;
-            for (int r = 0; r < R; ++r) {
-                int same = -1;
-                for (int q = 0; q < r && same < 0; ++q)
-                    if (prefix[q] == prefix[r]) same = group[q];
-                if (same < 0) { gprefix[g] = prefix[r]; same = g++; }
-                group[r] = same;
-            }
-            n_groups = g;
-        }
-        __syncthreads();
-        const int G = n_groups;
-        for (int i = tid; i < G * 256; i += 256) (&hist[0][0])[i] = 0;
-        __syncthreads();
-        for (long long i0 = 0; i0 < a.n; i0 += 256) {      // every lane takes every turn (the ballots below are wave-wide)
-            const long long i = i0 + tid;
-            const bool in = i < a.n;
-            const unsigned long long k = select_key(in ? c[i] : 0.0);
-            const unsigned long long head = pass ? (k >> (shift + 8)) : 0ull;
-            const unsigned bin = (unsigned)(k >> shift) & 255u;
-            for (int g = 0; g < G; ++g) {
-                // The high bytes of a posterior sample hardly vary (same sign, same exponent): whole waves
-                // land in one bin, and 64 atomics on one LDS word take 64 turns.  The lanes that share the
-                // first matching lane's bin add once, together; the others add for themselves.
-                const bool m = in && head == gprefix[g];
-                const unsigned long long todo = __ballot(m);
-                if (!todo) continue;
-                const int leader = __ffsll((long long)todo) - 1;
-                const unsigned b0 = (unsigned)__builtin_amdgcn_readlane((int)bin, leader);
-                const unsigned long long same = __ballot(m && bin == b0);
-                if ((int)(tid & 63) == leader) atomicAdd(&hist[g][b0], (unsigned)__popcll(same));
-                else if (m && bin != b0) atomicAdd(&hist[g][bin], 1u);
-            }
-        }
-        __syncthreads();
-        if (tid < R) {
-            const unsigned *h = hist[group[tid]];
-            long long before = 0, want = rem[tid];
-            int b = 0;
-            for (; b < 255; ++b) {
-                const long long cnt = h[b];
-                if (want < before + cnt) break;
-                before += cnt;
-            }
-            rem[tid] = want - before;
-            prefix[tid] = (prefix[tid] << 8) | (unsigned long long)b;
-        }
-        __syncthreads();
-    }
-    if (tid < a.n_p) {
-        const double x = select_value(prefix[2 * tid]), y = select_value(prefix[2 * tid + 1]), t = a.t[tid];
-        const double d = y - x;
-        // numpy.lib._function_base_impl._lerp, as k_percentile_lerp
-        a.out[(long long)tid * a.columns + col] = t >= 0.5 ? y - d * (1.0 - t) : x + d * t;
-    }
-}
-
-// The same selection with the column held in REGISTERS (1024 lanes x VPT keys, read from memory once),
-// narrowing a RANGE of keys instead of a prefix, and finished by counting.
+// One 1024-lane workgroup per column, narrowing a RANGE of keys and finishing by counting.  VPT > 0: the
+// column is held in REGISTERS (VPT keys per lane, read from memory once); VPT = 0: longer columns are re-read
+// from memory in each of the three or four sweeps (min/max, one or two histograms, the survivors).
 //   * Every rank keeps [base, base + 2^s): the keys that can still be it.  It starts as [min, max] of the
 //     column; a pass histograms (key - base) >> (s - 8) -- 256 equal slices of the range -- finds the slice
 //     that holds the rank and makes it the new range.  Radix digits of the keys themselves would put a column
@@ -218,13 +137,14 @@ __global__ __launch_bounds__(256) void k_segmented_select(const SelectArgs a)
 //     posterior sample -- then the survivors go to LDS and each rank is found by counting the smaller ones.
 //   * Ranks with the same range share a histogram and a survivor list (the two neighbours of a percentile
 //     usually do until the end).
-// Columns of up to 40,960 values: the model-space band of a spectrum (samples x walkers), most parameter columns.
+// Register form: columns of up to 40,960 values -- the model-space band of a spectrum (samples x walkers), most
+// parameter columns.
 constexpr int SEL_CAP = 192;            // survivors that are finished by counting (all ranks together)
 
 // (two workgroups per CU when the keys leave room: the phases of one hide behind the other's)
 template <int VPT>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(VPT <= 16 ? 8 : 4, VPT <= 16 ? 8 : 4)))
-void k_segmented_select_regs(const SelectArgs a)
+void k_segmented_select(const SelectArgs a)
 {
     __shared__ unsigned hist[SEL_R][256];
     __shared__ unsigned long long base[SEL_R];       // low end of each rank's range of keys
@@ -240,17 +160,30 @@ void k_segmented_select_regs(const SelectArgs a)
     const long long col = blockIdx.x;
     const double *__restrict__ c = a.cols + col * a.n;
     const int R = 2 * a.n_p;
-    unsigned long long key[VPT];
+    unsigned long long key[VPT > 0 ? VPT : 1];
 #pragma unroll
     for (int j = 0; j < VPT; ++j) {
         const long long i = (long long)j * 1024 + tid;
         key[j] = i < a.n ? select_key(__builtin_nontemporal_load(c + i)) : 0ull;
     }
     const int mine = (int)((a.n - tid + 1023) / 1024);      // how many of them are real (<= VPT)
-    unsigned long long kmin = ~0ull, kmax = 0ull;
+    // f(key) for every key of the column this lane is responsible for
+    auto for_each_key = [&](auto &&f) {
+        if constexpr (VPT > 0) {
 #pragma unroll
-    for (int j = 0; j < VPT; ++j)
-        if (j < mine) { kmin = key[j] < kmin ? key[j] : kmin; kmax = key[j] > kmax ? key[j] : kmax; }
+            for (int j = 0; j < VPT; ++j)
+                if (j < mine) f(key[j]);
+        } else {
+            long long i = tid;
+            for (; i + 3 * 1024 < a.n; i += 4 * 1024) {       // four loads in flight per lane
+                const double v0 = c[i], v1 = c[i + 1024], v2 = c[i + 2048], v3 = c[i + 3072];
+                f(select_key(v0)); f(select_key(v1)); f(select_key(v2)); f(select_key(v3));
+            }
+            for (; i < a.n; i += 1024) f(select_key(c[i]));
+        }
+    };
+    unsigned long long kmin = ~0ull, kmax = 0ull;
+    for_each_key([&](unsigned long long k) { kmin = k < kmin ? k : kmin; kmax = k > kmax ? k : kmax; });
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         const unsigned long long lo_ = __shfl_xor(kmin, d, 64), hi_ = __shfl_xor(kmax, d, 64);
@@ -296,16 +229,12 @@ void k_segmented_select_regs(const SelectArgs a)
         const int G = n_groups;
         for (int i = tid; i < G * 256; i += 1024) (&hist[0][0])[i] = 0;
         __syncthreads();
-#pragma unroll
-        for (int j = 0; j < VPT; ++j) {
-            if (j < mine) {
-                const unsigned long long k = key[j];
-                for (int g = 0; g < G; ++g) {
-                    const unsigned long long d = k - gbase[g];
-                    if (in_range(d)) atomicAdd(&hist[g][(unsigned)(d >> shift)], 1u);
-                }
+        for_each_key([&](unsigned long long k) {
+            for (int g = 0; g < G; ++g) {
+                const unsigned long long d = k - gbase[g];
+                if (in_range(d)) atomicAdd(&hist[g][(unsigned)(d >> shift)], 1u);
             }
-        }
+        });
         __syncthreads();
         if (wave < R) {                   // wave w finds the slice of rank w: scan of the 256 counts, four per lane
             const unsigned *h = hist[group[wave]];
@@ -350,14 +279,10 @@ void k_segmented_select_regs(const SelectArgs a)
             for (int g = 0; g < G; ++g) { goffset[g] = off; off += gsize[g]; gcount[g] = 0; }
         }
         __syncthreads();
-#pragma unroll
-        for (int j = 0; j < VPT; ++j) {
-            if (j < mine) {
-                const unsigned long long k = key[j];
-                for (int g = 0; g < G; ++g)
-                    if (in_range(k - gbase[g])) cand[goffset[g] + atomicAdd(&gcount[g], 1u)] = k;
-            }
-        }
+        for_each_key([&](unsigned long long k) {
+            for (int g = 0; g < G; ++g)
+                if (in_range(k - gbase[g])) cand[goffset[g] + atomicAdd(&gcount[g], 1u)] = k;
+        });
         __syncthreads();
         if (wave < R) {                   // wave w: the survivor of its group that has exactly rem[w] smaller ones
             const int g = group[wave];
@@ -529,15 +454,15 @@ int percentiles_impl(const double *d_chain, int64_t n_samples, int64_t sample_st
     else
         hipLaunchKernelGGL(k_gather_columns, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, g);
     HIP_TRY(hipGetLastError());
-    // few percentiles, and enough columns to fill the chip with one workgroup each or columns short enough for the
-    // register-resident kernel: select, do not sort
+    // few percentiles: select, do not sort (one workgroup per column; even a handful of very long columns beats
+    // sorting them: benchmarks/micro/select_long_columns.py)
     const char *force_sort = std::getenv("BISIP_PERCENTILE_SORT");
-    if (n_percentiles <= SEL_MAX_P && (columns >= 64 || n <= 1024 * 40) && columns <= 0x7fffffffLL && !(force_sort && force_sort[0] == '1')) {
+    if (n_percentiles <= SEL_MAX_P && columns <= 0x7fffffffLL && !(force_sort && force_sort[0] == '1')) {
         SelectArgs sa{cols, n, columns, n_percentiles, d_lo, d_t, d_out};
-        if (n <= 1024 * 8) hipLaunchKernelGGL(k_segmented_select_regs<8>, dim3((unsigned)columns), dim3(1024), 0, st, sa);
-        else if (n <= 1024 * 16) hipLaunchKernelGGL(k_segmented_select_regs<16>, dim3((unsigned)columns), dim3(1024), 0, st, sa);
-        else if (n <= 1024 * 40) hipLaunchKernelGGL(k_segmented_select_regs<40>, dim3((unsigned)columns), dim3(1024), 0, st, sa);
-        else hipLaunchKernelGGL(k_segmented_select, dim3((unsigned)columns), dim3(256), 0, st, sa);
+        if (n <= 1024 * 8) hipLaunchKernelGGL(k_segmented_select<8>, dim3((unsigned)columns), dim3(1024), 0, st, sa);
+        else if (n <= 1024 * 16) hipLaunchKernelGGL(k_segmented_select<16>, dim3((unsigned)columns), dim3(1024), 0, st, sa);
+        else if (n <= 1024 * 40) hipLaunchKernelGGL(k_segmented_select<40>, dim3((unsigned)columns), dim3(1024), 0, st, sa);
+        else hipLaunchKernelGGL(k_segmented_select<0>, dim3((unsigned)columns), dim3(1024), 0, st, sa);
         HIP_TRY(hipGetLastError());
         return BISIP_OK;
     }
