@@ -76,6 +76,7 @@ if [ "$what" = micro ] || [ "$what" = all ]; then
   CFG5_ENV="A=1" bash benchmarks/micro/cfg5_pmc.sh > "$out/micro_cfg5_pmc.txt" 2>&1
   bash benchmarks/micro/batch_pd_pmc.sh > "$out/micro_batch_pd_pmc.txt" 2>&1
   python3 benchmarks/micro/batch_logprob_rate.py 2>/dev/null > "$out/micro_batch_logprob_rate.txt"
+  python3 benchmarks/micro/model_percentile_single.py 2>/dev/null > "$out/micro_model_percentile_single.txt"
   python3 benchmarks/micro/select_vs_sort.py 2>/dev/null > "$out/micro_select_vs_sort.txt"
   python3 benchmarks/micro/select_long_columns.py 2>/dev/null >> "$out/micro_select_vs_sort.txt"
   python3 benchmarks/micro/persistent_crossover.py 2>/dev/null | grep "it/s" > "$out/micro_persistent_crossover.txt"

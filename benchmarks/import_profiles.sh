@@ -26,7 +26,7 @@ for f in cfg4_fused_device_chain cfg4_sharded_python cfg4_sharded_rccl-own cfg4_
 done
 cpy "$(newest $src/prof_cfg5/runc kernel_stats.csv)"    $dst/${tag}_cfg5_kernel_stats.csv
 cpy "$(newest $src/prof_batch_models/runc kernel_stats.csv)" $dst/${tag}_batch_models_kernel_stats.csv
-for m in issue_latency row_latency half_step_phases forward_rows_variants grid_barrier post_run_stall cfg5_pmc batch_pd_pmc batch_logprob_rate select_vs_sort persistent_crossover; do
+for m in issue_latency row_latency half_step_phases forward_rows_variants grid_barrier post_run_stall cfg5_pmc batch_pd_pmc batch_logprob_rate select_vs_sort model_percentile_single persistent_crossover; do
   cpy $src/micro_$m.txt $dst/${tag}_micro_$m.txt
 done
 python3 benchmarks/summarize_pmc.py $src $dst $tag

@@ -251,6 +251,7 @@ FILES = [
     (f'{ROUND}_micro_batch_pd_pmc.txt', '`bash benchmarks/micro/batch_pd_pmc.sh`', 'SQ counters of the persistent kernel on a PolynomialDecomposition batch, per wave (divide by the half-steps of a launch)'),
     (f'{ROUND}_micro_batch_logprob_rate.txt', '`python benchmarks/micro/batch_logprob_rate.py`', 'bulk log-probability of a 512-spectrum batch, every model: the single-spectrum kernels\' rates'),
     (f'{ROUND}_micro_select_vs_sort.txt', '`python benchmarks/micro/select_vs_sort.py`', 'percentiles of 131,072 columns by radix selection and by the segmented sort: time, and that the doubles are the same'),
+    (f'{ROUND}_micro_model_percentile_single.txt', '`python benchmarks/micro/model_percentile_single.py`', 'get_model_percentile of one model over a 160,000-row chain: the device call against forward + np.percentile'),
     (f'{ROUND}_micro_forward_rows_variants.txt', '`benchmarks/micro/forward_rows_variants`', 'output path of the batched forward kernels (whole rows at N = 20, 16-frequency tiles at N = 32 / 64)'),
     (f'{ROUND}_micro_persistent_crossover.txt', '`python benchmarks/micro/persistent_crossover.py`', 'persistent kernel vs launch per half-step by ensemble size and model: the automatic rule'),
     (f'{ROUND}_micro_grid_barrier.txt', '`benchmarks/micro/grid_barrier`', 'cost of a device-wide barrier (with and without a row exchange) for 64 / 128 / 256 workgroups'),
