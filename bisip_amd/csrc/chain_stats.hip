@@ -108,9 +108,9 @@ struct SelectArgs {
     const double *cols;     // (columns, n), each column contiguous
     long long n, columns;
     int n_p;
-    const long long *lo;    // (n_p,) lower order statistic
-    const double *t;        // (n_p,) weight of the upper one
-    double *out;            // (n_p, columns)
+    long long lo[SEL_MAX_P];   // lower order statistic of each percentile (in the kernarg segment: no upload, no wait)
+    double t[SEL_MAX_P];       // weight of the upper one
+    double *out;               // (n_p, columns)
 };
 
 __device__ __forceinline__ unsigned long long select_key(double v)
@@ -442,10 +442,6 @@ int percentiles_impl(const double *d_chain, int64_t n_samples, int64_t sample_st
         lo[k] = (long long)f;
         t[k] = v - f;
     }
-    HIP_TRY(hipMemcpyAsync(d_lo, lo.data(), sizeof(long long) * n_percentiles, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(d_t, t.data(), sizeof(double) * n_percentiles, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipStreamSynchronize(st));   // lo / t are stack-lifetime host buffers
-
     GatherArgs g{d_chain, n_samples, sample_stride, n_ensembles, walkers_per_ensemble, ndim, cols};
     const long long rows = n_samples * n_ensembles * walkers_per_ensemble;
     const long long tiles = n_samples * n_ensembles * ((walkers_per_ensemble + 63) / 64) * ((ndim + 63) / 64);
@@ -458,7 +454,9 @@ int percentiles_impl(const double *d_chain, int64_t n_samples, int64_t sample_st
     // sorting them: benchmarks/micro/select_long_columns.py)
     const char *force_sort = std::getenv("BISIP_PERCENTILE_SORT");
     if (n_percentiles <= SEL_MAX_P && columns <= 0x7fffffffLL && !(force_sort && force_sort[0] == '1')) {
-        SelectArgs sa{cols, n, columns, n_percentiles, d_lo, d_t, d_out};
+        SelectArgs sa{};
+        sa.cols = cols; sa.n = n; sa.columns = columns; sa.n_p = n_percentiles; sa.out = d_out;
+        for (int k = 0; k < n_percentiles; ++k) { sa.lo[k] = lo[k]; sa.t[k] = t[k]; }
         if (n <= 1024 * 8) hipLaunchKernelGGL(k_segmented_select<8>, dim3((unsigned)columns), dim3(1024), 0, st, sa);
         else if (n <= 1024 * 16) hipLaunchKernelGGL(k_segmented_select<16>, dim3((unsigned)columns), dim3(1024), 0, st, sa);
         else if (n <= 1024 * 40) hipLaunchKernelGGL(k_segmented_select<40>, dim3((unsigned)columns), dim3(1024), 0, st, sa);
@@ -466,6 +464,10 @@ int percentiles_impl(const double *d_chain, int64_t n_samples, int64_t sample_st
         HIP_TRY(hipGetLastError());
         return BISIP_OK;
     }
+    HIP_TRY(hipMemcpyAsync(d_lo, lo.data(), sizeof(long long) * n_percentiles, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_t, t.data(), sizeof(double) * n_percentiles, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));   // lo / t are stack-lifetime host buffers
+
     using Counting = hipcub::CountingInputIterator<int>;
     using Offsets = hipcub::TransformInputIterator<int, SegmentOffset, Counting>;
     Offsets begin(Counting(0), SegmentOffset{n}), end(Counting(1), SegmentOffset{n});
