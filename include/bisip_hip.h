@@ -278,7 +278,9 @@ int bisip_chain_moments_dev(const double *d_chain, int64_t n_samples, int64_t sa
  * (n_percentiles,) in [0, 100].  d_out: (n_percentiles, n_ensembles, ndim).  d_work:
  * bisip_chain_percentiles_workspace() BYTES of device memory (two column-major copies of the
  * used samples + the sort's scratch; 0 is returned for a shape that is not supported:
- * more than 2^31 values).  Asynchronous on stream after a short synchronous upload. */
+ * more than 2^31 values).  At most 8 percentiles per call are found by selecting the order statistics they
+ * need (asynchronous on stream), more by sorting the columns (after a short synchronous upload); the doubles
+ * are numpy.percentile's either way. */
 int64_t bisip_chain_percentiles_workspace(int64_t n_samples, int64_t n_ensembles,
                                           int64_t walkers_per_ensemble, int ndim, int n_percentiles);
 int bisip_chain_percentiles_dev(const double *d_chain, int64_t n_samples, int64_t sample_stride,
