@@ -450,18 +450,23 @@ int percentiles_impl(const double *d_chain, int64_t n_samples, int64_t sample_st
     else
         hipLaunchKernelGGL(k_gather_columns, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, g);
     HIP_TRY(hipGetLastError());
-    // few percentiles: select, do not sort (one workgroup per column; even a handful of very long columns beats
-    // sorting them: benchmarks/micro/select_long_columns.py)
+    // Select, do not sort: up to SEL_MAX_P percentiles per launch, one workgroup per column.  More percentiles
+    // than that go through in groups when the columns are few (a handful of very long columns is where the
+    // segmented sort is at its worst: benchmarks/micro/select_long_columns.py); with many columns AND many
+    // percentiles one sort serves them all.
     const char *force_sort = std::getenv("BISIP_PERCENTILE_SORT");
-    if (n_percentiles <= SEL_MAX_P && columns <= 0x7fffffffLL && !(force_sort && force_sort[0] == '1')) {
-        SelectArgs sa{};
-        sa.cols = cols; sa.n = n; sa.columns = columns; sa.n_p = n_percentiles; sa.out = d_out;
-        for (int k = 0; k < n_percentiles; ++k) { sa.lo[k] = lo[k]; sa.t[k] = t[k]; }
-        if (n <= 1024 * 8) hipLaunchKernelGGL(k_segmented_select<8>, dim3((unsigned)columns), dim3(1024), 0, st, sa);
-        else if (n <= 1024 * 16) hipLaunchKernelGGL(k_segmented_select<16>, dim3((unsigned)columns), dim3(1024), 0, st, sa);
-        else if (n <= 1024 * 40) hipLaunchKernelGGL(k_segmented_select<40>, dim3((unsigned)columns), dim3(1024), 0, st, sa);
-        else hipLaunchKernelGGL(k_segmented_select<0>, dim3((unsigned)columns), dim3(1024), 0, st, sa);
-        HIP_TRY(hipGetLastError());
+    if ((n_percentiles <= SEL_MAX_P || columns < 64) && columns <= 0x7fffffffLL && !(force_sort && force_sort[0] == '1')) {
+        for (int k0 = 0; k0 < n_percentiles; k0 += SEL_MAX_P) {
+            SelectArgs sa{};
+            sa.cols = cols; sa.n = n; sa.columns = columns; sa.out = d_out + (long long)k0 * columns;
+            sa.n_p = n_percentiles - k0 < SEL_MAX_P ? n_percentiles - k0 : SEL_MAX_P;
+            for (int k = 0; k < sa.n_p; ++k) { sa.lo[k] = lo[k0 + k]; sa.t[k] = t[k0 + k]; }
+            if (n <= 1024 * 8) hipLaunchKernelGGL(k_segmented_select<8>, dim3((unsigned)columns), dim3(1024), 0, st, sa);
+            else if (n <= 1024 * 16) hipLaunchKernelGGL(k_segmented_select<16>, dim3((unsigned)columns), dim3(1024), 0, st, sa);
+            else if (n <= 1024 * 40) hipLaunchKernelGGL(k_segmented_select<40>, dim3((unsigned)columns), dim3(1024), 0, st, sa);
+            else hipLaunchKernelGGL(k_segmented_select<0>, dim3((unsigned)columns), dim3(1024), 0, st, sa);
+            HIP_TRY(hipGetLastError());
+        }
         return BISIP_OK;
     }
     HIP_TRY(hipMemcpyAsync(d_lo, lo.data(), sizeof(long long) * n_percentiles, hipMemcpyHostToDevice, st));

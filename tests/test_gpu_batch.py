@@ -380,6 +380,32 @@ def test_batch_operands_do_not_depend_on_threads_or_on_shared_frequencies(monkey
         assert np.array_equal(got[key], got[None]) and np.array_equal(got[key, 'wide'], got[None, 'wide'])
 
 
+def test_many_percentiles_of_few_long_columns(monkeypatch):
+    """More than 8 percentiles: groups of 8 by selection when the columns are few (7 columns of a long chain),
+    one segmented sort when they are many -- NumPy's doubles either way."""
+    import torch
+    from bisip_amd import _hip
+    rng = np.random.RandomState(4)
+    p = np.concatenate([np.linspace(0, 100, 21), [2.5, 97.5]])
+    for n, E, Wp, ndim in ((900, 1, 50, 7), (30, 16, 40, 7)):            # 7 columns of 45,000 values; 112 columns of 1,200
+        full = rng.standard_normal((n, E * Wp, ndim)) * rng.uniform(0.1, 5, ndim) + rng.uniform(-2, 2, ndim)
+        t = torch.from_numpy(full).cuda()
+        nbytes = _hip.chain_percentiles_workspace(n, E, Wp, ndim, p.size)
+        work = torch.empty(nbytes, dtype=torch.uint8, device='cuda')
+        used = full.reshape(n, E, Wp, ndim).transpose(1, 0, 2, 3).reshape(E, n * Wp, ndim)
+        want = np.percentile(used, p, axis=1)
+        for force in (None, '1'):
+            if force:
+                monkeypatch.setenv('BISIP_PERCENTILE_SORT', force)
+            else:
+                monkeypatch.delenv('BISIP_PERCENTILE_SORT', raising=False)
+            out = torch.full((p.size, E, ndim), float('nan'), dtype=torch.float64, device='cuda')
+            _hip.chain_percentiles_dev(t.data_ptr(), n, E * Wp * ndim, E, Wp, ndim, p, out.data_ptr(), work.data_ptr(), nbytes,
+                                       torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            assert np.array_equal(out.cpu().numpy(), want)
+
+
 @pytest.mark.parametrize('variant', ['reduced', 'reduced_comp'])
 def test_bulk_batch_logprob_streams_like_the_single_spectrum_kernel(variant):
     """E x Wp >= 131072 rows with Wp a multiple of the workgroup: the batch takes the headline kernel's
