@@ -36,7 +36,10 @@
 extern "C" {
 #endif
 
-#define BISIP_ABI_VERSION 1
+/* 2: entry points added since 1 (all additions, nothing changed or removed): loglike_z, forward_percentiles,
+ * column / grouped percentiles, forward_spectrum(s), stretch_run_sharded + rccl_*, ctx_set_spectrum_offset,
+ * ctx_reduced_check, polydecomp_reduced_estimates, read_tables; BISIP_VARIANT_REDUCED_COMP, BISIP_ERCCL. */
+#define BISIP_ABI_VERSION 2
 
 /* model_id -- the four reference model classes (src/bisip/models.py:182,232,274,308) */
 #define BISIP_MODEL_POLYDECOMP 0 /* PolynomialDecomposition -> Decomp_cyth  */

@@ -29,7 +29,7 @@ def test_abi_exports_every_declared_symbol(hip_lib):
         assert hasattr(hip_lib, name), f'{name} declared in include/bisip_hip.h but not exported'
         assert name in _hip.SYMBOLS, f'{name} has no ctypes prototype in bisip_amd/_hip.py'
     assert set(_hip.SYMBOLS) == set(names)
-    assert hip_lib.bisip_abi_version() == 1
+    assert hip_lib.bisip_abi_version() == 2
     assert isinstance(hip_lib.bisip_last_error(), bytes)
 
 
