@@ -6,7 +6,7 @@
 //   1. k_gather_columns: (sample, walker, parameter) -> one contiguous column per
 //      (ensemble, parameter), coalesced on both sides;
 //   2. the two order statistics each percentile needs: radix selection, one workgroup per column
-//      (k_segmented_select) -- or, for many percentiles / few long columns, a rocPRIM segmented
+//      (k_segmented_select) -- or, for more than 8 percentiles of many columns, a rocPRIM segmented
 //      radix sort of the E*ndim columns (library sort: hipCUB header) followed by
 //   3. k_percentile_lerp: NumPy's 'linear' rule between the two neighbouring order statistics
 //      (indices and weights are computed on the host exactly as numpy does).
