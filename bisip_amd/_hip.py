@@ -109,6 +109,10 @@ SYMBOLS = {
                                                   ctypes.c_void_p, ctypes.c_void_p]),
     'bisip_forward_spectra_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
                                                  ctypes.c_void_p, ctypes.c_void_p]),
+    'bisip_forward_columns_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
+                                                 ctypes.c_void_p, ctypes.c_void_p]),
+    'bisip_columns_percentiles_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, _dp, ctypes.c_int,
+                                                     ctypes.c_void_p, ctypes.c_void_p]),
     'bisip_ctx_reduced_check': (ctypes.c_int, [ctypes.c_void_p, _dp, ctypes.c_int64, _dp, _dp]),
     'bisip_read_tables': (ctypes.c_int, [ctypes.POINTER(ctypes.c_char_p), ctypes.c_int64, ctypes.c_int, ctypes.c_int64,
                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
@@ -406,6 +410,12 @@ class HipContext:
         _check(self._lib.bisip_forward_spectrum_dev(self._h, int(spectrum), ctypes.c_void_p(d_theta_ptr), int(W),
                                                     ctypes.c_void_p(d_Z_ptr), ctypes.c_void_p(stream)))
 
+    def forward_columns_dev(self, first_spectrum, n_spectra, d_theta_ptr, W, d_cols_ptr, stream=0):
+        """Batch (or single) context: the responses of W rows over n_spectra consecutive spectra, written
+        column-major (n_spectra, 2N, W / n_spectra) -- what columns_percentiles_dev reads (device pointers)."""
+        _check(self._lib.bisip_forward_columns_dev(self._h, int(first_spectrum), int(n_spectra), ctypes.c_void_p(d_theta_ptr),
+                                                   int(W), ctypes.c_void_p(d_cols_ptr), ctypes.c_void_p(stream)))
+
     def forward_spectra_dev(self, first_spectrum, n_spectra, d_theta_ptr, W, d_Z_ptr, stream=0):
         """Batch context: forward of W rows over n_spectra consecutive spectra, W / n_spectra rows each
         (a multiple of 64 when n_spectra > 1), one launch (device pointers)."""
@@ -508,6 +518,13 @@ def column_percentiles_dev(d_rows_ptr, n_rows, n_cols, percentiles, d_out_ptr, d
     p = _c(percentiles).ravel()
     _check(load_library().bisip_column_percentiles_dev(d_rows_ptr, int(n_rows), int(n_cols), _p(p), p.size,
                                                        d_out_ptr, d_work_ptr, int(work_bytes), stream))
+
+
+def columns_percentiles_dev(d_cols_ptr, n_columns, n, percentiles, d_out_ptr, stream=0):
+    """np.percentile of n_columns contiguous device columns of n values: d_out (len(p), n_columns).  Device
+    pointers (ints); no workspace."""
+    p = _c(percentiles).ravel()
+    _check(load_library().bisip_columns_percentiles_dev(d_cols_ptr, int(n_columns), int(n), _p(p), p.size, d_out_ptr, stream))
 
 
 def grouped_percentiles_workspace(n_groups, n_rows, n_cols, n_percentiles):

@@ -175,9 +175,9 @@ class SpectraBatch:
     def get_model_percentile(self, p=(2.5, 50, 97.5), discard=0, thin=1):
         """Percentiles of the MODEL response over every spectrum's chain, ``(len(p), E, 2, N)`` -- per
         spectrum what the reference's ``get_model_percentile`` returns (src/bisip/utils.py:17-35): the
-        band a fit is plotted with.  On the device, many spectra per pass: one forward launch per
-        spectrum over its samples, one segmented sort for the pass; with ``chain='device'`` the
-        chain never leaves HBM."""
+        band a fit is plotted with.  On the device, many spectra per pass: one forward launch that
+        writes the responses column by column, one selection of the order statistics; with
+        ``chain='device'`` the chain never leaves HBM."""
         import torch
         if self._sampler is None:
             raise AssertionError('Model is not fitted!')
@@ -197,29 +197,21 @@ class SpectraBatch:
             raise ValueError(f'no samples left with discard={discard}, thin={thin} of {int(t.shape[0])} stored')
         rows_per = n * Wp
         cols = 2 * N
-        # spectra per pass: one sort holds at most 2^31 values, and the responses of a pass stay under ~8 GB
-        G = int(min(E, (2 ** 31 - 1) // (rows_per * cols), max(1, (8 << 30) // (rows_per * cols * 8))))
-        if G < 1:
-            raise ValueError('more than 2^31 model values per spectrum: thin the chain')
+        # spectra per pass: the responses of a pass stay under ~8 GB
+        G = int(min(E, max(1, (8 << 30) // (rows_per * cols * 8))))
         out = np.empty((p.size, E, cols))
         grid = used.reshape(n, E, Wp, ndim)
         for g0 in range(0, E, G):
             g1 = min(E, g0 + G)
             k = g1 - g0
             rows = grid[:, g0:g1].permute(1, 0, 2, 3).reshape(k, rows_per, ndim)   # one copy: spectrum-major
-            Z = be.empty((k, rows_per, cols), torch.float64)
-            if rows_per % 64 == 0:           # whole 64-row blocks per spectrum: one launch for the pass
-                self.ctx.forward_spectra_dev(g0, k, rows.data_ptr(), k * rows_per, Z.data_ptr(), be.stream())
-            else:
-                for e in range(k):
-                    self.ctx.forward_spectrum_dev(g0 + e, rows[e].data_ptr(), rows_per, Z[e].data_ptr(), be.stream())
-            nbytes = _hip.grouped_percentiles_workspace(k, rows_per, cols, p.size)
-            work = be.empty((nbytes,), torch.uint8)
-            res = be.empty((p.size, k, cols), torch.float64)
-            _hip.grouped_percentiles_dev(Z.data_ptr(), k, rows_per, cols, p, res.data_ptr(), work.data_ptr(), nbytes, be.stream())
+            Zc = be.empty((k, cols, rows_per), torch.float64)                      # one column per (spectrum, part, frequency)
+            self.ctx.forward_columns_dev(g0, k, rows.data_ptr(), k * rows_per, Zc.data_ptr(), be.stream())
+            res = be.empty((p.size, k * cols), torch.float64)
+            _hip.columns_percentiles_dev(Zc.data_ptr(), k * cols, rows_per, p, res.data_ptr(), be.stream())
             be.synchronize()
-            out[:, g0:g1] = res.cpu().numpy()
-            del rows, Z, work, res
+            out[:, g0:g1] = res.cpu().numpy().reshape(p.size, k, cols)
+            del rows, Zc, res
         return out.reshape(p.size, E, 2, N)
 
     def get_param_std(self, discard=0, thin=1):

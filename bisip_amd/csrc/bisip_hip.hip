@@ -501,6 +501,16 @@ int bisip_forward_spectra_dev(bisip_ctx *c, int64_t first_spectrum, int64_t n_sp
     return dispatch_forward(c, d_theta, W, d_Z, (hipStream_t)stream, first_spectrum, n_spectra);
 }
 
+int bisip_forward_columns_dev(bisip_ctx *c, int64_t first_spectrum, int64_t n_spectra, const double *d_theta, int64_t W,
+                              double *d_cols, void *stream)
+{
+    if (!c) return fail(BISIP_EINVAL, "null context");
+    if (W < 0) return fail(BISIP_EINVAL, "W=%lld < 0", (long long)W);
+    if (W > 0 && (!d_theta || !d_cols)) return fail(BISIP_EINVAL, "null buffer");
+    HIP_TRY(hipSetDevice(c->device));
+    return dispatch_forward_columns(c, d_theta, W, d_cols, (hipStream_t)stream, first_spectrum, n_spectra);
+}
+
 int bisip_forward_spectrum_dev(bisip_ctx *c, int64_t spectrum, const double *d_theta, int64_t W, double *d_Z, void *stream)
 {
     return bisip_forward_spectra_dev(c, spectrum, 1, d_theta, W, d_Z, stream);

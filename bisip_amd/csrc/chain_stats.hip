@@ -343,6 +343,43 @@ int64_t percentiles_workspace(int64_t n_samples, int64_t n_ensembles, int64_t wa
     return (int64_t)(2 * align256((size_t)items * 8) + align256(temp) + align256((size_t)n_percentiles * 16));
 }
 
+// numpy's virtual index for method='linear', evaluated as numpy does: its table of methods gives
+// 'linear' the closed form (n - 1) * q, not the general n*q + (alpha + q*(1 - alpha - beta)) - 1
+// (numpy/lib/_function_base_impl.py:_QuantileMethods) -- the two differ in the last bits of the
+// weight, which shows as soon as neighbouring order statistics are far apart (integer data)
+int percentile_ranks(long long n, const double *percentiles, int n_percentiles, std::vector<long long> &lo, std::vector<double> &t)
+{
+    for (int k = 0; k < n_percentiles; ++k) {
+        if (!(percentiles[k] >= 0.0 && percentiles[k] <= 100.0)) return fail(BISIP_EINVAL, "percentiles must be in [0, 100]");
+        const double q = percentiles[k] / 100.0;
+        double v = (double)(n - 1) * q;
+        if (v < 0) v = 0;
+        if (v > (double)(n - 1)) v = (double)(n - 1);
+        const double f = std::floor(v);
+        lo[k] = (long long)f;
+        t[k] = v - f;
+    }
+    return BISIP_OK;
+}
+
+// the order statistics of `columns` contiguous columns of n values, SEL_MAX_P percentiles per launch
+int select_columns(const double *cols, long long n, long long columns, int n_percentiles, const std::vector<long long> &lo,
+                   const std::vector<double> &t, double *d_out, hipStream_t st)
+{
+    for (int k0 = 0; k0 < n_percentiles; k0 += SEL_MAX_P) {
+        SelectArgs sa{};
+        sa.cols = cols; sa.n = n; sa.columns = columns; sa.out = d_out + (long long)k0 * columns;
+        sa.n_p = n_percentiles - k0 < SEL_MAX_P ? n_percentiles - k0 : SEL_MAX_P;
+        for (int k = 0; k < sa.n_p; ++k) { sa.lo[k] = lo[k0 + k]; sa.t[k] = t[k0 + k]; }
+        if (n <= 1024 * 8) hipLaunchKernelGGL(k_segmented_select<8>, dim3((unsigned)columns), dim3(1024), 0, st, sa);
+        else if (n <= 1024 * 16) hipLaunchKernelGGL(k_segmented_select<16>, dim3((unsigned)columns), dim3(1024), 0, st, sa);
+        else if (n <= 1024 * 40) hipLaunchKernelGGL(k_segmented_select<40>, dim3((unsigned)columns), dim3(1024), 0, st, sa);
+        else hipLaunchKernelGGL(k_segmented_select<0>, dim3((unsigned)columns), dim3(1024), 0, st, sa);
+        HIP_TRY(hipGetLastError());
+    }
+    return BISIP_OK;
+}
+
 int percentiles_impl(const double *d_chain, int64_t n_samples, int64_t sample_stride, int64_t n_ensembles,
                      int64_t walkers_per_ensemble, int ndim, const double *percentiles, int n_percentiles,
                      double *d_out, void *d_work, int64_t work_bytes, void *stream);
@@ -387,6 +424,19 @@ int bisip_grouped_percentiles_dev(const double *d_rows, int64_t n_groups, int64_
                             n_percentiles, d_out, d_work, work_bytes, stream);
 }
 
+int bisip_columns_percentiles_dev(const double *d_cols, int64_t n_columns, int64_t n, const double *percentiles,
+                                  int n_percentiles, double *d_out, void *stream)
+{
+    if (!d_cols || !percentiles || !d_out) return fail(BISIP_EINVAL, "null argument");
+    if (n_columns < 1 || n_columns > 0x7fffffffLL || n < 1 || n_percentiles < 1 || n_percentiles > 1024)
+        return fail(BISIP_EINVAL, "bad shape");
+    std::vector<long long> lo(n_percentiles);
+    std::vector<double> t(n_percentiles);
+    int rc = percentile_ranks(n, percentiles, n_percentiles, lo, t);
+    if (rc != BISIP_OK) return rc;
+    return select_columns(d_cols, n, n_columns, n_percentiles, lo, t, d_out, (hipStream_t)stream);
+}
+
 int bisip_chain_percentiles_dev(const double *d_chain, int64_t n_samples, int64_t sample_stride,
                                 int64_t n_ensembles, int64_t walkers_per_ensemble, int ndim,
                                 const double *percentiles, int n_percentiles, double *d_out,
@@ -427,21 +477,11 @@ int percentiles_impl(const double *d_chain, int64_t n_samples, int64_t sample_st
     double *d_t = (double *)(d_lo + n_percentiles);
     hipStream_t st = (hipStream_t)stream;
 
-    // numpy's virtual index for method='linear', evaluated as numpy does: its table of methods gives
-    // 'linear' the closed form (n - 1) * q, not the general n*q + (alpha + q*(1 - alpha - beta)) - 1
-    // (numpy/lib/_function_base_impl.py:_QuantileMethods) -- the two differ in the last bits of the
-    // weight, which shows as soon as neighbouring order statistics are far apart (integer data)
     std::vector<long long> lo(n_percentiles);
     std::vector<double> t(n_percentiles);
-    for (int k = 0; k < n_percentiles; ++k) {
-        const double q = percentiles[k] / 100.0;
-        double v = (double)(n - 1) * q;
-        if (v < 0) v = 0;
-        if (v > (double)(n - 1)) v = (double)(n - 1);
-        const double f = std::floor(v);
-        lo[k] = (long long)f;
-        t[k] = v - f;
-    }
+    rc = percentile_ranks(n, percentiles, n_percentiles, lo, t);
+    if (rc != BISIP_OK) return rc;
+
     GatherArgs g{d_chain, n_samples, sample_stride, n_ensembles, walkers_per_ensemble, ndim, cols};
     const long long rows = n_samples * n_ensembles * walkers_per_ensemble;
     const long long tiles = n_samples * n_ensembles * ((walkers_per_ensemble + 63) / 64) * ((ndim + 63) / 64);
@@ -456,18 +496,7 @@ int percentiles_impl(const double *d_chain, int64_t n_samples, int64_t sample_st
     // percentiles one sort serves them all.
     const char *force_sort = std::getenv("BISIP_PERCENTILE_SORT");
     if ((n_percentiles <= SEL_MAX_P || columns < 64) && columns <= 0x7fffffffLL && !(force_sort && force_sort[0] == '1')) {
-        for (int k0 = 0; k0 < n_percentiles; k0 += SEL_MAX_P) {
-            SelectArgs sa{};
-            sa.cols = cols; sa.n = n; sa.columns = columns; sa.out = d_out + (long long)k0 * columns;
-            sa.n_p = n_percentiles - k0 < SEL_MAX_P ? n_percentiles - k0 : SEL_MAX_P;
-            for (int k = 0; k < sa.n_p; ++k) { sa.lo[k] = lo[k0 + k]; sa.t[k] = t[k0 + k]; }
-            if (n <= 1024 * 8) hipLaunchKernelGGL(k_segmented_select<8>, dim3((unsigned)columns), dim3(1024), 0, st, sa);
-            else if (n <= 1024 * 16) hipLaunchKernelGGL(k_segmented_select<16>, dim3((unsigned)columns), dim3(1024), 0, st, sa);
-            else if (n <= 1024 * 40) hipLaunchKernelGGL(k_segmented_select<40>, dim3((unsigned)columns), dim3(1024), 0, st, sa);
-            else hipLaunchKernelGGL(k_segmented_select<0>, dim3((unsigned)columns), dim3(1024), 0, st, sa);
-            HIP_TRY(hipGetLastError());
-        }
-        return BISIP_OK;
+        return select_columns(cols, n, columns, n_percentiles, lo, t, d_out, st);
     }
     HIP_TRY(hipMemcpyAsync(d_lo, lo.data(), sizeof(long long) * n_percentiles, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_t, t.data(), sizeof(double) * n_percentiles, hipMemcpyHostToDevice, st));

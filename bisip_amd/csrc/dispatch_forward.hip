@@ -33,6 +33,18 @@ int launch_forward(const bisip_ctx *c, const double *theta, int64_t W, double *Z
     return BISIP_OK;
 }
 
+// column-major output for `count` consecutive spectra starting with `spectrum`, W / count rows each
+template <class M>
+int launch_forward_columns(const bisip_ctx *c, const double *theta, int64_t W, double *cols, hipStream_t st, long long spectrum,
+                           long long count)
+{
+    LaunchArgs a = make_args(c, theta, cols, W, c->d_cb + spectrum * c->cb_stride);
+    a.Wp = W / count; a.cb_stride = c->cb_stride;
+    hipLaunchKernelGGL((k_forward_columns<M>), dim3((unsigned)((W + 63) / 64)), dim3(64), 0, st, a);
+    HIP_TRY(hipGetLastError());
+    return BISIP_OK;
+}
+
 template <class M>
 int launch_forward_batch(const bisip_ctx *c, const double *theta, int64_t W, double *Z, hipStream_t st)
 {
@@ -72,6 +84,35 @@ int dispatch_forward_batch(const bisip_ctx *c, const double *theta, int64_t W, d
 
 namespace bisip {
 namespace host {
+
+int dispatch_forward_columns(const bisip_ctx *c, const double *theta, int64_t W, double *cols, hipStream_t st, long long spectrum,
+                             long long count)
+{
+    if (W == 0) return BISIP_OK;
+    if (spectrum < 0 || count < 1 || spectrum + count > c->E) return fail(BISIP_EINVAL, "spectra [%lld, %lld) of %d", spectrum, spectrum + count, c->E);
+    if (W % count) return fail(BISIP_EINVAL, "W=%lld rows do not divide over %lld spectra", (long long)W, count);
+    if ((W + 63) / 64 > 0x7fffffffLL) return fail(BISIP_EINVAL, "W=%lld exceeds the launch grid limit", (long long)W);
+    if (((uintptr_t)theta % 8) || ((uintptr_t)cols % 8)) return fail(BISIP_EINVAL, "buffers must be 8-byte aligned");
+    switch (c->model_id) {
+    case BISIP_MODEL_POLYDECOMP:
+        switch (c->P) {
+#define X(p) case p: return launch_forward_columns<PDCollapsed<p>>(c, theta, W, cols, st, spectrum, count);
+            PD_CASES(X)
+#undef X
+        }
+        break;
+    case BISIP_MODEL_COLECOLE:
+        switch (c->D) {
+#define X(d) case d: return launch_forward_columns<ColeCole<d>>(c, theta, W, cols, st, spectrum, count);
+            CC_CASES(X)
+#undef X
+        }
+        break;
+    case BISIP_MODEL_DIAS2000: return launch_forward_columns<Dias>(c, theta, W, cols, st, spectrum, count);
+    case BISIP_MODEL_SHIN2015: return launch_forward_columns<Shin>(c, theta, W, cols, st, spectrum, count);
+    }
+    return fail(BISIP_EUNSUPPORTED, "no forward kernel for this model shape");
+}
 
 int dispatch_forward(const bisip_ctx *c, const double *theta, int64_t W, double *Z, hipStream_t st, long long spectrum,
                      long long count)

@@ -118,6 +118,8 @@ template <int P> struct CoopLimit<PDCollapsed<P>> { static constexpr long long v
 int dispatch_logprob(const bisip_ctx *c, const double *theta, int64_t W, double *out, hipStream_t st);
 int dispatch_forward(const bisip_ctx *c, const double *theta, int64_t W, double *Z, hipStream_t st, long long spectrum = -1,
                      long long count = 1);
+int dispatch_forward_columns(const bisip_ctx *c, const double *theta, int64_t W, double *cols, hipStream_t st, long long spectrum,
+                             long long count);
 
 // dispatch_stretch.hip
 enum StretchKind { STRETCH_HALF, STRETCH_EVAL, STRETCH_PERSIST };

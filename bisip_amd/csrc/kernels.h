@@ -1274,6 +1274,33 @@ __global__ __launch_bounds__(64) void k_forward_tiled16(const LaunchArgs a)
     }
 }
 
+// forward() written COLUMN-major: out (spectra, 2N, Wp) -- one contiguous column per (spectrum, part, frequency).
+// What the percentile kernels read (chain_stats.hip), so the model-space bands of a survey need no
+// row -> column transposition (a 27 GB round trip for 4096 spectra): lane = walker, every store instruction
+// writes 64 consecutive doubles of one column, no LDS staging needed.  Same M::eval, same values as Z.
+template <class M>
+__global__ __launch_bounds__(64) void k_forward_columns(const LaunchArgs a)
+{
+    constexpr int NDIM = M::NDIM;
+    const int N = a.N;
+    const long long row = (long long)blockIdx.x * 64 + threadIdx.x;
+    if (row >= a.W) return;
+    double th[NDIM];
+#pragma unroll
+    for (int q = 0; q < NDIM; ++q) th[q] = a.theta[row * NDIM + q];
+    const typename M::Setup s = M::setup(th);
+    const long long Wp = a.Wp ? a.Wp : a.W;
+    const long long e = row / Wp, w = row - e * Wp;     // a block of 64 rows may straddle two spectra here: per lane
+    const double *__restrict__ cb = a.cb + e * a.cb_stride;
+    double *__restrict__ col = a.out + e * 2 * N * Wp + w;
+    for (int j = 0; j < N; ++j) {
+        double zr, zi;
+        M::eval(s, cb + (long long)j * M::REC + 4, zr, zi);
+        __builtin_nontemporal_store(zr, col + (long long)j * Wp);
+        __builtin_nontemporal_store(zi, col + (long long)(N + j) * Wp);
+    }
+}
+
 // Batched forward(), N <= JC: whole rows.  Lane = walker computes all N frequencies (2N doubles in
 // registers); SUB walkers at a time go through LDS laid out exactly like Z ([re 0..N) [im 0..N)
 // per walker), so the SUB*2N doubles of a pass are ONE contiguous span of Z and every store

@@ -37,7 +37,7 @@ extern "C" {
 #endif
 
 /* 2: entry points added since 1 (all additions, nothing changed or removed): loglike_z, forward_percentiles,
- * column / grouped percentiles, forward_spectrum(s), stretch_run_sharded + rccl_*, ctx_set_spectrum_offset,
+ * column / grouped / columns percentiles, forward_spectrum(s) / forward_columns, stretch_run_sharded + rccl_*, ctx_set_spectrum_offset,
  * ctx_reduced_check, polydecomp_reduced_estimates, read_tables; BISIP_VARIANT_REDUCED_COMP, BISIP_ERCCL. */
 #define BISIP_ABI_VERSION 2
 
@@ -123,6 +123,11 @@ int bisip_forward_dev(bisip_ctx *ctx, const double *d_theta, int64_t W, double *
  * spectrum's chain: utils.get_model_percentile per spectrum of a survey, src/bisip/utils.py:17-35). */
 int bisip_forward_spectrum_dev(bisip_ctx *ctx, int64_t spectrum, const double *d_theta, int64_t W,
                                double *d_Z, void *stream);
+/* The same responses written COLUMN-major, d_cols (n_spectra, 2N, W / n_spectra): one contiguous column per
+ * (spectrum, part, frequency) -- the layout bisip_columns_percentiles_dev reads, so the model-space bands of
+ * a survey need no transposition.  Any number of rows per spectrum. */
+int bisip_forward_columns_dev(bisip_ctx *ctx, int64_t first_spectrum, int64_t n_spectra, const double *d_theta,
+                              int64_t W, double *d_cols, void *stream);
 /* ... or to n_spectra consecutive spectra starting with first_spectrum, W / n_spectra rows each
  * (a multiple of 64 when n_spectra > 1), in one launch. */
 int bisip_forward_spectra_dev(bisip_ctx *ctx, int64_t first_spectrum, int64_t n_spectra, const double *d_theta,
@@ -297,6 +302,12 @@ int64_t bisip_column_percentiles_workspace(int64_t n_rows, int n_cols, int n_per
 int bisip_column_percentiles_dev(const double *d_rows, int64_t n_rows, int n_cols,
                                  const double *percentiles, int n_percentiles, double *d_out,
                                  void *d_work, int64_t work_bytes, void *stream);
+
+/* np.percentile of n_columns contiguous columns of n values each (d_cols (n_columns, n): what
+ * bisip_forward_columns_dev writes): d_out (n_percentiles, n_columns).  Selection of the order statistics,
+ * no workspace, asynchronous on stream. */
+int bisip_columns_percentiles_dev(const double *d_cols, int64_t n_columns, int64_t n, const double *percentiles,
+                                  int n_percentiles, double *d_out, void *stream);
 
 /* The same for n_groups stacked arrays (n_groups, n_rows, n_cols) in one sort: d_out
  * (n_percentiles, n_groups, n_cols) -- the model responses of many spectra's chains at once. */

@@ -548,3 +548,41 @@ def test_percentiles_by_selection_equal_the_sorted_ones(n, E, Wp, ndim, kind, mo
     ok = np.isfinite(want)
     assert np.array_equal(outs['select'][ok], want[ok])            # order statistics, weights and _lerp are NumPy's: same doubles
     assert np.array_equal(np.isnan(outs['select']), np.isnan(want)) or kind == 'signs'
+
+
+def test_forward_columns_and_their_percentiles():
+    """bisip_forward_columns_dev writes the responses column-major (what the percentile kernels read);
+    bisip_columns_percentiles_dev takes np.percentile of such columns.  Same values as forward() transposed,
+    for whole and ragged row counts, a range of spectra and a single-spectrum context; NumPy's percentiles."""
+    import torch
+    import bisip_amd
+    from bisip_amd import _hip
+    E = 5
+    b = bisip_amd.SpectraBatch('PeltonColeCole', _tables(E), nwalkers=64, n_modes=2)
+    lo, hi = b.param_bounds
+    st = torch.cuda.current_stream().cuda_stream
+    for rows in (128, 77):
+        th = torch.from_numpy(np.random.RandomState(rows).uniform(lo, hi, (3, rows, lo.size))).cuda()
+        cols = torch.empty((3, 64, rows), dtype=torch.float64, device='cuda')
+        b.ctx.forward_columns_dev(1, 3, th.data_ptr(), 3 * rows, cols.data_ptr(), st)            # spectra 1, 2, 3
+        torch.cuda.synchronize()
+        p = np.array([2.5, 50.0, 97.5])
+        out = torch.empty((3, 3 * 64), dtype=torch.float64, device='cuda')
+        _hip.columns_percentiles_dev(cols.data_ptr(), 3 * 64, rows, p, out.data_ptr(), st)
+        torch.cuda.synchronize()
+        for k, e in enumerate((1, 2, 3)):
+            single = _hip.HipContext(1, b.w[e], b.zn[e], b.zn_err[e], b.param_bounds, n_modes=2)
+            Z = single.forward(th[k].cpu().numpy())                                              # (rows, 2, N)
+            assert np.array_equal(cols[k].cpu().numpy(), Z.reshape(rows, 64).T)
+            assert np.array_equal(out.cpu().numpy().reshape(3, 3, 64)[:, k], np.percentile(Z.reshape(rows, 64), p, axis=0))
+            if k == 0:       # a single-spectrum context takes the same call
+                c1 = torch.empty((64, rows), dtype=torch.float64, device='cuda')
+                single.forward_columns_dev(0, 1, th[k].data_ptr(), rows, c1.data_ptr(), st)
+                torch.cuda.synchronize()
+                assert np.array_equal(c1.cpu().numpy(), Z.reshape(rows, 64).T)
+            single.close()
+    with pytest.raises(ValueError):
+        b.ctx.forward_columns_dev(3, 3, th.data_ptr(), 3 * rows, cols.data_ptr(), st)           # spectra 3..5 of 5
+    with pytest.raises(ValueError):
+        b.ctx.forward_columns_dev(0, 2, th.data_ptr(), 3 * 77, cols.data_ptr(), st)             # 231 rows over 2 spectra
+    b.close()
