@@ -847,21 +847,20 @@ int bisip_forward_percentiles(bisip_ctx *c, const double *theta, int64_t W, cons
     if (c->E > 1) return fail(BISIP_EUNSUPPORTED, "bisip_forward_percentiles takes a single-spectrum context");
     if (W < 1 || !theta || !percentiles || !out || n_percentiles < 1) return fail(BISIP_EINVAL, "bad argument");
     const int ncols = 2 * c->N;
-    const int64_t pw = bisip_column_percentiles_workspace(W, ncols, n_percentiles);
-    if (pw <= 0) return fail(BISIP_EUNSUPPORTED, "%lld x %d model values exceed the 2^31 items of one device sort", (long long)W, ncols);
     HIP_TRY(hipSetDevice(c->device));
+    // the responses are written column by column (k_forward_columns) and the order statistics selected from
+    // the columns: no transposition, no sort, no 2^31 limit
     const size_t tb = ((size_t)W * c->ndim * sizeof(double) + 255) & ~(size_t)255;
     const size_t zb = ((size_t)W * ncols * sizeof(double) + 255) & ~(size_t)255;
     const size_t ob = ((size_t)n_percentiles * ncols * sizeof(double) + 255) & ~(size_t)255;
-    int rc = ensure_ws(c, tb + zb + ob + (size_t)pw);
+    int rc = ensure_ws(c, tb + zb + ob);
     if (rc != BISIP_OK) return rc;
     char *base = (char *)c->d_ws;
-    double *d_theta = (double *)base, *d_Z = (double *)(base + tb), *d_out = (double *)(base + tb + zb);
-    void *d_work = base + tb + zb + ob;
+    double *d_theta = (double *)base, *d_cols = (double *)(base + tb), *d_out = (double *)(base + tb + zb);
     HIP_TRY(hipMemcpyAsync(d_theta, theta, (size_t)W * c->ndim * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    rc = dispatch_forward(c, d_theta, W, d_Z, c->stream);
+    rc = dispatch_forward_columns(c, d_theta, W, d_cols, c->stream, 0, 1);
     if (rc != BISIP_OK) return rc;
-    rc = bisip_column_percentiles_dev(d_Z, W, ncols, percentiles, n_percentiles, d_out, d_work, pw, c->stream);
+    rc = bisip_columns_percentiles_dev(d_cols, ncols, W, percentiles, n_percentiles, d_out, c->stream);
     if (rc != BISIP_OK) return rc;
     HIP_TRY(hipMemcpyAsync(out, d_out, (size_t)n_percentiles * ncols * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));

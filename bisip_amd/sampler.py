@@ -1001,9 +1001,9 @@ class DeviceEnsembleSampler(_SamplerBase):
     def model_percentiles(self, p=(2.5, 50, 97.5), discard=0, thin=1):
         """``np.percentile(forward(get_chain(discard, thin, flat=True)), p, axis=0)`` -- the
         reference's get_model_percentile (src/bisip/utils.py:17-35) -- without the chain leaving
-        the device: batched forward over the stored samples, then a column sort.  One ensemble
-        only; returns ``(len(p), 2, N)``.  NotImplementedError when the responses exceed one device
-        sort (2^31 values): the caller then reduces on the host."""
+        the device: batched forward over the stored samples, written column by column, then the
+        selection of the order statistics from each column.  One ensemble only (NotImplementedError
+        otherwise); returns ``(len(p), 2, N)``."""
         import torch
         from . import _hip
         if self.n_ensembles != 1:
@@ -1017,14 +1017,10 @@ class DeviceEnsembleSampler(_SamplerBase):
         be, ctx = self.backend, self.backend.ctx
         p = np.atleast_1d(np.asarray(p, dtype=np.float64))
         n, cols = int(rows.shape[0]), 2 * ctx.N
-        nbytes = _hip.column_percentiles_workspace(n, cols, p.size)
-        if nbytes <= 0:
-            raise NotImplementedError('more than 2^31 model values: reduce on the host')
-        Z = be.empty((n, cols), torch.float64)
-        ctx.forward_dev(rows.data_ptr(), n, Z.data_ptr(), be.stream())
-        work = be.empty((nbytes,), torch.uint8)
+        Zc = be.empty((cols, n), torch.float64)                  # the responses, one column per (part, frequency)
+        ctx.forward_columns_dev(0, 1, rows.data_ptr(), n, Zc.data_ptr(), be.stream())
         out = be.empty((p.size, cols), torch.float64)
-        _hip.column_percentiles_dev(Z.data_ptr(), n, cols, p, out.data_ptr(), work.data_ptr(), nbytes, be.stream())
+        _hip.columns_percentiles_dev(Zc.data_ptr(), cols, n, p, out.data_ptr(), be.stream())
         be.synchronize()
         return out.cpu().numpy().reshape(p.size, 2, ctx.N)
 

@@ -320,8 +320,8 @@ int bisip_grouped_percentiles_dev(const double *d_rows, int64_t n_groups, int64_
  * (src/bisip/utils.py:17-35: a Python loop of forward() over the chain, then np.percentile
  * over axis 0) in one call: theta (W, ndim) host -> forward on the device -> per-(part,
  * frequency) percentiles on the device -> out (n_percentiles, 2, N) host.  Only theta goes up
- * and n_percentiles*2N doubles come back.  BISIP_EUNSUPPORTED when W*2N exceeds 2^31 values
- * (use bisip_forward and reduce on the host).  Single-spectrum contexts. */
+ * and n_percentiles*2N doubles come back (the responses are written column by column and the order
+ * statistics selected from the columns: the same doubles as np.percentile).  Single-spectrum contexts. */
 int bisip_forward_percentiles(bisip_ctx *ctx, const double *theta, int64_t W,
                               const double *percentiles, int n_percentiles, double *out);
 
