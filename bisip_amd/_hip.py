@@ -377,7 +377,7 @@ class HipContext:
 
     def forward_percentiles(self, theta, p):
         """``np.percentile(forward(theta), p, axis=0)`` computed on the device: theta (W, ndim)
-        host -> (len(p), 2, N) host.  Raises NotImplementedError when W*2N exceeds one device sort."""
+        host -> (len(p), 2, N) host (single-spectrum contexts; a batch context raises NotImplementedError)."""
         theta = self._theta2d(theta)
         p = _c(np.atleast_1d(p)).ravel()
         out = np.empty((p.size, 2, self.N), dtype=np.float64)

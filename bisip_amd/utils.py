@@ -188,14 +188,10 @@ class utils(object):
             except NotImplementedError:
                 pass
         chain = np.ascontiguousarray(self.parse_chain(chain, **kwargs), dtype=np.float64)
-        try:
-            # forward over the chain and the percentiles over axis 0 both on the device: only the
-            # chain goes up and (len(p), 2, N) comes back (bisip_forward_percentiles)
-            out = self._context().forward_percentiles(chain, p)
-            return out if np.ndim(p) else out[0]
-        except NotImplementedError:      # more than 2^31 model values: reduce on the host
-            results = self.forward(chain, self.data['w'])
-            return np.percentile(results, p, axis=0)
+        # forward over the chain and the percentiles over axis 0 both on the device: only the chain goes
+        # up and (len(p), 2, N) comes back (bisip_forward_percentiles) -- np.percentile's own doubles
+        out = self._context().forward_percentiles(chain, p)
+        return out if np.ndim(p) else out[0]
 
     def _device_chain_sampler(self, chain, kwargs):
         """The sampler, when its chain lives in HBM (fit(chain='device')) and the caller asked for a
