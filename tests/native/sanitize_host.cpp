@@ -1,10 +1,14 @@
 // Driver for the AddressSanitizer/UBSan build of the library's host-only code
-// (host_precompute.cpp, host_rng.cpp); built and run by tests/test_host_sanitizers.py.
+// (host_precompute.cpp, host_rng.cpp, host_ingest.cpp); built and run by tests/test_host_sanitizers.py.
 // GPU sanitizers are not available on the target pool, so the host side -- the part that
 // indexes caller-shaped arrays -- is checked here on the CPU.
 #include <cmath>
+#include <stdexcept>
 #include <cstdint>
+#include <atomic>
 #include <cstdio>
+#include <cstring>
+#include <string>
 #include <vector>
 
 #include "../../bisip_amd/csrc/host_precompute.h"
@@ -64,8 +68,105 @@ static void stream(int64_t W, int64_t n_steps)
     }
 }
 
-int main()
+// the file parser on well-formed and hostile inputs (it must flag, never read out of bounds)
+static void ingest(const char *dir)
 {
+    struct Case { const char *name; std::string text; int want; };
+    std::string good = "freq,amp,pha,amp_err,pha_err\n";
+    for (int r = 0; r < 4; ++r) good += "1.5e3, 2.25 ,-3,+4.0,5e-1\r\n";
+    const Case cases[] = {
+        {"good.csv", good, 0},
+        {"no_newline.csv", "h\n1,2,3,4,5\n1,2,3,4,5\n1,2,3,4,5\n1,2,3,4,5", 0},
+        {"comments.csv", "h\n# c\n1,2,3,4,5 # x\n\n1,2,3,4,5\n1,2,3,4,5\n1,2,3,4,5\n", 0},
+        {"extra_cols.csv", "h\n1,2,3,4,5,6,7\n1,2,3,4,5,6,7\n1,2,3,4,5,6,7\n1,2,3,4,5,6,7\n", 0},
+        {"empty.csv", "", 1},
+        {"only_header.csv", "h\n", 1},
+        {"short_row.csv", "h\n1,2,3,4\n1,2,3,4,5\n1,2,3,4,5\n1,2,3,4,5\n", 1},
+        {"ragged.csv", "h\n1,2,3,4,5\n1,2,3,4,5,6\n1,2,3,4,5\n1,2,3,4,5\n", 1},
+        {"too_many_rows.csv", "h\n1,2,3,4,5\n1,2,3,4,5\n1,2,3,4,5\n1,2,3,4,5\n1,2,3,4,5\n", 1},
+        {"words.csv", "h\n1,2,3,4,nan\n1,2,3,4,5\n1,2,3,4,5\n1,2,3,4,5\n", 1},
+        {"hex.csv", "h\n0x10,2,3,4,5\n1,2,3,4,5\n1,2,3,4,5\n1,2,3,4,5\n", 1},
+        {"empty_field.csv", "h\n1,,3,4,5\n1,2,3,4,5\n1,2,3,4,5\n1,2,3,4,5\n", 1},
+        {"trailing_comma.csv", "h\n1,2,3,4,5,\n1,2,3,4,5,\n1,2,3,4,5,\n1,2,3,4,5,\n", 1},
+        {"blanks.csv", "h\n1,2,3,4,5\n   \n1,2,3,4,5\n1,2,3,4,5\n1,2,3,4,5\n", 1},
+        {"signs.csv", "h\n+-1,2,3,4,5\n1,2,3,4,5\n1,2,3,4,5\n1,2,3,4,5\n", 1},
+        {"huge_number.csv", "h\n1e999999,2,3,4,5\n1,2,3,4,5\n1,2,3,4,5\n1,2,3,4,5\n", 1},
+        {"binary.csv", std::string("h\n") + std::string(3, '\0') + ",\xff\xfe,3,4,5\n1,2,3,4,5\n1,2,3,4,5\n1,2,3,4,5\n", 1},
+    };
+    std::vector<std::string> paths;
+    std::vector<int> want;
+    for (const Case &c : cases) {
+        const std::string p = std::string(dir) + "/" + c.name;
+        FILE *f = std::fopen(p.c_str(), "wb");
+        EXPECT(f != nullptr);
+        if (!f) continue;
+        std::fwrite(c.text.data(), 1, c.text.size(), f);
+        std::fclose(f);
+        paths.push_back(p);
+        want.push_back(c.want);
+    }
+    paths.push_back(std::string(dir) + "/does_not_exist.csv");
+    want.push_back(1);
+    std::vector<const char *> cp;
+    for (auto &p : paths) cp.push_back(p.c_str());
+    for (int threads : {1, 3, 0}) {
+        std::vector<double> tables(cp.size() * 4 * 5, -1.0);
+        std::vector<int32_t> status(cp.size(), 7);
+        bisip::read_tables(cp.data(), (int64_t)cp.size(), 1, 4, tables.data(), status.data(), threads);
+        for (size_t i = 0; i < cp.size(); ++i) EXPECT(status[i] == want[i]);
+        EXPECT(tables[0] == 1500.0 && tables[1] == 2.25 && tables[2] == -3.0 && tables[3] == 4.0 && tables[4] == 0.5);
+        EXPECT(tables[3 * 4 * 5 + 4] == 5.0);          // extra columns ignored
+    }
+}
+
+// blocks of work on host threads: every index exactly once; an exception comes back to the caller
+static void blocks()
+{
+    for (int64_t n : {0, 1, 7, 64, 1000}) {
+        std::vector<std::atomic<int>> hit((size_t)(n > 0 ? n : 1));
+        for (auto &h : hit) h = 0;
+        bisip::parallel_blocks(n, 3, [&](int64_t lo, int64_t hi) { for (int64_t i = lo; i < hi; ++i) hit[(size_t)i]++; });
+        for (int64_t i = 0; i < n; ++i) EXPECT(hit[(size_t)i] == 1);
+    }
+    bool thrown = false;
+    try {
+        bisip::parallel_blocks(1000, 1, [&](int64_t lo, int64_t) { if (lo > 0) throw std::runtime_error("x"); });
+    } catch (const std::runtime_error &) { thrown = true; }
+    EXPECT(thrown || bisip::host_threads() == 1);
+}
+
+// the probing that decides which reduced kernel runs, and the after-the-fact reference
+static void reduced(int N, int S, int D)
+{
+    std::vector<double> w(N), taus(S), lt((size_t)D * S), zn(2 * N), err(2 * N);
+    for (int j = 0; j < N; ++j) w[j] = 2 * M_PI * std::pow(10.0, 3.8 - 5.7 * (N > 1 ? (double)j / (N - 1) : 0.0));
+    for (int k = 0; k < S; ++k) {
+        const double l = -6.0 + 8.0 * (S > 1 ? (double)k / (S - 1) : 0.0);
+        taus[k] = std::pow(10.0, l);
+        for (int p = 0; p < D; ++p) lt[(size_t)p * S + k] = std::pow(l, p);
+    }
+    for (int i = 0; i < 2 * N; ++i) { zn[i] = (i < N ? 0.8 : -0.05) + 0.01 * std::sin(i); err[i] = 0.002 + 1e-4 * (i % 7); }
+    bisip::PolyDecompOperands o;
+    bisip::polydecomp_kernel_sums(N, w.data(), S, taus.data(), D, lt.data(), 1.0, o);
+    bisip::polydecomp_reduce(zn.data(), err.data(), o);
+    const int n = D + 1;
+    std::vector<double> lo(n, -1.0), hi(n, 1.0), bh(n), e(n), el(n);
+    lo[0] = 0.9; hi[0] = 1.1;
+    const double lconst = bisip::loglike_const(2 * N, err.data());
+    for (bool comp : {false, true}) {
+        const double est = bisip::reduced_center(n, o.R, o.qty, o.bhat_ls, o.rest, lconst, lo.data(), hi.data(), comp, bh.data(), e.data(), el.data());
+        EXPECT(est >= 0.0 || est != est);
+    }
+    std::vector<double> th(n, 0.01);
+    th[0] = 1.0;
+    EXPECT(std::isfinite(bisip::reduced_logp_reference(n, o.R, o.qty, o.rest, lconst, th.data())));
+}
+
+int main(int argc, char **argv)
+{
+    if (argc > 1) ingest(argv[1]);
+    blocks();
+    for (int N : {2, 20}) for (int D : {1, 6, 11}) reduced(N, 2 * N, D);
     for (int N : {1, 2, 20, 33}) for (int S : {1, 7, 40}) for (int D : {1, 6, 11})
         for (double c : {1.0, 0.5}) operands(N, S, D, c);
     for (int64_t W : {2, 3, 32, 33, 1000}) stream(W, 7);
