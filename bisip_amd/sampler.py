@@ -936,6 +936,10 @@ class DeviceEnsembleSampler(_SamplerBase):
                 self.timing['enqueue_s'] += time.perf_counter() - t_b - t_alloc
         except BaseException:
             self._dev = None             # the device ensemble is part-way through a chunk: nothing to continue from
+            try:                         # nothing of this run may still be writing when its buffers go back to the allocator
+                be.synchronize()         # (the stream draw runs on a side stream)
+            except Exception:
+                pass
             raise
         finally:
             if ahead is not None:        # an error above: let the worker finish with the RandomState first
