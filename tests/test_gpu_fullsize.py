@@ -175,3 +175,19 @@ def test_headline_full_size_properties():
     want = oracle.logprob(_oracle_problem(g, 'PolynomialDecomposition'), theta[pick], n_threads=8)
     assert_logp_close(a[pick], want)
     ctx.close()
+
+
+def test_bench_cfg5_extra_on_one_rank(one_rank_rccl_group, capsys):
+    """bench.py's multi-GPU extras print a BASELINE config 5 record (every rank its own block of spectra, no
+    collective on the data path).  The pool gives one GPU: the same function on a one-rank RCCL group."""
+    import json
+    import sys
+    import torch
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    import bench
+    bench.batch_extra(one_rank_rccl_group, torch, 0, 1, 0, spectra_per_gpu=64, walkers=64, iterations=400)
+    err = capsys.readouterr().err
+    rec = json.loads([ln for ln in err.splitlines() if ln.startswith('{"sampler_cfg5"')][-1])['sampler_cfg5']
+    assert rec['n_gpus'] == 1 and rec['spectra'] == 64 and rec['iterations'] == 400 and rec['path'] == 'persistent'
+    assert rec['finite_means'] and rec['walker_steps_per_s'] > 1e7 and rec['collectives_on_the_data_path'] == 0
