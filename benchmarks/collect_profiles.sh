@@ -56,6 +56,7 @@ if [ "$what" = sampler ] || [ "$what" = all ]; then
   python3 benchmarks/cfg5_batch.py --chain device --steps 500 --thin-by 40 --no-persistent > "$out/cfg5_device_chain_launches.json" 2>> "$out/cfg5.err"
   python3 benchmarks/cfg5_batch.py --steps 100 --thin-by 10 > "$out/cfg5_host_chain.json" 2>> "$out/cfg5.err"
   python3 benchmarks/batch_models.py > "$out/batch_models.jsonl" 2>> "$out/cfg5.err"
+  python3 benchmarks/soak.py > "$out/soak.json" 2>> "$out/cfg5.err"
   (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$scratch/prof_sampler" -- \
       python3 "$repo/benchmarks/sampler_bench.py" > "$out/sampler_under_rocprof.jsonl" 2> "$out/prof_sampler.err")
   keep "$scratch/prof_sampler" prof_sampler

@@ -19,6 +19,7 @@ cpy $src/batch_setup.jsonl             $dst/${tag}_batch_setup.jsonl
 cpy $src/survey.jsonl                  $dst/${tag}_survey.jsonl
 cpy $src/sampler_bench.jsonl           $dst/${tag}_sampler_bench.jsonl
 cpy $src/batch_models.jsonl            $dst/${tag}_batch_models.jsonl
+cpy $src/soak.json                     $dst/${tag}_soak.json
 cpy "$(newest $src/prof_sampler/runc kernel_stats.csv)" $dst/${tag}_sampler_kernel_stats.csv
 for f in cfg4_fused_device_chain cfg4_sharded_python cfg4_sharded_rccl-own cfg4_sharded_rccl \
          cfg5_device_chain cfg5_device_chain_launches cfg5_host_chain; do

@@ -243,6 +243,7 @@ FILES = [
     (f'{ROUND}_batch_models.jsonl, {ROUND}_batch_models_kernel_stats.csv', '`python benchmarks/batch_models.py` (and `--only Polynomial` under `rocprofv3 --kernel-trace --stats`)', 'the batch-of-spectra sampler for every model at the cfg5 shape; the trace shows the stream draw next to the sampler kernel'),
     (f'{ROUND}_survey.jsonl', '`python benchmarks/survey.py [--model PeltonColeCole]`', 'a 4096-spectrum survey end to end: files to posterior summaries and model bands'),
     (f'{ROUND}_batch_setup.jsonl', '`python benchmarks/batch_setup.py`', 'what surrounds a survey run: batch context creation (host precompute on threads), a short fit, the summaries'),
+    (f'{ROUND}_soak.json', '`python benchmarks/soak.py`', 'twenty 100,000-iteration fits and twenty 10,000-iteration batch fits in one process: device memory constant, posterior means within 0.02 sigma of each other, identical summaries for identical seeds'),
     (f'{ROUND}_fuzz_*_summary.jsonl', '`python benchmarks/fuzz_parity.py --cases 1500 --seed S` (S = 41..43; 3000 cases each at S = 4242, 101..103, 201..204; 2000 at S = 104 and 3000 at S = 205 with boxes widened x2, x3), `fuzz_sampler.py --cases 1500 --seed 2` (and 5, 6), `fuzz_batch.py --cases 500 --seed 1` (and 4, 7)', 'randomised campaigns: violations, worst errors, which kernel AUTO ran'),
     (f'{ROUND}_micro_issue_latency.txt', '`benchmarks/micro/issue_latency`', 'cycles per fp64 FMA for 1/2/4/8 independent chains at 1, 2, 4 waves per SIMD; placement of 1-, 2-, 4-, 8-, 16-wave workgroups'),
     (f'{ROUND}_micro_row_latency.txt', '`benchmarks/micro/row_latency`', 'cycles of one log-probability row at one wave per SIMD, records from the scalar cache vs staged in LDS'),
