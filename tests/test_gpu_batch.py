@@ -124,12 +124,17 @@ def test_batch_persistent_equals_launch_path():
     """E ensembles: one workgroup each (persistent) == one launch per half-step over all."""
     import bisip_amd
     from bisip_amd.sampler import DeviceEnsembleSampler
-    for model, kw, ndim in [('PeltonColeCole', dict(n_modes=2), 7), ('PolynomialDecomposition', {}, 7)]:
+    for model, kw, ndim, variant in [('PeltonColeCole', dict(n_modes=2), 7, 'auto'), ('PolynomialDecomposition', {}, 7, 'auto'),
+                                     ('PolynomialDecomposition', {}, 7, 'reduced_comp'), ('PolynomialDecomposition', {}, 7, 'collapsed'),
+                                     ('Dias2000', {}, 5, 'auto')]:
         for E, Wp in [(7, 64), (3, 30), (5, 256)]:
             batch = bisip_amd.SpectraBatch(model, _tables(E), nwalkers=Wp, nsteps=12, **kw)
+            batch.ctx.set_variant(variant)
             rng = np.random.RandomState(E + Wp)
             if model == 'PeltonColeCole':
                 centre = np.array([1.0, 0.15, 0.5, -1.5, -12.0, 0.45, 0.6])
+            elif model == 'Dias2000':
+                centre = np.array([1.0, 0.5, -8.0, 10.0, 0.5])
             else:
                 centre = np.array([1.0, 0.005, -0.003, -0.001, 0.0005, 0.0002, 0.00001])
             p0 = (centre + 1e-4 * rng.randn(E, Wp, ndim)).reshape(E * Wp, ndim)
