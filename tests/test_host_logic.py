@@ -5,6 +5,7 @@ reference's surface, and a missing GPU fails loudly."""
 
 import os
 import re
+import subprocess
 import sys
 
 import numpy as np
@@ -29,8 +30,29 @@ def test_abi_exports_every_declared_symbol(hip_lib):
         assert hasattr(hip_lib, name), f'{name} declared in include/bisip_hip.h but not exported'
         assert name in _hip.SYMBOLS, f'{name} has no ctypes prototype in bisip_amd/_hip.py'
     assert set(_hip.SYMBOLS) == set(names)
-    assert hip_lib.bisip_abi_version() == 2
+    import __graft_entry__
+    assert hip_lib.bisip_abi_version() == __graft_entry__.header_abi_version()
     assert isinstance(hip_lib.bisip_last_error(), bytes)
+
+
+def test_driver_build_entry_point_runs():
+    """`__graft_entry__.build()` is the driver's and README's build command (reference analogue:
+    setup.py:34-56); the makes are no-ops when the tree is built."""
+    import __graft_entry__
+    __graft_entry__.build()
+
+
+def test_readme_test_counts_match_collection():
+    """README's hand-typed `(N tests)` figures against what pytest collects."""
+    readme = open(os.path.join(ROOT, 'README.md')).read()
+    stated = {m.group(1): int(m.group(2)) for m in
+              re.finditer(r'`-m ("not gpu"|gpu)` \((\d+) tests\)', readme)}
+    assert set(stated) == {'"not gpu"', 'gpu'}, stated
+    for marker, count in stated.items():
+        out = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(ROOT, 'tests'), '--collect-only', '-q',
+                              '-m', marker.strip('"')], capture_output=True, text=True, cwd=ROOT).stdout
+        got = int(re.search(r'(\d+)(?:/\d+)? tests collected', out).group(1))
+        assert got == count, f'README says {count} tests for -m {marker}, pytest collects {got}'
 
 
 def test_library_is_in_tree_and_built_for_gfx950():
