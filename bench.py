@@ -14,9 +14,14 @@ each GPU gets the same W.
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
 
 With --gpus N > 1 and no RANK in the environment the parent -- before it imports torch or
-touches a GPU -- starts `python -m torch.distributed.run ... bench.py <same flags>` as a child
-process, relays rank 0's JSON line and exits with the child's status (a failed rank is a
-failed run; nothing is retried).  Prints ONE JSON line on rank 0.
+touches a GPU -- starts `python -m torch.distributed.run ... bench.py <same flags> --no-extras`
+as a child process, relays rank 0's JSON line and exits with that group's status (a failed rank
+is a failed run; nothing is retried).  Prints ONE JSON line on rank 0.
+
+The sampler-mode measurements of BASELINE configs 4 and 5 ("extras", stderr only) never share a
+process with the headline: they run in a SECOND group of ranks (`--extras-only`), started as a
+fresh child process only after the headline line is out, under a wall-clock limit, and their
+exit status is ignored -- a crash, abort or hang there cannot cost the measured line.
 """
 
 import argparse
@@ -176,6 +181,22 @@ def cpu_baseline(data, taus, log_taus, bounds, theta, gpu_logp):
     return out, err, same_inf
 
 
+def rank_parity(data, taus, log_taus, bounds, theta, gpu_logp, rows=4096):
+    """This rank's first `rows` log-probabilities against the oracle: (max relative error over
+    finite rows, 1.0 if the -inf rows agree else 0.0).  The checker of the N > 1 line."""
+    import numpy as np
+    import oracle
+    prob = oracle.OracleProblem('PolynomialDecomposition', data['w'], data['zn'], data['zn_err'],
+                                bounds, taus=taus, log_taus=log_taus, c_exp=C_EXP)
+    n = min(rows, theta.shape[0])
+    ref = oracle.logprob(prob, theta[:n], n_threads=1)
+    got = np.asarray(gpu_logp[:n])
+    fin = np.isfinite(ref)
+    same_inf = np.array_equal(np.isneginf(got), np.isneginf(ref)) and not np.isnan(got).any()
+    err = float(np.max(np.abs(got[fin] - ref[fin]) / np.maximum(1.0, np.abs(ref[fin])))) if fin.any() else 0.0
+    return err, float(same_inf), n
+
+
 def free_port():
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
@@ -184,29 +205,114 @@ def free_port():
     return port
 
 
-def self_launch(n, argv):
-    """Parent of a multi-GPU run: start the ranks, relay rank 0's line, exit with their status.
-    Nothing here imports torch or touches the GPU."""
+EXTRAS_TIMEOUT_S = 300.0
+_ELASTIC_VARS = ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'GROUP_RANK', 'ROLE_RANK', 'ROLE_NAME',
+                 'ROLE_WORLD_SIZE', 'GROUP_WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'TORCHELASTIC_RUN_ID',
+                 'TORCHELASTIC_RESTART_COUNT', 'TORCHELASTIC_MAX_RESTARTS', 'TORCHELASTIC_USE_AGENT_STORE',
+                 'TORCHELASTIC_ERROR_FILE', 'TORCH_NCCL_ASYNC_ERROR_HANDLING', 'NCCL_ASYNC_ERROR_HANDLING',
+                 'OMP_NUM_THREADS')
+
+
+def gpus_enumerated():
+    """GPUs the kernel driver lists (KFD topology nodes with SIMDs), read from sysfs so that the
+    parent of a multi-GPU run can refuse an impossible --gpus without touching a GPU.  None when
+    the topology is not there to read (no amdgpu driver: the CPU rehearsal)."""
+    import glob
+    nodes = glob.glob('/sys/class/kfd/kfd/topology/nodes/*/properties')
+    if not nodes:
+        return None
+    n = 0
+    for path in nodes:
+        try:
+            props = dict(ln.split()[:2] for ln in open(path) if len(ln.split()) >= 2)
+        except OSError:       # a node this user may not read: not one of ours
+            continue
+        n += int(props.get('simd_count', '0')) > 0
+    return n
+
+
+def rank_group_env():
+    """Environment of a fresh group of ranks: nothing inherited from a rendezvous this process
+    may itself be part of.  HSA_ENABLE_IPC_MODE_LEGACY=0: the host driver of these machines only
+    supports dmabuf IPC; with the legacy mode RCCL's intra-node P2P set-up (and any sharing of
+    device memory between processes) fails with `hipIpcGetMemHandle: invalid argument`.  It is
+    read when the HSA runtime starts, so it has to be in the environment of the ranks."""
+    env = {k: v for k, v in os.environ.items() if k not in _ELASTIC_VARS}
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env['OMP_NUM_THREADS'] = os.environ.get('OMP_NUM_THREADS', '1')   # torchrun would set it anyway, with a warning
+    return env
+
+
+def launch_group(n, argv, timeout=None):
+    """One group of n ranks of this file under torch.distributed.run, as a child process in its
+    own session; returns (status, stdout).  At the limit the group -- exactly the process group
+    started here -- is ended and the status is -9."""
+    import signal
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}',
            '--master-addr', '127.0.0.1', '--master-port', str(free_port()),
            os.path.abspath(__file__)] + list(argv)
-    env = dict(os.environ)
-    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-    env.setdefault('OMP_NUM_THREADS', '1')      # torchrun would set it anyway, with a warning
-    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
-    out, _ = proc.communicate()
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=rank_group_env(), start_new_session=True)
+    try:
+        out, _ = proc.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(proc.pid, signal.SIGTERM)
+            out, _ = proc.communicate(timeout=15)
+        except subprocess.TimeoutExpired:
+            os.killpg(proc.pid, signal.SIGKILL)
+            out, _ = proc.communicate()
+        except ProcessLookupError:
+            out, _ = proc.communicate()
+        return -9, out
+    return proc.returncode, out
+
+
+def run_extras_group(n, argv):
+    """The cfg4 / cfg5 sampler measurements in their own group of ranks.  Whatever happens to that
+    group -- non-zero exit, abort, hang -- is reported on stderr and goes no further."""
+    argv = [a for a in argv if a not in ('--no-extras', '--extras-only')] + ['--extras-only']
+    try:
+        rc, out = launch_group(n, argv, timeout=EXTRAS_TIMEOUT_S)
+    except Exception as ex:      # noqa: BLE001 -- nothing here may change the run's status
+        print(f'bench.py: the extras group could not be started: {type(ex).__name__}: {ex}', file=sys.stderr)
+        return
+    for ln in out.splitlines():
+        print(ln, file=sys.stderr)
+    if rc != 0:
+        what = f'ended at its {EXTRAS_TIMEOUT_S:.0f} s limit' if rc == -9 else f'ended with status {rc}'
+        print(f'bench.py: the extras group (cfg4 / cfg5 sampler measurements) {what}; the result line '
+              'above is not affected', file=sys.stderr, flush=True)
+
+
+def self_launch(n, args, argv):
+    """Parent of a multi-GPU run: start the ranks, relay rank 0's line, then -- in a second group,
+    after the line is out -- the extras; exit with the FIRST group's status.  Nothing here imports
+    torch or touches the GPU."""
+    have = gpus_enumerated()
+    if not args.rehearse_cpu and not args.same_device and have is not None and have < n:
+        print(f'bench.py: --gpus {n} but this machine enumerates {have} GPU(s) '
+              '(/sys/class/kfd/kfd/topology/nodes/*/properties with simd_count > 0)', file=sys.stderr)
+        sys.exit(2)
+    if args.extras_only:
+        rc, out = launch_group(n, argv, timeout=EXTRAS_TIMEOUT_S)
+        for ln in out.splitlines():
+            print(ln, file=sys.stderr)
+        sys.exit(rc if rc >= 0 else 1)
+    rc, out = launch_group(n, [a for a in argv if a != '--no-extras'] + ['--no-extras'])
     lines = out.splitlines()
     result = [ln for ln in lines if ln.startswith('{"metric"')]
     for ln in lines:
         if not ln.startswith('{"metric"'):
             print(ln, file=sys.stderr)
-    if proc.returncode != 0:
-        print(f'bench.py: the {n}-rank run failed with status {proc.returncode}', file=sys.stderr)
-        sys.exit(proc.returncode)
+    if rc != 0:
+        print(f'bench.py: the {n}-rank run failed with status {rc}', file=sys.stderr)
+        sys.exit(rc if rc > 0 else 1)
     if len(result) != 1:
         print(f'bench.py: expected one result line from rank 0, got {len(result)}', file=sys.stderr)
         sys.exit(1)
-    print(result[0])
+    print(result[0], flush=True)
+    if not args.no_extras:
+        run_extras_group(n, argv)
     sys.exit(0)
 
 
@@ -226,8 +332,12 @@ def main():
     ap.add_argument('--rehearse-cpu', action='store_true',
                     help='control flow only (launch, rendezvous, barriers, reductions, the JSON line) with '
                          'NO kernel: value is null.  For the CPU test of the multi-rank path; never a measurement')
-    ap.add_argument('--no-sampler-extra', action='store_true',
-                    help='N > 1: skip the sharded-sampler (cfg4) measurement that follows the result line')
+    ap.add_argument('--no-extras', '--no-sampler-extra', dest='no_extras', action='store_true',
+                    help='N > 1: skip the cfg4 / cfg5 sampler measurements that follow the result line '
+                         '(they run in a second group of ranks, never in the processes of the headline)')
+    ap.add_argument('--extras-only', action='store_true',
+                    help='N > 1: ONLY the cfg4 / cfg5 sampler measurements (what the second group runs); '
+                         'lines on stderr, no result line')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-variants', action='store_true')
     ap.add_argument('--pmc-pass', action='store_true',
@@ -238,7 +348,9 @@ def main():
     if args.gpus < 1:
         ap.error('--gpus must be >= 1')
     if args.gpus > 1 and 'RANK' not in os.environ:
-        self_launch(args.gpus, sys.argv[1:])     # does not return
+        self_launch(args.gpus, args, sys.argv[1:])     # does not return
+    if args.extras_only and args.gpus == 1:
+        ap.error('--extras-only needs --gpus N > 1')
 
     # read by the HSA runtime when the GPU is first touched: set before anything initialises it
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
@@ -254,6 +366,10 @@ def main():
     if rehearse and args.backend != 'gloo':
         ap.error('--rehearse-cpu needs --backend gloo')
     if not rehearse:
+        if not args.same_device and torch.cuda.device_count() < world:     # counting devices does not initialise one
+            if rank == 0:
+                print(f'bench.py: {world} ranks but torch sees {torch.cuda.device_count()} GPU(s)', file=sys.stderr)
+            sys.exit(2)
         torch.cuda.set_device(local_rank)
     if 'RANK' in os.environ:   # launched by torch.distributed.run: one rank per GPU over RCCL
         import torch.distributed as dist
@@ -270,6 +386,20 @@ def main():
             print(f'bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}', file=sys.stderr)
         sys.exit(2)
     coll_dev = f'cuda:{local_rank}' if (args.backend == 'nccl' and not rehearse) else 'cpu'
+
+    if args.extras_only:
+        # the second group of a multi-GPU run: nothing of the headline lives in these processes
+        if os.environ.get('BISIP_BENCH_INJECT_EXTRAS_ABORT') and rank == world - 1:
+            os.abort()                                 # tests: a rank of the extras dies hard
+        if rehearse:
+            dist.barrier()
+            if rank == 0:
+                print(json.dumps({'extras_rehearsal': {'pid': os.getpid(), 'ranks': world}}), file=sys.stderr, flush=True)
+        else:
+            sampler_extra(args, dist, torch, rank, world, local_rank)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
 
     ndim = POLY_DEG + 2
     W = int(args.walkers)
@@ -325,6 +455,18 @@ def main():
             wall, kern_ms = time_launches(step, args.steps, 0, torch, stream, dist)
 
     ranks_seen, per_rank_kernel_ms = 1, [kern_ms]
+    parity = None
+    if dist is not None and world > 1 and not rehearse:
+        # every rank checks its own shard (its own theta, seed 2024 + rank): a value summed over
+        # N GPUs comes with evidence from each of them
+        err, same_inf, n_chk = rank_parity(data, taus, log_taus, bounds, theta, out_t[:4096].cpu().numpy())
+        e = torch.tensor([err], dtype=torch.float64, device=coll_dev)
+        ok = torch.tensor([same_inf], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(e, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        parity = {'max_rel_err_vs_oracle': float(e[0]), 'neg_inf_rows_match': bool(ok[0] > 0), 'tolerance': 1e-10,
+                  'rows_per_rank': n_chk, 'ranks_checked': world,
+                  'reduction': 'all_reduce MAX of the error, MIN of the -inf agreement, over all ranks'}
     if dist is not None:
         t = torch.tensor([wall, kern_ms], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -346,6 +488,7 @@ def main():
         }
         if rehearse:
             result['rehearsal'] = 'control flow only: no kernel ran, not a measurement'
+            result['rank0_pid'] = os.getpid()
             result['config'] = {'workload': 'none (--rehearse-cpu)', 'backend': args.backend}
         else:
             bytes_per_eval = 8 * (ndim + 1)            # read one theta row, write one logp
@@ -372,6 +515,8 @@ def main():
                                                'WRITE_SIZE passes of this command (FETCH_SIZE x2, gfx950)'
                                                if traffic is not None else None},
             })
+            if parity is not None:
+                result['parity'] = parity
             if world == 1:
                 counts = load_json('valu_counts.json')
                 gpu_logp = out_t.cpu().numpy()
@@ -384,25 +529,43 @@ def main():
                     result['parity'] = {'max_rel_err_vs_oracle': err, 'neg_inf_rows_match': same_inf,
                                         'tolerance': 1e-10}
         print(json.dumps(result), flush=True)
-    if dist is not None and world > 1 and not rehearse and not args.no_sampler_extra:
-        # AFTER the result line is out: the sampler-mode path of the north star (cfg4) on these
-        # same ranks.  Goes to stderr; cannot change the line above, and a watchdog ends the
-        # process cleanly should a collective ever hang.
-        sampler_extra(args, dist, torch, rank, world, local_rank)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if world > 1 and not args.no_extras and rank == 0:
+        # Started by the driver's own torch.distributed.run (no parent of ours to do it): AFTER the
+        # result line is out and the process group is gone, rank 0 lets go of its device memory and
+        # starts the extras as a fresh child process -- `bench.py --extras-only`, which launches its
+        # own group of ranks -- waits for it within its limit and exits 0 whatever became of it.
+        if not rehearse:
+            del theta_t, out_t
+            ctx.close()
+            torch.cuda.empty_cache()
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__)] +
+                               [a for a in sys.argv[1:] if a != '--extras-only'] + ['--extras-only'],
+                               env=rank_group_env(), stdout=subprocess.PIPE, text=True, timeout=EXTRAS_TIMEOUT_S + 60)
+            for ln in r.stdout.splitlines():
+                print(ln, file=sys.stderr)
+            if r.returncode != 0:
+                print(f'bench.py: the extras group ended with status {r.returncode}; the result line above is '
+                      'not affected', file=sys.stderr, flush=True)
+        except Exception as ex:      # noqa: BLE001 -- includes the timeout; never the run's status
+            print(f'bench.py: extras not completed: {type(ex).__name__}: {ex}', file=sys.stderr, flush=True)
 
 
 def sampler_extra(args, dist, torch, rank, world, local_rank, walkers=32768, steps=200):
-    """BASELINE config 4 on the ranks of this run: Debye decomposition (S = 40 relaxation times,
-    the bundled 20-frequency grid, poly_deg 5), 32768 walkers sharded over the GPUs, one RCCL
-    all-gather per stretch half-step, driven by bisip_stretch_run_sharded_dev on the
-    communicator torch.distributed built.  One JSON line on rank 0's STDERR."""
+    """BASELINE config 4 on a group of ranks of its own: Debye decomposition (S = 40 relaxation
+    times, the bundled 20-frequency grid, poly_deg 5), 32768 walkers sharded over the GPUs, one
+    all-gather per stretch half-step.  Three drivers of the same sharded half-step, least risky
+    first, each with its own JSON line on rank 0's STDERR as soon as it is done: the Python loop
+    over torch.distributed, then (RCCL groups) the C loop bisip_stretch_run_sharded_dev on a
+    communicator of its own and on the one torch.distributed built.  Between them BASELINE
+    config 5 (batch_extra: whole replicas, no collective)."""
     import threading
     import numpy as np
-    watchdog = threading.Timer(180.0, lambda: (print('bench.py: sampler extra timed out', file=sys.stderr,
-                                                     flush=True), os._exit(0)))
+    watchdog = threading.Timer(EXTRAS_TIMEOUT_S - 30, lambda: (print('bench.py: sampler extra timed out', file=sys.stderr,
+                                                                     flush=True), os._exit(0)))
     watchdog.daemon = True
     watchdog.start()
     try:
@@ -428,35 +591,38 @@ def sampler_extra(args, dist, torch, rank, world, local_rank, walkers=32768, ste
             dist.barrier()
             return s, time.perf_counter() - t0
 
-        sharded = dict(distributed=True, force_sharded_path=True)
         if args.same_device:
             steps = 40                                 # rehearsal through host memory: keep it short
-        run(20, **sharded)                         # clocks, communicator, allocations
-        s, dt = run(steps, **sharded)
-        final = torch.from_numpy(np.ascontiguousarray(s._coords))
-        if args.backend == 'nccl':
-            final = final.to(f'cuda:{local_rank}')
-        every = torch.empty((world * final.shape[0], final.shape[1]), dtype=final.dtype, device=final.device)
-        dist.all_gather_into_tensor(every, final)      # rank r's state = rows [r*W, (r+1)*W)
-        every = every.view(world, final.shape[0], final.shape[1])
-        same = bool(all(torch.equal(every[0], every[r]) for r in range(world)))
         run(20)
         f, dtf = run(steps)                        # every rank alone, fused half-steps, same stream
-        rec = {'sampler_cfg4': {
-            'config': 'Debye decomposition S=40 N=20 poly_deg=5, stretch move', 'walkers': walkers,
-            'n_gpus': world, 'iterations': steps, 'driver': s.last_path,
-            'us_per_half_step': dt / steps / 2 * 1e6, 'walker_steps_per_s': walkers * steps / dt,
-            'payload_bytes_per_rank_per_half_step': -(-(walkers // 2) // world) * 9 * 8,
-            'state_identical_on_every_rank': same,
-            'equals_single_gpu_fused_chain': bool(np.array_equal(s._coords, f._coords)),
-            'single_gpu_fused_us_per_half_step': dtf / steps / 2 * 1e6,
-            'single_gpu_fused_walker_steps_per_s': walkers * steps / dtf}}
-        s.close()
-        if rank == 0:
-            print(json.dumps(rec), file=sys.stderr, flush=True)
-        if not args.same_device:
-            batch_extra(dist, torch, rank, world, local_rank)
-    except Exception as ex:      # never turns a measured headline into a failed run
+        fused = np.array(f._coords)
+        loops = ['python'] + (['rccl-own', 'rccl'] if args.backend == 'nccl' else [])
+        for i, loop in enumerate(loops):
+            sharded = dict(distributed=True, force_sharded_path=True, sharded_loop=loop)
+            run(20, **sharded)[0].close()              # clocks, communicator, allocations
+            s, dt = run(steps, **sharded)
+            final = torch.from_numpy(np.ascontiguousarray(s._coords))
+            if args.backend == 'nccl':
+                final = final.to(f'cuda:{local_rank}')
+            every = torch.empty((world * final.shape[0], final.shape[1]), dtype=final.dtype, device=final.device)
+            dist.all_gather_into_tensor(every, final)      # rank r's state = rows [r*W, (r+1)*W)
+            every = every.view(world, final.shape[0], final.shape[1])
+            same = bool(all(torch.equal(every[0], every[r]) for r in range(world)))
+            rec = {'sampler_cfg4': {
+                'config': 'Debye decomposition S=40 N=20 poly_deg=5, stretch move', 'walkers': walkers,
+                'n_gpus': world, 'iterations': steps, 'driver': s.last_path, 'sharded_loop': loop,
+                'us_per_half_step': dt / steps / 2 * 1e6, 'walker_steps_per_s': walkers * steps / dt,
+                'payload_bytes_per_rank_per_half_step': -(-(walkers // 2) // world) * 9 * 8,
+                'state_identical_on_every_rank': same,
+                'equals_single_gpu_fused_chain': bool(np.array_equal(s._coords, fused)),
+                'single_gpu_fused_us_per_half_step': dtf / steps / 2 * 1e6,
+                'single_gpu_fused_walker_steps_per_s': walkers * steps / dtf}}
+            s.close()
+            if rank == 0:
+                print(json.dumps(rec), file=sys.stderr, flush=True)
+            if i == 0 and not args.same_device:
+                batch_extra(dist, torch, rank, world, local_rank)
+    except Exception as ex:      # reported; the group's status is ignored by whoever started it
         print(f'bench.py: sampler extra failed on rank {rank}: {type(ex).__name__}: {ex}', file=sys.stderr, flush=True)
     finally:
         watchdog.cancel()
@@ -512,6 +678,9 @@ def time_variants(ctx, args, step, W, torch, stream, counts):
         _, ms = time_launches(step, k, 2, torch, stream)
         rec = {'evals_per_s': W / (ms * 1e-3), 'kernel_ms': ms, 'kernel': ctx.kernel_name,
                'hbm_frac': 64 * W / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        if v == 'wave':
+            rec['note'] = ('not a product path: the north star\'s one-wave-per-walker mapping, kept as a measured '
+                           'comparison; AUTO never selects it')
         rv = valu_roofline(v, W, ms, counts)
         if rv:
             rec['roofline_valu'] = rv

@@ -498,13 +498,22 @@ class HipStretchBackend:
         if dist.get_backend(group) != 'nccl':
             return None, False
         if prefer == 'torch':
+            # Borrow-or-own is decided BY THE GROUP: a rank that borrowed while another fell through
+            # to the broadcast below would issue different collectives and hang.  The first
+            # all-reduce also makes torch build its (lazily created) communicator on every rank.
+            torch = self.torch
+            flag = torch.ones(1, dtype=torch.int32, device=self.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            ptr = 0
             try:
                 pg = group if group is not None else dist.distributed_c10d._get_default_group()
                 ptr = int(pg._get_backend(self.device)._comm_ptr())
-                if ptr:
-                    return ptr, False
-            except Exception:      # older / newer torch without the accessor, or a lazy communicator
-                pass
+            except Exception:      # older / newer torch without the accessor
+                ptr = 0
+            flag.fill_(1 if ptr else 0)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            if int(flag.item()):
+                return ptr, False
         ids = [_hip.rccl_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=dist.get_global_rank(group, 0) if group is not None else 0,
                                    group=group)
@@ -618,7 +627,7 @@ class DeviceEnsembleSampler(_SamplerBase):
     def __init__(self, nwalkers, ndim, ctx=None, a=2.0, live_dangerously=False, group=None,
                  distributed=False, backend=None, chunk=None, rng='numpy', seed=None,
                  n_ensembles=1, force_sharded_path=False, persistent=None, chain_on_device=False,
-                 sharded_loop='rccl'):
+                 sharded_loop='python'):
         if rng not in ('numpy', 'philox'):
             raise ValueError("rng must be 'numpy' or 'philox'")
         # n_ensembles > 1: independent ensembles of `nwalkers` walkers each (batch of spectra),
@@ -637,11 +646,14 @@ class DeviceEnsembleSampler(_SamplerBase):
         self.rng = rng
         # run eval -> all_gather -> apply even with one rank (benchmarks the sharded path)
         self.force_sharded_path = bool(force_sharded_path)
-        # who runs the sharded half-step loop: 'rccl' = one C call per chunk enqueues eval ->
-        # ncclAllGather -> apply for every half-step (bisip_stretch_run_sharded_dev) on the
-        # communicator torch.distributed already has; 'rccl-own' = the same on a communicator
-        # of this sampler's own; 'python' = the per-half-step loop over torch.distributed (what
-        # gloo groups and injected test backends always use).  Same chain every way.
+        # who runs the sharded half-step loop: 'python' (default) = the per-half-step loop over
+        # torch.distributed (what gloo groups and injected test backends always use); 'rccl' = one
+        # C call per chunk enqueues eval -> ncclAllGather -> apply for every half-step
+        # (bisip_stretch_run_sharded_dev) on the communicator torch.distributed already has;
+        # 'rccl-own' = the same on a communicator of this sampler's own.  Same chain every way.
+        # The C loop is 5x faster with one rank but has never met a second
+        # rank on hardware (this pool gives one GPU, and RCCL refuses two ranks on one device), so it
+        # is opt-in until `bench.py --gpus N`'s extras have shown it equal to the Python loop there.
         if sharded_loop not in ('rccl', 'rccl-own', 'python'):
             raise ValueError("sharded_loop must be 'rccl', 'rccl-own' or 'python'")
         self.sharded_loop = sharded_loop

@@ -169,26 +169,85 @@ def test_batch_replica_sharding():
     assert all(b - a == 512 for a, b in blocks)
 
 
-def _run_bench(*flags):
+def _run_bench(*flags, env=None, launcher=()):
     import subprocess
-    return subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), *flags], capture_output=True,
-                          text=True, timeout=600, cwd=ROOT)
+    e = dict(os.environ)
+    e.update(env or {})
+    return subprocess.run([sys.executable, *launcher, os.path.join(ROOT, 'bench.py'), *flags], capture_output=True,
+                          text=True, timeout=600, cwd=ROOT, env=e)
+
+
+def _result_lines(r):
+    return [ln for ln in r.stdout.splitlines() if ln.strip()]
 
 
 def test_bench_starts_its_own_ranks():
     """`python bench.py --gpus 2` with no RANK in the environment must itself become a 2-rank run
     (the parent starts torch.distributed.run before touching any GPU) and say so: n_gpus 2,
     ranks_seen 2 from an all-reduce over the ranks.  --rehearse-cpu runs the whole control flow
-    (launch, rendezvous, barriers, reductions, the one JSON line) with no kernel -- value is null."""
+    (launch, rendezvous, barriers, reductions, the one JSON line) with no kernel -- value is null.
+    The extras (cfg4 / cfg5) run AFTER the line, in a second group of ranks: other processes."""
     import json
     r = _run_bench('--gpus', '2', '--backend', 'gloo', '--rehearse-cpu', '--steps', '3', '--warmup', '1')
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    lines = _result_lines(r)
     assert len(lines) == 1                      # rank 0's line only; everything else went to stderr
     rec = json.loads(lines[0])
     assert rec['n_gpus'] == 2 and rec['ranks_seen'] == 2
     assert rec['value'] is None and 'not a measurement' in rec['rehearsal']
     assert rec['steps'] == 3 and rec['warmup'] == 1 and rec['scaling'] == 'weak'
+    extras = [json.loads(ln) for ln in r.stderr.splitlines() if ln.startswith('{"extras_rehearsal"')]
+    assert len(extras) == 1, r.stderr[-2000:]
+    assert extras[0]['extras_rehearsal']['ranks'] == 2
+    assert extras[0]['extras_rehearsal']['pid'] != rec['rank0_pid']      # not the headline's processes
+
+
+def test_bench_headline_survives_a_crash_in_the_extras():
+    """A rank of the extras group aborts (SIGABRT, as a failed assertion inside a native library
+    would): the run still exits 0 with its one result line, and says what happened on stderr."""
+    import json
+    r = _run_bench('--gpus', '2', '--backend', 'gloo', '--rehearse-cpu', '--steps', '2', '--warmup', '1',
+                   env={'BISIP_BENCH_INJECT_EXTRAS_ABORT': '1'})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = _result_lines(r)
+    assert len(lines) == 1 and json.loads(lines[0])['ranks_seen'] == 2
+    assert 'the extras group' in r.stderr and 'not affected' in r.stderr
+    assert not [ln for ln in r.stderr.splitlines() if ln.startswith('{"extras_rehearsal"')]
+
+
+@pytest.mark.parametrize('crash', [False, True])
+def test_bench_under_the_drivers_own_launcher(crash):
+    """The driver starts the ranks itself (`python -m torch.distributed.run ... bench.py --gpus 2`):
+    there is no parent of ours, so rank 0 -- after the line is out and the process group is gone --
+    starts the extras as a fresh child process and exits 0 whatever becomes of it."""
+    import json
+    launcher = ('-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+                '--master-port', str(_free_port()))
+    r = _run_bench('--gpus', '2', '--backend', 'gloo', '--rehearse-cpu', '--steps', '2', '--warmup', '1',
+                   launcher=launcher, env={'BISIP_BENCH_INJECT_EXTRAS_ABORT': '1'} if crash else {'OMP_NUM_THREADS': '1'})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in _result_lines(r) if ln.startswith('{"metric"')]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 2 and rec['ranks_seen'] == 2
+    extras = [json.loads(ln) for ln in r.stderr.splitlines() if ln.startswith('{"extras_rehearsal"')]
+    if crash:
+        assert not extras and 'not affected' in r.stderr
+    else:
+        assert len(extras) == 1 and extras[0]['extras_rehearsal']['pid'] != rec['rank0_pid']
+
+
+def test_bench_refuses_more_gpus_than_enumerated(tmp_path, monkeypatch):
+    """The parent counts GPUs from the KFD topology in sysfs (no GPU call) and refuses an
+    impossible --gpus with a clear message."""
+    sys.path.insert(0, ROOT)
+    import bench
+    n = bench.gpus_enumerated()
+    assert n is None or n >= 0
+    if n is None:
+        return               # no amdgpu driver here: nothing to refuse against (the GPU box has one)
+    r = _run_bench('--gpus', str(n + 1), '--no-extras')
+    assert r.returncode == 2 and 'enumerates' in r.stderr
 
 
 def test_bench_fails_when_a_rank_fails():

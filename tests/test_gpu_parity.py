@@ -943,7 +943,11 @@ def test_bench_two_ranks_on_one_device():
     assert rec['config']['global_walkers'] == 2 << 20 and rec['config']['kernel'] == 'k_logprob_pd_reduced'
     assert len(rec['roofline']['per_rank_kernel_ms']) == 2 and min(rec['roofline']['per_rank_kernel_ms']) > 0
     assert rec['value'] > 1e8 and 'cpu_baseline' not in rec       # rank-0-at-N=1 extras stay out
-    # after the result line the same two ranks ran BASELINE config 4's sharded stretch move (here
+    # every rank checked its own shard against the oracle; the line carries the reduction
+    par = rec['parity']
+    assert par['ranks_checked'] == 2 and par['rows_per_rank'] == 4096 and par['neg_inf_rows_match'] is True
+    assert par['max_rel_err_vs_oracle'] <= 1e-10
+    # after the result line a SECOND group of two ranks ran BASELINE config 4's sharded stretch move (here
     # over gloo through host memory, each rank evaluating its half of every half-step with the
     # real kernels): every rank holds the same ensemble, and it is the single-GPU chain
     extra = [json.loads(ln) for ln in r.stderr.splitlines() if ln.startswith('{"sampler_cfg4"')]
