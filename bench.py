@@ -132,6 +132,37 @@ def time_launches(fn, steps, warmup, torch, stream, dist=None):
     return wall, kern_ms
 
 
+def engine_clock_ghz(fn, kernel_ms, torch, launches=40):
+    """The engine clock the chip holds while `fn`'s kernel runs: a one-wave probe
+    (bisip_clock_probe_dev) on a side stream brackets a window inside a back-to-back series of
+    `fn` launches with reads of the shader clock and of the constant 100 MHz counter.  Untimed;
+    the timed blocks never have a probe beside them."""
+    from bisip_amd import _hip
+    side = torch.cuda.Stream()
+    buf = torch.zeros(4, dtype=torch.int64, device='cuda')
+    window_us = min(max(kernel_ms * 1e3 * launches / 4.0, 50.0), 5000.0)
+    torch.cuda.synchronize()
+    for _ in range(launches // 4):
+        fn()
+    _hip.clock_probe_dev(buf.data_ptr(), window_us, side.cuda_stream)
+    for _ in range(launches - launches // 4):
+        fn()
+    torch.cuda.synchronize()
+    t0, t1, r0, r1 = (int(x) for x in buf.cpu())
+    if r1 <= r0:
+        return None
+    return (t1 - t0) / (r1 - r0) * 0.1
+
+
+def with_clock(rv, clock_ghz):
+    """fp64-issue fraction at the clock the chip actually held (DVFS) beside the one at 2.4 GHz."""
+    if rv and clock_ghz:
+        rv['clock_ghz'] = clock_ghz
+        rv['frac_at_clock'] = rv['achieved'] / (N_SIMD * clock_ghz * 1e9 / 4.0)
+        rv['cycles_per_valu_instr_per_simd'] = N_SIMD * clock_ghz * 1e9 / rv['achieved']
+    return rv
+
+
 def cpu_baseline(data, taus, log_taus, bounds, theta, gpu_logp):
     """Oracle (CPU restatement of the reference loop, libm cpow) on a bounded sample of
     the same workload, on this box's host cores.  Also the parity spot-check."""
@@ -518,6 +549,7 @@ def main():
             if parity is not None:
                 result['parity'] = parity
             if world == 1:
+                result['roofline']['clock_ghz'] = engine_clock_ghz(step, kern_ms, torch)
                 counts = load_json('valu_counts.json')
                 gpu_logp = out_t.cpu().numpy()
                 if not args.no_variants:
@@ -681,7 +713,8 @@ def time_variants(ctx, args, step, W, torch, stream, counts):
         if v == 'wave':
             rec['note'] = ('not a product path: the north star\'s one-wave-per-walker mapping, kept as a measured '
                            'comparison; AUTO never selects it')
-        rv = valu_roofline(v, W, ms, counts)
+        rec['clock_ghz'] = engine_clock_ghz(step, ms, torch)
+        rv = with_clock(valu_roofline(v, W, ms, counts), rec['clock_ghz'])
         if rv:
             rec['roofline_valu'] = rv
         variants[v] = rec
@@ -715,7 +748,8 @@ def time_zoo(data, args, torch, stream, counts, local_rank):
         rec = {'evals_per_s': ZOO_WALKERS / (ms * 1e-3), 'kernel_ms': ms, 'kernel': ctx.kernel_name,
                'walkers': ZOO_WALKERS, 'n_freq': N_FREQ,
                'hbm_frac': 8 * (ndim + 1) * ZOO_WALKERS / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
-        rv = valu_roofline(label, ZOO_WALKERS, ms, counts)
+        rec['clock_ghz'] = engine_clock_ghz(fn, ms, torch)
+        rv = with_clock(valu_roofline(label, ZOO_WALKERS, ms, counts), rec['clock_ghz'])
         if rv:
             rec['roofline_valu'] = rv
         out[label] = rec

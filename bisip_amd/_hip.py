@@ -127,6 +127,7 @@ SYMBOLS = {
                                                  _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
     'bisip_polydecomp_reduced_estimates': (ctypes.c_int, [ctypes.c_int, _dp, _dp, _dp, ctypes.POINTER(ModelDesc),
                                                           _dp, _dp, _dp]),
+    'bisip_clock_probe_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p]),
     'bisip_abi_version': (ctypes.c_int, []),
     'bisip_device_count': (ctypes.c_int, []),
     'bisip_last_error': (ctypes.c_char_p, []),
@@ -458,6 +459,13 @@ class HipContext:
 
 
 RCCL_ID_BYTES = 128
+
+
+def clock_probe_dev(d_out_ptr, window_us, stream=0):
+    """One wavefront that brackets ``window_us`` with (shader clock, 100 MHz clock) reads into the
+    four int64 at ``d_out_ptr``: enqueue it on a side stream next to a kernel under measurement;
+    engine clock in GHz = (out[1] - out[0]) / (out[3] - out[2]) * 0.1."""
+    _check(load_library().bisip_clock_probe_dev(ctypes.c_void_p(d_out_ptr), float(window_us), ctypes.c_void_p(stream)))
 
 
 def rccl_unique_id():

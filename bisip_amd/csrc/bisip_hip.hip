@@ -198,9 +198,38 @@ static int guarded(F &&body)
     }
 }
 
+namespace {
+// one wave; sleeps (s_sleep: no issue slots taken from the kernel under measurement) until the
+// 100 MHz counter has advanced by `ticks`, at most `max_polls` polls so that the wave always ends
+__global__ __launch_bounds__(64) void k_clock_probe(long long *out, long long ticks, int max_polls)
+{
+    const long long t0 = clock64(), r0 = wall_clock64();
+    long long r1 = r0;
+    for (int i = 0; i < max_polls && r1 - r0 < ticks; ++i) {
+        __builtin_amdgcn_s_sleep(64);
+        r1 = wall_clock64();
+    }
+    const long long t1 = clock64();
+    r1 = wall_clock64();
+    if (threadIdx.x == 0) { out[0] = t0; out[1] = t1; out[2] = r0; out[3] = r1; }
+}
+}  // namespace
+
 extern "C" {
 
 int bisip_abi_version(void) { return BISIP_ABI_VERSION; }
+
+int bisip_clock_probe_dev(int64_t *d_out, double window_us, void *stream)
+{
+    if (!d_out) return fail(BISIP_EINVAL, "bisip_clock_probe_dev: null output");
+    if (!(window_us > 0.0) || window_us > 1e5) return fail(BISIP_EINVAL, "bisip_clock_probe_dev: window_us out of (0, 1e5]");
+    const long long ticks = (long long)(window_us * 100.0);
+    // one poll sleeps 64*64 = 4096 cycles (~2 us): bound the loop at 4x the polls the window needs
+    const int max_polls = (int)(window_us * 2.0) + 64;
+    hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long *)d_out, ticks, max_polls);
+    HIP_TRY(hipGetLastError());
+    return BISIP_OK;
+}
 
 const char *bisip_last_error(void) { return g_err; }
 

@@ -38,8 +38,9 @@ extern "C" {
 
 /* 2: entry points added since 1 (all additions, nothing changed or removed): loglike_z, forward_percentiles,
  * column / grouped / columns percentiles, forward_spectrum(s) / forward_columns, stretch_run_sharded + rccl_*, ctx_set_spectrum_offset,
- * ctx_reduced_check, polydecomp_reduced_estimates, read_tables; BISIP_VARIANT_REDUCED_COMP, BISIP_ERCCL. */
-#define BISIP_ABI_VERSION 2
+ * ctx_reduced_check, polydecomp_reduced_estimates, read_tables; BISIP_VARIANT_REDUCED_COMP, BISIP_ERCCL.
+ * 3: clock_probe_dev, ctx_reduced_guard (additions only). */
+#define BISIP_ABI_VERSION 3
 
 /* model_id -- the four reference model classes (src/bisip/models.py:182,232,274,308) */
 #define BISIP_MODEL_POLYDECOMP 0 /* PolynomialDecomposition -> Decomp_cyth  */
@@ -392,6 +393,14 @@ int bisip_polydecomp_operands(int N, const double *w, const double *zn, const do
 int bisip_polydecomp_reduced_estimates(int N, const double *w, const double *zn, const double *zn_err,
                                        const bisip_model_desc *desc, const double *lo,
                                        const double *hi, double *est);
+
+/* Measurement aid (no reference counterpart): ONE wavefront that reads the shader clock counter
+ * (s_memtime) and the constant 100 MHz counter (s_memrealtime), idles for window_us and reads both
+ * again; d_out (4 x int64, device) = shader ticks begin/end, 100 MHz ticks begin/end.  Enqueued on a
+ * stream of its own beside a kernel under measurement it tells the engine clock the chip holds under
+ * that kernel's load -- fp64-dense kernels run at 1.9-2.1 GHz, not at the 2.4 GHz the issue peak is
+ * quoted at (benchmarks/micro/collapsed_r3.hip) -- without touching the kernel itself. */
+int bisip_clock_probe_dev(int64_t *d_out, double window_us, void *stream);
 
 int bisip_abi_version(void);
 int bisip_device_count(void);

@@ -65,7 +65,7 @@ def test_cfg4_full_size_fused_python_sharded_and_rccl_loop_agree(one_rank_rccl_g
         'python loop': run(distributed=True, force_sharded_path=True, sharded_loop='python'),
         'C loop, torch communicator': run(distributed=True, force_sharded_path=True, sharded_loop='rccl'),
         'C loop, own communicator (group)': run(distributed=True, force_sharded_path=True, sharded_loop='rccl-own'),
-        'C loop, own communicator (no group)': run(force_sharded_path=True),
+        'C loop, own communicator (no group)': run(force_sharded_path=True, sharded_loop='rccl'),
     }
     want_path = {'python loop': 'sharded'}
     for name, s in results.items():
