@@ -127,6 +127,8 @@ SYMBOLS = {
                                                  _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
     'bisip_polydecomp_reduced_estimates': (ctypes.c_int, [ctypes.c_int, _dp, _dp, _dp, ctypes.POINTER(ModelDesc),
                                                           _dp, _dp, _dp]),
+    'bisip_ctx_reduced_guard': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int64),
+                                               _dp, ctypes.POINTER(ctypes.c_int)]),
     'bisip_clock_probe_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p]),
     'bisip_abi_version': (ctypes.c_int, []),
     'bisip_device_count': (ctypes.c_int, []),
@@ -278,6 +280,9 @@ class HipContext:
         self.device = int(device)
         self.model_id = int(model_id)
         self.n_modes = int(n_modes)
+        # bisip_logprob's guard of the QR-reduced kernels (see logprob)
+        self._guarded = self.model_id == MODEL_POLYDECOMP
+        self._calls, self._escalations_seen, self._guard_warned = 0, 0, False
         if variant != 'auto':
             self.set_variant(variant)
 
@@ -363,11 +368,42 @@ class HipContext:
         return _c(theta)
 
     def logprob(self, theta):
-        """theta (W, ndim) host -> logp (W,) host."""
+        """theta (W, ndim) host -> logp (W,) host.
+
+        PolynomialDecomposition: the library measures the QR-reduced kernel on rows of this very
+        batch on the first call and every 2^n-th after it (bisip_ctx_reduced_guard); a context on
+        'auto' that fails moves to the next formulation and re-evaluates the batch -- reported here
+        as a RuntimeWarning -- and a caller-forced reduced variant past the tolerance is named."""
         theta = self._theta2d(theta)
         out = np.empty(theta.shape[0], dtype=np.float64)
         _check(self._lib.bisip_logprob(self._h, _p(theta), theta.shape[0], _p(out)))
+        if self._guarded and theta.shape[0]:
+            self._calls += 1
+            if self._calls & (self._calls - 1) == 0:
+                self._report_guard()
         return out
+
+    def reduced_guard(self, enable=None):
+        """(checks made, worst relative error seen, formulation changes) of the guard bisip_logprob runs
+        on the QR-reduced kernels; ``enable`` True / False switches it on / off."""
+        n, w, e = ctypes.c_int64(0), ctypes.c_double(0.0), ctypes.c_int(0)
+        _check(self._lib.bisip_ctx_reduced_guard(self._h, -1 if enable is None else int(bool(enable)),
+                                                 ctypes.byref(n), ctypes.cast(ctypes.byref(w), _dp), ctypes.byref(e)))
+        return int(n.value), float(w.value), int(e.value)
+
+    def _report_guard(self):
+        import warnings
+        _, worst, esc = self.reduced_guard()
+        if esc > self._escalations_seen:
+            self._escalations_seen = esc
+            warnings.warn(f'the QR-reduced kernel was {worst:.1e} (relative) away from the exact log-probability on '
+                          f'rows of this batch; the context now runs {self.kernel_name} and the batch was '
+                          're-evaluated with it', RuntimeWarning, stacklevel=3)
+        elif worst > 1e-10 and not self._guard_warned and self.variant in ('reduced', 'reduced_comp'):
+            self._guard_warned = True
+            warnings.warn(f'the {self.variant!r} kernel is {worst:.1e} (relative) away from the exact log-probability '
+                          "on rows of this batch (tolerance 1e-10); use variant='auto' or 'reduced_comp'",
+                          RuntimeWarning, stacklevel=3)
 
     def forward(self, theta):
         """theta (W, ndim) host -> Z (W, 2, N) host."""

@@ -1,6 +1,8 @@
 // bisip_hip.hip -- C ABI (include/bisip_hip.h) over the kernels in kernels.h.
 // Host side: context = device copies of the walker-independent operands + the prior
 // box; every call is one kernel launch on the caller's stream.
+#include <cstdlib>
+
 #include "host.h"
 #include "host_precompute.h"
 #include "chain_kernels.h"
@@ -37,8 +39,11 @@ int effective_variant(const bisip_ctx *c)
     // else the compensated kernel under the same test (ill-conditioned designs: high degree,
     // small exponent), else the per-frequency form, which mirrors the reference's sums
     if (2 * c->N < c->P + 2) return BISIP_VARIANT_COLLAPSED;
-    if (c->red[0].err <= BISIP_REDUCED_ERR_MAX) return BISIP_VARIANT_REDUCED;
-    if (c->red[1].err <= BISIP_REDUCED_ERR_MAX) return BISIP_VARIANT_REDUCED_COMP;
+    if (c->red[0].err <= BISIP_REDUCED_ERR_MAX && !c->demoted[0]) return BISIP_VARIANT_REDUCED;
+    // the compensated form is the most accurate formulation there is (the per-frequency sums cancel as
+    // badly as the plain triangle on nearly collinear designs): it is given up only
+    // for an estimate ten times past the gate -- on the shell logp = 0 that is 1e-10, the tolerance itself
+    if (c->red[1].err <= 10.0 * BISIP_REDUCED_ERR_MAX && !c->demoted[1]) return BISIP_VARIANT_REDUCED_COMP;
     return BISIP_VARIANT_COLLAPSED;
 }
 
@@ -118,6 +123,41 @@ const char *name_for(const bisip_ctx *c)
 
 }  // namespace
 
+// May ColeCole<D> / Shin take ONE reciprocal per group of denominators (kernels.h: rcp_batch_n)?  Only
+// if, everywhere inside the prior box, every denominator of a frequency lies in [1, 2^225], so that a
+// product of four is a normal number: exponents y = c log2e (ln w + log_tau) (ColeCole) or
+// log2e (n ln w + log_Q) (Shin) bounded by 110, cos(c pi/2) >= 0 (c or n within [0, 1]: the real part
+// of each denominator term is then >= 1), and for Shin R <= 1 (1/R >= 1; its clamp at 1e70 bounds the
+// other side).  The reference's default boxes pass with y <= 26; a user who widens a box past this
+// gets the one-reciprocal-per-term code.
+static int bound_flags(const bisip_ctx *c)
+{
+    constexpr double LOG2E = 1.4426950408889634, YMAX = 110.0;
+    const double *lo = c->bounds.lo, *hi = c->bounds.hi;
+    const double lw = std::fmax(std::fabs(c->lnw_min), std::fabs(c->lnw_max));
+    auto finite = [](double a, double b) { return std::isfinite(a) && std::isfinite(b); };
+    if (c->model_id == BISIP_MODEL_COLECOLE) {
+        const int D = c->D;
+        for (int i = 0; i < D; ++i) {
+            const double llo = lo[1 + D + i], lhi = hi[1 + D + i], clo = lo[1 + 2 * D + i], chi = hi[1 + 2 * D + i];
+            if (!finite(llo, lhi) || !finite(clo, chi) || clo < 0.0 || chi > 1.0) return 0;
+            const double span = lw + std::fmax(std::fabs(llo), std::fabs(lhi));
+            if (chi * span * LOG2E > YMAX) return 0;
+        }
+        return D >= 2 ? BOUNDS_BATCH_RCP : 0;
+    }
+    if (c->model_id == BISIP_MODEL_SHIN2015) {
+        for (int i = 0; i < 2; ++i) {
+            const double rlo = lo[i], rhi = hi[i], qlo = lo[2 + i], qhi = hi[2 + i], nlo = lo[4 + i], nhi = hi[4 + i];
+            if (!finite(rlo, rhi) || !finite(qlo, qhi) || !finite(nlo, nhi)) return 0;
+            if (rlo < 0.0 || rhi > 1.0 || nlo < 0.0 || nhi > 1.0) return 0;
+            if ((nhi * lw + std::fmax(std::fabs(qlo), std::fabs(qhi))) * LOG2E > YMAX) return 0;
+        }
+        return BOUNDS_BATCH_RCP;
+    }
+    return 0;
+}
+
 // PolynomialDecomposition, reduced form: (re)choose the expansion point bhat for the current
 // prior box (host_precompute.h:reduced_center), record the kernel's estimated rounding error,
 // refresh the kernarg copy of spectrum 0 and the device copies of a batch.
@@ -143,7 +183,8 @@ static int recenter_reduced(bisip_ctx *c)
         bisip_ctx::ReducedTier &T = c->red[tier];
         const bool wanted = tier == 0 ? (c->variant == BISIP_VARIANT_AUTO || c->variant == BISIP_VARIANT_REDUCED)
                                       : (c->variant == BISIP_VARIANT_REDUCED_COMP ||
-                                         (c->variant == BISIP_VARIANT_AUTO && !(c->red[0].err <= BISIP_REDUCED_ERR_MAX)));
+                                         (c->variant == BISIP_VARIANT_AUTO &&
+                                          (!(c->red[0].err <= BISIP_REDUCED_ERR_MAX) || c->demoted[0])));
         if (T.valid || !wanted) continue;
         const size_t E = c->reduced.size();
         std::vector<double> red(c->E > 1 ? red_doubles * E : 0), est(E);
@@ -334,6 +375,13 @@ static int build_context(bisip_ctx **out, int device, int model_id, int E, int N
     c->P = P; c->D = D; c->S = S;
     for (int q = 0; q < MAXD; ++q) { c->bounds.lo[q] = 0.0; c->bounds.hi[q] = 0.0; }
     for (int q = 0; q < ndim; ++q) { c->bounds.lo[q] = lo[q]; c->bounds.hi[q] = hi[q]; }
+    c->lnw_min = INFINITY; c->lnw_max = -INFINITY;
+    for (long long j = 0; j < (long long)N * E; ++j) {
+        const double l = std::log(w[j]);
+        c->lnw_min = std::fmin(c->lnw_min, l);
+        c->lnw_max = std::fmax(c->lnw_max, l);
+    }
+    c->bounds.flags = bound_flags(c);
 
     const int rec = model_id == BISIP_MODEL_POLYDECOMP ? 4 + 2 * (P + 1) : 8;
     c->cb_stride = (long long)N * rec;
@@ -458,6 +506,8 @@ int bisip_ctx_set_bounds(bisip_ctx *c, const double *lo, const double *hi)
     for (int q = 0; q < c->ndim; ++q) same = same && c->bounds.lo[q] == lo[q] && c->bounds.hi[q] == hi[q];
     if (same) return BISIP_OK;
     for (int q = 0; q < c->ndim; ++q) { c->bounds.lo[q] = lo[q]; c->bounds.hi[q] = hi[q]; }
+    c->bounds.flags = bound_flags(c);
+    c->demoted[0] = c->demoted[1] = false;                            // observed on the old box
     for (auto &t : c->red) { t.valid = false; t.err = INFINITY; }     // estimates and expansion points belong to the old box
     const int rc = guarded([&] { return recenter_reduced(c); });   // the reduced form expands about a point of the box
     c->kernel_name = name_for(c);                                  // AUTO may change formulation with the box
@@ -647,29 +697,36 @@ int bisip_stretch_run_dev(bisip_ctx *c, const bisip_stretch_args *first, int64_t
     return BISIP_OK;
 }
 
+// rows lo, lo + stride, ... < hi of a (W, ndim) batch against the reduced form in long double
+static double reduced_check_rows(const bisip_ctx *c, const double *theta, int64_t W, const double *logp,
+                                 int64_t lo, int64_t hi, int64_t stride)
+{
+    const int n = c->P + 2;
+    const int64_t per = c->E > 1 ? W / c->E : W;
+    double w = 0.0;
+    for (int64_t i = lo; i < hi; i += stride) {
+        const double *th = theta + i * c->ndim;
+        if (!in_prior_host(th, c)) continue;                  // the prior decides those rows, exactly
+        const bisip_ctx::ReducedHost &rh = c->reduced[(size_t)(per ? i / per : 0)];
+        const double want = reduced_logp_reference(n, rh.R, rh.qty, rh.rest, rh.lconst, th);
+        const double scale = std::fabs(want) > 1.0 ? std::fabs(want) : 1.0;
+        const double rel = std::fabs(logp[i] - want) / scale;
+        if (!(rel <= w)) w = rel;                              // NaN counts as worst
+    }
+    return w;
+}
+
 int bisip_ctx_reduced_check(bisip_ctx *c, const double *theta, int64_t W, const double *logp, double *worst_rel)
 {
     if (!c || !theta || !logp || !worst_rel) return fail(BISIP_EINVAL, "null argument");
     if (c->model_id != BISIP_MODEL_POLYDECOMP || c->reduced.empty())
         return fail(BISIP_EUNSUPPORTED, "only PolynomialDecomposition contexts have a QR-reduced form");
     if (W < 0 || (c->E > 1 && W % c->E)) return fail(BISIP_EINVAL, "W=%lld is not a multiple of the %d spectra", (long long)W, c->E);
-    const int n = c->P + 2;
-    const int64_t per = c->E > 1 ? W / c->E : W;
     std::vector<double> worst((size_t)host_threads() + 1, 0.0);
     return guarded([&] {
         std::atomic<int> slot{0};
         parallel_blocks(W, 4096, [&](int64_t lo, int64_t hi) {
-            double w = 0.0;
-            for (int64_t i = lo; i < hi; ++i) {
-                const double *th = theta + i * c->ndim;
-                if (!in_prior_host(th, c)) continue;                  // the prior decides those rows, exactly
-                const bisip_ctx::ReducedHost &rh = c->reduced[(size_t)(per ? i / per : 0)];
-                const double want = reduced_logp_reference(n, rh.R, rh.qty, rh.rest, rh.lconst, th);
-                const double scale = std::fabs(want) > 1.0 ? std::fabs(want) : 1.0;
-                const double rel = std::fabs(logp[i] - want) / scale;
-                if (!(rel <= w)) w = rel;                              // NaN counts as worst
-            }
-            worst[(size_t)slot.fetch_add(1)] = w;
+            worst[(size_t)slot.fetch_add(1)] = reduced_check_rows(c, theta, W, logp, lo, hi, 1);
         });
         double all = 0.0;
         for (double w : worst)
@@ -677,6 +734,16 @@ int bisip_ctx_reduced_check(bisip_ctx *c, const double *theta, int64_t W, const 
         *worst_rel = all;
         return (int)BISIP_OK;
     });
+}
+
+int bisip_ctx_reduced_guard(bisip_ctx *c, int enable, int64_t *n_checks, double *worst_rel, int *escalations)
+{
+    if (!c) return fail(BISIP_EINVAL, "null context");
+    if (enable == 0 || enable == 1) c->guard_on = enable == 1;
+    if (n_checks) *n_checks = c->guard_checks;
+    if (worst_rel) *worst_rel = c->guard_worst;
+    if (escalations) *escalations = c->guard_escalations;
+    return BISIP_OK;
 }
 
 int bisip_read_tables(const char *const *paths, int64_t n_files, int headers, int64_t n_rows,
@@ -802,12 +869,53 @@ void bisip_philox4x32(const uint32_t *counter, const uint32_t *key, uint32_t *ou
     for (int i = 0; i < 4; ++i) out[i] = r.v[i];
 }
 
+static int logprob_host_once(bisip_ctx *c, const double *theta, int64_t W, double *logp);
+
+// The QR-reduced kernels were chosen from an error ESTIMATE on probe rows (recenter_reduced); here the
+// kernel that just ran is MEASURED on up to 256 rows of the caller's own batch against the reduced form
+// in long double -- on the first call of a context and on every 2^n-th after it, so a long emcee run pays
+// a few dozen checks of ~50 us.  Past GUARD_TOL (a tenth of the parity tolerance) a context on
+// BISIP_VARIANT_AUTO closes that tier, moves to the next formulation (compensated, then per-frequency),
+// and the batch is evaluated again with it; a caller-forced variant is only recorded
+// (bisip_ctx_reduced_guard reports both).
+static int guard_after_logprob(bisip_ctx *c, const double *theta, int64_t W, double *logp)
+{
+    constexpr double GUARD_TOL = 1e-11;
+    if (!c->guard_on || c->model_id != BISIP_MODEL_POLYDECOMP || c->reduced.empty()) return BISIP_OK;
+    if (c->E > 1 && W % c->E) return BISIP_OK;
+    const int64_t call = ++c->guard_calls;
+    if (call & (call - 1)) return BISIP_OK;                       // 1, 2, 4, 8, ...
+    for (int round = 0; round < 2; ++round) {
+        const int v = effective_variant(c);
+        if (v != BISIP_VARIANT_REDUCED && v != BISIP_VARIANT_REDUCED_COMP) return BISIP_OK;
+        const int64_t stride = W > 256 ? W / 256 : 1;
+        const double worst = reduced_check_rows(c, theta, W, logp, 0, W, stride);
+        ++c->guard_checks;
+        if (!(worst <= c->guard_worst)) c->guard_worst = worst;
+        if (worst <= GUARD_TOL || c->variant != BISIP_VARIANT_AUTO) return BISIP_OK;
+        c->demoted[v == BISIP_VARIANT_REDUCED ? 0 : 1] = true;
+        ++c->guard_escalations;
+        int rc = guarded([&] { return recenter_reduced(c); });    // the next tier may not have been estimated yet
+        if (rc != BISIP_OK) return rc;
+        c->kernel_name = name_for(c);
+        rc = logprob_host_once(c, theta, W, logp);
+        if (rc != BISIP_OK) return rc;
+    }
+    return BISIP_OK;
+}
+
 int bisip_logprob(bisip_ctx *c, const double *theta, int64_t W, double *logp)
 {
     if (!c) return fail(BISIP_EINVAL, "null context");
     if (W < 0) return fail(BISIP_EINVAL, "W=%lld < 0", (long long)W);
     if (W == 0) return BISIP_OK;
     if (!theta || !logp) return fail(BISIP_EINVAL, "null buffer");
+    const int rc = logprob_host_once(c, theta, W, logp);
+    return rc != BISIP_OK ? rc : guard_after_logprob(c, theta, W, logp);
+}
+
+static int logprob_host_once(bisip_ctx *c, const double *theta, int64_t W, double *logp)
+{
     HIP_TRY(hipSetDevice(c->device));
     const size_t tb = (size_t)W * c->ndim * sizeof(double), ob = (size_t)W * sizeof(double);
     const size_t tb_al = (tb + 255) & ~(size_t)255;

@@ -47,6 +47,7 @@ struct bisip_ctx {
     int P = 0, D = 0, S = 0;
     double c_exp = 1.0, lconst = 0.0;
     bisip::Bounds bounds{};
+    double lnw_min = 0.0, lnw_max = 0.0;   // over every frequency of every spectrum (bound_flags)
     int E = 1;                      // spectra in the context (batch of spectra: E > 1)
     double *d_cb = nullptr;        // records for k_forward (and k_logprob of CC/Dias/Shin): (E, N, REC)
     double *d_cb_lp = nullptr;     // PolynomialDecomposition: 1/sigma-weighted log-prob records (E, N, REC)
@@ -62,6 +63,13 @@ struct bisip_ctx {
         void *d_red = nullptr;                  // (E,) ReducedArgs<P>  batch only
     };
     ReducedTier red[2];
+    // bisip_logprob measures the reduced kernel it ran on rows of its own batches (first call, then
+    // every 2^n-th); a tier found wanting is closed to BISIP_VARIANT_AUTO until the box changes
+    bool demoted[2] = {false, false};
+    bool guard_on = true;
+    int64_t guard_calls = 0, guard_checks = 0;
+    double guard_worst = 0.0;
+    int guard_escalations = 0;
     std::vector<double> Rpacked;   // spectrum 0, packed upper triangle
     double rest = 0.0;
     // per spectrum, for re-centring the reduced form when the prior box changes

@@ -27,7 +27,13 @@ typedef double dbl2 __attribute__((ext_vector_type(2)));
 struct Bounds {
     double lo[MAXD];
     double hi[MAXD];
+    // BOUNDS_BATCH_RCP: set by the host (bound_flags in bisip_hip.hip) when, everywhere inside this
+    // box, the denominators of one frequency of ColeCole<D> / Shin stay within [1, 2^225]: their
+    // product over a group of <= 4 neither overflows nor underflows, so ONE reciprocal serves the
+    // group (rcp_batch).  Wave-uniform (kernel argument): the choice is a scalar branch.
+    int flags = 0;
 };
+constexpr int BOUNDS_BATCH_RCP = 1;
 
 struct LaunchArgs {
     const double *__restrict__ theta;  // (W, NDIM) row-major
@@ -203,6 +209,69 @@ __device__ __forceinline__ void rcp_nr_n(const double (&x)[K], double (&r)[K])
     for (int k = 0; k < K; ++k) r[k] = fma(r[k], e[k], r[k]);
 }
 
+// 1/x_k for K values from ONE reciprocal of their product (Montgomery's trick): 3(K-1)
+// multiplications + rcp_nr instead of K rcp_nr.  v_rcp_f64 issues at a quarter of the FMA rate, so a
+// reciprocal costs 8 issue slots and a pair by this route 11 instead of 16.  F independent groups
+// (one per frequency) run in lockstep.  The caller guarantees that products of K arguments stay
+// normal (BOUNDS_BATCH_RCP).  Groups are always formed WITHIN one frequency, in every kernel, so a
+// walker's value does not depend on which kernel evaluated it.
+template <int F, int K>
+__device__ __forceinline__ void rcp_batch_n(const double (&x)[F][K], double (&r)[F][K])
+{
+    if constexpr (K == 1) {
+        double xx[F], rr[F];
+#pragma unroll
+        for (int f = 0; f < F; ++f) xx[f] = x[f][0];
+        rcp_nr_n<F>(xx, rr);
+#pragma unroll
+        for (int f = 0; f < F; ++f) r[f][0] = rr[f];
+    } else {
+        double pre[F][K], top[F], inv[F];
+#pragma unroll
+        for (int f = 0; f < F; ++f) pre[f][0] = x[f][0];
+#pragma unroll
+        for (int k = 1; k < K; ++k)
+#pragma unroll
+            for (int f = 0; f < F; ++f) pre[f][k] = pre[f][k - 1] * x[f][k];
+#pragma unroll
+        for (int f = 0; f < F; ++f) top[f] = pre[f][K - 1];
+        rcp_nr_n<F>(top, inv);
+#pragma unroll
+        for (int k = K - 1; k >= 1; --k)
+#pragma unroll
+            for (int f = 0; f < F; ++f) { r[f][k] = inv[f] * pre[f][k - 1]; inv[f] = inv[f] * x[f][k]; }
+#pragma unroll
+        for (int f = 0; f < F; ++f) r[f][0] = inv[f];
+    }
+}
+
+// D reciprocals per frequency in groups of at most 4 (the product of 4 denominators <= 2^225 is normal)
+template <int F, int D>
+__device__ __forceinline__ void rcp_groups(const double (&x)[F][D], double (&r)[F][D])
+{
+    if constexpr (D <= 4) rcp_batch_n<F, D>(x, r);
+    else {
+        constexpr int H = D - 4;
+        double xa[F][4], ra[F][4], xb[F][H], rb[F][H];
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) xa[f][k] = x[f][k];
+#pragma unroll
+            for (int k = 0; k < H; ++k) xb[f][k] = x[f][4 + k];
+        }
+        rcp_batch_n<F, 4>(xa, ra);
+        rcp_groups<F, H>(xb, rb);
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) r[f][k] = ra[f][k];
+#pragma unroll
+            for (int k = 0; k < H; ++k) r[f][4 + k] = rb[f][k];
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------
 // Forward models.  Each exposes
 //   NDIM, REC (doubles per frequency record; rec[0..3] = y_re, y_im, 1/s2_re, 1/s2_im)
@@ -239,6 +308,7 @@ struct PDCollapsed {
         }
         return s;
     }
+    __device__ static __forceinline__ void configure(Setup &, int) {}
     // Log-prob records are pre-weighted by 1/sigma (rows of the weighted design matrix):
     //   rec = ys_re, ys_im, -s_re, pad | s_re*G_re[0..P] | s_im*G_im[0..P]
     // so (y - Z)/sigma = ys + r0*(-s) + sum_p b_p (s G_p): 2(P+1)+1 FMAs, and the caller
@@ -280,10 +350,13 @@ struct ColeCole {
         double r0;
         double m[D], lt[D], c[D], cs[D], sn[D];
         double A[D], c2[D], clt2[D], C;  // residual(): m r0, c log2e, c log2e lt, r0 - sum A
+        int batch;                       // residual(): one reciprocal per group of modes (BOUNDS_BATCH_RCP)
     };
+    __device__ static __forceinline__ void configure(Setup &s, int flags) { s.batch = D >= 2 && (flags & BOUNDS_BATCH_RCP); }
     __device__ static __forceinline__ Setup setup(const double (&th)[NDIM])
     {
         Setup s;
+        s.batch = 0;
         s.r0 = th[0];
         s.C = th[0];
 #pragma unroll
@@ -300,48 +373,66 @@ struct ColeCole {
         return s;
     }
     // Z = (r0 - sum A_i) + sum A_i (1+x_i)^-1  =>  y - Z accumulates -A_i conj(1+x_i)/|1+x_i|^2
+    // F frequencies in lockstep (F = 1: the bulk loop; F = 2: one wave per SIMD, residual2): per
+    // frequency the D exponentials, then the D reciprocals -- one per mode, or (s.batch) one per group
+    // of modes -- then the modes accumulated in ascending order.  Same operations per frequency for
+    // every F, so the same bits.
+    template <int F>
+    __device__ static __forceinline__ void residual_n(const Setup &s, const double *const (&rec)[F],
+                                                      double (&rr)[F], double (&ri)[F])
+    {
+        constexpr int K = F * D;     // value k = (frequency k / D, mode k % D)
+        double y[K], e[K], dr[F][D], di[F][D], den[F][D], inv[F][D];
+#pragma unroll
+        for (int k = 0; k < K; ++k) y[k] = fma(s.c2[k % D], rec[k / D][5], s.clt2[k % D]);
+        exp2_finite_n<K>(y, e);
+#pragma unroll
+        for (int f = 0; f < F; ++f)
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                dr[f][i] = fma(e[f * D + i], s.cs[i], 1.0);   // >= 1 because cos(c pi/2) >= 0
+                di[f][i] = e[f * D + i] * s.sn[i];
+            }
+#pragma unroll
+        for (int f = 0; f < F; ++f)
+#pragma unroll
+            for (int i = 0; i < D; ++i) den[f][i] = fma(dr[f][i], dr[f][i], di[f][i] * di[f][i]);
+        if (D >= 2 && s.batch) rcp_groups<F, D>(den, inv);
+        else {
+            double flat[K], r[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) flat[k] = den[k / D][k % D];
+            rcp_nr_n<K>(flat, r);
+#pragma unroll
+            for (int k = 0; k < K; ++k) inv[k / D][k % D] = r[k];
+        }
+#pragma unroll
+        for (int f = 0; f < F; ++f) { rr[f] = rec[f][0] - s.C; ri[f] = rec[f][1]; }
+#pragma unroll
+        for (int i = 0; i < D; ++i) {          // per frequency: modes accumulate in ascending order
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                const double t = s.A[i] * inv[f][i];
+                rr[f] = fma(-t, dr[f][i], rr[f]);
+                ri[f] = fma(t, di[f][i], ri[f]);
+            }
+        }
+    }
     __device__ static __forceinline__ void residual(const Setup &s, const double *__restrict__ rec,
                                                     double &rr, double &ri)
     {
-        const double lnw = rec[5];
-        rr = rec[0] - s.C;
-        ri = rec[1];
-#pragma unroll
-        for (int i = 0; i < D; ++i) {
-            const double e = exp2_finite(fma(s.c2[i], lnw, s.clt2[i]));
-            const double dr = fma(e, s.cs[i], 1.0);  // >= 1
-            const double di = e * s.sn[i];
-            const double t = s.A[i] * rcp_nr(fma(dr, dr, di * di));
-            rr = fma(-t, dr, rr);
-            ri = fma(t, di, ri);
-        }
+        const double *const r1[1] = {rec};
+        double a[1], b[1];
+        residual_n<1>(s, r1, a, b);
+        rr = a[0];
+        ri = b[0];
     }
     __device__ static __forceinline__ void residual2(const Setup &s, const double *__restrict__ ra,
                                                      const double *__restrict__ rb, double (&rr)[2],
                                                      double (&ri)[2])
     {
-        constexpr int K = 2 * D;     // value k = (frequency k / D, mode k % D)
-        const double lnw[2] = {ra[5], rb[5]};
-        double y[K], e[K], dr[K], di[K], den[K], inv[K];
-#pragma unroll
-        for (int k = 0; k < K; ++k) y[k] = fma(s.c2[k % D], lnw[k / D], s.clt2[k % D]);
-        exp2_finite_n<K>(y, e);
-#pragma unroll
-        for (int k = 0; k < K; ++k) { dr[k] = fma(e[k], s.cs[k % D], 1.0); di[k] = e[k] * s.sn[k % D]; }
-#pragma unroll
-        for (int k = 0; k < K; ++k) den[k] = fma(dr[k], dr[k], di[k] * di[k]);
-        rcp_nr_n<K>(den, inv);
-        rr[0] = ra[0] - s.C; rr[1] = rb[0] - s.C;
-        ri[0] = ra[1]; ri[1] = rb[1];
-#pragma unroll
-        for (int i = 0; i < D; ++i) {          // per frequency: modes accumulate in ascending order
-#pragma unroll
-            for (int f = 0; f < 2; ++f) {
-                const double t = s.A[i] * inv[f * D + i];
-                rr[f] = fma(-t, dr[f * D + i], rr[f]);
-                ri[f] = fma(t, di[f * D + i], ri[f]);
-            }
-        }
+        const double *const r2[2] = {ra, rb};
+        residual_n<2>(s, r2, rr, ri);
     }
     // Z = (r0 - sum A_i) + sum A_i conj(1+x_i)/|1+x_i|^2   (m = w, ln w, sqrt w)
     __device__ static __forceinline__ void eval(const Setup &s, const double *__restrict__ m,
@@ -379,9 +470,10 @@ struct Dias {
         s.tau = exp_finite(th[2]);
         // delta = 0 or m = 1 (prior bounds; forward() may be asked for them) make tau' infinite;
         // the reference's complex arithmetic then gives Z = r0 (1 - m).  A huge finite tau'
-        // reaches the same limit without inf * 0 (NaN, from 0/0, is kept).
+        // reaches the same limit without inf * 0 (NaN, from 0/0, is kept); 1e100 leaves X^2 + Y^2 of
+        // den() finite for |mu|^2 up to 1e45.
         double taup = s.tau * (1.0 / th[4] - 1.0) / (1.0 - s.m);
-        if (fabs(taup) > 1e120) taup = copysign(1e120, taup);
+        if (fabs(taup) > 1e100) taup = copysign(1e100, taup);
         s.taup = taup;
         s.taupp = (s.tau * s.tau) * (th[3] * th[3]);
         s.A = th[0] * th[1];
@@ -389,63 +481,63 @@ struct Dias {
         s.teh = s.tau * fabs(th[3]) * 0.70710678118654752440;
         return s;
     }
-    // Z = r0 (1-m) + r0 m / den;  (i w tau'')^0.5 = sqrt(w) tau |eta| (1+i)/sqrt(2) with sqrt(w_j)
-    // precomputed per frequency, so no square root per (walker, frequency).
+    // Z = r0 (1-m) + r0 m / den,  den = 1 + i a (1 + 1/mu),  a = w tau',  mu = i w tau + (i w tau'')^0.5.
+    // (i w tau'')^0.5 = sqrt(w) tau |eta| (1+i)/sqrt(2) with sqrt(w_j) precomputed per frequency, so no
+    // square root per (walker, frequency); and with m2 = |mu|^2 the inner division disappears:
+    //   1 + 1/mu = (m2 + conj(mu))/m2   =>   den = (X + iY)/m2,  X = m2 + a Im(mu),  Y = a (m2 + Re(mu)),
+    //   1/den = m2 (X - iY)/(X^2 + Y^2):  ONE reciprocal per frequency instead of two (v_rcp_f64 issues
+    // at a quarter of the FMA rate: 21 instructions / 24 issue slots per frequency instead of 26 / 32).
+    // Inside the prior a > 0, mu has non-negative parts and |mu| >= w tau > 0: X, Y > 0, nothing cancels.
+    __device__ static __forceinline__ void configure(Setup &, int) {}
+    struct Den { double X, Y, t; };   // t = A m2 / (X^2 + Y^2)
+    __device__ static __forceinline__ Den den(const Setup &s, double w, double sqrtw)
+    {
+        const double mur = sqrtw * s.teh, mui = fma(w, s.tau, mur);
+        const double m2 = fma(mur, mur, mui * mui);
+        const double a = w * s.taup;
+        Den d;
+        d.X = fma(a, mui, m2);
+        d.Y = a * (m2 + mur);
+        d.t = (s.A * m2) * rcp_nr(fma(d.X, d.X, d.Y * d.Y));
+        return d;
+    }
     __device__ static __forceinline__ void residual(const Setup &s, const double *__restrict__ rec,
                                                     double &rr, double &ri)
     {
-        const double w = rec[4];
-        const double mur = rec[6] * s.teh, mui = fma(w, s.tau, mur);
-        const double inv = rcp_nr(fma(mur, mur, mui * mui));       // |mu| >= w tau > 0
-        const double tr = fma(mur, inv, 1.0), nti = mui * inv;     // 1 + 1/mu = tr - i nti
-        const double a = w * s.taup;
-        const double dr = fma(a, nti, 1.0), di = a * tr;           // den = 1 + i a (1 + 1/mu), Re >= 1
-        const double t = s.A * rcp_nr(fma(dr, dr, di * di));
-        rr = fma(-t, dr, rec[0] - s.C);
-        ri = fma(t, di, rec[1]);
+        const Den d = den(s, rec[4], rec[6]);
+        rr = fma(-d.t, d.X, rec[0] - s.C);
+        ri = fma(d.t, d.Y, rec[1]);
     }
     __device__ static __forceinline__ void residual2(const Setup &s, const double *__restrict__ ra,
                                                      const double *__restrict__ rb, double (&rr)[2],
                                                      double (&ri)[2])
     {
         const double *__restrict__ rec[2] = {ra, rb};
-        double mur[2], mui[2], den1[2], inv1[2], dr[2], di[2], den2[2], inv2[2];
+        double X[2], Y[2], m2[2], D[2], inv[2];
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
-            mur[f] = rec[f][6] * s.teh;
-            mui[f] = fma(rec[f][4], s.tau, mur[f]);
-            den1[f] = fma(mur[f], mur[f], mui[f] * mui[f]);
-        }
-        rcp_nr_n<2>(den1, inv1);
-#pragma unroll
-        for (int f = 0; f < 2; ++f) {
-            const double tr = fma(mur[f], inv1[f], 1.0), nti = mui[f] * inv1[f];
+            const double mur = rec[f][6] * s.teh, mui = fma(rec[f][4], s.tau, mur);
+            m2[f] = fma(mur, mur, mui * mui);
             const double a = rec[f][4] * s.taup;
-            dr[f] = fma(a, nti, 1.0);
-            di[f] = a * tr;
-            den2[f] = fma(dr[f], dr[f], di[f] * di[f]);
+            X[f] = fma(a, mui, m2[f]);
+            Y[f] = a * (m2[f] + mur);
+            D[f] = fma(X[f], X[f], Y[f] * Y[f]);
         }
-        rcp_nr_n<2>(den2, inv2);
+        rcp_nr_n<2>(D, inv);
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
-            const double t = s.A * inv2[f];
-            rr[f] = fma(-t, dr[f], rec[f][0] - s.C);
-            ri[f] = fma(t, di[f], rec[f][1]);
+            const double t = (s.A * m2[f]) * inv[f];
+            rr[f] = fma(-t, X[f], rec[f][0] - s.C);
+            ri[f] = fma(t, Y[f], rec[f][1]);
         }
     }
-    // Z = r0 (1-m) + r0 m conj(den)/|den|^2   (m = w, ln w, sqrt w)
+    // Z = r0 (1-m) + r0 m m2 (X - iY)/(X^2 + Y^2)   (m = w, ln w, sqrt w)
     __device__ static __forceinline__ void eval(const Setup &s, const double *__restrict__ m,
                                                 double &zr, double &zi)
     {
-        const double w = m[0];
-        const double mur = m[2] * s.teh, mui = fma(w, s.tau, mur);
-        const double inv = rcp_nr(fma(mur, mur, mui * mui));       // |mu| >= w tau > 0
-        const double tr = fma(mur, inv, 1.0), nti = mui * inv;     // 1 + 1/mu = tr - i nti
-        const double a = w * s.taup;
-        const double dr = fma(a, nti, 1.0), di = a * tr;           // den = 1 + i a (1 + 1/mu), Re >= 1
-        const double t = s.A * rcp_nr(fma(dr, dr, di * di));
-        zr = fma(t, dr, s.C);
-        zi = -(t * di);
+        const Den d = den(s, m[0], m[2]);
+        zr = fma(d.t, d.X, s.C);
+        zi = -(d.t * d.Y);
     }
 };
 
@@ -457,17 +549,20 @@ struct Shin {
     struct Setup {
         double invR[2], Q[2], n[2], cs[2], sn[2];
         double n2[2], lq2[2];  // residual(): n log2e, log_Q log2e
+        int batch;             // residual(): one reciprocal for both elements (BOUNDS_BATCH_RCP)
     };
     __device__ static __forceinline__ Setup setup(const double (&th)[NDIM])
     {
         Setup s;
+        s.batch = 0;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             // R = 0 (a prior bound; forward() may be asked for it) makes the term vanish in the
             // reference: 1/0 = inf, inf^-1 = 0.  Clamping 1/R keeps |y|^2 finite here and the
-            // term at <= 1e-150 instead of inf * 0.
+            // term at <= 1e-70 instead of inf * 0; 1e70 (not 1e150) so that the PRODUCT of the two
+            // elements' |y|^2 stays finite as well (rcp_batch_n).
             double ir = 1.0 / th[i];
-            if (fabs(ir) > 1e150) ir = copysign(1e150, ir);
+            if (fabs(ir) > 1e70) ir = copysign(1e70, ir);
             s.invR[i] = ir;
             s.Q[i] = exp_finite(th[2 + i]);
             s.n[i] = th[4 + i];
@@ -477,48 +572,62 @@ struct Shin {
         }
         return s;
     }
-    // Q (iw)^n = 2^(n log2e ln w + log_Q log2e) (cs + i sn);  Z = sum_i conj(y_i)/|y_i|^2
+    __device__ static __forceinline__ void configure(Setup &s, int flags) { s.batch = flags & BOUNDS_BATCH_RCP; }
+    // Q (iw)^n = 2^(n log2e ln w + log_Q log2e) (cs + i sn);  Z = sum_i conj(y_i)/|y_i|^2.
+    // F frequencies in lockstep; per frequency the two elements' reciprocals come from one
+    // reciprocal of the product of the |y_i|^2 when s.batch says that product stays normal.
+    template <int F>
+    __device__ static __forceinline__ void residual_n(const Setup &s, const double *const (&rec)[F],
+                                                      double (&rr)[F], double (&ri)[F])
+    {
+        constexpr int K = 2 * F;     // value k = (frequency k / 2, element k % 2)
+        double y[K], p[K], yr[F][2], yi[F][2], den[F][2], inv[F][2];
+#pragma unroll
+        for (int k = 0; k < K; ++k) y[k] = fma(s.n2[k % 2], rec[k / 2][5], s.lq2[k % 2]);
+        exp2_finite_n<K>(y, p);
+#pragma unroll
+        for (int f = 0; f < F; ++f)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                yr[f][i] = fma(p[f * 2 + i], s.cs[i], s.invR[i]);    // yr >= 1/R > 1
+                yi[f][i] = p[f * 2 + i] * s.sn[i];
+                den[f][i] = fma(yr[f][i], yr[f][i], yi[f][i] * yi[f][i]);
+            }
+        if (s.batch) rcp_batch_n<F, 2>(den, inv);
+        else {
+            double flat[K], r[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) flat[k] = den[k / 2][k % 2];
+            rcp_nr_n<K>(flat, r);
+#pragma unroll
+            for (int k = 0; k < K; ++k) inv[k / 2][k % 2] = r[k];
+        }
+#pragma unroll
+        for (int f = 0; f < F; ++f) { rr[f] = rec[f][0]; ri[f] = rec[f][1]; }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                rr[f] = fma(-yr[f][i], inv[f][i], rr[f]);
+                ri[f] = fma(yi[f][i], inv[f][i], ri[f]);
+            }
+        }
+    }
     __device__ static __forceinline__ void residual(const Setup &s, const double *__restrict__ rec,
                                                     double &rr, double &ri)
     {
-        const double lnw = rec[5];
-        rr = rec[0];
-        ri = rec[1];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const double p = exp2_finite(fma(s.n2[i], lnw, s.lq2[i]));
-            const double yr = fma(p, s.cs[i], s.invR[i]), yi = p * s.sn[i];  // yr >= 1/R > 1
-            const double inv = rcp_nr(fma(yr, yr, yi * yi));
-            rr = fma(-yr, inv, rr);
-            ri = fma(yi, inv, ri);
-        }
+        const double *const r1[1] = {rec};
+        double a[1], b[1];
+        residual_n<1>(s, r1, a, b);
+        rr = a[0];
+        ri = b[0];
     }
     __device__ static __forceinline__ void residual2(const Setup &s, const double *__restrict__ ra,
                                                      const double *__restrict__ rb, double (&rr)[2],
                                                      double (&ri)[2])
     {
-        const double lnw[2] = {ra[5], rb[5]};
-        double y[4], p[4], yr[4], yi[4], den[4], inv[4];     // k = (frequency k / 2, element k % 2)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) y[k] = fma(s.n2[k % 2], lnw[k / 2], s.lq2[k % 2]);
-        exp2_finite_n<4>(y, p);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            yr[k] = fma(p[k], s.cs[k % 2], s.invR[k % 2]);
-            yi[k] = p[k] * s.sn[k % 2];
-            den[k] = fma(yr[k], yr[k], yi[k] * yi[k]);
-        }
-        rcp_nr_n<4>(den, inv);
-        rr[0] = ra[0]; rr[1] = rb[0];
-        ri[0] = ra[1]; ri[1] = rb[1];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-            for (int f = 0; f < 2; ++f) {
-                rr[f] = fma(-yr[f * 2 + i], inv[f * 2 + i], rr[f]);
-                ri[f] = fma(yi[f * 2 + i], inv[f * 2 + i], ri[f]);
-            }
-        }
+        const double *const r2[2] = {ra, rb};
+        residual_n<2>(s, r2, rr, ri);
     }
     // Z = sum_i conj(y_i)/|y_i|^2,  y_i = Q (iw)^n + 1/R   (m = w, ln w, sqrt w)
     __device__ static __forceinline__ void eval(const Setup &s, const double *__restrict__ m,
@@ -628,7 +737,8 @@ __device__ __forceinline__ double logprob_row(const double (&th)[M::NDIM], const
 {
     static_assert(L == 1 || L == 2 || L == 4, "lanes per walker");
     if (!in_prior<M::NDIM>(th, b)) return -__builtin_inf();  // never touches the forward model
-    const typename M::Setup s = M::setup(th);
+    typename M::Setup s = M::setup(th);
+    M::configure(s, b.flags);
     double acc0 = 0.0, acc1 = 0.0;
     if constexpr (L == 1 && LDSREC && M::REC == 8 && !M::WEIGHTED) {
         // records staged in LDS (persistent sampler): two frequencies at a time, their dependency

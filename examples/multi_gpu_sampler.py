@@ -1,11 +1,16 @@
 #!/usr/bin/env python3
 """One big ensemble, its walkers sharded over the GPUs of a node (BASELINE config 4's shape): one
 process per GPU, every rank holds the whole ensemble and the same random stream, evaluates its
-block of each half-step, and one RCCL all-gather per half-step rebuilds the state -- all enqueued
-by one C call per chunk (bisip_stretch_run_sharded_dev) on the communicator torch.distributed made.
+block of each half-step, and one RCCL all-gather per half-step rebuilds the state.
 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
-        examples/multi_gpu_sampler.py
+        examples/multi_gpu_sampler.py [python|rccl|rccl-own]
+
+The argument picks who drives the half-steps: 'python' (default) = eval / all_gather_into_tensor / apply
+from Python over torch.distributed; 'rccl' = all of a chunk enqueued by one C call
+(bisip_stretch_run_sharded_dev) on the communicator torch.distributed made, 'rccl-own' = on one
+of the sampler's own.  The C loop is 5x faster with one rank but has not yet run with more than
+one rank on hardware, hence not the default.
 
 Every rank ends with the same chain, bit for bit the chain a single GPU would have produced.
 (At this size one GPU is the faster machine -- DESIGN.md §4 has the break-even; the sharded form
@@ -38,7 +43,8 @@ p0 = centre + 1e-4 * np.random.RandomState(2024).randn(W, 7)      # the same sta
 
 np.random.seed(7)                                                  # the same stream on every rank
 sampler = DeviceEnsembleSampler(W, 7, model._context(), rng='philox', seed=11, distributed=True,
-                                force_sharded_path=True, persistent=False, chain_on_device=True)
+                                force_sharded_path=True, persistent=False, chain_on_device=True,
+                                sharded_loop=sys.argv[1] if len(sys.argv) > 1 else 'python')
 sampler.run_mcmc(p0, nsteps)
 mean, std = sampler.param_moments(discard=nsteps // 2)
 if rank == 0:

@@ -344,6 +344,17 @@ int bisip_numpy_stretch_stream(uint32_t *mt_key, int32_t *mt_pos, int64_t W, dou
  * up.  PolynomialDecomposition contexts only (BISIP_EUNSUPPORTED otherwise). */
 int bisip_ctx_reduced_check(bisip_ctx *ctx, const double *theta, int64_t W, const double *logp, double *worst_rel);
 
+/* bisip_logprob (the host-buffer entry emcee calls) measures the QR-reduced kernel it ran on up to 256
+ * rows of the caller's own batch -- on a context's first call and every 2^n-th after it -- the way
+ * bisip_ctx_reduced_check does.  Past 1e-11 a context on BISIP_VARIANT_AUTO moves to the next
+ * formulation (compensated, then per-frequency) and evaluates the batch again with it; the choice holds
+ * until bisip_ctx_set_bounds.  A caller-forced variant is measured and left alone.  enable: 1 / 0 turn
+ * the guard on (default) / off, anything else leaves it; outputs (each may be NULL): checks made so far,
+ * the worst relative error any of them saw, how many times the context changed formulation.
+ * The device-pointer entry bisip_logprob_dev never synchronises and is not guarded: its callers hold
+ * the rows and can call bisip_ctx_reduced_check (the device sampler's fit() does). */
+int bisip_ctx_reduced_guard(bisip_ctx *ctx, int enable, int64_t *n_checks, double *worst_rel, int *escalations);
+
 /* Host: read n_files 5-column spectrum files (freq, amp, pha, amp_err, pha_err; comma separated,
  * `headers` lines skipped, '#' comments and blank lines ignored -- what the reference reads one
  * at a time with np.loadtxt(skiprows=headers, delimiter=','), src/bisip/utils.py:121-123) on

@@ -699,6 +699,132 @@ def test_posterior_valley_walkers_on_nearly_collinear_designs(n_freq, poly_deg, 
     ctx.close()
 
 
+def _shell_rows(ops, bounds, n_rows, seed):
+    """Rows ON the shell log-probability = 0 of the linear model: b = b_ls + s R^-1 z with s such that
+    rest + s^2 |z|^2 = 2 lconst.  There the tolerance's denominator max(1, |logp|) is 1 and the absolute
+    error of a chi^2 of several hundred counts."""
+    n = ops['R'].shape[0]
+    z = np.random.RandomState(seed).randn(n_rows, n)
+    sc = np.sqrt((2.0 * ops['lconst'] - ops['rest']) / (z * z).sum(axis=1))
+    db = np.linalg.solve(ops['R'], (z * sc[:, None]).T).T
+    b = ops['bhat'][None, :] + db
+    t = np.concatenate([b[:, :1], b[:, 1:] / b[:, :1]], axis=1)
+    return np.ascontiguousarray(t[np.all((bounds[0] < t) & (t < bounds[1]), axis=1)])
+
+
+def test_logprob_guard_moves_a_context_off_a_reduced_kernel_that_fails_on_its_batch(monkeypatch):
+    """bisip_logprob -- what log_prob() and emcee's vectorised callback call -- measures the QR-reduced
+    kernel on rows of the caller's own batch (first call, then every 2^n-th) and a context on 'auto' that
+    is more than 1e-11 off moves to the compensated kernel and evaluates the batch again: no fit() needed.
+    The batch: rows on the shell logp = 0 of a degree-7 design, where the plain triangle's cancellation
+    shows as an absolute error.  The context: built with the shell probes of the estimate switched off
+    (BISIP_SHELL_WEIGHT=0, i.e. round 2's estimate), so that its estimate passes and AUTO starts on the
+    plain kernel -- with them on, AUTO picks the compensated kernel by itself."""
+    import warnings
+    from bisip_amd import _hip
+    n_freq, poly_deg, c_exp, idx = 32, 7, 1.0, 0
+    monkeypatch.setenv('BISIP_SHELL_WEIGHT', '0')
+    ctx, bounds, d, taus, log_taus = _pd_context(n_freq, poly_deg, c_exp, idx)
+    monkeypatch.delenv('BISIP_SHELL_WEIGHT')
+    assert ctx.variant == 'reduced' and ctx.reduced_error <= 1e-12            # the estimate passed
+    ops = _hip.polydecomp_operands(d['w'], d['zn'], d['zn_err'], taus, log_taus, c_exp)
+    theta = _shell_rows(ops, bounds, 6000, 5)
+    assert len(theta) > 1000
+    # what the plain kernel does on these rows (guard off), measured by the library's own checker
+    ctx.reduced_guard(False)
+    plain = ctx.logprob(theta)
+    assert np.abs(plain).max() < 1.0                                          # on the shell
+    far = ctx.reduced_check(theta[::max(1, len(theta) // 256)], plain[::max(1, len(theta) // 256)])
+    assert far > 1e-11, far
+    ctx.reduced_guard(True)
+    with pytest.warns(RuntimeWarning, match='k_logprob_pd_reduced_comp'):
+        got = ctx.logprob(theta)
+    checks, worst, moves = ctx.reduced_guard()
+    assert ctx.variant == 'reduced_comp' and moves == 1 and checks == 2 and worst == far
+    assert ctx.reduced_check(theta, got) <= 2e-12
+    ref = _pd_context(n_freq, poly_deg, c_exp, idx, variant='reduced_comp')[0]
+    assert np.array_equal(got, ref.logprob(theta))                            # the batch was re-evaluated
+    ref.close()
+    # the choice holds for later calls (no new warning), until the prior box changes
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        for _ in range(9):
+            assert np.array_equal(ctx.logprob(theta[:50]), got[:50])
+    assert ctx.reduced_guard()[2] == 1 and ctx.reduced_guard()[0] >= 4        # calls 2, 4, 8 were measured too
+    ctx.close()
+    # with the shell probes in the estimate AUTO never starts on the plain kernel here
+    ctx2 = _pd_context(n_freq, poly_deg, c_exp, idx)[0]
+    assert ctx2.variant == 'reduced_comp'
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        assert ctx2.reduced_check(theta, ctx2.logprob(theta)) <= 2e-12
+    assert ctx2.reduced_guard()[2] == 0
+    ctx2.close()
+    # a variant the caller forced is measured, named in a warning past the tolerance, and left alone
+    monkeypatch.setenv('BISIP_SHELL_WEIGHT', '0')
+    ctx3 = _pd_context(48, 9, 1.0, 0, variant='reduced')[0]
+    monkeypatch.delenv('BISIP_SHELL_WEIGHT')
+    d3, taus3, log_taus3 = _pd_context(48, 9, 1.0, 0)[2:]
+    ops3 = _hip.polydecomp_operands(d3['w'], d3['zn'], d3['zn_err'], taus3, log_taus3, 1.0)
+    rows3 = _shell_rows(ops3, bounds=np.array([[0.9] + [-1.0] * 10, [1.1] + [1.0] * 10]), n_rows=20000, seed=6)
+    if len(rows3) > 256:
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter('always')
+            ctx3.logprob(rows3)
+        assert ctx3.variant == 'reduced' and ctx3.reduced_guard()[2] == 0
+        if ctx3.reduced_guard()[1] > 1e-10:
+            assert any("variant='auto'" in str(w.message) for w in rec)
+    ctx3.close()
+
+
+def test_shared_reciprocal_is_switched_off_by_boxes_it_would_overflow_in():
+    """ColeCole<D> (D >= 2) and Shin take ONE reciprocal per group of denominators of a frequency when
+    the prior box keeps their products normal (bound_flags, kernels.h: rcp_batch_n).  Default boxes and a
+    box widened to tau = e^60 s still do; a box that lets c reach 30 (denominators that overflow) must
+    fall back to one reciprocal per term -- a NaN here would be the shared reciprocal at work."""
+    import oracle
+    from bisip_amd import _hip
+    from bisip_amd.batch import default_params
+    d = _synthetic_problem(32, 1)
+    rng = np.random.RandomState(8)
+    for n_modes, widen in ((2, None), (4, None), (4, 'tau'), (2, 'c'), (3, 'c')):
+        bounds = np.array(list(default_params('PeltonColeCole', n_modes=n_modes).values()), float).T
+        D = n_modes
+        if widen == 'tau':
+            bounds[1, 1 + D:1 + 2 * D] = 60.0
+        if widen == 'c':
+            bounds[1, 1 + 2 * D:] = 30.0
+        theta = rng.uniform(bounds[0], bounds[1], (3000, bounds.shape[1]))
+        if widen == 'tau':
+            theta[:500, 1 + D:1 + 2 * D] = rng.uniform(55, 60, (500, D))     # denominators ~ 2^200 each
+            theta[:500, 1 + 2 * D:] = rng.uniform(0.95, 1.0, (500, D))
+        if widen == 'c':
+            theta[:500, 1 + 2 * D:] = rng.uniform(25, 30, (500, D))           # e^2 overflows
+            theta[:500, 1 + D:1 + 2 * D] = rng.uniform(3, 5, (500, D))
+        prob = oracle.OracleProblem('PeltonColeCole', d['w'], d['zn'], d['zn_err'], bounds, n_modes=n_modes)
+        with np.errstate(all='ignore'):
+            want = oracle.logprob(prob, theta, n_threads=4)
+        ctx = _hip.HipContext(1, d['w'], d['zn'], d['zn_err'], bounds, n_modes=n_modes)
+        got = ctx.logprob(theta)
+        ok = np.isfinite(want)
+        assert ok.mean() > 0.8 and np.isfinite(got[ok]).all(), (n_modes, widen)
+        err = np.abs(got[ok] - want[ok]) / np.maximum(1.0, np.abs(want[ok]))
+        assert err.max() <= 1e-10, (n_modes, widen, err.max())
+        # the same rows through set_bounds on a context created with the default box
+        ctx.close()
+    # Shin: R next to 0 inside the open box (1/R clamped at 1e70: the partner element must survive)
+    bounds = np.array(list(default_params('Shin2015').values()), float).T
+    theta = rng.uniform(bounds[0], bounds[1], (2000, 6))
+    theta[:300, 0] = 10.0 ** rng.uniform(-300, -60, 300)
+    theta[300:600, 1] = 10.0 ** rng.uniform(-300, -60, 300)
+    prob = oracle.OracleProblem('Shin2015', d['w'], d['zn'], d['zn_err'], bounds)
+    with np.errstate(all='ignore'):
+        want = oracle.logprob(prob, theta, n_threads=4)
+    ctx = _hip.HipContext(3, d['w'], d['zn'], d['zn_err'], bounds)
+    assert_logp_close(ctx.logprob(theta), want)
+    ctx.close()
+
+
 def test_unsupported_shapes_fail_loudly():
     from bisip_amd import _hip
     d = _synthetic_problem(8)
