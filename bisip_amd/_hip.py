@@ -282,7 +282,7 @@ class HipContext:
         self.n_modes = int(n_modes)
         # bisip_logprob's guard of the QR-reduced kernels (see logprob)
         self._guarded = self.model_id == MODEL_POLYDECOMP
-        self._calls, self._escalations_seen, self._guard_warned = 0, 0, False
+        self._calls, self._escalations_seen, self._guard_warned, self._forced = 0, 0, False, False
         if variant != 'auto':
             self.set_variant(variant)
 
@@ -314,6 +314,7 @@ class HipContext:
     def set_variant(self, variant):
         v = VARIANTS[variant] if isinstance(variant, str) else int(variant)
         _check(self._lib.bisip_ctx_set_variant(self._h, v))
+        self._forced = v != VARIANTS['auto']
 
     @property
     def variant(self):
@@ -399,7 +400,7 @@ class HipContext:
             warnings.warn(f'the QR-reduced kernel was {worst:.1e} (relative) away from the exact log-probability on '
                           f'rows of this batch; the context now runs {self.kernel_name} and the batch was '
                           're-evaluated with it', RuntimeWarning, stacklevel=3)
-        elif worst > 1e-10 and not self._guard_warned and self.variant in ('reduced', 'reduced_comp'):
+        elif worst > 1e-10 and self._forced and not self._guard_warned and self.variant in ('reduced', 'reduced_comp'):
             self._guard_warned = True
             warnings.warn(f'the {self.variant!r} kernel is {worst:.1e} (relative) away from the exact log-probability '
                           "on rows of this batch (tolerance 1e-10); use variant='auto' or 'reduced_comp'",

@@ -40,10 +40,7 @@ int effective_variant(const bisip_ctx *c)
     // small exponent), else the per-frequency form, which mirrors the reference's sums
     if (2 * c->N < c->P + 2) return BISIP_VARIANT_COLLAPSED;
     if (c->red[0].err <= BISIP_REDUCED_ERR_MAX && !c->demoted[0]) return BISIP_VARIANT_REDUCED;
-    // the compensated form is the most accurate formulation there is (the per-frequency sums cancel as
-    // badly as the plain triangle on nearly collinear designs): it is given up only
-    // for an estimate ten times past the gate -- on the shell logp = 0 that is 1e-10, the tolerance itself
-    if (c->red[1].err <= 10.0 * BISIP_REDUCED_ERR_MAX && !c->demoted[1]) return BISIP_VARIANT_REDUCED_COMP;
+    if (c->red[1].err <= BISIP_REDUCED_ERR_MAX && !c->demoted[1]) return BISIP_VARIANT_REDUCED_COMP;
     return BISIP_VARIANT_COLLAPSED;
 }
 
@@ -129,33 +126,36 @@ const char *name_for(const bisip_ctx *c)
 // log2e (n ln w + log_Q) (Shin) bounded by 110, cos(c pi/2) >= 0 (c or n within [0, 1]: the real part
 // of each denominator term is then >= 1), and for Shin R <= 1 (1/R >= 1; its clamp at 1e70 bounds the
 // other side).  The reference's default boxes pass with y <= 26; a user who widens a box past this
-// gets the one-reciprocal-per-term code.
+// gets the one-reciprocal-per-term code, and past y = 500 (where a squared magnitude overflows) the
+// exponent clamp as well (BOUNDS_CLAMP_EXP).
 static int bound_flags(const bisip_ctx *c)
 {
-    constexpr double LOG2E = 1.4426950408889634, YMAX = 110.0;
+    constexpr double LOG2E = 1.4426950408889634, YMAX = 110.0, YCLAMP = 500.0;
     const double *lo = c->bounds.lo, *hi = c->bounds.hi;
     const double lw = std::fmax(std::fabs(c->lnw_min), std::fabs(c->lnw_max));
-    auto finite = [](double a, double b) { return std::isfinite(a) && std::isfinite(b); };
+    auto mag = [](double a, double b) { return std::fmax(std::fabs(a), std::fabs(b)); };   // inf for an open side, NaN-safe below
+    bool batch = true;
+    double ymax = 0.0;
     if (c->model_id == BISIP_MODEL_COLECOLE) {
         const int D = c->D;
         for (int i = 0; i < D; ++i) {
             const double llo = lo[1 + D + i], lhi = hi[1 + D + i], clo = lo[1 + 2 * D + i], chi = hi[1 + 2 * D + i];
-            if (!finite(llo, lhi) || !finite(clo, chi) || clo < 0.0 || chi > 1.0) return 0;
-            const double span = lw + std::fmax(std::fabs(llo), std::fabs(lhi));
-            if (chi * span * LOG2E > YMAX) return 0;
+            const double y = mag(clo, chi) * (lw + mag(llo, lhi)) * LOG2E;
+            ymax = y <= ymax ? ymax : y;                  // NaN (a NaN bound) propagates as "unbounded"
+            batch = batch && clo >= 0.0 && chi <= 1.0;
         }
-        return D >= 2 ? BOUNDS_BATCH_RCP : 0;
-    }
-    if (c->model_id == BISIP_MODEL_SHIN2015) {
+        batch = batch && D >= 2;
+    } else if (c->model_id == BISIP_MODEL_SHIN2015) {
         for (int i = 0; i < 2; ++i) {
             const double rlo = lo[i], rhi = hi[i], qlo = lo[2 + i], qhi = hi[2 + i], nlo = lo[4 + i], nhi = hi[4 + i];
-            if (!finite(rlo, rhi) || !finite(qlo, qhi) || !finite(nlo, nhi)) return 0;
-            if (rlo < 0.0 || rhi > 1.0 || nlo < 0.0 || nhi > 1.0) return 0;
-            if ((nhi * lw + std::fmax(std::fabs(qlo), std::fabs(qhi))) * LOG2E > YMAX) return 0;
+            const double y = (mag(nlo, nhi) * lw + mag(qlo, qhi)) * LOG2E;
+            ymax = y <= ymax ? ymax : y;
+            batch = batch && rlo >= 0.0 && rhi <= 1.0 && nlo >= 0.0 && nhi <= 1.0;
         }
-        return BOUNDS_BATCH_RCP;
+    } else {
+        return 0;
     }
-    return 0;
+    return (batch && ymax <= YMAX ? BOUNDS_BATCH_RCP : 0) | (ymax <= YCLAMP ? 0 : BOUNDS_CLAMP_EXP);
 }
 
 // PolynomialDecomposition, reduced form: (re)choose the expansion point bhat for the current

@@ -210,14 +210,37 @@ double reduced_chi2_double(int n, const std::vector<double> &R, const double *bh
     return chi2;
 }
 
-// the same quantity from the unrounded operands, in long double
+// the same quantity from the unrounded operands, to about twice the precision of long double: every row
+// qty_i - sum_j R_ij b_j is accumulated as an unevaluated sum of two long doubles (TwoProduct by fmal,
+// TwoSum; Ogita-Rump-Oishi Dot2, b_j = R0 a_j split the same way).  Plain long double is NOT enough to
+// judge the compensated kernel: on degree 9-10 designs the terms reach 1e8 against a row sum of ~10 and
+// a 64-bit mantissa leaves 1e-10 of error in a log-probability on the shell logp = 0 -- more than the
+// kernel being judged (whose double-double rows are good to ~1e-30).
+static inline void two_sum(ld a, ld b, ld &s, ld &err)
+{
+    s = a + b;
+    const ld bb = s - a;
+    err = (a - (s - bb)) + (b - bb);
+}
+
 ld reduced_chi2_exact(int n, const std::vector<double> &R, const std::vector<ld> &qty, double rest,
                       const double *th)
 {
     ld chi2 = rest;
     for (int i = 0; i < n; ++i) {
-        ld u = qty[i];
-        for (int j = i; j < n; ++j) u -= (ld)R[(size_t)i * n + j] * (j == 0 ? (ld)th[0] : (ld)th[0] * (ld)th[j]);
+        ld hi = qty[i], lo = 0.0L;
+        for (int j = i; j < n; ++j) {
+            // b = b_h + b_l exactly (R0 and a_j are doubles: their product fits two long doubles)
+            ld b_h = (ld)th[0], b_l = 0.0L;
+            if (j != 0) { b_h = (ld)th[0] * (ld)th[j]; b_l = fmal((ld)th[0], (ld)th[j], -b_h); }
+            const ld r = -(ld)R[(size_t)i * n + j];
+            const ld p = r * b_h, pe = fmal(r, b_h, -p);
+            ld s, se;
+            two_sum(hi, p, s, se);
+            hi = s;
+            lo += se + pe + r * b_l;
+        }
+        const ld u = hi + lo;
         chi2 += u * u;
     }
     return chi2;

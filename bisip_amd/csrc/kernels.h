@@ -34,6 +34,12 @@ struct Bounds {
     int flags = 0;
 };
 constexpr int BOUNDS_BATCH_RCP = 1;
+// BOUNDS_CLAMP_EXP: somewhere in this box an exponent y of 2^y = |(i w tau)^c| (ColeCole) or Q w^n
+// (Shin) exceeds 500: 2^y squared would overflow, the denominator become inf and rcp_nr(inf) NaN where
+// the reference's term quietly vanishes.  Clamping y at 500 keeps everything finite and the term at
+// <= 2^-500.  Only boxes a user widened far beyond the reference's (c up to 22 and more) set it.
+constexpr int BOUNDS_CLAMP_EXP = 2;
+constexpr double EXP2_CLAMP = 500.0;
 
 struct LaunchArgs {
     const double *__restrict__ theta;  // (W, NDIM) row-major
@@ -350,13 +356,18 @@ struct ColeCole {
         double r0;
         double m[D], lt[D], c[D], cs[D], sn[D];
         double A[D], c2[D], clt2[D], C;  // residual(): m r0, c log2e, c log2e lt, r0 - sum A
-        int batch;                       // residual(): one reciprocal per group of modes (BOUNDS_BATCH_RCP)
+        int batch, clamp;                // residual(): BOUNDS_BATCH_RCP (one reciprocal per group of modes), BOUNDS_CLAMP_EXP
     };
-    __device__ static __forceinline__ void configure(Setup &s, int flags) { s.batch = D >= 2 && (flags & BOUNDS_BATCH_RCP); }
+    __device__ static __forceinline__ void configure(Setup &s, int flags)
+    {
+        s.batch = D >= 2 && (flags & BOUNDS_BATCH_RCP);
+        s.clamp = flags & BOUNDS_CLAMP_EXP;
+    }
     __device__ static __forceinline__ Setup setup(const double (&th)[NDIM])
     {
         Setup s;
         s.batch = 0;
+        s.clamp = 0;
         s.r0 = th[0];
         s.C = th[0];
 #pragma unroll
@@ -385,6 +396,10 @@ struct ColeCole {
         double y[K], e[K], dr[F][D], di[F][D], den[F][D], inv[F][D];
 #pragma unroll
         for (int k = 0; k < K; ++k) y[k] = fma(s.c2[k % D], rec[k / D][5], s.clt2[k % D]);
+        if (s.clamp) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) y[k] = fmin(y[k], EXP2_CLAMP);
+        }
         exp2_finite_n<K>(y, e);
 #pragma unroll
         for (int f = 0; f < F; ++f)
@@ -443,7 +458,9 @@ struct ColeCole {
         zi = 0.0;
 #pragma unroll
         for (int i = 0; i < D; ++i) {
-            const double e = exp2_finite(fma(s.c2[i], lnw, s.clt2[i]));
+            double y = fma(s.c2[i], lnw, s.clt2[i]);
+            y = y > EXP2_CLAMP ? EXP2_CLAMP : y;     // any theta may be asked of forward(); NaN stays NaN
+            const double e = exp2_finite(y);
             const double dr = fma(e, s.cs[i], 1.0);  // 1 + x, >= 1 because cos(c pi/2) >= 0
             const double di = e * s.sn[i];
             const double t = s.A[i] * rcp_nr(fma(dr, dr, di * di));
@@ -549,12 +566,13 @@ struct Shin {
     struct Setup {
         double invR[2], Q[2], n[2], cs[2], sn[2];
         double n2[2], lq2[2];  // residual(): n log2e, log_Q log2e
-        int batch;             // residual(): one reciprocal for both elements (BOUNDS_BATCH_RCP)
+        int batch, clamp;      // residual(): BOUNDS_BATCH_RCP (one reciprocal for both elements), BOUNDS_CLAMP_EXP
     };
     __device__ static __forceinline__ Setup setup(const double (&th)[NDIM])
     {
         Setup s;
         s.batch = 0;
+        s.clamp = 0;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             // R = 0 (a prior bound; forward() may be asked for it) makes the term vanish in the
@@ -572,7 +590,11 @@ struct Shin {
         }
         return s;
     }
-    __device__ static __forceinline__ void configure(Setup &s, int flags) { s.batch = flags & BOUNDS_BATCH_RCP; }
+    __device__ static __forceinline__ void configure(Setup &s, int flags)
+    {
+        s.batch = flags & BOUNDS_BATCH_RCP;
+        s.clamp = flags & BOUNDS_CLAMP_EXP;
+    }
     // Q (iw)^n = 2^(n log2e ln w + log_Q log2e) (cs + i sn);  Z = sum_i conj(y_i)/|y_i|^2.
     // F frequencies in lockstep; per frequency the two elements' reciprocals come from one
     // reciprocal of the product of the |y_i|^2 when s.batch says that product stays normal.
@@ -584,6 +606,10 @@ struct Shin {
         double y[K], p[K], yr[F][2], yi[F][2], den[F][2], inv[F][2];
 #pragma unroll
         for (int k = 0; k < K; ++k) y[k] = fma(s.n2[k % 2], rec[k / 2][5], s.lq2[k % 2]);
+        if (s.clamp) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) y[k] = fmin(y[k], EXP2_CLAMP);
+        }
         exp2_finite_n<K>(y, p);
 #pragma unroll
         for (int f = 0; f < F; ++f)
@@ -638,7 +664,9 @@ struct Shin {
         zi = 0.0;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const double p = exp2_finite(fma(s.n2[i], lnw, s.lq2[i]));
+            double y = fma(s.n2[i], lnw, s.lq2[i]);
+            y = y > EXP2_CLAMP ? EXP2_CLAMP : y;     // any theta may be asked of forward(); NaN stays NaN
+            const double p = exp2_finite(y);
             const double yr = fma(p, s.cs[i], s.invR[i]), yi = p * s.sn[i];  // yr >= 1/R > 1
             const double inv = rcp_nr(fma(yr, yr, yi * yi));
             zr = fma(yr, inv, zr);
