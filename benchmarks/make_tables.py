@@ -256,7 +256,7 @@ FILES = [
     (f'{ROUND}_micro_forward_rows_variants.txt', '`benchmarks/micro/forward_rows_variants`', 'output path of the batched forward kernels (whole rows at N = 20, 16-frequency tiles at N = 32 / 64)'),
     (f'{ROUND}_micro_persistent_crossover.txt', '`python benchmarks/micro/persistent_crossover.py`', 'persistent kernel vs launch per half-step by ensemble size and model: the automatic rule'),
     (f'{ROUND}_micro_grid_barrier.txt', '`benchmarks/micro/grid_barrier`', 'cost of a device-wide barrier (with and without a row exchange) for 64 / 128 / 256 workgroups'),
-    (f'{ROUND}_micro_post_run_stall.txt', '`python benchmarks/micro/post_run_stall.py kernel`, `upload_cost4.py plain`', 'the sporadic 20-30 ms delay of the first device work after a synchronisation early in a process'),
+    (f'{ROUND}_micro_post_run_stall.txt', '`python benchmarks/micro/post_run_stall.py kernel`, `upload_cost.py plain`', 'the sporadic 20-30 ms delay of the first device work after a synchronisation early in a process'),
 ]
 
 

@@ -90,8 +90,11 @@ __global__ __launch_bounds__(256) void k_percentile_lerp(const LerpArgs a)
     const long long lo = a.lo[k], hi = lo + 1 < a.n ? lo + 1 : a.n - 1;
     const double x = c[lo], y = c[hi], t = a.t[k];
     const double d = y - x;
+    // a NaN anywhere in the column makes every percentile of it NaN (np.percentile); the radix sort
+    // puts NaNs at the ends (sign bit set: first, clear: last)
+    const bool has_nan = c[0] != c[0] || c[a.n - 1] != c[a.n - 1];
     // numpy.lib._function_base_impl._lerp
-    a.out[idx] = t >= 0.5 ? y - d * (1.0 - t) : x + d * t;
+    a.out[idx] = has_nan ? __builtin_nan("") : (t >= 0.5 ? y - d * (1.0 - t) : x + d * t);
 }
 
 // ---------------------------------------------------------------------------------
@@ -194,6 +197,13 @@ void k_segmented_select(const SelectArgs a)
     kmin = wmin[0]; kmax = wmax[0];
 #pragma unroll
     for (int w = 1; w < 16; ++w) { kmin = wmin[w] < kmin ? wmin[w] : kmin; kmax = wmax[w] > kmax ? wmax[w] : kmax; }
+    // A NaN in the column: every percentile of it is NaN, as np.percentile (and so the reference's
+    // get_model_percentile) returns.  Keys of NaNs lie beyond those of the infinities at either end.
+    // kmin / kmax are the same in every lane: the whole workgroup leaves here, before any later barrier.
+    if (kmax > 0xfff0000000000000ull || kmin < 0x000fffffffffffffull) {
+        if (tid < a.n_p) a.out[(long long)tid * a.columns + col] = __builtin_nan("");
+        return;
+    }
     int s = kmax == kmin ? 0 : 64 - __clzll((long long)(kmax - kmin));     // bits of (key - base) still open; the same for every rank
     if (tid < R) {
         const long long lo = a.lo[tid >> 1];

@@ -196,16 +196,18 @@ class _SamplerBase:
                 self._in_group = True
         self._random = np.random.mtrand.RandomState()
         self._random.set_state(np.random.get_state())
+        self._coords = None
+        self._lp = None
         self.reset()
 
     def reset(self):
+        """emcee's reset(): the stored samples and the acceptance counts go; the ensemble's current
+        state stays, so ``run_mcmc(None, n)`` continues from it."""
         self.iteration = 0          # stored samples
         self._moves_done = 0        # stretch-move iterations performed (= stored * thin_by)
         self._chain_parts = []      # one (n, W, ndim) array per run_mcmc call
         self._log_prob_parts = []
         self._accepted = np.zeros(self.nwalkers)
-        self._coords = None
-        self._lp = None
 
     @staticmethod
     def _joined(parts, empty_shape):
@@ -417,6 +419,27 @@ class HipStretchBackend:
         """status |= 2 when any of logp is NaN -- on the device, no host round trip."""
         torch = self.torch
         status_t.bitwise_or_(torch.isnan(logp_t).any().to(torch.int32) * 2)
+
+    def snapshot(self, dev_t):
+        """Start a device->host copy of a small tensor AS IT IS NOW (ordered after the work queued so
+        far, on a side stream, so work queued later does not delay it).  Returns (pinned host tensor,
+        event of the copy's completion)."""
+        torch = self.torch
+        if not hasattr(self, '_copy_stream'):
+            self._copy_stream = torch.cuda.Stream(self.device)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        frozen = dev_t.clone()                   # on the compute stream, before anything later touches dev_t
+        ev2 = torch.cuda.Event()
+        ev2.record(torch.cuda.current_stream(self.device))
+        host = torch.empty(dev_t.shape, dtype=dev_t.dtype, pin_memory=True)
+        self._copy_stream.wait_event(ev2)
+        with torch.cuda.stream(self._copy_stream):
+            host.copy_(frozen, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(self._copy_stream)
+        frozen.record_stream(self._copy_stream)
+        return host, done
 
     def empty(self, shape, dtype):
         return self.torch.empty(shape, dtype=dtype, device=self.device)
@@ -688,6 +711,15 @@ class DeviceEnsembleSampler(_SamplerBase):
         self._dev = None
         self._iterations_run = 0   # philox counter: iterations done so far (stored or not)
 
+    def reset(self):
+        """emcee's reset(): forget the stored samples and the acceptance counts; the ensemble itself
+        stays where it is, so ``run_mcmc(None, n)`` continues from it."""
+        super().reset()
+        dev = getattr(self, '_dev', None)
+        if dev is not None:
+            dev['naccept'].zero_()            # the device counter belongs to the counts just forgotten
+        self._accepted_before = np.zeros(self.nwalkers)
+
     def _sharded_comm(self):
         """The RCCL communicator of the C half-step loop (made on first use), or None: groups
         that do not run over RCCL and injected test backends keep the Python loop."""
@@ -728,6 +760,11 @@ class DeviceEnsembleSampler(_SamplerBase):
             dev['logp'] = be.empty((W,), torch.float64)
             be.logprob(dev['coords'], dev['logp'])
             be.flag_nan(dev['logp'], dev['status'])
+            # ... and its copy to the host starts now, beside whatever is queued next: run_mcmc looks at
+            # it once the first chunk is enqueued, so a NaN in the initial state raises before the run,
+            # as in emcee, at the price of one wait that the chunk's kernels overlap
+            if hasattr(be, 'snapshot'):
+                dev['status0'] = be.snapshot(dev['status'])
         else:
             dev['logp'] = be.tensor(lp, torch.float64, slot='b')
         self._dev = dev
@@ -867,6 +904,8 @@ class DeviceEnsembleSampler(_SamplerBase):
             sizes.append(min(max(1, self._chunk_steps(nsteps * thin_by) // thin_by), left))
             left -= sizes[-1]
         ahead = None                             # (worker thread, its result holder) for the next chunk
+        rng_state0 = self._random.get_state() if self.rng == 'numpy' else None
+        nan_initial = False
         try:
             for k, ns in enumerate(sizes):
                 t_a = time.perf_counter()
@@ -931,6 +970,12 @@ class DeviceEnsembleSampler(_SamplerBase):
                 self._advance(st, n, nh, it0)
                 if self.rng == 'philox' and len(sizes) > 1 and perm_ev is not None:
                     free_ev[k % 2] = be.mark()
+                early = self._dev.pop('status0', None) if k == 0 else None
+                if early is not None:
+                    early[1].synchronize()               # the initial log-probabilities only: not this chunk
+                    if int(early[0][0]) & 2:
+                        nan_initial = True
+                        raise ValueError('Probability function returned NaN')
                 t_alloc = 0.0
                 if not self.chain_on_device:
                     if chain_host is None:
@@ -956,6 +1001,8 @@ class DeviceEnsembleSampler(_SamplerBase):
         finally:
             if ahead is not None:        # an error above: let the worker finish with the RandomState first
                 ahead[0].join()
+            if nan_initial and rng_state0 is not None:
+                self._random.set_state(rng_state0)     # emcee raises before drawing anything
         if chain_host is None and dev_chain is None:  # nsteps == 0
             chain_host, logp_host = be.host_buffer((0, W, ndim)), be.host_buffer((0, W))
         t_d = time.perf_counter()

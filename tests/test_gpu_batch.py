@@ -515,7 +515,9 @@ def test_forward_over_a_range_of_spectra():
 @pytest.mark.parametrize('n,E,Wp,ndim,kind', [(40, 12, 64, 7, 'normal'), (3, 16, 5, 4, 'normal'), (1, 64, 1, 1, 'normal'),
                                                (25, 10, 33, 8, 'ties'), (60, 9, 50, 9, 'signs'), (7, 70, 300, 1, 'tight'),
                                                # columns of more than 40,960 values select from memory, not from registers
-                                               (700, 10, 64, 7, 'normal'), (650, 64, 70, 1, 'tight'), (41, 8, 1000, 8, 'signs')])
+                                               (700, 10, 64, 7, 'normal'), (650, 64, 70, 1, 'tight'), (41, 8, 1000, 8, 'signs'),
+                                               # a NaN in a column makes that column's percentiles NaN, as in NumPy
+                                               (40, 12, 64, 7, 'nans'), (700, 10, 64, 7, 'nans')])
 def test_percentiles_by_selection_equal_the_sorted_ones(n, E, Wp, ndim, kind, monkeypatch):
     """With enough columns the percentiles come from a radix SELECTION of the two order statistics each
     needs (k_segmented_select) instead of a segmented sort: same doubles as the sort path (forced with
@@ -535,6 +537,10 @@ def test_percentiles_by_selection_equal_the_sorted_ones(n, E, Wp, ndim, kind, mo
         full[3, :, 0] = 0.0
     elif kind == 'tight':
         full = 1.0 + rng.randint(0, 1 << 20, size=full.shape) * 2.0 ** -52      # same exponent, same high mantissa bits
+    elif kind == 'nans':
+        full[5, 3, 0] = np.nan                                 # one NaN in column (ensemble 0, parameter 0)
+        full[7, Wp + 1, 2] = -np.nan                           # sign bit set: sorts to the other end
+        full[:, 2 * Wp:3 * Wp, 1] = np.nan                     # a column of nothing else
     assert E * ndim >= 64
     t = torch.from_numpy(full).cuda()
     p = np.array([0.0, 2.5, 50.0, 33.3, 97.5, 99.99, 100.0, 16.0])
@@ -558,6 +564,9 @@ def test_percentiles_by_selection_equal_the_sorted_ones(n, E, Wp, ndim, kind, mo
     ok = np.isfinite(want)
     assert np.array_equal(outs['select'][ok], want[ok])            # order statistics, weights and _lerp are NumPy's: same doubles
     assert np.array_equal(np.isnan(outs['select']), np.isnan(want)) or kind == 'signs'
+    if kind == 'nans':
+        assert np.isnan(want[:, 0, 0]).all() and np.isnan(want[:, 1, 2]).all() and np.isnan(want[:, 2, 1]).all()
+        assert np.isnan(want).sum() == 3 * p.size
 
 
 def test_forward_columns_and_their_percentiles():

@@ -428,6 +428,42 @@ def test_model_percentiles_on_the_device():
         assert np.array_equal(m.get_model_percentile(50, chain), got[1])
 
 
+def test_fit_picks_the_random_stream_by_ensemble_size():
+    """fit(rng='auto'), the default: NumPy's host stream in emcee's order for the ensembles the reference's
+    tutorials use (np.random.seed pins the chain, bit for bit the host sampler's); from 2048 walkers on the
+    device's Philox stream, announced by a UserWarning that names rng='numpy'."""
+    import warnings
+    import bisip_amd
+    path = bisip_amd.DataFiles()['SIP-K389175']
+    small = bisip_amd.PolynomialDecomposition(path, nwalkers=32, nsteps=20)
+    np.random.seed(4)
+    with warnings.catch_warnings():
+        warnings.simplefilter('error', UserWarning)
+        small.fit()
+    assert small.sampler.rng == 'numpy'
+    host = bisip_amd.PolynomialDecomposition(path, nwalkers=32, nsteps=20)
+    np.random.seed(4)
+    host.fit(sampler='host')
+    assert np.array_equal(small.get_chain(), host.get_chain())
+    big = bisip_amd.PolynomialDecomposition(path, nwalkers=2048, nsteps=10)
+    centre = np.array([1.0, 0.005, -0.003, -0.001, 0.0005, 0.0002, 0.00001])
+    p0 = centre + 1e-4 * np.random.RandomState(1).randn(2048, 7)
+    np.random.seed(4)
+    with pytest.warns(UserWarning, match="rng='numpy'"):
+        big.fit(p0)
+    assert big.sampler.rng == 'philox' and big.get_chain().shape == (10, 2048, 7)
+    first = big.get_chain()
+    np.random.seed(4)                        # the Philox key comes from the seeded global state
+    with pytest.warns(UserWarning):
+        big.fit(p0)
+    assert np.array_equal(big.get_chain(), first)
+    with warnings.catch_warnings():
+        warnings.simplefilter('error', UserWarning)
+        np.random.seed(4)
+        big.fit(p0, rng='numpy')
+    assert big.sampler.rng == 'numpy' and not np.array_equal(big.get_chain(), first)
+
+
 def test_faithful_variant_fit_uses_the_host_loop():
     """The stretch-move kernels exist for the reduced / collapsed formulations; a model pinned
     to `faithful` samples through the host loop around that very kernel, and the C entry

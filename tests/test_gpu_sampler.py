@@ -163,6 +163,64 @@ def test_out_of_prior_start_and_nan_detection():
     ctx.close()
 
 
+def test_nan_in_the_initial_log_probability_raises_before_the_run():
+    """emcee raises 'Probability function returned NaN' for the initial state before it samples.  The
+    device sampler computes and checks the initial log-probabilities on the device without a host
+    round trip; the flag's copy to the host starts at once and is looked at as soon as the first
+    chunk is enqueued -- not after millions of iterations -- and the host's random stream is put back."""
+    import time
+    from bisip_amd.sampler import DeviceEnsembleSampler
+    g = np.load(_case('case15_'))
+    ctx = make_ctx(g, 'PeltonColeCole')
+    p0 = _start(g, 32, 1)
+    np.random.seed(4)
+    s = DeviceEnsembleSampler(32, 4, ctx, persistent=False)
+    s.run_mcmc(p0, 5)                                        # kernels loaded, allocator warm
+    real = s.backend.logprob
+
+    def poisoned(coords, out):
+        real(coords, out)
+        out[3] = float('nan')
+    s.backend.logprob = poisoned
+    state = s._random.get_state()
+    t0 = time.perf_counter()
+    with pytest.raises(ValueError, match='returned NaN'):
+        s.run_mcmc(p0, 400000)                               # ~4 s of half-steps if it ran to the end
+    assert time.perf_counter() - t0 < 1.5
+    after = s._random.get_state()
+    assert state[2] == after[2] and np.array_equal(state[1], after[1])
+    s.backend.logprob = real
+    s.run_mcmc(p0, 5)                                        # and the sampler is usable again
+    assert np.isfinite(s.get_log_prob()).all()
+    ctx.close()
+
+
+def test_reset_forgets_the_acceptance_counts_on_the_device_too():
+    """run, reset(), run(None, n) -- which emcee allows: the acceptance fraction is that of the second
+    run alone (the device counter restarts with it), never above 1."""
+    from bisip_amd.sampler import DeviceEnsembleSampler, EnsembleSampler
+    import oracle
+    g = np.load(_case('case15_'))
+    ctx = make_ctx(g, 'PeltonColeCole')
+    p0 = _start(g, 32, 2)
+    for kw in (dict(persistent=False), dict(persistent=True)):
+        np.random.seed(9)
+        s = DeviceEnsembleSampler(32, 4, ctx, **kw)
+        s.run_mcmc(p0, 300)
+        s.reset()
+        s.run_mcmc(None, 40)
+        np.random.seed(9)
+        h = EnsembleSampler(32, 4, ctx.logprob)
+        h.run_mcmc(p0, 300)
+        h.reset()
+        h.run_mcmc(None, 40)
+        assert s.get_chain().shape == (40, 32, 4)
+        assert np.array_equal(s.get_chain(), h.get_chain())
+        assert np.array_equal(s.acceptance_fraction, h.acceptance_fraction)
+        assert 0.0 <= s.acceptance_fraction.min() and s.acceptance_fraction.max() <= 1.0
+    ctx.close()
+
+
 def test_philox_draw_kernel_matches_contract():
     """bisip_stretch_draw_dev against the NumPy statement of the philox contract."""
     import torch
