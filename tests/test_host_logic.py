@@ -287,10 +287,12 @@ def test_cpu_quota_is_within_the_machine():
 
 def test_reduced_kernel_tiers_estimates_on_the_host():
     """What BISIP_VARIANT_AUTO decides on, without a GPU: the host emulates the plain and the
-    compensated QR-reduced arithmetic against long double on probe rows (prior box, small
-    coefficients, least-squares clouds, posterior draws).  Well-conditioned designs -- the
-    headline shape, the bundled spectra -- pass with the plain form; nearly collinear ones
-    (degree 8-10) need, and pass with, the compensated one."""
+    compensated QR-reduced arithmetic against a compensated long-double evaluation on probe rows
+    (prior box, small coefficients, least-squares clouds, posterior draws from 1 to 30 sigma, and
+    the shell log-probability = 0, where the absolute error of a chi^2 of several hundred counts;
+    shell probes weigh a tenth).  Well-conditioned designs -- the headline shape, the bundled
+    Debye decompositions -- pass with the plain form; nearly collinear ones (degree 8-10) need, and
+    pass with, the compensated one, which reads 1e-14 everywhere."""
     import bisip_amd
     from bench import make_problem
     from bisip_amd import _hip
@@ -306,11 +308,11 @@ def test_reduced_kernel_tiers_estimates_on_the_host():
 
     data, taus, log_taus, bounds = make_problem()
     plain, comp = _hip.polydecomp_reduced_estimates(data['w'], data['zn'], data['zn_err'], taus, log_taus, 1.0, bounds)
-    assert plain < 1e-13 and comp < 1e-13
+    assert plain < 1e-12 and comp < 1e-13           # plain: 6e-12 absolute on the shell, 1e-15 elsewhere
     for name, path in bisip_amd.DataFiles().items():
-        for P, c in ((5, 1.0), (4, 0.5)):
+        for P, c in ((5, 1.0), (4, 1.0), (4, 0.5)):
             plain, comp = estimates(load_data(path), P, c)
-            assert plain <= 1e-12 and comp <= 1e-12, (name, P, c, plain, comp)
+            assert plain <= 1e-12 and comp <= 1e-13, (name, P, c, plain, comp)
     needs_comp = 0
     for n_freq, P, c, idx in [(32, 10, 0.5, 0), (33, 10, 0.5, 3), (20, 10, 0.5, 7), (80, 10, 0.5, 1), (32, 8, 0.5, 2), (48, 9, 1.0, 4)]:
         plain, comp = estimates(columns_to_data(synthetic_columns(n_freq, idx), 'mrad'), P, c)
