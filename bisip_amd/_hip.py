@@ -130,6 +130,8 @@ SYMBOLS = {
     'bisip_ctx_reduced_guard': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int64),
                                                _dp, ctypes.POINTER(ctypes.c_int)]),
     'bisip_clock_probe_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p]),
+    'bisip_polydecomp_reduced_reference': (ctypes.c_int, [ctypes.c_int, _dp, _dp, _dp, ctypes.POINTER(ModelDesc),
+                                                          _dp, ctypes.c_int64, _dp]),
     'bisip_abi_version': (ctypes.c_int, []),
     'bisip_device_count': (ctypes.c_int, []),
     'bisip_last_error': (ctypes.c_char_p, []),
@@ -224,6 +226,25 @@ def polydecomp_reduced_estimates(w, zn, zn_err, taus, log_taus, c_exp, bounds):
     est = np.empty(2)
     _check(lib.bisip_polydecomp_reduced_estimates(w.size, _p(w), _p(zn), _p(zn_err), ctypes.byref(desc), _p(lo), _p(hi), _p(est)))
     return float(est[0]), float(est[1])
+
+
+def polydecomp_reduced_reference(w, zn, zn_err, taus, log_taus, c_exp, theta):
+    """Host-only, no GPU: the PolynomialDecomposition log-likelihood of the rows of ``theta`` with nothing
+    rounded to double on the way (bisip_polydecomp_reduced_reference): the yardstick of the reduced
+    kernels' estimates, checks and guard."""
+    w, zn, zn_err, taus = _c(w), _c(zn), _c(zn_err), _c(taus).ravel()
+    log_taus = _c(log_taus).reshape(-1, taus.size)
+    theta = _c(theta).reshape(-1, log_taus.shape[0] + 1)
+    desc = ModelDesc()
+    desc.poly_deg = log_taus.shape[0] - 1
+    desc.c_exp = float(c_exp)
+    desc.n_taus = taus.size
+    desc.taus = _p(taus)
+    desc.log_taus = _p(log_taus)
+    out = np.empty(theta.shape[0])
+    _check(load_library().bisip_polydecomp_reduced_reference(w.size, _p(w), _p(zn), _p(zn_err), ctypes.byref(desc),
+                                                            _p(theta), theta.shape[0], _p(out)))
+    return out
 
 
 def device_count():

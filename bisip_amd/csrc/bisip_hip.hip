@@ -178,7 +178,7 @@ static int recenter_reduced(bisip_ctx *c)
 {
     if (c->model_id != BISIP_MODEL_POLYDECOMP || c->reduced.empty()) return BISIP_OK;
     const int n = c->P + 2;
-    const size_t red_doubles = (size_t)n * (n + 1) / 2 + 3 * (size_t)n + 1;  // == sizeof(ReducedArgs<P>)/8
+    const size_t tri = (size_t)n * (n + 1) / 2;
     for (int tier = 0; tier < 2; ++tier) {
         bisip_ctx::ReducedTier &T = c->red[tier];
         const bool wanted = tier == 0 ? (c->variant == BISIP_VARIANT_AUTO || c->variant == BISIP_VARIANT_REDUCED)
@@ -187,21 +187,28 @@ static int recenter_reduced(bisip_ctx *c)
                                           (!(c->red[0].err <= BISIP_REDUCED_ERR_MAX) || c->demoted[0])));
         if (T.valid || !wanted) continue;
         const size_t E = c->reduced.size();
+        // == sizeof(ReducedArgs<P, COMP>)/8: the compensated tier's image starts with the triangle's low word
+        const size_t red_doubles = tri + 3 * (size_t)n + 1 + (tier == 1 ? tri : 0);
         std::vector<double> red(c->E > 1 ? red_doubles * E : 0), est(E);
         // the probing of every spectrum (reduced_center emulates the kernel on ~200 rows per
         // candidate) is independent of the others: blocks of spectra on host threads
         parallel_blocks((int64_t)E, 4, [&](int64_t e_lo, int64_t e_hi) {
-            std::vector<double> bh(n), ev(n), el(n), Rp;
+            std::vector<double> bh(n), ev(n), el(n), Rp, Rlo;
             for (int64_t e = e_lo; e < e_hi; ++e) {
                 const bisip_ctx::ReducedHost &rh = c->reduced[(size_t)e];
-                est[(size_t)e] = reduced_center(n, rh.R, rh.qty, rh.bhat_ls, rh.rest, rh.lconst, c->bounds.lo,
+                est[(size_t)e] = reduced_center(n, rh.R, rh.Rl, rh.qty, rh.bhat_ls, rh.rest, rh.lconst, c->bounds.lo,
                                                 c->bounds.hi, tier == 1, bh.data(), ev.data(), el.data());
                 Rp.clear();
+                Rlo.clear();
                 for (int i = 0; i < n; ++i)
-                    for (int j = i; j < n; ++j) Rp.push_back(rh.R[(size_t)i * n + j]);
-                if (e == 0) { c->Rpacked = Rp; T.bhat = bh; T.evec = ev; T.elo = el; c->rest = rh.rest; }
-                if (c->E > 1) {  // ReducedArgs<P> image: R | bhat | e | elo | rest
+                    for (int j = i; j < n; ++j) {
+                        Rp.push_back(rh.R[(size_t)i * n + j]);
+                        Rlo.push_back((double)(rh.Rl[(size_t)i * n + j] - (long double)rh.R[(size_t)i * n + j]));
+                    }
+                if (e == 0) { c->Rpacked = Rp; c->Rlo_packed = Rlo; T.bhat = bh; T.evec = ev; T.elo = el; c->rest = rh.rest; }
+                if (c->E > 1) {  // ReducedArgs<P, COMP> image: [Rlo |] R | bhat | e | elo | rest
                     double *dst = &red[red_doubles * (size_t)e];
+                    if (tier == 1) dst = std::copy(Rlo.begin(), Rlo.end(), dst);
                     dst = std::copy(Rp.begin(), Rp.end(), dst);
                     dst = std::copy(bh.begin(), bh.end(), dst);
                     dst = std::copy(ev.begin(), ev.end(), dst);
@@ -320,7 +327,28 @@ int bisip_polydecomp_reduced_estimates(int N, const double *w, const double *zn,
         const double lconst = loglike_const(2 * N, zn_err);
         std::vector<double> bh(n), ev(n), el(n);
         for (int tier = 0; tier < 2; ++tier)
-            est[tier] = reduced_center(n, o.R, o.qty, o.bhat_ls, o.rest, lconst, lo, hi, tier == 1, bh.data(), ev.data(), el.data());
+            est[tier] = reduced_center(n, o.R, o.Rl, o.qty, o.bhat_ls, o.rest, lconst, lo, hi, tier == 1, bh.data(), ev.data(), el.data());
+        return (int)BISIP_OK;
+    });
+}
+
+int bisip_polydecomp_reduced_reference(int N, const double *w, const double *zn, const double *zn_err,
+                                       const bisip_model_desc *desc, const double *theta, int64_t W, double *logp)
+{
+    if (!w || !zn || !zn_err || !desc || !desc->taus || !desc->log_taus || (W > 0 && (!theta || !logp)))
+        return fail(BISIP_EINVAL, "null argument");
+    if (N < 1 || W < 0 || desc->poly_deg < 0 || desc->poly_deg > BISIP_MAX_POLY_DEG || desc->n_taus < 1)
+        return fail(BISIP_EINVAL, "bad shape");
+    if (2 * N < desc->poly_deg + 2) return fail(BISIP_EUNSUPPORTED, "2N < poly_deg + 2: the design has no triangle");
+    return guarded([&] {
+        PolyDecompOperands o;
+        const int D = desc->poly_deg + 1, n = D + 1;
+        polydecomp_operands(N, w, desc->n_taus, desc->taus, D, desc->log_taus, desc->c_exp, zn, zn_err, o);
+        const double lconst = loglike_const(2 * N, zn_err);
+        parallel_blocks(W, 512, [&](int64_t lo, int64_t hi) {
+            for (int64_t i = lo; i < hi; ++i)
+                logp[i] = reduced_logp_reference(n, o.Rl, o.qty, o.rest, lconst, theta + i * n);
+        });
         return (int)BISIP_OK;
     });
 }
@@ -431,7 +459,7 @@ static int build_context(bisip_ctx **out, int device, int model_id, int E, int N
                 }
             }
             bisip_ctx::ReducedHost &rh = c->reduced[(size_t)e];
-            rh.R = o.R; rh.qty = o.qty; rh.bhat_ls = o.bhat_ls; rh.rest = o.rest; rh.lconst = lconsts[e];
+            rh.R = o.R; rh.Rl = o.Rl; rh.qty = o.qty; rh.bhat_ls = o.bhat_ls; rh.rest = o.rest; rh.lconst = lconsts[e];
             if (E == 1) {
                 const int JB = 16, nb = (N + JB - 1) / JB;
                 const size_t blk_stride = 4 * (size_t)JB + (size_t)S * 2 * JB;
@@ -708,7 +736,7 @@ static double reduced_check_rows(const bisip_ctx *c, const double *theta, int64_
         const double *th = theta + i * c->ndim;
         if (!in_prior_host(th, c)) continue;                  // the prior decides those rows, exactly
         const bisip_ctx::ReducedHost &rh = c->reduced[(size_t)(per ? i / per : 0)];
-        const double want = reduced_logp_reference(n, rh.R, rh.qty, rh.rest, rh.lconst, th);
+        const double want = reduced_logp_reference(n, rh.Rl, rh.qty, rh.rest, rh.lconst, th);
         const double scale = std::fabs(want) > 1.0 ? std::fabs(want) : 1.0;
         const double rel = std::fabs(logp[i] - want) / scale;
         if (!(rel <= w)) w = rel;                              // NaN counts as worst
@@ -874,13 +902,13 @@ static int logprob_host_once(bisip_ctx *c, const double *theta, int64_t W, doubl
 // The QR-reduced kernels were chosen from an error ESTIMATE on probe rows (recenter_reduced); here the
 // kernel that just ran is MEASURED on up to 256 rows of the caller's own batch against the reduced form
 // in long double -- on the first call of a context and on every 2^n-th after it, so a long emcee run pays
-// a few dozen checks of ~50 us.  Past GUARD_TOL (a tenth of the parity tolerance) a context on
+// a few dozen checks of ~50 us.  Past GUARD_TOL (a fifth of the parity tolerance) a context on
 // BISIP_VARIANT_AUTO closes that tier, moves to the next formulation (compensated, then per-frequency),
 // and the batch is evaluated again with it; a caller-forced variant is only recorded
 // (bisip_ctx_reduced_guard reports both).
 static int guard_after_logprob(bisip_ctx *c, const double *theta, int64_t W, double *logp)
 {
-    constexpr double GUARD_TOL = 1e-11;
+    constexpr double GUARD_TOL = 2e-11;
     if (!c->guard_on || c->model_id != BISIP_MODEL_POLYDECOMP || c->reduced.empty()) return BISIP_OK;
     if (c->E > 1 && W % c->E) return BISIP_OK;
     const int64_t call = ++c->guard_calls;

@@ -56,8 +56,8 @@ template <int P, bool COMP>
 int launch_reduced(const bisip_ctx *c, const double *theta, int64_t W, double *out, hipStream_t st)
 {
     const LaunchArgs a = make_args(c, theta, out, W, nullptr);
-    ReducedArgs<P> r;
-    fill_reduced<P>(c, COMP, r);
+    ReducedArgs<P, COMP> r;
+    fill_reduced<P, COMP>(c, r);
     const bool vec = ((uintptr_t)theta % 16) == 0;
     if (W < SMALL_W) {
         const unsigned grid = (unsigned)((W + BLK_SMALL - 1) / BLK_SMALL);

@@ -22,7 +22,7 @@ template <int P, bool COMP>
 int stretch_reduced(const bisip_ctx *c, const StretchWork &a, hipStream_t st)
 {
     ReducedLP<P, COMP> lp;
-    fill_reduced<P>(c, COMP, lp.r);
+    fill_reduced<P, COMP>(c, lp.r);
     lp.lconst = c->lconst;
     lp.b = c->bounds;
     return launch_stretch(a, lp, st);

@@ -32,7 +32,7 @@ template <int P, bool U, bool COMP>
 int stretch_reduced_batch(const bisip_ctx *c, const StretchWork &a, long long Wp, hipStream_t st)
 {
     BatchReducedLP<P, U, COMP> lp;
-    lp.red = reinterpret_cast<const ReducedArgs<P> *>(c->red[COMP ? 1 : 0].d_red); lp.Wp = Wp; lp.lconst = c->d_lconst;
+    lp.red = reinterpret_cast<const ReducedArgs<P, COMP> *>(c->red[COMP ? 1 : 0].d_red); lp.Wp = Wp; lp.lconst = c->d_lconst;
     lp.b = c->bounds;
     return launch_stretch(a, lp, st);
 }

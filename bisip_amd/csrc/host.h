@@ -71,10 +71,12 @@ struct bisip_ctx {
     double guard_worst = 0.0;
     int guard_escalations = 0;
     std::vector<double> Rpacked;   // spectrum 0, packed upper triangle
+    std::vector<double> Rlo_packed;   // ... and its low word (R = Rpacked + Rlo_packed to twice the precision)
     double rest = 0.0;
     // per spectrum, for re-centring the reduced form when the prior box changes
     struct ReducedHost {
         std::vector<double> R;                  // (n,n)
+        std::vector<long double> Rl;            // (n,n) the same, unrounded (R = (double)Rl)
         std::vector<long double> qty, bhat_ls;  // (n,)
         double rest = 0.0, lconst = 0.0;
     };
@@ -100,10 +102,11 @@ int effective_variant(const bisip_ctx *c);
 inline bool is_reduced(int v) { return v == BISIP_VARIANT_REDUCED || v == BISIP_VARIANT_REDUCED_COMP; }
 
 // kernarg image of spectrum 0's reduced operands for the tier a variant runs
-template <int P>
-inline void fill_reduced(const bisip_ctx *c, bool comp, ReducedArgs<P> &r)
+template <int P, bool COMP>
+inline void fill_reduced(const bisip_ctx *c, ReducedArgs<P, COMP> &r)
 {
-    const bisip_ctx::ReducedTier &t = c->red[comp ? 1 : 0];
+    const bisip_ctx::ReducedTier &t = c->red[COMP ? 1 : 0];
+    if constexpr (COMP) std::memcpy(r.Rlo, c->Rlo_packed.data(), sizeof(r.Rlo));
     std::memcpy(r.R, c->Rpacked.data(), sizeof(r.R));
     std::memcpy(r.bhat, t.bhat.data(), sizeof(r.bhat));
     std::memcpy(r.e, t.evec.data(), sizeof(r.e));

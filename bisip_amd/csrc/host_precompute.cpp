@@ -83,13 +83,17 @@ void polydecomp_kernel_sums(int N, const double *w, int S, const double *taus, i
         }
     o.G_re.resize((size_t)N * D); o.G_im.resize((size_t)N * D);
     for (size_t i = 0; i < (size_t)N * D; ++i) { o.G_re[i] = (double)Gr[i]; o.G_im[i] = (double)Gi[i]; }
+    o.Gl_re = Gr;
+    o.Gl_im = Gi;
 }
 
 void polydecomp_reduce(const double *zn, const double *zn_err, PolyDecompOperands &o)
 {
     const int N = o.N, D = o.D;
-    // Weighted design matrix of the linear model Z = R0 - sum_p (R0 a_p) G_p, built from
-    // the ROUNDED G (what the collapsed kernel uses), rows = (real j..., imag j...).
+    // Weighted design matrix of the linear model Z = R0 - sum_p (R0 a_p) G_p, rows = (real j..., imag
+    // j...), built from the UNROUNDED kernel sums: the reduced form stands for the reference's formula,
+    // not for the per-frequency kernel's rounded operands (rounding G to double moves a log-probability
+    // on the shell logp = 0 of a degree-9 design by 1e-9, like rounding R does).
     const int n = D + 1, m = 2 * N;
     std::vector<ld> A((size_t)m * n), y(m);
     for (int i = 0; i < m; ++i) {
@@ -99,7 +103,7 @@ void polydecomp_reduce(const double *zn, const double *zn_err, PolyDecompOperand
         y[i] = (ld)zn[i] * s;
         A[(size_t)i * n + 0] = im ? 0.0L : s;
         for (int p = 0; p < D; ++p)
-            A[(size_t)i * n + 1 + p] = -s * (ld)(im ? o.G_im[(size_t)j * D + p] : o.G_re[(size_t)j * D + p]);
+            A[(size_t)i * n + 1 + p] = -s * (im ? o.Gl_im[(size_t)j * D + p] : o.Gl_re[(size_t)j * D + p]);
     }
     // Householder QR, applied to y as well (column-wise backward stable).
     const int steps = n < m ? n : m;
@@ -127,8 +131,12 @@ void polydecomp_reduce(const double *zn, const double *zn_err, PolyDecompOperand
         for (int i = c; i < m; ++i) y[i] -= f * v[i - c];
     }
     o.R.assign((size_t)n * n, 0.0);
+    o.Rl.assign((size_t)n * n, 0.0L);
     for (int i = 0; i < n && i < m; ++i)
-        for (int j = i; j < n; ++j) o.R[(size_t)i * n + j] = (double)A[(size_t)i * n + j];
+        for (int j = i; j < n; ++j) {
+            o.Rl[(size_t)i * n + j] = A[(size_t)i * n + j];
+            o.R[(size_t)i * n + j] = (double)A[(size_t)i * n + j];
+        }
     ld rest = 0;
     for (int i = n; i < m; ++i) rest += y[i] * y[i];
     o.rest = (double)rest;
@@ -136,12 +144,12 @@ void polydecomp_reduce(const double *zn, const double *zn_err, PolyDecompOperand
     // least-squares solution where the triangle is well conditioned, 0 elsewhere.
     std::vector<ld> bh(n, 0.0L);
     ld rmax = 0;
-    for (int i = 0; i < n && i < m; ++i) { ld a = fabsl((ld)o.R[(size_t)i * n + i]); if (a > rmax) rmax = a; }
+    for (int i = 0; i < n && i < m; ++i) { ld a = fabsl(o.Rl[(size_t)i * n + i]); if (a > rmax) rmax = a; }
     for (int i = (n < m ? n : m) - 1; i >= 0; --i) {
-        ld rii = (ld)o.R[(size_t)i * n + i];
+        ld rii = o.Rl[(size_t)i * n + i];
         if (fabsl(rii) <= 1e-13L * rmax) { bh[i] = 0; continue; }
         ld s = y[i];
-        for (int j = i + 1; j < n; ++j) s -= (ld)o.R[(size_t)i * n + j] * bh[j];
+        for (int j = i + 1; j < n; ++j) s -= o.Rl[(size_t)i * n + j] * bh[j];
         bh[i] = s / rii;
     }
     o.bhat.resize(n);
@@ -160,8 +168,8 @@ void polydecomp_reduce(const double *zn, const double *zn_err, PolyDecompOperand
 namespace {
 
 // logprob_row_reduced<P, COMP> (kernels.h) in the same double arithmetic, operation for operation
-double reduced_chi2_double(int n, const std::vector<double> &R, const double *bhat, const double *e,
-                           const double *elo, double rest, const double *th, bool comp)
+double reduced_chi2_double(int n, const std::vector<double> &R, const std::vector<ld> &Rl, const double *bhat,
+                           const double *e, const double *elo, double rest, const double *th, bool comp)
 {
     double chi2 = rest;
     std::vector<double> d(n), dl(n);
@@ -203,6 +211,7 @@ double reduced_chi2_double(int n, const std::vector<double> &R, const double *bh
             s = t;
             c += er + l;
             c = std::fma(Rk, dl[j], c);
+            c = std::fma((double)(Rl[(size_t)i * n + j] - (ld)Rk), d[j], c);     // Rlo, as the kernel holds it
         }
         const double u = s + c;
         chi2 = std::fma(u, u, chi2);
@@ -223,7 +232,7 @@ static inline void two_sum(ld a, ld b, ld &s, ld &err)
     err = (a - (s - bb)) + (b - bb);
 }
 
-ld reduced_chi2_exact(int n, const std::vector<double> &R, const std::vector<ld> &qty, double rest,
+ld reduced_chi2_exact(int n, const std::vector<ld> &R, const std::vector<ld> &qty, double rest,
                       const double *th)
 {
     ld chi2 = rest;
@@ -233,7 +242,7 @@ ld reduced_chi2_exact(int n, const std::vector<double> &R, const std::vector<ld>
             // b = b_h + b_l exactly (R0 and a_j are doubles: their product fits two long doubles)
             ld b_h = (ld)th[0], b_l = 0.0L;
             if (j != 0) { b_h = (ld)th[0] * (ld)th[j]; b_l = fmal((ld)th[0], (ld)th[j], -b_h); }
-            const ld r = -(ld)R[(size_t)i * n + j];
+            const ld r = -R[(size_t)i * n + j];
             const ld p = r * b_h, pe = fmal(r, b_h, -p);
             ld s, se;
             two_sum(hi, p, s, se);
@@ -260,11 +269,12 @@ struct Lcg {   // deterministic probe points, no <random>
 static double shell_weight()
 {
     const char *s = std::getenv("BISIP_SHELL_WEIGHT");
-    const double w = s ? std::atof(s) : 0.1;
-    return w >= 0.0 && w <= 1.0 ? w : 0.1;
+    const double w = s ? std::atof(s) : 0.05;
+    return w >= 0.0 && w <= 1.0 ? w : 0.05;
 }
 
-double reduced_center(int n, const std::vector<double> &R, const std::vector<long double> &qty,
+double reduced_center(int n, const std::vector<double> &R, const std::vector<long double> &Rl,
+                      const std::vector<long double> &qty,
                       const std::vector<long double> &bhat_ls, double rest, double lconst,
                       const double *lo, const double *hi, bool comp, double *out_bhat, double *out_e,
                       double *out_elo)
@@ -360,8 +370,10 @@ double reduced_center(int n, const std::vector<double> &R, const std::vector<lon
     // above practically never see it (measured on the GPU, benchmarks/valley_rows.py: 3000 rows per scale
     // found 1e-11 ... 2.5e-10 on degree 7-9 designs whose 32 probes per scale had read < 1e-12).  These
     // probes are ON the shell: b = b_ls + s R^-1 z with s such that rest + s^2 |z|^2 = 2 lconst.  No double
-    // formulation gets below ~1e-12 there (one rounding of chi^2 ~ 1e3 is 1e-13), so they count at a
-    // tenth: the gate 1e-12 then reads "1e-11 on the shell", the same margin bisip_logprob's guard keeps.
+    // formulation gets below ~1e-12 there (one rounding of chi^2 ~ 1e3 is 1e-13; the plain triangle of the
+    // headline's degree-5 design reads 9e-12, of which 5e-12 is the rounding of R itself), so they count
+    // at a twentieth: the gate 1e-12 then reads "2e-11 on the shell" -- a fifth of the tolerance, where
+    // the region is sampled directly -- the same bar bisip_logprob's guard applies to real batches.
     const size_t n_regular = probes.size();
     if (ls_ok && 2.0 * lconst - rest > 0.0) {
         bool solvable = true;
@@ -422,8 +434,10 @@ double reduced_center(int n, const std::vector<double> &R, const std::vector<lon
     }
     for (const auto &c : cand) {
         for (int i = 0; i < n; ++i) {
+            // plain: with the triangle the kernel holds, so that its identity is exact for THAT triangle;
+            // compensated: with the unrounded one, which R + Rlo stands for
             ld s = qty[i];
-            for (int j = i; j < n; ++j) s -= (ld)R[(size_t)i * n + j] * (ld)c[j];
+            for (int j = i; j < n; ++j) s -= (comp ? Rl[(size_t)i * n + j] : (ld)R[(size_t)i * n + j]) * (ld)c[j];
             e[i] = (double)s;
             elo[i] = (double)(s - (ld)e[i]);
         }
@@ -431,8 +445,8 @@ double reduced_center(int n, const std::vector<double> &R, const std::vector<lon
         const double w_shell = shell_weight();
         for (size_t ip = 0; ip < probes.size(); ++ip) {
             const auto &t = probes[ip];
-            const ld exact = reduced_chi2_exact(n, R, qty, rest, t.data());
-            const double got = reduced_chi2_double(n, R, c.data(), e.data(), elo.data(), rest, t.data(), comp);
+            const ld exact = reduced_chi2_exact(n, Rl, qty, rest, t.data());
+            const double got = reduced_chi2_double(n, R, Rl, c.data(), e.data(), elo.data(), rest, t.data(), comp);
             const ld lp = -0.5L * exact + (ld)lconst;
             const ld scale = fabsl(lp) > 1.0L ? fabsl(lp) : 1.0L;
             double rel = (double)(fabsl(-0.5L * ((ld)got - exact)) / scale);
@@ -447,10 +461,10 @@ double reduced_center(int n, const std::vector<double> &R, const std::vector<lon
     return best;
 }
 
-double reduced_logp_reference(int n, const std::vector<double> &R, const std::vector<long double> &qty,
+double reduced_logp_reference(int n, const std::vector<long double> &Rl, const std::vector<long double> &qty,
                               double rest, double lconst, const double *theta)
 {
-    return (double)(-0.5L * reduced_chi2_exact(n, R, qty, rest, theta) + (ld)lconst);
+    return (double)(-0.5L * reduced_chi2_exact(n, Rl, qty, rest, theta) + (ld)lconst);
 }
 
 int host_threads()

@@ -19,8 +19,9 @@ struct PolyDecompOperands {
     std::vector<double> bhat;         // (n,)  expansion point (least-squares solution)
     std::vector<double> e;            // (n,)  Q^T y - R bhat
     double rest = 0.0;
-    // unrounded, for reduced_center(): first n entries of Q^T y and the least-squares solution
-    std::vector<long double> qty, bhat_ls;
+    // unrounded, for reduced_center(): first n entries of Q^T y and the least-squares solution,
+    // the triangle itself (R = (double)Rl) and the kernel sums the design matrix is built from
+    std::vector<long double> qty, bhat_ls, Rl, Gl_re, Gl_im;
 };
 
 // reference: C_Debye at src/bisip/cython_funcs.pyx:46-47, Decomp_cyth :75-94,
@@ -47,7 +48,11 @@ void polydecomp_operands(int N, const double *w, int S, const double *taus, int 
 // returns its worst relative log-probability error.  out_e + out_elo = Q^T y - R bhat to twice
 // the working precision.  The caller (AUTO variant) takes the plain kernel while its estimate
 // is <= 1e-12, else the compensated one, else the per-frequency form.
-double reduced_center(int n, const std::vector<double> &R, const std::vector<long double> &qty,
+// R is the triangle as the kernels hold it (double); Rl the unrounded one: the yardstick is the reduced
+// form with Rl, so the plain kernel's estimate includes what rounding R costs; the compensated kernel
+// carries Rlo = Rl - R and its e + elo is formed with Rl.
+double reduced_center(int n, const std::vector<double> &R, const std::vector<long double> &Rl,
+                      const std::vector<long double> &qty,
                       const std::vector<long double> &bhat_ls, double rest, double lconst,
                       const double *lo, const double *hi, bool comp, double *out_bhat, double *out_e,
                       double *out_elo);
@@ -73,7 +78,7 @@ void read_tables(const char *const *paths, int64_t n_files, int headers, int64_t
 
 // The reduced form's log-likelihood of one theta row from the unrounded operands, in long double:
 // what the reduced kernels compute, without their rounding (reduced_center's yardstick).
-double reduced_logp_reference(int n, const std::vector<double> &R, const std::vector<long double> &qty,
+double reduced_logp_reference(int n, const std::vector<long double> &Rl, const std::vector<long double> &qty,
                               double rest, double lconst, const double *theta);
 
 // -0.5 * sum_i 2*ln(zn_err_i^2), the walker-independent term of src/bisip/models.py:62

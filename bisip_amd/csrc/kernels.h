@@ -914,8 +914,19 @@ __global__ __launch_bounds__(BLK) void k_logprob_x2(const LaunchArgs a)
 // Per walker: n products, n subtractions, n(n+1)/2 FMAs, n squares -- the kernel is
 // then bound by streaming theta in and logp out (8*(ndim+1) B/eval).
 // ---------------------------------------------------------------------------------
+// The compensated form also carries the LOW word of the triangle, R = R + Rlo to twice the working
+// precision.  Rounding R itself to double is a formulation error no arithmetic can undo: on a degree-9
+// design it leaves 1e-9 ... 3e-8 in a log-probability on the shell logp = 0 (60-digit evaluation of the
+// reference's formula, benchmarks/exact_shell_rows.py) -- as much as the reference's own rounding there.
+template <int P, bool COMP>
+struct ReducedLow {};
 template <int P>
-struct ReducedArgs {
+struct ReducedLow<P, true> {
+    double Rlo[(P + 2) * (P + 3) / 2];
+};
+
+template <int P, bool COMP = false>
+struct ReducedArgs : ReducedLow<P, COMP> {
     static constexpr int n = P + 2;
     double R[n * (n + 1) / 2];  // packed upper triangle, row-major
     double bhat[n];
@@ -941,14 +952,14 @@ __device__ __forceinline__ void two_diff(double a, double b, double &s, double &
 //     fma (TwoProduct), the subtraction's from TwoSum -- d + dl is exact;
 //   * each row  e_i + sum_j R_ij d_j  is accumulated as a double-double (Ogita-Rump-Oishi Dot2:
 //     TwoProduct per term, TwoSum per addition, the error terms summed separately), plus the
-//     first-order terms R_ij dl_j and the low word of e_i.
+//     first-order terms R_ij dl_j, Rlo_ij d_j and the low word of e_i.
 // Result: as if the row sums were formed in twice the working precision and rounded once --
 // measured on posterior-valley probes 1e-13 .. 1e-16 relative where the plain form AND the
 // per-frequency form (the reference's own kind of sum) give 1e-12 .. 7e-11.  ~11 flops per
 // matrix entry instead of 1, still independent of the number of frequencies.
 template <int P, bool COMP = false>
 __device__ __forceinline__ double logprob_row_reduced(const double (&th)[P + 2],
-                                                      const ReducedArgs<P> &r, double lconst,
+                                                      const ReducedArgs<P, COMP> &r, double lconst,
                                                       const Bounds &b)
 {
     constexpr int n = P + 2;
@@ -992,6 +1003,7 @@ __device__ __forceinline__ double logprob_row_reduced(const double (&th)[P + 2],
                 s = t;
                 c += er + l;
                 c = fma(Rk, dl[j], c);
+                c = fma(r.Rlo[k], d[j], c);
             }
             const double u = s + c;
             chi2 = fma(u, u, chi2);
@@ -1003,7 +1015,7 @@ __device__ __forceinline__ double logprob_row_reduced(const double (&th)[P + 2],
 
 template <int P, int BLK, bool VEC, bool COMP = false>
 __global__ __launch_bounds__(BLK) void k_logprob_pd_reduced(const LaunchArgs a,
-                                                            const ReducedArgs<P> r)
+                                                            const ReducedArgs<P, COMP> r)
 {
     constexpr int NDIM = P + 2;
     __shared__ __attribute__((aligned(16))) double lds[BLK * NDIM];
@@ -1220,7 +1232,7 @@ __global__ __launch_bounds__(64) void k_logprob_batch_reduced(const BatchArgs a)
 #pragma unroll
     for (int q = 0; q < NDIM; ++q) th[q] = a.theta[row * NDIM + q];
     const long long e = spectrum_of<UNIFORM>(row, a.Wp);
-    const ReducedArgs<P> *__restrict__ r = reinterpret_cast<const ReducedArgs<P> *>(a.red) + e;
+    const ReducedArgs<P, COMP> *__restrict__ r = reinterpret_cast<const ReducedArgs<P, COMP> *>(a.red) + e;
     a.out[row] = logprob_row_reduced<P, COMP>(th, *r, a.lconst[e], a.b);
 }
 
@@ -1241,7 +1253,7 @@ __global__ __launch_bounds__(BLK) void k_logprob_batch_reduced_stream(const Batc
 #pragma unroll
     for (int q = 0; q < NDIM; ++q) th[q] = lds[threadIdx.x * NDIM + q];
     const unsigned e = (unsigned)row0 / (unsigned)a.Wp;          // one spectrum per workgroup (Wp % BLK == 0)
-    const ReducedArgs<P> *__restrict__ r = reinterpret_cast<const ReducedArgs<P> *>(a.red) + e;
+    const ReducedArgs<P, COMP> *__restrict__ r = reinterpret_cast<const ReducedArgs<P, COMP> *>(a.red) + e;
     a.out[row] = logprob_row_reduced<P, COMP>(th, *r, a.lconst[e], a.b);
 }
 

@@ -80,7 +80,7 @@ struct ReducedLP {
     static constexpr int NDIM = P + 2;
     static constexpr int L = 1;
     static constexpr bool CAN_STAGE = false;
-    ReducedArgs<P> r;
+    ReducedArgs<P, COMP> r;
     double lconst;
     Bounds b;
     __device__ __forceinline__ double operator()(const double (&th)[NDIM], int, int) const
@@ -89,13 +89,13 @@ struct ReducedLP {
     }
     // a copy of the kernarg operands in VECTOR registers (see BatchReducedLP::Local: as scalars
     // they do not fit and return lane by lane in every half-step)
-    struct Local { ReducedArgs<P> r; };
+    struct Local { ReducedArgs<P, COMP> r; };
     __device__ __forceinline__ Local local(long long) const
     {
         Local loc{r};
         double *v = reinterpret_cast<double *>(&loc.r);
 #pragma unroll
-        for (int i = 0; i < (int)(sizeof(ReducedArgs<P>) / sizeof(double)); ++i) asm volatile("" : "+v"(v[i]));
+        for (int i = 0; i < (int)(sizeof(ReducedArgs<P, COMP>) / sizeof(double)); ++i) asm volatile("" : "+v"(v[i]));
         return loc;
     }
     template <bool STAGED>
@@ -145,7 +145,7 @@ struct BatchReducedLP {
     static constexpr int NDIM = P + 2;
     static constexpr int L = 1;
     static constexpr bool CAN_STAGE = false;
-    const ReducedArgs<P> *red;
+    const ReducedArgs<P, COMP> *red;
     long long Wp;
     const double *lconst;
     Bounds b;
@@ -158,7 +158,7 @@ struct BatchReducedLP {
     // ONCE per launch into registers: read where they lie they were ~25 vector loads per half-step,
     // each a trip to memory that the 130 instructions of a half-step cannot hide (SQ counters of the
     // 512 x 256 batch: 4,300 cycles per half-step, 1,900 of them waiting; benchmarks/micro/batch_pd_pmc.sh).
-    struct Local { ReducedArgs<P> r; double lconst; };
+    struct Local { ReducedArgs<P, COMP> r; double lconst; };
     __device__ __forceinline__ Local local(long long e) const
     {
         // through the vector path on purpose: as wave-uniform values the 100 dwords would overflow the

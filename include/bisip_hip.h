@@ -39,7 +39,7 @@ extern "C" {
 /* 2: entry points added since 1 (all additions, nothing changed or removed): loglike_z, forward_percentiles,
  * column / grouped / columns percentiles, forward_spectrum(s) / forward_columns, stretch_run_sharded + rccl_*, ctx_set_spectrum_offset,
  * ctx_reduced_check, polydecomp_reduced_estimates, read_tables; BISIP_VARIANT_REDUCED_COMP, BISIP_ERCCL.
- * 3: clock_probe_dev, ctx_reduced_guard (additions only). */
+ * 3: clock_probe_dev, ctx_reduced_guard, polydecomp_reduced_reference (additions only). */
 #define BISIP_ABI_VERSION 3
 
 /* model_id -- the four reference model classes (src/bisip/models.py:182,232,274,308) */
@@ -346,7 +346,7 @@ int bisip_ctx_reduced_check(bisip_ctx *ctx, const double *theta, int64_t W, cons
 
 /* bisip_logprob (the host-buffer entry emcee calls) measures the QR-reduced kernel it ran on up to 256
  * rows of the caller's own batch -- on a context's first call and every 2^n-th after it -- the way
- * bisip_ctx_reduced_check does.  Past 1e-11 a context on BISIP_VARIANT_AUTO moves to the next
+ * bisip_ctx_reduced_check does.  Past 2e-11 a context on BISIP_VARIANT_AUTO moves to the next
  * formulation (compensated, then per-frequency) and evaluates the batch again with it; the choice holds
  * until bisip_ctx_set_bounds.  A caller-forced variant is measured and left alone.  enable: 1 / 0 turn
  * the guard on (default) / off, anything else leaves it; outputs (each may be NULL): checks made so far,
@@ -412,6 +412,17 @@ int bisip_polydecomp_reduced_estimates(int N, const double *w, const double *zn,
  * that kernel's load -- fp64-dense kernels run at 1.9-2.1 GHz, not at the 2.4 GHz the issue peak is
  * quoted at (benchmarks/micro/collapsed_r3.hip) -- without touching the kernel itself. */
 int bisip_clock_probe_dev(int64_t *d_out, double window_us, void *stream);
+
+/* Host-only yardstick (no GPU, no prior): the PolynomialDecomposition log-likelihood
+ * -0.5 (chi^2 + sum 2 ln sigma^2) of src/bisip/models.py:59-62 + cython_funcs.pyx:75-94 for W rows of theta,
+ * from the QR-reduced form with NOTHING rounded to double on the way: kernel sums, Householder QR and
+ * Q^T y in x87 long double, every row q_i - sum_j R_ij b_j accumulated as an unevaluated sum of two long
+ * doubles.  Agrees with a 60-digit evaluation of the reference's per-frequency formula to ~1e-12 where
+ * the reference's own double arithmetic is 1e-9 ... 1e-7 away (rows on the shell logp = 0 of degree 8-10
+ * designs; tests/test_oracle_golden.py pins it with mpmath).  It is what bisip_ctx_reduced_check,
+ * bisip_logprob's guard and the estimate behind BISIP_VARIANT_AUTO measure against.  Needs 2N >= poly_deg+2. */
+int bisip_polydecomp_reduced_reference(int N, const double *w, const double *zn, const double *zn_err,
+                                       const bisip_model_desc *desc, const double *theta, int64_t W, double *logp);
 
 int bisip_abi_version(void);
 int bisip_device_count(void);

@@ -154,12 +154,12 @@ static void reduced(int N, int S, int D)
     lo[0] = 0.9; hi[0] = 1.1;
     const double lconst = bisip::loglike_const(2 * N, err.data());
     for (bool comp : {false, true}) {
-        const double est = bisip::reduced_center(n, o.R, o.qty, o.bhat_ls, o.rest, lconst, lo.data(), hi.data(), comp, bh.data(), e.data(), el.data());
+        const double est = bisip::reduced_center(n, o.R, o.Rl, o.qty, o.bhat_ls, o.rest, lconst, lo.data(), hi.data(), comp, bh.data(), e.data(), el.data());
         EXPECT(est >= 0.0 || est != est);
     }
     std::vector<double> th(n, 0.01);
     th[0] = 1.0;
-    EXPECT(std::isfinite(bisip::reduced_logp_reference(n, o.R, o.qty, o.rest, lconst, th.data())));
+    EXPECT(std::isfinite(bisip::reduced_logp_reference(n, o.Rl, o.qty, o.rest, lconst, th.data())));
 }
 
 int main(int argc, char **argv)

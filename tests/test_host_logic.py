@@ -290,7 +290,7 @@ def test_reduced_kernel_tiers_estimates_on_the_host():
     compensated QR-reduced arithmetic against a compensated long-double evaluation on probe rows
     (prior box, small coefficients, least-squares clouds, posterior draws from 1 to 30 sigma, and
     the shell log-probability = 0, where the absolute error of a chi^2 of several hundred counts;
-    shell probes weigh a tenth).  Well-conditioned designs -- the headline shape, the bundled
+    shell probes weigh a twentieth).  Well-conditioned designs -- the headline shape, the bundled
     Debye decompositions -- pass with the plain form; nearly collinear ones (degree 8-10) need, and
     pass with, the compensated one, which reads 1e-14 everywhere."""
     import bisip_amd
@@ -308,7 +308,7 @@ def test_reduced_kernel_tiers_estimates_on_the_host():
 
     data, taus, log_taus, bounds = make_problem()
     plain, comp = _hip.polydecomp_reduced_estimates(data['w'], data['zn'], data['zn_err'], taus, log_taus, 1.0, bounds)
-    assert plain < 1e-12 and comp < 1e-13           # plain: 6e-12 absolute on the shell, 1e-15 elsewhere
+    assert plain < 1e-12 and comp < 1e-13           # plain: 9e-12 absolute on the shell, 1e-15 elsewhere
     for name, path in bisip_amd.DataFiles().items():
         for P, c in ((5, 1.0), (4, 1.0), (4, 0.5)):
             plain, comp = estimates(load_data(path), P, c)
@@ -320,6 +320,62 @@ def test_reduced_kernel_tiers_estimates_on_the_host():
         assert comp <= plain
         needs_comp += plain > 1e-12
     assert needs_comp >= 3
+
+
+def test_reduced_yardstick_is_pinned_by_fifty_digit_arithmetic():
+    """bisip_polydecomp_reduced_reference -- what the reduced kernels' estimates, checks and guard measure
+    against -- equals a 50-digit evaluation of the reference's own per-frequency formula
+    (cython_funcs.pyx:75-94 + models.py:59-62) to a few 1e-12, on rows where the reference's double
+    arithmetic (the oracle, bit for bit) is 5e-10 away: the shell log-probability = 0 and the 1-30 sigma
+    valley of degree 8-9 designs.  On a degree-5 design both are at rounding level."""
+    mp = pytest.importorskip('mpmath')
+    import oracle
+    from bisip_amd import _hip
+    from bisip_amd.synthetic import synthetic_columns
+    from bisip_amd.utils import columns_to_data
+    sys.path.insert(0, os.path.join(ROOT, 'benchmarks'))
+    from fuzz_parity import valley_rows
+    mp.mp.dps = 50
+
+    def exact_logp(d, taus, log_taus, c_exp, rows):
+        w = [mp.mpf(float(x)) for x in d['w']]
+        ta = [mp.mpf(float(x)) for x in taus]
+        K = [[1 - 1 / (1 + (mp.mpc(0, 1) * wj * tk) ** mp.mpf(float(c_exp))) for tk in ta] for wj in w]
+        out = []
+        for th in rows:
+            r0, a = mp.mpf(float(th[0])), [mp.mpf(float(x)) for x in th[1:]]
+            M = [mp.fsum(a[p] * mp.mpf(float(log_taus[p, k])) for p in range(len(a))) for k in range(len(ta))]
+            tot = mp.mpf(0)
+            for j in range(len(w)):
+                Z = r0 * (1 - mp.fsum(M[k] * K[j][k] for k in range(len(ta))))
+                for part, val in ((0, Z.real), (1, Z.imag)):
+                    s2 = mp.mpf(float(d['zn_err'][part, j])) ** 2
+                    tot += (mp.mpf(float(d['zn'][part, j])) - val) ** 2 / s2 + 2 * mp.log(s2)
+            out.append(-tot / 2)
+        return out
+
+    seen_reference_off = 0
+    for n_freq, P, c_exp, idx, tol in ((20, 9, 1.0, 0, 2e-11), (32, 8, 0.5, 1, 2e-11), (20, 5, 1.0, 2, 1e-13)):
+        d = columns_to_data(synthetic_columns(n_freq, idx), 'mrad')
+        per = np.log10(1. / d['w'])
+        lt = np.linspace(np.floor(per.min() - 1), np.floor(per.max() + 1), 2 * n_freq)
+        taus, log_taus = 10 ** lt, np.array([lt ** i for i in range(P + 1)])
+        bounds = np.array([[0.9] + [-1.0] * (P + 1), [1.1] + [1.0] * (P + 1)])
+        ops = _hip.polydecomp_operands(d['w'], d['zn'], d['zn_err'], taus, log_taus, c_exp)
+        rows = valley_rows(ops, bounds, np.random.RandomState(3), 60)[:8]
+        assert len(rows) == 8
+        exact = exact_logp(d, taus, log_taus, c_exp, rows)
+        mine = _hip.polydecomp_reduced_reference(d['w'], d['zn'], d['zn_err'], taus, log_taus, c_exp, rows)
+        free = np.array([np.full(P + 2, -np.inf), np.full(P + 2, np.inf)])
+        prob = oracle.OracleProblem('PolynomialDecomposition', d['w'], d['zn'], d['zn_err'], free,
+                                    taus=taus, log_taus=log_taus, c_exp=c_exp)
+        ref = oracle.logprob(prob, rows)
+        err_mine = max(float(abs(mp.mpf(float(a)) - b)) for a, b in zip(mine, exact))
+        err_ref = max(float(abs(mp.mpf(float(a)) - b)) for a, b in zip(ref, exact))
+        assert err_mine <= tol, (n_freq, P, c_exp, err_mine)
+        seen_reference_off += err_ref > 1e-10
+        print(f'N={n_freq} P={P} c={c_exp}: yardstick {err_mine:.1e}, reference arithmetic {err_ref:.1e} from the exact value')
+    assert seen_reference_off == 2
 
 
 def test_design_tables_are_generated():
