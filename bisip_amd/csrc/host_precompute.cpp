@@ -339,28 +339,32 @@ double reduced_center(int n, const std::vector<double> &R, const std::vector<lon
         // the plain kernel on 10-sigma rows of degree 8-10 designs it had passed read 1e-10 ... 2e-8.
         bool solvable = true;
         for (int i = 0; i < n; ++i) solvable = solvable && R[(size_t)i * n + i] != 0.0;
-        for (int k = 0; solvable && k < 128; ++k) {
-            const double sc = k < 32 ? 1.0 : (k < 64 ? 3.0 : (k < 96 ? 10.0 : 30.0));
-            std::vector<ld> z(n), db(n, 0.0L);
-            for (int j = 0; j < n; ++j) {   // sum of 12 uniforms - 6: unit variance, no libm
-                double a = 0.0;
-                for (int r = 0; r < 12; ++r) a += rng.uni();
-                z[j] = (ld)(sc * (a - 6.0));
+        // 32 probes INSIDE the box per scale (a narrowed box keeps few of the draws: up to 600 tries each)
+        for (int scale_i = 0; solvable && scale_i < 4; ++scale_i) {
+            const double sc = scale_i == 0 ? 1.0 : (scale_i == 1 ? 3.0 : (scale_i == 2 ? 10.0 : 30.0));
+            int kept = 0;
+            for (int k = 0; k < 600 && kept < 32; ++k) {
+                std::vector<ld> z(n), db(n, 0.0L);
+                for (int j = 0; j < n; ++j) {   // sum of 12 uniforms - 6: unit variance, no libm
+                    double a = 0.0;
+                    for (int r = 0; r < 12; ++r) a += rng.uni();
+                    z[j] = (ld)(sc * (a - 6.0));
+                }
+                for (int i = n - 1; i >= 0; --i) {
+                    ld acc = z[i];
+                    for (int j = i + 1; j < n; ++j) acc -= (ld)R[(size_t)i * n + j] * db[j];
+                    db[i] = acc / (ld)R[(size_t)i * n + i];
+                }
+                std::vector<double> t(n);
+                const ld b0 = bhat_ls[0] + db[0];
+                t[0] = (double)b0;
+                bool fin = std::isfinite(t[0]) && t[0] != 0.0;
+                for (int j = 1; j < n; ++j) {
+                    t[j] = (double)((bhat_ls[j] + db[j]) / b0);
+                    fin = fin && std::isfinite(t[j]);
+                }
+                if (fin && (!finite_box || inside(t))) { probes.push_back(t); ++kept; }
             }
-            for (int i = n - 1; i >= 0; --i) {
-                ld acc = z[i];
-                for (int j = i + 1; j < n; ++j) acc -= (ld)R[(size_t)i * n + j] * db[j];
-                db[i] = acc / (ld)R[(size_t)i * n + i];
-            }
-            std::vector<double> t(n);
-            const ld b0 = bhat_ls[0] + db[0];
-            t[0] = (double)b0;
-            bool fin = std::isfinite(t[0]) && t[0] != 0.0;
-            for (int j = 1; j < n; ++j) {
-                t[j] = (double)((bhat_ls[j] + db[j]) / b0);
-                fin = fin && std::isfinite(t[j]);
-            }
-            if (fin && (!finite_box || inside(t))) probes.push_back(t);
         }
     }
     // The shell log-probability = 0.  The parity tolerance is |d logp| <= 1e-10 max(1, |logp|): where the
@@ -378,7 +382,8 @@ double reduced_center(int n, const std::vector<double> &R, const std::vector<lon
     if (ls_ok && 2.0 * lconst - rest > 0.0) {
         bool solvable = true;
         for (int i = 0; i < n; ++i) solvable = solvable && R[(size_t)i * n + i] != 0.0;
-        for (int k = 0; solvable && k < 64; ++k) {
+        int kept = 0;     // 96 probes inside the box, up to 3000 tries (a narrowed box keeps few of the draws)
+        for (int k = 0; solvable && k < 3000 && kept < 96; ++k) {
             std::vector<ld> z(n), db(n, 0.0L);
             ld zz = 0.0L;
             for (int j = 0; j < n; ++j) {
@@ -402,7 +407,7 @@ double reduced_center(int n, const std::vector<double> &R, const std::vector<lon
                 t[j] = (double)((bhat_ls[j] + db[j]) / b0);
                 fin = fin && std::isfinite(t[j]);
             }
-            if (fin && (!finite_box || inside(t))) probes.push_back(t);
+            if (fin && (!finite_box || inside(t))) { probes.push_back(t); ++kept; }
         }
     }
     // candidates for the expansion point
