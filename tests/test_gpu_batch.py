@@ -372,17 +372,19 @@ def test_batch_operands_do_not_depend_on_threads_or_on_shared_frequencies(monkey
         lo, hi = batch.param_bounds
         theta = np.random.RandomState(8).uniform(lo, hi, (E, Wp, lo.size))
         got[threads] = batch.log_prob(theta)
+        v_default = batch.ctx.variant             # a batch runs the formulation its least accurate spectrum needs
         # a wider box re-centres every spectrum's reduced form (the other threaded loop)
         wide = batch.param_bounds.copy()
         wide[:, 1:] *= 1.5
         batch.ctx.set_bounds(wide)
+        v_wide = batch.ctx.variant
         got[threads, 'wide'] = batch.ctx.logprob(theta.reshape(-1, lo.size)).reshape(E, Wp)
         if threads is None:
             assert_logp_close(got[threads], _oracle_logp(batch, theta))
             for e in (0, 2, 3, 4, 12, 13, 36):
-                for bounds, key in ((batch.param_bounds, None), (wide, (None, 'wide'))):
+                for bounds, key, v in ((batch.param_bounds, None, v_default), (wide, (None, 'wide'), v_wide)):
                     single = _hip.HipContext(0, batch.w[e], batch.zn[e], batch.zn_err[e], bounds, poly_deg=4,
-                                             c_exp=0.7, taus=batch.taus, log_taus=batch.log_taus)
+                                             c_exp=0.7, taus=batch.taus, log_taus=batch.log_taus, variant=v)
                     assert np.array_equal(single.logprob(theta[e]), got[key][e])
                     single.close()
         batch.close()
