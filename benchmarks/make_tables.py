@@ -21,7 +21,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROF = os.path.join(ROOT, 'profiles')
-ROUND = 'r02'
+ROUND = 'r03'
 
 
 def jload(name):
@@ -90,11 +90,16 @@ def table_variants():
     for group, title in (('variants', 'PolynomialDecomposition P=5, N=32, W=2^24'), ('kernels', 'N=32, W=2^22')):
         for label, v in b[group].items():
             rv = v.get('roofline_valu')
-            rows.append([f'`{label}`', title, f"{sci(v['evals_per_s'])}", f"{v['kernel_ms'] * 1e3:.1f}",
+            rows.append([f'`{label}`' + (' (not a product path)' if label == 'wave' else ''), title, f"{sci(v['evals_per_s'])}", f"{v['kernel_ms'] * 1e3:.1f}",
                          f"{v['hbm_frac']:.3f}", f"{rv['valu_wave_instr_per_eval']:.2f}" if rv else '-',
-                         f"**{rv['frac']:.2f}**" if rv else '-'])
+                         f"{rv['frac']:.2f}" if rv else '-',
+                         f"{v['clock_ghz']:.2f}" if v.get('clock_ghz') else '-',
+                         f"{rv['cycles_per_valu_instr_per_simd']:.2f}" if rv and rv.get('cycles_per_valu_instr_per_simd') else '-',
+                         f"**{rv['frac_at_clock']:.2f}**" if rv and rv.get('frac_at_clock') else '-'])
     return md(rows, ['kernel', 'workload', 'evals/s', 'us per launch', 'fraction of HBM peak',
-                     'VALU wave-instr per eval (PMC)', 'fraction of fp64 issue peak (2.4 GHz)'])
+                     'VALU wave-instr per eval (PMC)', 'fraction of fp64 issue peak at 2.4 GHz',
+                     'engine clock held, GHz (in-run probe)', 'cycles per VALU instr per SIMD',
+                     'fraction of fp64 issue peak at that clock'])
 
 
 def table_sweep():
@@ -207,6 +212,28 @@ def table_fuzz():
                      'AUTO on PolynomialDecomposition designs with 2N >= P+2'])
 
 
+def table_valley():
+    rows = []
+    for d in jlines(f'{ROUND}_fuzz_valley_summary.jsonl'):
+        v, a = d['valley_rows'], d['auto_on_polydecomp']
+        rows.append([d['seed'], d['cases'], v['cases'], d['violations'], f"{v['worst_auto_vs_exact']:.1e}", f"{v['worst_comp_vs_exact']:.1e}",
+                     f"{v['worst_reference_vs_exact']:.1e}", v['cases_where_reference_is_off'], f"{v['worst_per_frequency_vs_exact']:.1e}",
+                     f"{a['reduced']} + {a['reduced_comp']} + {a['collapsed']}"])
+    return md(rows, ['seed', 'cases', 'PolynomialDecomposition cases with valley / shell rows', 'violations (more than 1e-10 from the reference AND from the exact value)',
+                     'AUTO: worst distance from the exact value', 'compensated kernel: the same', "the REFERENCE's arithmetic (oracle): the same",
+                     'cases where the reference is more than 1e-10 from the exact value', 'per-frequency forms (collapsed / faithful / wave): the same, not judged',
+                     'AUTO ran plain + compensated + collapsed'])
+
+
+def table_latency():
+    rows = []
+    for d in jlines(f'{ROUND}_micro_small_call_latency.jsonl'):
+        u = d['us_per_call']
+        rows.append([d['model'], f"`{d['kernel']}`"] + [f"{u[w]['ctx.logprob']:.1f} / {u[w]['model.log_prob']:.1f}" for w in ('16', '32', '64', '256', '4096')])
+    return md(rows, ['one log-probability call, host buffers in and out: us per call, `ctx.logprob` / `model.log_prob`', 'kernel',
+                     '16 rows', '32 rows', '64 rows', '256 rows', '4096 rows'])
+
+
 def table_auto_by_degree():
     tot = {}
     for d in jlines(f'{ROUND}_fuzz_parity_summary.jsonl'):
@@ -224,6 +251,7 @@ TABLES = {
     'host_path': table_host_path, 'samplers': table_samplers, 'cfg4': table_cfg4, 'cfg5': table_cfg5,
     'fuzz': table_fuzz, 'auto_by_degree': table_auto_by_degree, 'ingest': table_ingest,
     'batch_setup': table_batch_setup, 'batch_models': table_batch_models, 'survey': table_survey,
+    'valley': table_valley, 'latency': table_latency,
 }
 
 FILES = [
@@ -244,7 +272,11 @@ FILES = [
     (f'{ROUND}_survey.jsonl', '`python benchmarks/survey.py [--model PeltonColeCole]`', 'a 4096-spectrum survey end to end: files to posterior summaries and model bands'),
     (f'{ROUND}_batch_setup.jsonl', '`python benchmarks/batch_setup.py`', 'what surrounds a survey run: batch context creation (host precompute on threads), a short fit, the summaries'),
     (f'{ROUND}_soak.json', '`python benchmarks/soak.py`', 'twenty 100,000-iteration fits and twenty 10,000-iteration batch fits in one process: device memory constant, posterior means within 0.02 sigma of each other, identical summaries for identical seeds'),
-    (f'{ROUND}_fuzz_*_summary.jsonl', '`python benchmarks/fuzz_parity.py --cases 1500 --seed S` (S = 41..43; 3000 cases each at S = 4242, 101..103, 201..204; 2000 at S = 104 and 3000 at S = 205 with boxes widened x2, x3), `fuzz_sampler.py --cases 1500 --seed 2` (and 5, 6), `fuzz_batch.py --cases 500 --seed 1` (and 4, 7)', 'randomised campaigns: violations, worst errors, which kernel AUTO ran'),
+    (f'{ROUND}_fuzz_*_summary.jsonl', '`python benchmarks/fuzz_parity.py --cases 3000 --seed S` (S = 41..44; S = 45, 46 with `--widen 1.5`, `--widen 3`), `fuzz_sampler.py --cases 1500 --seed 2` (and 5), `fuzz_batch.py --cases 500 --seed 1` (and 4)', 'randomised campaigns of this round (earlier rounds: `r02_fuzz_*`, 41,000 problems): violations, worst errors, which kernel AUTO ran'),
+    (f'{ROUND}_fuzz_valley_summary.jsonl', '`python benchmarks/fuzz_parity.py --cases 1500 --seed S --valley` (S = 301..303)', 'half of the checked PolynomialDecomposition rows along the valley of chi^2 / on the shell logp = 0: distances of every formulation AND of the reference from the exact value'),
+    (f'{ROUND}_valley_rows.jsonl', '`python benchmarks/valley_rows.py`', 'the kernel AUTO picks, measured on 3000 valley rows per scale (1 ... 1000 sigma) of 216 designs of degree 5-10'),
+    (f'{ROUND}_micro_collapsed_r3.txt', '`benchmarks/micro/collapsed_r3`', 'PDCollapsed: the shipped kernel against LDS-staged records, 4 rows per lane, single-wave workgroups and persistent waves, each with the engine clock it ran at and cycles per VALU instruction'),
+    (f'{ROUND}_micro_small_call_latency.jsonl', '`python benchmarks/micro/small_call_latency.py`', 'one emcee-sized log-probability call with host buffers, every model, 16 ... 4096 rows'),
     (f'{ROUND}_micro_issue_latency.txt', '`benchmarks/micro/issue_latency`', 'cycles per fp64 FMA for 1/2/4/8 independent chains at 1, 2, 4 waves per SIMD; placement of 1-, 2-, 4-, 8-, 16-wave workgroups'),
     (f'{ROUND}_micro_row_latency.txt', '`benchmarks/micro/row_latency`', 'cycles of one log-probability row at one wave per SIMD, records from the scalar cache vs staged in LDS'),
     (f'{ROUND}_micro_half_step_phases.txt', '`benchmarks/micro/half_step_phases`', 'phases of the cfg5 half-step launch by s_memtime'),
@@ -264,12 +296,12 @@ def readme():
     out = [f'# profiles/ -- measured evidence, round {int(ROUND[1:])} (one MI355X, ROCm 7.2)', '',
            'Generated by `python benchmarks/make_tables.py` from the files in this directory; the commands are what',
            '`bash benchmarks/collect_profiles.sh all` runs on the GPU box (rocprofv3 from `/tmp`, `TMPDIR=/tmp`).',
-           'Files named `r01_*` are the previous round\'s and are kept for comparison.', '',
+           'Files named `r01_*` / `r02_*` are earlier rounds\' and are kept for comparison.', '',
            md([[f'`{f}`', c, w] for f, c, w in FILES], ['file', 'command', 'what to read']), '']
     for name, title in (('bench', 'Headline'), ('variants', 'Formulations and the other kernels, with both rooflines'),
                         ('sweep', 'Every log-probability kernel at the BASELINE shapes'), ('forward', 'Batched forward'),
                         ('host_path', 'Host-buffer entry'), ('samplers', '`fit()` workloads'), ('cfg4', 'BASELINE config 4'),
-                        ('cfg5', 'BASELINE config 5'), ('batch_models', 'Batch of spectra, every model'), ('survey', 'A survey end to end'), ('ingest', 'Survey ingest'), ('batch_setup', 'Survey set-up'), ('fuzz', 'Randomised campaigns'), ('auto_by_degree', 'Which kernel AUTO ran, by polynomial degree')):
+                        ('cfg5', 'BASELINE config 5'), ('batch_models', 'Batch of spectra, every model'), ('survey', 'A survey end to end'), ('ingest', 'Survey ingest'), ('batch_setup', 'Survey set-up'), ('fuzz', 'Randomised campaigns'), ('valley', 'Valley / shell rows: every formulation and the reference against the exact value'), ('auto_by_degree', 'Which kernel AUTO ran, by polynomial degree'), ('latency', 'One call with host buffers')):
         out += [f'## {title}', '', TABLES[name](), '']
     return '\n'.join(out)
 

@@ -188,12 +188,15 @@ static int recenter_reduced(bisip_ctx *c)
         if (T.valid || !wanted) continue;
         const size_t E = c->reduced.size();
         // == sizeof(ReducedArgs<P, COMP>)/8: the compensated tier's image starts with the triangle's low word
-        const size_t red_doubles = tri + 3 * (size_t)n + 1 + (tier == 1 ? tri : 0);
+        // as floats, an even number of them
+        const size_t lo_floats = (tri + 1) & ~(size_t)1;
+        const size_t red_doubles = tri + 3 * (size_t)n + 1 + (tier == 1 ? lo_floats / 2 : 0);
         std::vector<double> red(c->E > 1 ? red_doubles * E : 0), est(E);
         // the probing of every spectrum (reduced_center emulates the kernel on ~200 rows per
         // candidate) is independent of the others: blocks of spectra on host threads
         parallel_blocks((int64_t)E, 4, [&](int64_t e_lo, int64_t e_hi) {
-            std::vector<double> bh(n), ev(n), el(n), Rp, Rlo;
+            std::vector<double> bh(n), ev(n), el(n), Rp;
+            std::vector<float> Rlo;
             for (int64_t e = e_lo; e < e_hi; ++e) {
                 const bisip_ctx::ReducedHost &rh = c->reduced[(size_t)e];
                 est[(size_t)e] = reduced_center(n, rh.R, rh.Rl, rh.qty, rh.bhat_ls, rh.rest, rh.lconst, c->bounds.lo,
@@ -203,12 +206,13 @@ static int recenter_reduced(bisip_ctx *c)
                 for (int i = 0; i < n; ++i)
                     for (int j = i; j < n; ++j) {
                         Rp.push_back(rh.R[(size_t)i * n + j]);
-                        Rlo.push_back((double)(rh.Rl[(size_t)i * n + j] - (long double)rh.R[(size_t)i * n + j]));
+                        Rlo.push_back((float)(rh.Rl[(size_t)i * n + j] - (long double)rh.R[(size_t)i * n + j]));
                     }
+                Rlo.resize(lo_floats, 0.0f);
                 if (e == 0) { c->Rpacked = Rp; c->Rlo_packed = Rlo; T.bhat = bh; T.evec = ev; T.elo = el; c->rest = rh.rest; }
                 if (c->E > 1) {  // ReducedArgs<P, COMP> image: [Rlo |] R | bhat | e | elo | rest
                     double *dst = &red[red_doubles * (size_t)e];
-                    if (tier == 1) dst = std::copy(Rlo.begin(), Rlo.end(), dst);
+                    if (tier == 1) { std::memcpy(dst, Rlo.data(), lo_floats * sizeof(float)); dst += lo_floats / 2; }
                     dst = std::copy(Rp.begin(), Rp.end(), dst);
                     dst = std::copy(bh.begin(), bh.end(), dst);
                     dst = std::copy(ev.begin(), ev.end(), dst);

@@ -71,7 +71,7 @@ struct bisip_ctx {
     double guard_worst = 0.0;
     int guard_escalations = 0;
     std::vector<double> Rpacked;   // spectrum 0, packed upper triangle
-    std::vector<double> Rlo_packed;   // ... and its low word (R = Rpacked + Rlo_packed to twice the precision)
+    std::vector<float> Rlo_packed;    // ... and its low word (R = Rpacked + Rlo_packed to 64 bits: exact in a float), even count
     double rest = 0.0;
     // per spectrum, for re-centring the reduced form when the prior box changes
     struct ReducedHost {
@@ -106,7 +106,7 @@ template <int P, bool COMP>
 inline void fill_reduced(const bisip_ctx *c, ReducedArgs<P, COMP> &r)
 {
     const bisip_ctx::ReducedTier &t = c->red[COMP ? 1 : 0];
-    if constexpr (COMP) std::memcpy(r.Rlo, c->Rlo_packed.data(), sizeof(r.Rlo));
+    if constexpr (COMP) std::memcpy(r.Rlo, c->Rlo_packed.data(), sizeof(float) * c->Rlo_packed.size());
     std::memcpy(r.R, c->Rpacked.data(), sizeof(r.R));
     std::memcpy(r.bhat, t.bhat.data(), sizeof(r.bhat));
     std::memcpy(r.e, t.evec.data(), sizeof(r.e));

@@ -14,6 +14,7 @@
 namespace bisip {
 
 typedef long double ld;
+constexpr int BISIP_HOST_MAXN = 32;    // unknowns of the reduced form: poly_deg + 2 <= 12
 
 static const ld PI_L = 3.141592653589793238462643383279502884L;
 
@@ -211,7 +212,7 @@ double reduced_chi2_double(int n, const std::vector<double> &R, const std::vecto
             s = t;
             c += er + l;
             c = std::fma(Rk, dl[j], c);
-            c = std::fma((double)(Rl[(size_t)i * n + j] - (ld)Rk), d[j], c);     // Rlo, as the kernel holds it
+            c = std::fma((double)(float)(Rl[(size_t)i * n + j] - (ld)Rk), d[j], c);     // Rlo, as the kernel holds it (a float: <= 11 bits)
         }
         const double u = s + c;
         chi2 = std::fma(u, u, chi2);
@@ -232,22 +233,46 @@ static inline void two_sum(ld a, ld b, ld &s, ld &err)
     err = (a - (s - bb)) + (b - bb);
 }
 
+// a*b = p + err exactly, by Dekker's splitting of the 64-bit mantissas into 32 + 32 bits (glibc's fmal is a
+// software routine on x86: ~350 ns a call, which made a context's estimate take 60 ms)
+static inline void split32(ld a, ld &hi, ld &lo)
+{
+    const ld c = 4294967297.0L * a;      // 2^32 + 1
+    hi = c - (c - a);
+    lo = a - hi;
+}
+
+static inline void two_prod(ld a, ld b, ld &p, ld &err)
+{
+    p = a * b;
+    ld ah, al, bh, bl;
+    split32(a, ah, al);
+    split32(b, bh, bl);
+    err = ((ah * bh - p) + ah * bl + al * bh) + al * bl;
+}
+
 ld reduced_chi2_exact(int n, const std::vector<ld> &R, const std::vector<ld> &qty, double rest,
                       const double *th)
 {
     ld chi2 = rest;
+    // b = b_h + b_l exactly: R0 and a_j are doubles, their product two doubles (one hardware fma)
+    ld bh[BISIP_HOST_MAXN], bl[BISIP_HOST_MAXN];
+    bh[0] = (ld)th[0];
+    bl[0] = 0.0L;
+    for (int j = 1; j < n; ++j) {
+        const double p = th[0] * th[j];
+        bh[j] = (ld)p;
+        bl[j] = (ld)std::fma(th[0], th[j], -p);
+    }
     for (int i = 0; i < n; ++i) {
         ld hi = qty[i], lo = 0.0L;
         for (int j = i; j < n; ++j) {
-            // b = b_h + b_l exactly (R0 and a_j are doubles: their product fits two long doubles)
-            ld b_h = (ld)th[0], b_l = 0.0L;
-            if (j != 0) { b_h = (ld)th[0] * (ld)th[j]; b_l = fmal((ld)th[0], (ld)th[j], -b_h); }
             const ld r = -R[(size_t)i * n + j];
-            const ld p = r * b_h, pe = fmal(r, b_h, -p);
-            ld s, se;
+            ld p, pe, s, se;
+            two_prod(r, bh[j], p, pe);
             two_sum(hi, p, s, se);
             hi = s;
-            lo += se + pe + r * b_l;
+            lo += se + pe + r * bl[j];
         }
         const ld u = hi + lo;
         chi2 += u * u;
@@ -301,12 +326,12 @@ double reduced_center(int n, const std::vector<double> &R, const std::vector<lon
     };
     const bool ls_ok = std::isfinite((double)bhat_ls[0]) && bhat_ls[0] != 0.0L;
     if (finite_box) {
-        for (int k = 0; k < 48; ++k) {   // uniform in the prior box
+        for (int k = 0; k < 32; ++k) {   // uniform in the prior box
             std::vector<double> t(n);
             for (int j = 0; j < n; ++j) t[j] = lo[j] + (hi[j] - lo[j]) * rng.uni();
             probes.push_back(t);
         }
-        for (int k = 0; k < 32; ++k) {   // small coefficients: where a decent fit usually lies
+        for (int k = 0; k < 16; ++k) {   // small coefficients: where a decent fit usually lies
             std::vector<double> t(n);
             t[0] = lo[0] + (hi[0] - lo[0]) * rng.uni();
             for (int j = 1; j < n; ++j) {
@@ -318,8 +343,8 @@ double reduced_center(int n, const std::vector<double> &R, const std::vector<lon
         }
     }
     if (ls_ok)
-        for (int k = 0; k < 32; ++k) {   // around the least-squares solution (the posterior mode)
-            const double s = k < 16 ? 1e-3 : 1e-2;
+        for (int k = 0; k < 16; ++k) {   // around the least-squares solution (the posterior mode)
+            const double s = k < 8 ? 1e-3 : 1e-2;
             std::vector<double> t(n);
             t[0] = (double)bhat_ls[0] * (1.0 + s * rng.sym());
             bool fin = std::isfinite(t[0]);
@@ -329,6 +354,37 @@ double reduced_center(int n, const std::vector<double> &R, const std::vector<lon
             }
             if (fin && (!finite_box || inside(t))) probes.push_back(t);
         }
+    // theta of b = b_ls + s R^-1 z for a random direction z (unit variance per component: four uniforms; the
+    // shape of the distribution does not matter), s = `scale`, or, for scale < 0, such that the row lies ON
+    // the shell rest + s^2 |z|^2 = 2 lconst.  Plain double: where the probe lies need not be exact.  False
+    // when the row is not finite or not inside the box.
+    bool solvable = ls_ok;
+    for (int i = 0; i < n; ++i) solvable = solvable && R[(size_t)i * n + i] != 0.0;
+    double bls_d[BISIP_HOST_MAXN];
+    for (int j = 0; j < n; ++j) bls_d[j] = (double)bhat_ls[j];
+    std::vector<double> tpt(n);
+    auto valley_point = [&](double scale, std::vector<double> &t) {
+        double z[BISIP_HOST_MAXN], db[BISIP_HOST_MAXN], zz = 0.0;
+        for (int j = 0; j < n; ++j) {
+            z[j] = 1.7320508075688772 * (rng.uni() + rng.uni() + rng.uni() + rng.uni() - 2.0);
+            zz += z[j] * z[j];
+        }
+        if (!(zz > 0.0)) return false;
+        const double sc = scale >= 0.0 ? scale : std::sqrt((2.0 * lconst - rest) / zz);
+        for (int i = n - 1; i >= 0; --i) {
+            double acc = sc * z[i];
+            for (int j = i + 1; j < n; ++j) acc -= R[(size_t)i * n + j] * db[j];
+            db[i] = acc / R[(size_t)i * n + i];
+        }
+        const double b0 = bls_d[0] + db[0];
+        t[0] = b0;
+        if (!std::isfinite(b0) || b0 == 0.0) return false;
+        for (int j = 1; j < n; ++j) {
+            t[j] = (bls_d[j] + db[j]) / b0;
+            if (!std::isfinite(t[j])) return false;
+        }
+        return !finite_box || inside(t);
+    };
     if (ls_ok) {
         // where an ensemble sampler's walkers actually are: draws from the Gaussian posterior of the
         // linear model, b = b_ls + R^-1 z with z ~ N(0, I), and 3x, 10x and 30x wider: a converged
@@ -337,34 +393,12 @@ double reduced_center(int n, const std::vector<double> &R, const std::vector<lon
         // then cancel by many orders of magnitude although chi^2 stays within a few units (a few
         // hundred, at 10-30 sigma) of its minimum.  Round 2 probed 1x and 3x only: a NumPy emulation of
         // the plain kernel on 10-sigma rows of degree 8-10 designs it had passed read 1e-10 ... 2e-8.
-        bool solvable = true;
-        for (int i = 0; i < n; ++i) solvable = solvable && R[(size_t)i * n + i] != 0.0;
-        // 32 probes INSIDE the box per scale (a narrowed box keeps few of the draws: up to 600 tries each)
+        // 16 probes INSIDE the box per scale (a narrowed box keeps few of the draws: up to 300 tries each)
         for (int scale_i = 0; solvable && scale_i < 4; ++scale_i) {
             const double sc = scale_i == 0 ? 1.0 : (scale_i == 1 ? 3.0 : (scale_i == 2 ? 10.0 : 30.0));
             int kept = 0;
-            for (int k = 0; k < 600 && kept < 32; ++k) {
-                std::vector<ld> z(n), db(n, 0.0L);
-                for (int j = 0; j < n; ++j) {   // sum of 12 uniforms - 6: unit variance, no libm
-                    double a = 0.0;
-                    for (int r = 0; r < 12; ++r) a += rng.uni();
-                    z[j] = (ld)(sc * (a - 6.0));
-                }
-                for (int i = n - 1; i >= 0; --i) {
-                    ld acc = z[i];
-                    for (int j = i + 1; j < n; ++j) acc -= (ld)R[(size_t)i * n + j] * db[j];
-                    db[i] = acc / (ld)R[(size_t)i * n + i];
-                }
-                std::vector<double> t(n);
-                const ld b0 = bhat_ls[0] + db[0];
-                t[0] = (double)b0;
-                bool fin = std::isfinite(t[0]) && t[0] != 0.0;
-                for (int j = 1; j < n; ++j) {
-                    t[j] = (double)((bhat_ls[j] + db[j]) / b0);
-                    fin = fin && std::isfinite(t[j]);
-                }
-                if (fin && (!finite_box || inside(t))) { probes.push_back(t); ++kept; }
-            }
+            for (int k = 0; k < 300 && kept < 16; ++k)
+                if (valley_point(sc, tpt)) { probes.push_back(tpt); ++kept; }
         }
     }
     // The shell log-probability = 0.  The parity tolerance is |d logp| <= 1e-10 max(1, |logp|): where the
@@ -378,37 +412,11 @@ double reduced_center(int n, const std::vector<double> &R, const std::vector<lon
     // headline's degree-5 design reads 9e-12, of which 5e-12 is the rounding of R itself), so they count
     // at a twentieth: the gate 1e-12 then reads "2e-11 on the shell" -- a fifth of the tolerance, where
     // the region is sampled directly -- the same bar bisip_logprob's guard applies to real batches.
-    const size_t n_regular = probes.size();
+    size_t n_regular = probes.size();
     if (ls_ok && 2.0 * lconst - rest > 0.0) {
-        bool solvable = true;
-        for (int i = 0; i < n; ++i) solvable = solvable && R[(size_t)i * n + i] != 0.0;
-        int kept = 0;     // 96 probes inside the box, up to 3000 tries (a narrowed box keeps few of the draws)
-        for (int k = 0; solvable && k < 3000 && kept < 96; ++k) {
-            std::vector<ld> z(n), db(n, 0.0L);
-            ld zz = 0.0L;
-            for (int j = 0; j < n; ++j) {
-                double a = 0.0;
-                for (int r = 0; r < 12; ++r) a += rng.uni();
-                z[j] = (ld)(a - 6.0);
-                zz += z[j] * z[j];
-            }
-            if (!(zz > 0.0L)) continue;
-            const ld sc = sqrtl((ld)(2.0 * lconst - rest) / zz);
-            for (int i = n - 1; i >= 0; --i) {
-                ld acc = sc * z[i];
-                for (int j = i + 1; j < n; ++j) acc -= (ld)R[(size_t)i * n + j] * db[j];
-                db[i] = acc / (ld)R[(size_t)i * n + i];
-            }
-            std::vector<double> t(n);
-            const ld b0 = bhat_ls[0] + db[0];
-            t[0] = (double)b0;
-            bool fin = std::isfinite(t[0]) && t[0] != 0.0;
-            for (int j = 1; j < n; ++j) {
-                t[j] = (double)((bhat_ls[j] + db[j]) / b0);
-                fin = fin && std::isfinite(t[j]);
-            }
-            if (fin && (!finite_box || inside(t))) { probes.push_back(t); ++kept; }
-        }
+        int kept = 0;     // 64 probes inside the box, up to 1500 tries (a narrowed box keeps few of the draws)
+        for (int k = 0; solvable && k < 1500 && kept < 64; ++k)
+            if (valley_point(-1.0, tpt)) { probes.push_back(tpt); ++kept; }
     }
     // candidates for the expansion point
     std::vector<std::vector<double>> cand;
@@ -427,6 +435,20 @@ double reduced_center(int n, const std::vector<double> &R, const std::vector<lon
     cand.push_back(std::vector<double>(n, 0.0));
     double best = INFINITY;
     std::vector<double> e(n), elo(n);
+    // The compensated kernel's rows are double-doubles: its estimate reads 1e-14 on every design ever probed
+    // (TABLE:auto_by_degree); a third of the probes is plenty to notice if that ever stopped being true.
+    if (comp) {
+        std::vector<std::vector<double>> some;
+        size_t shell_from = 0;
+        for (size_t ip = 0; ip < probes.size(); ip += 3) {
+            if (ip < n_regular) shell_from = some.size() + 1;
+            some.push_back(probes[ip]);
+        }
+        probes.swap(some);
+        n_regular = shell_from;
+    }
+    std::vector<ld> exact_of(probes.size());
+    for (size_t ip = 0; ip < probes.size(); ++ip) exact_of[ip] = reduced_chi2_exact(n, Rl, qty, rest, probes[ip].data());
     if (probes.empty()) {
         // nothing to measure the kernel against (a non-finite box with no usable least-squares
         // solution): expand about zero and report "unknown", so AUTO takes the per-frequency form
@@ -450,7 +472,7 @@ double reduced_center(int n, const std::vector<double> &R, const std::vector<lon
         const double w_shell = shell_weight();
         for (size_t ip = 0; ip < probes.size(); ++ip) {
             const auto &t = probes[ip];
-            const ld exact = reduced_chi2_exact(n, Rl, qty, rest, t.data());
+            const ld exact = exact_of[ip];
             const double got = reduced_chi2_double(n, R, Rl, c.data(), e.data(), elo.data(), rest, t.data(), comp);
             const ld lp = -0.5L * exact + (ld)lconst;
             const ld scale = fabsl(lp) > 1.0L ? fabsl(lp) : 1.0L;

@@ -920,9 +920,12 @@ __global__ __launch_bounds__(BLK) void k_logprob_x2(const LaunchArgs a)
 // reference's formula, benchmarks/exact_shell_rows.py) -- as much as the reference's own rounding there.
 template <int P, bool COMP>
 struct ReducedLow {};
+// Rlo = Rl - (double)Rl of a long double Rl has at most 11 significant bits (64 - 53): a float holds it
+// exactly, at half the registers (the persistent sampler keeps a spectrum's operands in VGPRs).
 template <int P>
 struct ReducedLow<P, true> {
-    double Rlo[(P + 2) * (P + 3) / 2];
+    static constexpr int TRI = (P + 2) * (P + 3) / 2;
+    float Rlo[(TRI + 1) & ~1];         // even count: the doubles that follow stay 8-byte aligned
 };
 
 template <int P, bool COMP = false>
@@ -1003,7 +1006,7 @@ __device__ __forceinline__ double logprob_row_reduced(const double (&th)[P + 2],
                 s = t;
                 c += er + l;
                 c = fma(Rk, dl[j], c);
-                c = fma(r.Rlo[k], d[j], c);
+                c = fma((double)r.Rlo[k], d[j], c);
             }
             const double u = s + c;
             chi2 = fma(u, u, chi2);
