@@ -397,6 +397,9 @@ struct ColeCole {
 #pragma unroll
         for (int k = 0; k < K; ++k) y[k] = fma(s.c2[k % D], rec[k / D][5], s.clt2[k % D]);
         if (s.clamp) {
+            // a real branch (the flag is wave-uniform): left to itself the compiler turns this into a
+            // v_min + two selects per value on EVERY path (+3 instructions per frequency and mode, PMC)
+            asm volatile("; exponent clamp (BOUNDS_CLAMP_EXP)");
 #pragma unroll
             for (int k = 0; k < K; ++k) y[k] = fmin(y[k], EXP2_CLAMP);
         }
@@ -607,6 +610,9 @@ struct Shin {
 #pragma unroll
         for (int k = 0; k < K; ++k) y[k] = fma(s.n2[k % 2], rec[k / 2][5], s.lq2[k % 2]);
         if (s.clamp) {
+            // a real branch (the flag is wave-uniform): left to itself the compiler turns this into a
+            // v_min + two selects per value on EVERY path (+3 instructions per frequency and mode, PMC)
+            asm volatile("; exponent clamp (BOUNDS_CLAMP_EXP)");
 #pragma unroll
             for (int k = 0; k < K; ++k) y[k] = fmin(y[k], EXP2_CLAMP);
         }
