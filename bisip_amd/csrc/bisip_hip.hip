@@ -120,21 +120,21 @@ const char *name_for(const bisip_ctx *c)
 
 }  // namespace
 
-// May ColeCole<D> / Shin take ONE reciprocal per group of denominators (kernels.h: rcp_batch_n)?  Only
-// if, everywhere inside the prior box, every denominator of a frequency lies in [1, 2^225], so that a
-// product of four is a normal number: exponents y = c log2e (ln w + log_tau) (ColeCole) or
-// log2e (n ln w + log_Q) (Shin) bounded by 110, cos(c pi/2) >= 0 (c or n within [0, 1]: the real part
-// of each denominator term is then >= 1), and for Shin R <= 1 (1/R >= 1; its clamp at 1e70 bounds the
-// other side).  The reference's default boxes pass with y <= 26; a user who widens a box past this
-// gets the one-reciprocal-per-term code, and past y = 500 (where a squared magnitude overflows) the
-// exponent clamp as well (BOUNDS_CLAMP_EXP).
+// May ColeCole<D> / Shin run their FAST frequency loop -- ONE reciprocal per group of denominators
+// (kernels.h: rcp_batch_n), no exponent clamp?  Only if, everywhere inside the prior box, every denominator of
+// a frequency lies in [1, 2^225], so that a product of four is a normal number: exponents
+// y = c log2e (ln w + log_tau) (ColeCole) or log2e (n ln w + log_Q) (Shin) bounded by 110, cos(c pi/2) >= 0
+// (c or n within [0, 1]: the real part of each denominator term is then >= 1), and for Shin R <= 1 (1/R >= 1;
+// its clamp at 1e70 bounds the other side).  The reference's default boxes pass with y <= 26; a user who
+// widens a box past this gets the safe loop: one reciprocal per term, exponents clamped at 500 (where a
+// squared magnitude would overflow).
 static int bound_flags(const bisip_ctx *c)
 {
-    constexpr double LOG2E = 1.4426950408889634, YMAX = 110.0, YCLAMP = 500.0;
+    constexpr double LOG2E = 1.4426950408889634, YMAX = 110.0;
     const double *lo = c->bounds.lo, *hi = c->bounds.hi;
     const double lw = std::fmax(std::fabs(c->lnw_min), std::fabs(c->lnw_max));
-    auto mag = [](double a, double b) { return std::fmax(std::fabs(a), std::fabs(b)); };   // inf for an open side, NaN-safe below
-    bool batch = true;
+    auto mag = [](double a, double b) { return std::fmax(std::fabs(a), std::fabs(b)); };   // inf for an open side
+    bool ok = true;
     double ymax = 0.0;
     if (c->model_id == BISIP_MODEL_COLECOLE) {
         const int D = c->D;
@@ -142,20 +142,19 @@ static int bound_flags(const bisip_ctx *c)
             const double llo = lo[1 + D + i], lhi = hi[1 + D + i], clo = lo[1 + 2 * D + i], chi = hi[1 + 2 * D + i];
             const double y = mag(clo, chi) * (lw + mag(llo, lhi)) * LOG2E;
             ymax = y <= ymax ? ymax : y;                  // NaN (a NaN bound) propagates as "unbounded"
-            batch = batch && clo >= 0.0 && chi <= 1.0;
+            ok = ok && clo >= 0.0 && chi <= 1.0;
         }
-        batch = batch && D >= 2;
     } else if (c->model_id == BISIP_MODEL_SHIN2015) {
         for (int i = 0; i < 2; ++i) {
             const double rlo = lo[i], rhi = hi[i], qlo = lo[2 + i], qhi = hi[2 + i], nlo = lo[4 + i], nhi = hi[4 + i];
             const double y = (mag(nlo, nhi) * lw + mag(qlo, qhi)) * LOG2E;
             ymax = y <= ymax ? ymax : y;
-            batch = batch && rlo >= 0.0 && rhi <= 1.0 && nlo >= 0.0 && nhi <= 1.0;
+            ok = ok && rlo >= 0.0 && rhi <= 1.0 && nlo >= 0.0 && nhi <= 1.0;
         }
     } else {
         return 0;
     }
-    return (batch && ymax <= YMAX ? BOUNDS_BATCH_RCP : 0) | (ymax <= YCLAMP ? 0 : BOUNDS_CLAMP_EXP);
+    return ok && ymax <= YMAX ? BOUNDS_FAST : 0;
 }
 
 // PolynomialDecomposition, reduced form: (re)choose the expansion point bhat for the current

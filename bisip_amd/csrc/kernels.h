@@ -27,18 +27,18 @@ typedef double dbl2 __attribute__((ext_vector_type(2)));
 struct Bounds {
     double lo[MAXD];
     double hi[MAXD];
-    // BOUNDS_BATCH_RCP: set by the host (bound_flags in bisip_hip.hip) when, everywhere inside this
-    // box, the denominators of one frequency of ColeCole<D> / Shin stay within [1, 2^225]: their
-    // product over a group of <= 4 neither overflows nor underflows, so ONE reciprocal serves the
-    // group (rcp_batch).  Wave-uniform (kernel argument): the choice is a scalar branch.
+    // BOUNDS_FAST: set by the host (bound_flags in bisip_hip.hip) when, everywhere inside this box, the
+    // denominators of one frequency of ColeCole<D> / Shin stay within [1, 2^225] -- their product over a
+    // group of <= 4 neither overflows nor underflows, so ONE reciprocal serves the group (rcp_batch_n) --
+    // and no exponent needs clamping.  Wave-uniform (kernel argument): logprob_row picks, once per row,
+    // between two instantiations of the frequency loop (FAST / safe); the loop itself has no branch.
     int flags = 0;
 };
-constexpr int BOUNDS_BATCH_RCP = 1;
-// BOUNDS_CLAMP_EXP: somewhere in this box an exponent y of 2^y = |(i w tau)^c| (ColeCole) or Q w^n
-// (Shin) exceeds 500: 2^y squared would overflow, the denominator become inf and rcp_nr(inf) NaN where
-// the reference's term quietly vanishes.  Clamping y at 500 keeps everything finite and the term at
-// <= 2^-500.  Only boxes a user widened far beyond the reference's (c up to 22 and more) set it.
-constexpr int BOUNDS_CLAMP_EXP = 2;
+constexpr int BOUNDS_FAST = 1;
+// The safe loop clamps the exponent y of 2^y = |(i w tau)^c| (ColeCole) or Q w^n (Shin) at 500: beyond,
+// 2^y squared would overflow, the denominator become inf and rcp_nr(inf) NaN where the reference's term
+// quietly vanishes (a round-2 defect that boxes with c up to 22 and more exposed).  It takes one
+// reciprocal per term.  Only boxes a user widened far beyond the reference's run it.
 constexpr double EXP2_CLAMP = 500.0;
 
 struct LaunchArgs {
@@ -219,7 +219,7 @@ __device__ __forceinline__ void rcp_nr_n(const double (&x)[K], double (&r)[K])
 // multiplications + rcp_nr instead of K rcp_nr.  v_rcp_f64 issues at a quarter of the FMA rate, so a
 // reciprocal costs 8 issue slots and a pair by this route 11 instead of 16.  F independent groups
 // (one per frequency) run in lockstep.  The caller guarantees that products of K arguments stay
-// normal (BOUNDS_BATCH_RCP).  Groups are always formed WITHIN one frequency, in every kernel, so a
+// normal (BOUNDS_FAST).  Groups are always formed WITHIN one frequency, in every kernel, so a
 // walker's value does not depend on which kernel evaluated it.
 template <int F, int K>
 __device__ __forceinline__ void rcp_batch_n(const double (&x)[F][K], double (&r)[F][K])
@@ -314,12 +314,13 @@ struct PDCollapsed {
         }
         return s;
     }
-    __device__ static __forceinline__ void configure(Setup &, int) {}
+    static constexpr bool HAS_FAST = false;
     // Log-prob records are pre-weighted by 1/sigma (rows of the weighted design matrix):
     //   rec = ys_re, ys_im, -s_re, pad | s_re*G_re[0..P] | s_im*G_im[0..P]
     // so (y - Z)/sigma = ys + r0*(-s) + sum_p b_p (s G_p): 2(P+1)+1 FMAs, and the caller
     // squares without a further multiply.
     static constexpr bool WEIGHTED = true;
+    template <bool FAST = false>
     __device__ static __forceinline__ void residual(const Setup &s, const double *__restrict__ rec,
                                                     double &rr, double &ri)
     {
@@ -356,18 +357,11 @@ struct ColeCole {
         double r0;
         double m[D], lt[D], c[D], cs[D], sn[D];
         double A[D], c2[D], clt2[D], C;  // residual(): m r0, c log2e, c log2e lt, r0 - sum A
-        int batch, clamp;                // residual(): BOUNDS_BATCH_RCP (one reciprocal per group of modes), BOUNDS_CLAMP_EXP
     };
-    __device__ static __forceinline__ void configure(Setup &s, int flags)
-    {
-        s.batch = D >= 2 && (flags & BOUNDS_BATCH_RCP);
-        s.clamp = flags & BOUNDS_CLAMP_EXP;
-    }
+    static constexpr bool HAS_FAST = true;
     __device__ static __forceinline__ Setup setup(const double (&th)[NDIM])
     {
         Setup s;
-        s.batch = 0;
-        s.clamp = 0;
         s.r0 = th[0];
         s.C = th[0];
 #pragma unroll
@@ -385,23 +379,19 @@ struct ColeCole {
     }
     // Z = (r0 - sum A_i) + sum A_i (1+x_i)^-1  =>  y - Z accumulates -A_i conj(1+x_i)/|1+x_i|^2
     // F frequencies in lockstep (F = 1: the bulk loop; F = 2: one wave per SIMD, residual2): per
-    // frequency the D exponentials, then the D reciprocals -- one per mode, or (s.batch) one per group
-    // of modes -- then the modes accumulated in ascending order.  Same operations per frequency for
-    // every F, so the same bits.
-    template <int F>
+    // frequency the D exponentials, then the D reciprocals -- FAST: one per group of modes; safe: one per
+    // mode, exponents clamped -- then the modes accumulated in ascending order.  Same operations per
+    // frequency for every F, so the same bits.
+    template <int F, bool FAST>
     __device__ static __forceinline__ void residual_n(const Setup &s, const double *const (&rec)[F],
                                                       double (&rr)[F], double (&ri)[F])
     {
         constexpr int K = F * D;     // value k = (frequency k / D, mode k % D)
         double y[K], e[K], dr[F][D], di[F][D], den[F][D], inv[F][D];
 #pragma unroll
-        for (int k = 0; k < K; ++k) y[k] = fma(s.c2[k % D], rec[k / D][5], s.clt2[k % D]);
-        if (s.clamp) {
-            // a real branch (the flag is wave-uniform): left to itself the compiler turns this into a
-            // v_min + two selects per value on EVERY path (+3 instructions per frequency and mode, PMC)
-            asm volatile("; exponent clamp (BOUNDS_CLAMP_EXP)");
-#pragma unroll
-            for (int k = 0; k < K; ++k) y[k] = fmin(y[k], EXP2_CLAMP);
+        for (int k = 0; k < K; ++k) {
+            y[k] = fma(s.c2[k % D], rec[k / D][5], s.clt2[k % D]);
+            if constexpr (!FAST) y[k] = fmin(y[k], EXP2_CLAMP);
         }
         exp2_finite_n<K>(y, e);
 #pragma unroll
@@ -415,7 +405,7 @@ struct ColeCole {
         for (int f = 0; f < F; ++f)
 #pragma unroll
             for (int i = 0; i < D; ++i) den[f][i] = fma(dr[f][i], dr[f][i], di[f][i] * di[f][i]);
-        if (D >= 2 && s.batch) rcp_groups<F, D>(den, inv);
+        if constexpr (FAST && D >= 2) rcp_groups<F, D>(den, inv);
         else {
             double flat[K], r[K];
 #pragma unroll
@@ -436,21 +426,23 @@ struct ColeCole {
             }
         }
     }
+    template <bool FAST = false>
     __device__ static __forceinline__ void residual(const Setup &s, const double *__restrict__ rec,
                                                     double &rr, double &ri)
     {
         const double *const r1[1] = {rec};
         double a[1], b[1];
-        residual_n<1>(s, r1, a, b);
+        residual_n<1, FAST>(s, r1, a, b);
         rr = a[0];
         ri = b[0];
     }
+    template <bool FAST = false>
     __device__ static __forceinline__ void residual2(const Setup &s, const double *__restrict__ ra,
                                                      const double *__restrict__ rb, double (&rr)[2],
                                                      double (&ri)[2])
     {
         const double *const r2[2] = {ra, rb};
-        residual_n<2>(s, r2, rr, ri);
+        residual_n<2, FAST>(s, r2, rr, ri);
     }
     // Z = (r0 - sum A_i) + sum A_i conj(1+x_i)/|1+x_i|^2   (m = w, ln w, sqrt w)
     __device__ static __forceinline__ void eval(const Setup &s, const double *__restrict__ m,
@@ -508,7 +500,7 @@ struct Dias {
     //   1/den = m2 (X - iY)/(X^2 + Y^2):  ONE reciprocal per frequency instead of two (v_rcp_f64 issues
     // at a quarter of the FMA rate: 21 instructions / 24 issue slots per frequency instead of 26 / 32).
     // Inside the prior a > 0, mu has non-negative parts and |mu| >= w tau > 0: X, Y > 0, nothing cancels.
-    __device__ static __forceinline__ void configure(Setup &, int) {}
+    static constexpr bool HAS_FAST = false;
     struct Den { double X, Y, t; };   // t = A m2 / (X^2 + Y^2)
     __device__ static __forceinline__ Den den(const Setup &s, double w, double sqrtw)
     {
@@ -521,6 +513,7 @@ struct Dias {
         d.t = (s.A * m2) * rcp_nr(fma(d.X, d.X, d.Y * d.Y));
         return d;
     }
+    template <bool FAST = false>
     __device__ static __forceinline__ void residual(const Setup &s, const double *__restrict__ rec,
                                                     double &rr, double &ri)
     {
@@ -528,6 +521,7 @@ struct Dias {
         rr = fma(-d.t, d.X, rec[0] - s.C);
         ri = fma(d.t, d.Y, rec[1]);
     }
+    template <bool FAST = false>
     __device__ static __forceinline__ void residual2(const Setup &s, const double *__restrict__ ra,
                                                      const double *__restrict__ rb, double (&rr)[2],
                                                      double (&ri)[2])
@@ -569,13 +563,11 @@ struct Shin {
     struct Setup {
         double invR[2], Q[2], n[2], cs[2], sn[2];
         double n2[2], lq2[2];  // residual(): n log2e, log_Q log2e
-        int batch, clamp;      // residual(): BOUNDS_BATCH_RCP (one reciprocal for both elements), BOUNDS_CLAMP_EXP
     };
+    static constexpr bool HAS_FAST = true;
     __device__ static __forceinline__ Setup setup(const double (&th)[NDIM])
     {
         Setup s;
-        s.batch = 0;
-        s.clamp = 0;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             // R = 0 (a prior bound; forward() may be asked for it) makes the term vanish in the
@@ -593,28 +585,19 @@ struct Shin {
         }
         return s;
     }
-    __device__ static __forceinline__ void configure(Setup &s, int flags)
-    {
-        s.batch = flags & BOUNDS_BATCH_RCP;
-        s.clamp = flags & BOUNDS_CLAMP_EXP;
-    }
     // Q (iw)^n = 2^(n log2e ln w + log_Q log2e) (cs + i sn);  Z = sum_i conj(y_i)/|y_i|^2.
-    // F frequencies in lockstep; per frequency the two elements' reciprocals come from one
-    // reciprocal of the product of the |y_i|^2 when s.batch says that product stays normal.
-    template <int F>
+    // F frequencies in lockstep; FAST: per frequency the two elements' reciprocals come from one
+    // reciprocal of the product of the |y_i|^2; safe: one each, exponents clamped.
+    template <int F, bool FAST>
     __device__ static __forceinline__ void residual_n(const Setup &s, const double *const (&rec)[F],
                                                       double (&rr)[F], double (&ri)[F])
     {
         constexpr int K = 2 * F;     // value k = (frequency k / 2, element k % 2)
         double y[K], p[K], yr[F][2], yi[F][2], den[F][2], inv[F][2];
 #pragma unroll
-        for (int k = 0; k < K; ++k) y[k] = fma(s.n2[k % 2], rec[k / 2][5], s.lq2[k % 2]);
-        if (s.clamp) {
-            // a real branch (the flag is wave-uniform): left to itself the compiler turns this into a
-            // v_min + two selects per value on EVERY path (+3 instructions per frequency and mode, PMC)
-            asm volatile("; exponent clamp (BOUNDS_CLAMP_EXP)");
-#pragma unroll
-            for (int k = 0; k < K; ++k) y[k] = fmin(y[k], EXP2_CLAMP);
+        for (int k = 0; k < K; ++k) {
+            y[k] = fma(s.n2[k % 2], rec[k / 2][5], s.lq2[k % 2]);
+            if constexpr (!FAST) y[k] = fmin(y[k], EXP2_CLAMP);
         }
         exp2_finite_n<K>(y, p);
 #pragma unroll
@@ -625,7 +608,7 @@ struct Shin {
                 yi[f][i] = p[f * 2 + i] * s.sn[i];
                 den[f][i] = fma(yr[f][i], yr[f][i], yi[f][i] * yi[f][i]);
             }
-        if (s.batch) rcp_batch_n<F, 2>(den, inv);
+        if constexpr (FAST) rcp_batch_n<F, 2>(den, inv);
         else {
             double flat[K], r[K];
 #pragma unroll
@@ -645,21 +628,23 @@ struct Shin {
             }
         }
     }
+    template <bool FAST = false>
     __device__ static __forceinline__ void residual(const Setup &s, const double *__restrict__ rec,
                                                     double &rr, double &ri)
     {
         const double *const r1[1] = {rec};
         double a[1], b[1];
-        residual_n<1>(s, r1, a, b);
+        residual_n<1, FAST>(s, r1, a, b);
         rr = a[0];
         ri = b[0];
     }
+    template <bool FAST = false>
     __device__ static __forceinline__ void residual2(const Setup &s, const double *__restrict__ ra,
                                                      const double *__restrict__ rb, double (&rr)[2],
                                                      double (&ri)[2])
     {
         const double *const r2[2] = {ra, rb};
-        residual_n<2>(s, r2, rr, ri);
+        residual_n<2, FAST>(s, r2, rr, ri);
     }
     // Z = sum_i conj(y_i)/|y_i|^2,  y_i = Q (iw)^n + 1/R   (m = w, ln w, sqrt w)
     __device__ static __forceinline__ void eval(const Setup &s, const double *__restrict__ m,
@@ -765,15 +750,12 @@ __device__ __forceinline__ void lds_pair_wait(dbl2 (&v)[8])
 
 // LDSREC: o.cb points at records staged in LDS (16-byte aligned); the pipelined loop then
 // fetches the next pair with lds_pair_issue / lds_pair_wait around the current pair's arithmetic.
-template <class M, int L = 1, bool LDSREC = false>
-__device__ __forceinline__ double logprob_row(const double (&th)[M::NDIM], const ModelOperands &o,
-                                              const Bounds &b, const int g = 0)
+// FAST: the model's fast residual (ColeCole / Shin: shared reciprocals, no exponent clamp) -- a compile-time
+// choice inside the loop, made once per row by logprob_row from the wave-uniform BOUNDS_FAST.
+template <class M, int L, bool LDSREC, bool FAST>
+__device__ __forceinline__ void logprob_sums(const typename M::Setup &s, const ModelOperands &o, const int g,
+                                             double &acc0, double &acc1)
 {
-    static_assert(L == 1 || L == 2 || L == 4, "lanes per walker");
-    if (!in_prior<M::NDIM>(th, b)) return -__builtin_inf();  // never touches the forward model
-    typename M::Setup s = M::setup(th);
-    M::configure(s, b.flags);
-    double acc0 = 0.0, acc1 = 0.0;
     if constexpr (L == 1 && LDSREC && M::REC == 8 && !M::WEIGHTED) {
         // records staged in LDS (persistent sampler): two frequencies at a time, their dependency
         // chains interleaved (residual2), and the NEXT pair's records in flight while this pair is
@@ -795,7 +777,7 @@ __device__ __forceinline__ double logprob_row(const double (&th)[M::NDIM], const
         for (; j + 1 < o.N; j += 2, rec += R2) {
             lds_pair_issue((j + 3 < o.N) ? rec + R2 : rec, buf, cur[5]);   // last pair: a harmless re-read
             double rr[2], ri[2];
-            M::residual2(s, cur, cur + M::REC, rr, ri);
+            M::template residual2<FAST>(s, cur, cur + M::REC, rr, ri);
 #pragma unroll
             for (int f = 0; f < 2; ++f) {
                 acc0 = fma(rr[f] * rr[f], cur[f * M::REC + 2], acc0);
@@ -809,7 +791,7 @@ __device__ __forceinline__ double logprob_row(const double (&th)[M::NDIM], const
         }
         if (j < o.N) {
             double rr, ri;
-            M::residual(s, rec, rr, ri);
+            M::template residual<FAST>(s, rec, rr, ri);
             acc0 = fma(rr * rr, rec[2], acc0);
             acc1 = fma(ri * ri, rec[3], acc1);
         }
@@ -818,7 +800,7 @@ __device__ __forceinline__ double logprob_row(const double (&th)[M::NDIM], const
 #pragma unroll 2
         for (int j = 0; j < o.N; ++j, rec += M::REC) {
             double rr, ri;
-            M::residual(s, rec, rr, ri);
+            M::template residual<FAST>(s, rec, rr, ri);
             if constexpr (M::WEIGHTED) {
                 acc0 = fma(rr, rr, acc0);
                 acc1 = fma(ri, ri, acc1);
@@ -832,9 +814,25 @@ __device__ __forceinline__ double logprob_row(const double (&th)[M::NDIM], const
             const int j = (j0 + g < o.N) ? j0 + g : o.N - 1;   // clamp: its result is never adopted
             const double *__restrict__ rec = o.cb + (long long)j * M::REC;
             double rr, ri;
-            M::residual(s, rec, rr, ri);
+            M::template residual<FAST>(s, rec, rr, ri);
             rotate_sums<M, L, 0>(rr, ri, rec, j0, o.N, acc0, acc1);
         }
+    }
+}
+
+template <class M, int L = 1, bool LDSREC = false>
+__device__ __forceinline__ double logprob_row(const double (&th)[M::NDIM], const ModelOperands &o,
+                                              const Bounds &b, const int g = 0)
+{
+    static_assert(L == 1 || L == 2 || L == 4, "lanes per walker");
+    if (!in_prior<M::NDIM>(th, b)) return -__builtin_inf();  // never touches the forward model
+    const typename M::Setup s = M::setup(th);
+    double acc0 = 0.0, acc1 = 0.0;
+    if constexpr (M::HAS_FAST) {
+        if (b.flags & BOUNDS_FAST) logprob_sums<M, L, LDSREC, true>(s, o, g, acc0, acc1);
+        else logprob_sums<M, L, LDSREC, false>(s, o, g, acc0, acc1);
+    } else {
+        logprob_sums<M, L, LDSREC, false>(s, o, g, acc0, acc1);
     }
     return fma(-0.5, acc0 + acc1, o.lconst);
 }
