@@ -426,6 +426,14 @@ def test_model_percentiles_on_the_device():
         # a scalar percentile gives (2, N), as np.percentile does
         assert m.get_model_percentile(50, chain).shape == (2, 20)
         assert np.array_equal(m.get_model_percentile(50, chain), got[1])
+        # NumPy's behaviour at the edges: a percentile outside [0, 100] is a ValueError, and a NaN in the
+        # chain (a NaN response in every column) makes every percentile NaN
+        with pytest.raises(ValueError):
+            m.get_model_percentile([50, 101], chain)
+        bad = chain.copy()
+        bad[7, 0] = np.nan
+        with np.errstate(invalid='ignore'):
+            assert np.isnan(m.get_model_percentile([2.5, 50], bad)).all()
 
 
 def test_fit_picks_the_random_stream_by_ensemble_size():
