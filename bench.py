@@ -20,7 +20,7 @@ is a failed run; nothing is retried).  Prints ONE JSON line on rank 0.
 
 The sampler-mode measurements of BASELINE configs 4 and 5 ("extras", stderr only) never share a
 process with the headline: they run in a SECOND group of ranks (`--extras-only`), started as a
-fresh child process only after the headline line is out, under a wall-clock limit, and their
+fresh child process only after the headline line is out, under a wall-clock limit (180 s), and their
 exit status is ignored -- a crash, abort or hang there cannot cost the measured line.
 """
 
@@ -236,7 +236,7 @@ def free_port():
     return port
 
 
-EXTRAS_TIMEOUT_S = 300.0
+EXTRAS_TIMEOUT_S = 180.0      # the whole second group: ~20 s of start-up, ~20 s of sampling when all is well
 _ELASTIC_VARS = ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'GROUP_RANK', 'ROLE_RANK', 'ROLE_NAME',
                  'ROLE_WORLD_SIZE', 'GROUP_WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'TORCHELASTIC_RUN_ID',
                  'TORCHELASTIC_RESTART_COUNT', 'TORCHELASTIC_MAX_RESTARTS', 'TORCHELASTIC_USE_AGENT_STORE',
