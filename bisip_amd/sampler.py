@@ -427,12 +427,13 @@ class HipStretchBackend:
         torch = self.torch
         if not hasattr(self, '_copy_stream'):
             self._copy_stream = torch.cuda.Stream(self.device)
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(self.device))
         frozen = dev_t.clone()                   # on the compute stream, before anything later touches dev_t
         ev2 = torch.cuda.Event()
         ev2.record(torch.cuda.current_stream(self.device))
-        host = torch.empty(dev_t.shape, dtype=dev_t.dtype, pin_memory=True)
+        # pinned memory that outlives the sampler (pinning costs more than a short run); a previous
+        # snapshot's copy has long been waited for by the run that asked for it
+        nbytes = dev_t.numel() * dev_t.element_size()
+        host = _pinned_scratch(self._key + 'snapshot', nbytes)[:nbytes].view(dev_t.dtype).view(dev_t.shape)
         self._copy_stream.wait_event(ev2)
         with torch.cuda.stream(self._copy_stream):
             host.copy_(frozen, non_blocking=True)
