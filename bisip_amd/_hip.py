@@ -80,6 +80,8 @@ SYMBOLS = {
                                              ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]),
     'bisip_stretch_run_sharded_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(StretchArgs),
                                                      ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]),
+    'bisip_stretch_run_sharded_sim_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(StretchArgs),
+                                                         ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]),
     'bisip_rccl_unique_id': (ctypes.c_int, [ctypes.c_void_p]),
     'bisip_rccl_comm_create': (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int,
                                               ctypes.c_void_p, ctypes.c_int]),
@@ -499,6 +501,12 @@ class HipContext:
         """``comm``: an ncclComm_t as an integer (rccl_comm_create() or torch's _comm_ptr())."""
         _check(self._lib.bisip_stretch_run_sharded_dev(self._h, ctypes.c_void_p(comm), ctypes.byref(first_args),
                                                        int(W), int(n_steps), int(thin_by), ctypes.c_void_p(stream)))
+
+    def stretch_run_sharded_sim_dev(self, world, first_args, W, n_steps, thin_by=1, stream=0):
+        """The sharded half-step loop with every rank of a ``world``-rank group evaluated on this device in
+        turn and no collective (test aid: bisip_stretch_run_sharded_sim_dev)."""
+        _check(self._lib.bisip_stretch_run_sharded_sim_dev(self._h, int(world), ctypes.byref(first_args),
+                                                           int(W), int(n_steps), int(thin_by), ctypes.c_void_p(stream)))
 
     def stretch_persistent_dev(self, args, stream=0):
         """Returns False when the ensemble does not fit one workgroup (status -4)."""

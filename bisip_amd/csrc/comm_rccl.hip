@@ -121,22 +121,21 @@ int bisip_rccl_comm_destroy(void *comm)
     return BISIP_OK;
 }
 
-int bisip_stretch_run_sharded_dev(bisip_ctx *c, void *comm, const bisip_stretch_args *first, int64_t W,
-                                  int64_t n_steps, int64_t thin_by, void *stream)
+// The sharded half-step loop.  comm != nullptr: this process is rank `rank` of `world`; its block of every
+// half-step is evaluated into its slab of the gather buffer and one in-place ncclAllGather assembles the
+// others'.  comm == nullptr (bisip_stretch_run_sharded_sim_dev): EVERY rank's block is evaluated here, one
+// after another, into the slab that rank would have sent -- the same slot ranges, pads and slab offsets,
+// no collective -- so that the arithmetic a multi-rank run depends on can be checked on one GPU.
+static int run_sharded(bisip_ctx *c, void *comm, int world, int rank, const bisip_stretch_args *first, int64_t W,
+                       int64_t n_steps, int64_t thin_by, void *stream)
 {
-    if (!c || !comm || !first) return fail(BISIP_EINVAL, "null argument");
     if (c->E > 1) return fail(BISIP_EUNSUPPORTED, "a batch of spectra shards as whole replicas: no sharded half-step");
     if (thin_by < 1 || n_steps % thin_by) return fail(BISIP_EINVAL, "n_steps=%lld must be a multiple of thin_by=%lld", (long long)n_steps, (long long)thin_by);
     if (W < 2 || n_steps < 0) return fail(BISIP_EINVAL, "bad W=%lld or n_steps=%lld", (long long)W, (long long)n_steps);
     if (!first->coords || !first->logp || !first->active || !first->partner || !first->zz ||
         !first->factor || !first->logu || !first->status)
         return fail(BISIP_EINVAL, "null buffer");
-    int rc = load_rccl();
-    if (rc != BISIP_OK) return rc;
-    int world = 0, rank = 0;
-    RCCL_TRY(g_rccl.CommCount((ncclComm_t)comm, &world));
-    RCCL_TRY(g_rccl.CommUserRank((ncclComm_t)comm, &rank));
-    if (world < 1 || rank < 0 || rank >= world) return fail(BISIP_EINVAL, "communicator reports world=%d rank=%d", world, rank);
+    if (world < 1 || rank < 0 || rank >= world) return fail(BISIP_EINVAL, "bad world=%d rank=%d", world, rank);
     HIP_TRY(hipSetDevice(c->device));
     const int64_t nh = (W + 1) / 2;
     const int64_t row = c->ndim + 2;                     // position, log-prob, accepted
@@ -150,6 +149,7 @@ int bisip_stretch_run_sharded_dev(bisip_ctx *c, void *comm, const bisip_stretch_
     }
     bisip_stretch_args u = *first;
     u.world = world;
+    int rc = BISIP_OK;
     for (int64_t k = 0; k < n_steps; ++k) {
         for (int h = 0; h < 2; ++h) {
             const int64_t off = (k * 2 + h) * nh;
@@ -161,29 +161,54 @@ int bisip_stretch_run_sharded_dev(bisip_ctx *c, void *comm, const bisip_stretch_
             const int64_t srow = k / thin_by;
             u.chain_row = (store && first->chain_row) ? first->chain_row + srow * W * c->ndim : nullptr;
             u.logp_row = (store && first->logp_row) ? first->logp_row + srow * W : nullptr;
-            // this rank's block of the active half (dist.py:shard_range): the first m % world ranks
+            // a rank's block of the active half (dist.py:shard_range): the first m % world ranks
             // own one slot more
             const int64_t base = m / world, extra = m % world;
             const int64_t pad = (m + world - 1) / world;
-            u.slot_lo = rank * base + (rank < extra ? rank : extra);
-            u.slot_hi = u.slot_lo + base + (rank < extra ? 1 : 0);
             u.pad = pad;
-            double *mine = c->d_gather + rank * pad * row;
-            u.block = mine;
-            if (u.slot_hi > u.slot_lo) {
-                const StretchArgs a = to_device_args(&u);
-                rc = dispatch_stretch(c, StretchWork{STRETCH_EVAL, &a, nullptr}, 0, (hipStream_t)stream);
-                if (rc != BISIP_OK) return rc;
+            for (int r = comm ? rank : 0; r < (comm ? rank + 1 : world); ++r) {
+                u.slot_lo = r * base + (r < extra ? r : extra);
+                u.slot_hi = u.slot_lo + base + (r < extra ? 1 : 0);
+                u.block = c->d_gather + r * pad * row;
+                if (u.slot_hi > u.slot_lo) {
+                    const StretchArgs a = to_device_args(&u);
+                    rc = dispatch_stretch(c, StretchWork{STRETCH_EVAL, &a, nullptr}, 0, (hipStream_t)stream);
+                    if (rc != BISIP_OK) return rc;
+                }
             }
-            // in place: the send buffer IS this rank's slab of the receive buffer
-            RCCL_TRY(g_rccl.AllGather(mine, c->d_gather, (size_t)(pad * row), ncclDouble, (ncclComm_t)comm,
-                                      (hipStream_t)stream));
+            if (comm) {
+                // in place: the send buffer IS this rank's slab of the receive buffer
+                double *mine = c->d_gather + rank * pad * row;
+                RCCL_TRY(g_rccl.AllGather(mine, c->d_gather, (size_t)(pad * row), ncclDouble, (ncclComm_t)comm,
+                                          (hipStream_t)stream));
+            }
             u.block = c->d_gather;
             rc = dispatch_apply(c, to_device_args(&u), (hipStream_t)stream);
             if (rc != BISIP_OK) return rc;
         }
     }
     return BISIP_OK;
+}
+
+int bisip_stretch_run_sharded_dev(bisip_ctx *c, void *comm, const bisip_stretch_args *first, int64_t W,
+                                  int64_t n_steps, int64_t thin_by, void *stream)
+{
+    if (!c || !comm || !first) return fail(BISIP_EINVAL, "null argument");
+    int rc = load_rccl();
+    if (rc != BISIP_OK) return rc;
+    int world = 0, rank = 0;
+    RCCL_TRY(g_rccl.CommCount((ncclComm_t)comm, &world));
+    RCCL_TRY(g_rccl.CommUserRank((ncclComm_t)comm, &rank));
+    if (world < 1 || rank < 0 || rank >= world) return fail(BISIP_EINVAL, "communicator reports world=%d rank=%d", world, rank);
+    return run_sharded(c, comm, world, rank, first, W, n_steps, thin_by, stream);
+}
+
+int bisip_stretch_run_sharded_sim_dev(bisip_ctx *c, int world, const bisip_stretch_args *first, int64_t W,
+                                      int64_t n_steps, int64_t thin_by, void *stream)
+{
+    if (!c || !first) return fail(BISIP_EINVAL, "null argument");
+    if (world < 1 || world > 4096) return fail(BISIP_EINVAL, "world=%d out of [1, 4096]", world);
+    return run_sharded(c, nullptr, world, 0, first, W, n_steps, thin_by, stream);
 }
 
 }  // extern "C"

@@ -509,6 +509,13 @@ class HipStretchBackend:
         self.ctx.stretch_run_sharded_dev(comm, self._args(st, 0, 0, (W + 1) // 2, base=True), W, n_steps,
                                          st.get('thin', 1), self.stream())
 
+    def run_sharded_sim(self, st, n_steps, world):
+        """The same C loop with every rank of a ``world``-rank group evaluated on this device in turn and
+        no collective: the slot ranges, pads and slab offsets of a multi-rank run, on one GPU (test aid)."""
+        W = st['coords'].shape[0]
+        self.ctx.stretch_run_sharded_sim_dev(world, self._args(st, 0, 0, (W + 1) // 2, base=True), W, n_steps,
+                                             st.get('thin', 1), self.stream())
+
     def rccl_comm(self, group, world, rank, prefer='torch', in_group=True):
         """An ncclComm_t (int) spanning the ranks of ``group``, or None when the group does not
         run over RCCL (gloo: the caller keeps the Python eval / all_gather / apply loop).
@@ -678,8 +685,16 @@ class DeviceEnsembleSampler(_SamplerBase):
         # The C loop is 5x faster with one rank but has never met a second
         # rank on hardware (this pool gives one GPU, and RCCL refuses two ranks on one device), so it
         # is opt-in until `bench.py --gpus N`'s extras have shown it equal to the Python loop there.
+        # 'simulate:N' (test aid, one process): the C loop with all N ranks' blocks evaluated on this device
+        self.simulate_world = 0
+        if isinstance(sharded_loop, str) and sharded_loop.startswith('simulate:'):
+            self.simulate_world = int(sharded_loop.split(':', 1)[1])
+            if self.simulate_world < 1 or distributed:
+                raise ValueError("sharded_loop='simulate:N' needs N >= 1 and a single process")
+            sharded_loop = 'python'
+            self.force_sharded_path = True
         if sharded_loop not in ('rccl', 'rccl-own', 'python'):
-            raise ValueError("sharded_loop must be 'rccl', 'rccl-own' or 'python'")
+            raise ValueError("sharded_loop must be 'rccl', 'rccl-own', 'python' or 'simulate:N'")
         self.sharded_loop = sharded_loop
         self._comm, self._comm_owned, self._comm_tried = None, False, False
         # one rank and the ensemble fits a workgroup: ONE launch per chunk (workgroups of whole
@@ -843,6 +858,9 @@ class DeviceEnsembleSampler(_SamplerBase):
         elif single:
             be.run(st, n)
             self.last_path = 'launch-per-half-step'
+        elif self.simulate_world:
+            be.run_sharded_sim(st, n, self.simulate_world)
+            self.last_path = f'sharded-simulated-{self.simulate_world}'
         elif self._sharded_comm() is not None:
             be.run_sharded(st, n, self._comm)
             self.last_path = 'sharded-rccl'

@@ -39,7 +39,7 @@ extern "C" {
 /* 2: entry points added since 1 (all additions, nothing changed or removed): loglike_z, forward_percentiles,
  * column / grouped / columns percentiles, forward_spectrum(s) / forward_columns, stretch_run_sharded + rccl_*, ctx_set_spectrum_offset,
  * ctx_reduced_check, polydecomp_reduced_estimates, read_tables; BISIP_VARIANT_REDUCED_COMP, BISIP_ERCCL.
- * 3: clock_probe_dev, ctx_reduced_guard, polydecomp_reduced_reference (additions only). */
+ * 3: clock_probe_dev, ctx_reduced_guard, polydecomp_reduced_reference, stretch_run_sharded_sim_dev (additions only). */
 #define BISIP_ABI_VERSION 3
 
 /* model_id -- the four reference model classes (src/bisip/models.py:182,232,274,308) */
@@ -214,6 +214,13 @@ int bisip_stretch_run_dev(bisip_ctx *ctx, const bisip_stretch_args *first, int64
  * fails.  Single-spectrum contexts only (a batch of spectra shards as whole replicas). */
 int bisip_stretch_run_sharded_dev(bisip_ctx *ctx, void *comm, const bisip_stretch_args *first,
                                   int64_t W, int64_t n_steps, int64_t thin_by, void *stream);
+
+/* Test aid: the same loop with EVERY rank of a `world`-rank group evaluated on this device, one after
+ * another, each into the slab of the gather buffer it would have sent, and no collective -- the slot
+ * ranges, pads and slab offsets a multi-rank run depends on, checkable on one GPU (odd ensembles, more ranks
+ * than slots, empty shards).  The chain equals the fused single-GPU chain bit for bit. */
+int bisip_stretch_run_sharded_sim_dev(bisip_ctx *ctx, int world, const bisip_stretch_args *first, int64_t W,
+                                      int64_t n_steps, int64_t thin_by, void *stream);
 
 /* Stand-alone communicator for callers without one: rank 0 fills a BISIP_RCCL_ID_BYTES id
  * (ncclGetUniqueId), ships it to the other ranks by any means, and every rank creates its

@@ -221,6 +221,31 @@ def test_reset_forgets_the_acceptance_counts_on_the_device_too():
     ctx.close()
 
 
+@pytest.mark.parametrize('W,world', [(33, 2), (33, 3), (10, 8), (10, 64), (64, 5), (4096, 8), (4097, 7)])
+def test_sharded_c_loop_with_every_rank_simulated_on_one_gpu(W, world):
+    """The C half-step loop of the sharded sampler (bisip_stretch_run_sharded_dev: eval -> all-gather ->
+    apply) has only ever met ONE rank on hardware.  Its multi-rank arithmetic -- which slots a rank owns,
+    the pad of its slab, where the slab lies in the gather buffer, odd ensembles whose two halves differ,
+    more ranks than slots (empty shards) -- is the same code with every rank's block evaluated on this
+    device in turn and the all-gather left out (bisip_stretch_run_sharded_sim_dev): the chain must be the
+    fused single-GPU chain, bit for bit, in both random-stream modes."""
+    from bisip_amd.sampler import DeviceEnsembleSampler
+    g = np.load(_case('case15_'))
+    ctx = make_ctx(g, 'PeltonColeCole')
+    p0 = _start(g, W, 3)
+    for rng in ('numpy', 'philox'):
+        runs = {}
+        for name, kw in (('fused', dict(persistent=False)), ('simulated', dict(sharded_loop=f'simulate:{world}', persistent=False))):
+            np.random.seed(21)
+            s = DeviceEnsembleSampler(W, 4, ctx, rng=rng, seed=5, chunk=7, **kw)
+            s.run_mcmc(p0, 15, thin_by=1)
+            runs[name] = (s.get_chain(), s.get_log_prob(), s.acceptance_fraction, s.last_path)
+        assert runs['fused'][3] == 'launch-per-half-step' and runs['simulated'][3] == f'sharded-simulated-{world}'
+        for a, b in zip(runs['fused'][:3], runs['simulated'][:3]):
+            assert np.array_equal(a, b), (rng, W, world)
+    ctx.close()
+
+
 def test_philox_draw_kernel_matches_contract():
     """bisip_stretch_draw_dev against the NumPy statement of the philox contract."""
     import torch
