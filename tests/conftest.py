@@ -31,6 +31,12 @@ def extended_cases():
     return sorted(glob.glob(os.path.join(GOLDEN, 'ext*.npz')))
 
 
+def valley_cases():
+    """Rows along the flat valley of chi^2 / on the shell logp = 0 of PolynomialDecomposition designs, with the
+    REAL reference's log-probability and the exact value of its formula (50-digit mpmath); same script."""
+    return sorted(glob.glob(os.path.join(GOLDEN, 'valley*.npz')))
+
+
 def case_model(path):
     return os.path.basename(path).split('_')[1]
 

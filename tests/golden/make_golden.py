@@ -157,6 +157,8 @@ def main():
     ap.add_argument('--scratch', default='/tmp/bisip_ref_build')
     ap.add_argument('--only-extended', action='store_true',
                     help='regenerate only the ext*.npz cases (leaves the case*.npz files untouched)')
+    ap.add_argument('--only-valley', action='store_true',
+                    help='regenerate only the valley*.npz cases (leaves the others untouched)')
     args = ap.parse_args()
 
     pkg = build_reference(args.scratch)
@@ -176,6 +178,9 @@ def main():
 
     if args.only_extended:
         extended_cases(bisip, bundled, synth)
+        return
+    if args.only_valley:
+        valley_cases(bisip, bundled, synth)
         return
 
     # ---- (1) load_data fixtures (pins SURVEY §8 a12) -------------------------------
@@ -264,6 +269,74 @@ def main():
             fh.write(f'{aid}\t{cls}\t{kw}\t{th}\t{float(lp)!r}\n')
             print(aid, repr(lp))
     extended_cases(bisip, bundled, synth)
+    valley_cases(bisip, bundled, synth)
+
+
+def exact_logp(model, rows, digits=50):
+    """The reference's formula -- Decomp_cyth (src/bisip/cython_funcs.pyx:75-94) + _log_likelihood
+    (src/bisip/models.py:59-62) -- evaluated from the model's own double operands in `digits`-digit
+    arithmetic (mpmath), rounded once at the end.  What the reference would return without rounding."""
+    import mpmath as mp
+    mp.mp.dps = digits
+    d = model.data
+    w = [mp.mpf(float(x)) for x in d['w']]
+    taus = [mp.mpf(float(x)) for x in model.taus]
+    L = model.log_taus
+    c = mp.mpf(float(model.c_exp))
+    K = [[1 - 1 / (1 + (mp.mpc(0, 1) * wj * tk) ** c) for tk in taus] for wj in w]       # C_Debye per unit m
+    s2 = [[mp.mpf(float(d['zn_err'][p, j])) ** 2 for j in range(len(w))] for p in (0, 1)]
+    const = mp.fsum(2 * mp.log(v) for row in s2 for v in row)
+    out = []
+    for th in rows:
+        r0, a = mp.mpf(float(th[0])), [mp.mpf(float(x)) for x in th[1:]]
+        M = [mp.fsum(a[i] * mp.mpf(float(L[i, k])) for i in range(len(a))) for k in range(len(taus))]
+        tot = mp.mpf(0)
+        for j in range(len(w)):
+            Z = r0 * (1 - mp.fsum(M[k] * K[j][k] for k in range(len(taus))))
+            tot += (mp.mpf(float(d['zn'][0, j])) - Z.real) ** 2 / s2[0][j] + (mp.mpf(float(d['zn'][1, j])) - Z.imag) ** 2 / s2[1][j]
+        out.append(float(-(tot + const) / 2))
+    return np.array(out)
+
+
+def valley_cases(bisip, bundled, synth):
+    """Rows along the flat valley of chi^2 of PolynomialDecomposition designs -- b = b_ls + s R^-1 z, a third
+    at s = 1 ... 30 posterior sigmas, two thirds ON the shell log-probability = 0 -- with the REAL reference's
+    log-probability AND the exact value of its formula (50 digits).  On nearly collinear designs the two differ
+    by far more than the parity tolerance: these files record by how much, independently of this repository's
+    kernels and oracle (only WHERE the rows lie comes from its host code).  Files valley*.npz."""
+    sys.path.insert(0, os.path.join(REPO, 'benchmarks'))
+    from bisip_amd import _hip
+    from fuzz_parity import valley_rows
+    cases = [('SIP-K389175', bundled['SIP-K389175'], dict(poly_deg=5, c_exp=1.0)),
+             ('SIP-K389175', bundled['SIP-K389175'], dict(poly_deg=4, c_exp=0.5)),
+             ('SIP-K389175', bundled['SIP-K389175'], dict(poly_deg=8, c_exp=1.0)),
+             ('SIP-K389172', bundled['SIP-K389172'], dict(poly_deg=7, c_exp=0.5)),
+             ('synthetic-N32-i0', synth['synthetic-N32-i0'], dict(poly_deg=5, c_exp=1.0)),
+             ('synthetic-N32-i7', synth['synthetic-N32-i7'], dict(poly_deg=6, c_exp=1.0)),
+             ('synthetic-N64-i0', synth['synthetic-N64-i0'], dict(poly_deg=9, c_exp=0.5)),
+             ('synthetic-N20-i3', synth['synthetic-N20-i3'], dict(poly_deg=10, c_exp=1.0))]
+    manifest = []
+    for ci, (dname, path, kw) in enumerate(cases):
+        model = bisip.PolynomialDecomposition(path, nwalkers=32, nsteps=10, **kw)
+        d = model.data
+        bounds = np.asarray(model.param_bounds, float)
+        ops = _hip.polydecomp_operands(d['w'], d['zn'], d['zn_err'], model.taus, model.log_taus, model.c_exp)
+        theta = np.ascontiguousarray(valley_rows(ops, bounds, np.random.RandomState(6000 + ci), 400)[:48])
+        assert len(theta) >= 24, (dname, kw, len(theta))
+        _, logp = evaluate(model, theta)
+        exact = exact_logp(model, theta)
+        out = dict(theta=theta, logp=logp, logp_exact=exact, w=d['w'], zn=d['zn'], zn_err=d['zn_err'], bounds=bounds,
+                   log_tau=model.log_tau, log_taus=model.log_taus, taus=model.taus,
+                   poly_deg=np.int64(model.poly_deg), c_exp=np.float64(model.c_exp),
+                   raw=np.loadtxt(path, skiprows=1, delimiter=','), param_names=np.array(model.param_names))
+        fname = f'valley{ci:02d}_PolynomialDecomposition_{dname}.npz'
+        np.savez_compressed(os.path.join(HERE, fname), **out)
+        off = np.abs(logp - exact) / np.maximum(1.0, np.abs(exact))
+        manifest.append(f'{fname}\tPolynomialDecomposition\t{dname}\t{kw}\treference vs exact: max {off.max():.2e}')
+        print(f'{fname}: rows={len(theta)} logp in ({exact.min():.4g}, {exact.max():.4g}); the reference is up to '
+              f'{off.max():.2e} (relative to max(1, |logp|)) from the exact value of its formula')
+    with open(os.path.join(HERE, 'MANIFEST_VALLEY.tsv'), 'w') as fh:
+        fh.write('\n'.join(manifest) + '\n')
 
 
 def extended_cases(bisip, bundled, synth):
