@@ -274,7 +274,7 @@ FILES = [
     (f'{ROUND}_soak.json', '`python benchmarks/soak.py`', 'twenty 100,000-iteration fits and twenty 10,000-iteration batch fits in one process: device memory constant, posterior means within 0.02 sigma of each other, identical summaries for identical seeds'),
     (f'{ROUND}_fuzz_*_summary.jsonl', '`python benchmarks/fuzz_parity.py --cases 3000 --seed S` (S = 41..44, 47, 48; 1500 cases at S = 45, 46 with `--widen 1.5`, `--widen 3`), `fuzz_sampler.py --cases 1500 --seed 2` (and 5, 6), `fuzz_batch.py --cases 500 --seed 1` (and 4, 7)', 'randomised campaigns of this round (earlier rounds: `r02_fuzz_*`, 41,000 problems): violations, worst errors, which kernel AUTO ran'),
     (f'{ROUND}_fuzz_valley_summary.jsonl', '`python benchmarks/fuzz_parity.py --cases 1500 --seed S --valley` (S = 301..303; 3000 cases each at S = 304..306)', 'half of the checked PolynomialDecomposition rows along the valley of chi^2 / on the shell logp = 0: distances of every formulation AND of the reference from the exact value'),
-    (f'{ROUND}_valley_rows.jsonl', '`python benchmarks/valley_rows.py`', 'the kernel AUTO picks, measured on 3000 valley rows per scale (1 ... 1000 sigma) of 216 designs of degree 5-10'),
+    (f'{ROUND}_valley_rows.jsonl, {ROUND}_valley_rows_before.jsonl', '`python benchmarks/valley_rows.py`', 'the kernel AUTO picks, measured on 3000 valley rows per scale (1 ... 1000 sigma) of 216 designs of degree 5-10 (designs above 1e-11 are listed): with this round\'s estimate, and -- `_before` -- with round 2\'s, against plain long double'),
     (f'{ROUND}_micro_collapsed_r3.txt', '`benchmarks/micro/collapsed_r3`', 'PDCollapsed: the shipped kernel against LDS-staged records, 4 rows per lane, single-wave workgroups and persistent waves, each with the engine clock it ran at and cycles per VALU instruction'),
     (f'{ROUND}_micro_exp2_variants.txt', '`benchmarks/micro/exp2_variants`', 'a table-driven exp2 (16 / 32 entries in LDS) against the shipped degree-11 polynomial: cycles per exp2 per SIMD, clock, worst ulp -- not adopted'),
     (f'{ROUND}_micro_small_call_latency.jsonl', '`python benchmarks/micro/small_call_latency.py`', 'one emcee-sized log-probability call with host buffers, every model, 16 ... 4096 rows'),
