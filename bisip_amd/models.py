@@ -263,10 +263,14 @@ class Inversion(_utils.utils):
 
     def _check_reduced_kernel(self, ctx):
         """PolynomialDecomposition runs on a QR-reduced kernel chosen from an error ESTIMATE on probe
-        rows (HipContext.reduced_error).  After a fit, measure: the final ensemble's log-probabilities
-        against the reduced form in long double (host, microseconds for a few thousand rows).  The
-        result stays in ``reduced_check_``; beyond the parity tolerance it warns and names the way out."""
-        self.reduced_check_ = None
+        rows (HipContext.reduced_error).  After a fit, measure -- against the library's long-double
+        yardstick, on the host, microseconds for a few thousand rows -- (1) the final ensemble's
+        log-probabilities and (2) the 256 stored samples whose log-probability is nearest to ZERO: the
+        tolerance is relative to max(1, |logp|), so it is where a walker crossed logp = 0 on its way in
+        that a kernel's absolute error counts, not around the mode.  The worse of the two stays in
+        ``reduced_check_`` (the second alone in ``reduced_check_shell_``); beyond the parity tolerance it
+        warns and names the way out."""
+        self.reduced_check_ = self.reduced_check_shell_ = None
         if ctx.variant not in ('reduced', 'reduced_comp') or moves_sampler(self._sampler):
             return
         coords, lp = self._sampler._coords, self._sampler._lp
@@ -274,9 +278,16 @@ class Inversion(_utils.utils):
             return
         step = max(1, len(coords) // 4096)
         self.reduced_check_ = ctx.reduced_check(coords[::step], lp[::step])
+        where = 'the final ensemble'
+        if hasattr(self._sampler, 'rows_nearest_zero_logp'):
+            rows, rlp = self._sampler.rows_nearest_zero_logp(256)
+            if len(rows):
+                self.reduced_check_shell_ = ctx.reduced_check(rows, rlp)
+                if self.reduced_check_shell_ > self.reduced_check_:
+                    self.reduced_check_, where = self.reduced_check_shell_, 'the stored samples nearest to logp = 0'
         if not self.reduced_check_ <= self._LOGP_TOL:
             warnings.warn(f'the {ctx.variant!r} kernel is {self.reduced_check_:.1e} (relative) away from the exact '
-                          f'log-probability on the final ensemble (tolerance {self._LOGP_TOL:.0e}); '
+                          f'log-probability on {where} (tolerance {self._LOGP_TOL:.0e}); '
                           "refit with variant='reduced_comp' (or 'collapsed')", RuntimeWarning)
 
     def get_chain(self, **kwargs):

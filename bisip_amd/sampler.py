@@ -264,6 +264,28 @@ class _SamplerBase:
     def get_log_prob(self, discard=0, thin=1, flat=False):
         return self._get_value(self._log_prob, discard, thin, flat)
 
+    def rows_nearest_zero_logp(self, k=256):
+        """The k stored samples whose log-probability is nearest to zero, as (theta (k, ndim), logp (k,)) on
+        the host: where the relative tolerance max(1, |logp|) has denominator 1 -- the rows of a run on which a
+        kernel's absolute error shows (Inversion._check_reduced_kernel).  Chains kept in HBM are searched
+        there; only the k rows come back."""
+        parts_c, parts_l = self._chain_parts, self._log_prob_parts
+        if not parts_c:
+            return np.empty((0, self.ndim)), np.empty(0)
+        if all(isinstance(p, _DeviceSlabs) for p in parts_l) and all(isinstance(p, _DeviceSlabs) for p in parts_c):
+            import torch
+            lp = torch.cat([p.tensor().reshape(-1) for p in parts_l])
+            ch = torch.cat([p.tensor().reshape(-1, self.ndim) for p in parts_c])
+            score = torch.where(torch.isfinite(lp), lp.abs(), torch.full_like(lp, float('inf')))
+            idx = torch.topk(score, min(int(k), score.numel()), largest=False).indices
+            return ch[idx].cpu().numpy(), lp[idx].cpu().numpy()
+        lp = self.get_log_prob(flat=True)
+        ch = self.get_chain(flat=True)
+        score = np.where(np.isfinite(lp), np.abs(lp), np.inf)
+        k = min(int(k), score.size)
+        idx = np.argpartition(score, k - 1)[:k] if k else np.empty(0, dtype=int)
+        return np.ascontiguousarray(ch[idx]), lp[idx]
+
     @property
     def acceptance_fraction(self):
         return self._accepted / float(self._moves_done)

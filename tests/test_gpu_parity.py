@@ -387,6 +387,11 @@ def test_fit_with_the_chain_kept_on_the_device():
     dev.sampler.run_mcmc(None, 30)
     assert dev.get_chain().shape == (150, 300, 4) and np.array_equal(dev.get_chain()[:120], host.get_chain())
     assert np.allclose(dev.get_param_std(discard=100), dev.get_chain(discard=100, flat=True).std(axis=0), rtol=1e-9)
+    # the stored samples nearest to logp = 0 (what fit() measures a reduced kernel on) are found where the
+    # chain lies, the same rows as from the host copy
+    r_dev, l_dev = dev.sampler.rows_nearest_zero_logp(64)
+    lp_all = dev.sampler.get_log_prob(flat=True)
+    assert r_dev.shape == (64, 4) and np.abs(l_dev).max() <= np.sort(np.abs(lp_all))[63]
     with pytest.raises(ValueError):
         dev.fit(chain='somewhere')
 
@@ -403,15 +408,23 @@ def test_fit_measures_its_reduced_kernel_on_the_final_ensemble(monkeypatch):
     with warnings.catch_warnings():
         warnings.simplefilter('error', RuntimeWarning)
         m.fit()
-    assert m._context().variant == 'reduced' and 0.0 <= m.reduced_check_ <= 1e-12
-    # rows outside the prior are the prior's business; a wrong log-probability is found
+    # the worse of two measurements: the final ensemble (around the mode: 1e-14) and the stored samples
+    # nearest to logp = 0 -- this run starts uniform in the prior box and every walker crosses it on its
+    # way in: there the plain triangle of this degree-5 design is 1e-11 off, within the bar AUTO holds it to
+    assert m._context().variant == 'reduced' and 0.0 <= m.reduced_check_ <= 2e-11
     ctx = m._context()
     coords, lp = m.sampler._coords.copy(), m.sampler._lp.copy()
-    assert ctx.reduced_check(coords, lp) == m.reduced_check_
+    final = ctx.reduced_check(coords, lp)
+    assert final <= 1e-12 and m.reduced_check_shell_ is not None and m.reduced_check_ == max(final, m.reduced_check_shell_)
+    rows, rlp = m.sampler.rows_nearest_zero_logp(256)
+    chain_lp = m.sampler.get_log_prob(flat=True)
+    assert rows.shape == (256, 7) and np.abs(rlp).max() <= np.sort(np.abs(chain_lp))[255]
+    assert ctx.reduced_check(rows, rlp) == m.reduced_check_shell_
+    # rows outside the prior are the prior's business; a wrong log-probability is found
     lp[5] += 1e-6 * abs(lp[5])
     assert 0.5e-6 < ctx.reduced_check(coords, lp) < 2e-6
     coords[5, 0] = 2.0                               # now outside the box: not looked at
-    assert ctx.reduced_check(coords, lp) == m.reduced_check_ or ctx.reduced_check(coords, lp) <= 1e-12
+    assert ctx.reduced_check(coords, lp) <= 1e-12
     monkeypatch.setattr(bisip_amd.PolynomialDecomposition, '_LOGP_TOL', 1e-30)
     with pytest.warns(RuntimeWarning, match="variant='reduced_comp'"):
         m.fit()
