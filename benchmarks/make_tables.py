@@ -277,6 +277,7 @@ FILES = [
     (f'{ROUND}_valley_rows.jsonl, {ROUND}_valley_rows_before.jsonl', '`python benchmarks/valley_rows.py`', 'the kernel AUTO picks, measured on 3000 valley rows per scale (1 ... 1000 sigma) of 216 designs of degree 5-10 (designs above 1e-11 are listed): with this round\'s estimate, and -- `_before` -- with round 2\'s, against plain long double'),
     (f'{ROUND}_micro_collapsed_r3.txt', '`benchmarks/micro/collapsed_r3`', 'PDCollapsed: the shipped kernel against LDS-staged records, 4 rows per lane, single-wave workgroups and persistent waves, each with the engine clock it ran at and cycles per VALU instruction'),
     (f'{ROUND}_micro_exp2_variants.txt', '`benchmarks/micro/exp2_variants`', 'a table-driven exp2 (16 / 32 entries in LDS) against the shipped degree-11 polynomial: cycles per exp2 per SIMD, clock, worst ulp -- not adopted'),
+    (f'{ROUND}_micro_fit_speed_by_tier.txt', '`python benchmarks/micro/fit_speed_by_tier.py`', 'fit() iterations/s on the plain and on the compensated reduced kernel (32 / 256 / 4096 walkers), with fit()\'s own measurement of the kernel'),
     (f'{ROUND}_micro_small_call_latency.jsonl', '`python benchmarks/micro/small_call_latency.py`', 'one emcee-sized log-probability call with host buffers, every model, 16 ... 4096 rows'),
     (f'{ROUND}_micro_issue_latency.txt', '`benchmarks/micro/issue_latency`', 'cycles per fp64 FMA for 1/2/4/8 independent chains at 1, 2, 4 waves per SIMD; placement of 1-, 2-, 4-, 8-, 16-wave workgroups'),
     (f'{ROUND}_micro_row_latency.txt', '`benchmarks/micro/row_latency`', 'cycles of one log-probability row at one wave per SIMD, records from the scalar cache vs staged in LDS'),
