@@ -278,6 +278,7 @@ FILES = [
     (f'{ROUND}_micro_collapsed_r3.txt', '`benchmarks/micro/collapsed_r3`', 'PDCollapsed: the shipped kernel against LDS-staged records, 4 rows per lane, single-wave workgroups and persistent waves, each with the engine clock it ran at and cycles per VALU instruction'),
     (f'{ROUND}_micro_exp2_variants.txt', '`benchmarks/micro/exp2_variants`', 'a table-driven exp2 (16 / 32 entries in LDS) against the shipped degree-11 polynomial: cycles per exp2 per SIMD, clock, worst ulp -- not adopted'),
     (f'{ROUND}_micro_fit_speed_by_tier.txt', '`python benchmarks/micro/fit_speed_by_tier.py`', 'fit() iterations/s on the plain and on the compensated reduced kernel (32 / 256 / 4096 walkers), with fit()\'s own measurement of the kernel'),
+    (f'{ROUND}_micro_persistent_comp_by_degree.txt', '`python benchmarks/micro/persistent_comp_by_degree.py`, `batch_comp_by_degree.py`', 'the compensated kernel in the persistent sampler against one launch per half-step, by degree: persistent wins up to degree 5 (single ensembles and batches), the launch path from degree 7 (registers); the automatic rule follows'),
     (f'{ROUND}_micro_small_call_latency.jsonl', '`python benchmarks/micro/small_call_latency.py`', 'one emcee-sized log-probability call with host buffers, every model, 16 ... 4096 rows'),
     (f'{ROUND}_micro_issue_latency.txt', '`benchmarks/micro/issue_latency`', 'cycles per fp64 FMA for 1/2/4/8 independent chains at 1, 2, 4 waves per SIMD; placement of 1-, 2-, 4-, 8-, 16-wave workgroups'),
     (f'{ROUND}_micro_row_latency.txt', '`benchmarks/micro/row_latency`', 'cycles of one log-probability row at one wave per SIMD, records from the scalar cache vs staged in LDS'),

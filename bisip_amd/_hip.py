@@ -303,6 +303,7 @@ class HipContext:
         self.device = int(device)
         self.model_id = int(model_id)
         self.n_modes = int(n_modes)
+        self.poly_deg = int(poly_deg)
         # bisip_logprob's guard of the QR-reduced kernels (see logprob)
         self._guarded = self.model_id == MODEL_POLYDECOMP
         self._calls, self._escalations_seen, self._guard_warned, self._forced = 0, 0, False, False
@@ -355,6 +356,11 @@ class HipContext:
         measured crossovers, benchmarks/micro/persistent_crossover.py: the cheaper the kernel per
         walker, the longer one CU keeps up with launches that spread over the chip."""
         name = self.kernel_name
+        if 'reduced_comp' in name:
+            # the compensated triangle keeps ~12 live doubles per matrix entry in flight: from degree 6-7 the
+            # persistent kernel spills and the launch path is 30-70 % faster at every ensemble size
+            # (profiles/r03_micro_persistent_comp_by_degree.txt); 0 = never persistent
+            return 1024 if self.poly_deg <= 5 else (64 if self.poly_deg == 6 else 0)
         if 'reduced' in name:
             return 1024
         if 'Dias' in name:

@@ -733,7 +733,7 @@ class DeviceEnsembleSampler(_SamplerBase):
         # None = that rule; True / False force it.
         if persistent is None:
             limit = getattr(getattr(self.backend, 'ctx', None), 'persistent_walkers', 128)
-            persistent = int(nwalkers) <= limit or (int(nwalkers) <= 1024 and
+            persistent = int(nwalkers) <= limit or (limit > 0 and int(nwalkers) <= 1024 and
                                                     int(nwalkers) * self.n_ensembles >= 65536)
         self.persistent = bool(persistent)
         # keep the stored samples in HBM: nothing is copied to the host until get_chain() /
