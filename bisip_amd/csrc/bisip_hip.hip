@@ -154,7 +154,8 @@ static int bound_flags(const bisip_ctx *c)
     } else {
         return 0;
     }
-    return ok && ymax <= YMAX ? BOUNDS_FAST : 0;
+    if (!(ok && ymax <= YMAX)) return 0;
+    return c->grid_ok ? (BOUNDS_FAST | BOUNDS_GRID) : BOUNDS_FAST;
 }
 
 // PolynomialDecomposition, reduced form: (re)choose the expansion point bhat for the current
@@ -424,6 +425,7 @@ static int build_context(bisip_ctx **out, int device, int model_id, int E, int N
     // per-spectrum operands, blocks of spectra on host threads (each writes its own slots).  The
     // kernel sums K, G depend on the frequencies only: a block reuses them while consecutive
     // spectra share their frequency list, as the spectra of a survey usually do.
+    std::atomic<int> off_grid{0};
     parallel_blocks(E, 8, [&](int64_t e_lo, int64_t e_hi) {
         PolyDecompOperands o;
         const double *w_of_o = nullptr;
@@ -437,6 +439,11 @@ static int build_context(bisip_ctx **out, int device, int model_id, int E, int N
                 double *r = base + (size_t)j * rec;
                 r[0] = zne[j]; r[1] = zne[N + j]; r[2] = iv[j]; r[3] = iv[N + j];
                 if (model_id != BISIP_MODEL_POLYDECOMP) { r[4] = we[j]; r[5] = lnw[j]; r[6] = (double)sqrtl((long double)we[j]); }
+            }
+            if (model_id != BISIP_MODEL_POLYDECOMP) {
+                double dlnw = 0.0;
+                if (!grid_step(N, we, lnw.data(), &dlnw)) off_grid.store(1);
+                for (int j = 0; j < N; ++j) base[(size_t)j * rec + 7] = dlnw;
             }
             if (model_id != BISIP_MODEL_POLYDECOMP) continue;
             if (!w_of_o || std::memcmp(w_of_o, we, sizeof(double) * (size_t)N) != 0) {
@@ -482,6 +489,8 @@ static int build_context(bisip_ctx **out, int device, int model_id, int E, int N
             }
         }
     });
+    c->grid_ok = model_id != BISIP_MODEL_POLYDECOMP && off_grid.load() == 0 && std::getenv("BISIP_NO_GRID") == nullptr;
+    c->bounds.flags = bound_flags(c);
     if (!fb.empty() && P < 8) rc = upload(&c->d_cb_faithful, fb);
     c->lconst = lconsts[0];
     if (rc == BISIP_OK) rc = upload(&c->d_cb, cb);

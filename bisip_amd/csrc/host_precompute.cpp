@@ -417,6 +417,47 @@ double reduced_center(int n, const std::vector<double> &R, const std::vector<lon
         int kept = 0;     // 64 probes inside the box, up to 1500 tries (a narrowed box keeps few of the draws)
         for (int k = 0; solvable && k < 1500 && kept < 64; ++k)
             if (valley_point(-1.0, tpt)) { probes.push_back(tpt); ++kept; }
+        // A box that cuts the shell in a small patch keeps none of those draws (a degree-6 design of the
+        // fuzz campaign: 9 of 200,000; its estimate then never saw the shell and passed a kernel that read
+        // 1.1e-10 on the one row of a 20,000-row batch that lay there).  The box is convex in theta: between
+        // a probe with log-probability > 0 and one with < 0, both inside, the segment stays inside and
+        // crosses the shell -- found by bisection (plain double: where the probe lies need not be exact).
+        if (kept < 64 && finite_box) {
+            auto logp_of = [&](const std::vector<double> &t) {
+                double chi2 = rest;
+                for (int i = 0; i < n; ++i) {
+                    double u = (double)qty[i];
+                    for (int j = i; j < n; ++j) u -= R[(size_t)i * n + j] * (j ? t[0] * t[j] : t[0]);
+                    chi2 += u * u;
+                }
+                return lconst - 0.5 * chi2;
+            };
+            std::vector<size_t> pos, neg;
+            std::vector<std::vector<double>> ends(probes.begin(), probes.begin() + (long)n_regular);
+            for (int k = 0; k < 32; ++k) {       // more of the box, as far ends of the segments only
+                std::vector<double> t(n);
+                for (int j = 0; j < n; ++j) t[j] = lo[j] + (hi[j] - lo[j]) * rng.uni();
+                ends.push_back(t);
+            }
+            for (size_t ip = 0; ip < ends.size(); ++ip) {
+                if (!inside(ends[ip])) continue;
+                const double lp = logp_of(ends[ip]);
+                if (lp > 0.0) pos.push_back(ip);
+                else if (lp < 0.0) neg.push_back(ip);
+            }
+            for (int k = 0; !pos.empty() && !neg.empty() && kept < 64 && k < 128; ++k) {
+                const std::vector<double> &a = ends[pos[(size_t)(rng.uni() * (double)pos.size()) % pos.size()]];
+                const std::vector<double> &b = ends[neg[(size_t)(rng.uni() * (double)neg.size()) % neg.size()]];
+                double t0 = 0.0, t1 = 1.0;
+                for (int it = 0; it < 60; ++it) {
+                    const double tm = 0.5 * (t0 + t1);
+                    for (int j = 0; j < n; ++j) tpt[j] = a[j] + tm * (b[j] - a[j]);
+                    if (logp_of(tpt) > 0.0) t0 = tm; else t1 = tm;
+                }
+                for (int j = 0; j < n; ++j) tpt[j] = a[j] + t0 * (b[j] - a[j]);
+                if (inside(tpt) && std::fabs(logp_of(tpt)) < 1.0) { probes.push_back(tpt); ++kept; }
+            }
+        }
     }
     // candidates for the expansion point
     std::vector<std::vector<double>> cand;
@@ -492,6 +533,23 @@ double reduced_logp_reference(int n, const std::vector<long double> &Rl, const s
                               double rest, double lconst, const double *theta)
 {
     return (double)(-0.5L * reduced_chi2_exact(n, Rl, qty, rest, theta) + (ld)lconst);
+}
+
+bool grid_step(int N, const double *w, const double *lnw, double *dlnw)
+{
+    *dlnw = 0.0;
+    if (N < 8) return false;
+    for (int j = 0; j < N; ++j)
+        if (!(w[j] > 0.0) || !std::isfinite(w[j])) return false;
+    const ld first = logl((ld)w[0]), step = (logl((ld)w[N - 1]) - first) / (ld)(N - 1);
+    const double d = (double)step;
+    if (!std::isfinite(d) || d == 0.0) return false;
+    for (int j = 0; j < N; ++j) {
+        const ld want = logl((ld)w[j]), got = (ld)lnw[j & ~3] + (ld)(j & 3) * (ld)d;
+        if (!(fabsl(want - got) <= 4e-15L)) return false;
+    }
+    *dlnw = d;
+    return true;
 }
 
 int host_threads()

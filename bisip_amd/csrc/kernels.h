@@ -15,6 +15,7 @@
 // arithmetic).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include "../../include/bisip_hip.h"
 
@@ -35,6 +36,11 @@ struct Bounds {
     int flags = 0;
 };
 constexpr int BOUNDS_FAST = 1;
+// BOUNDS_GRID (only together with BOUNDS_FAST): the frequencies of every spectrum of the context lie on a
+// geometric grid, ln w_{4k+q} = ln w_{4k} + q * dlnw to 4e-15 (grid_step in host_precompute.cpp; rec[7] of
+// every record holds dlnw).  The exponentials of the per-frequency models are then taken once per block of
+// four frequencies and stepped by multiplication (GridSteps below).
+constexpr int BOUNDS_GRID = 2;
 // The safe loop clamps the exponent y of 2^y = |(i w tau)^c| (ColeCole) or Q w^n (Shin) at 500: beyond,
 // 2^y squared would overflow, the denominator become inf and rcp_nr(inf) NaN where the reference's term
 // quietly vanishes (a round-2 defect that boxes with c up to 22 and more exposed).  It takes one
@@ -382,18 +388,32 @@ struct ColeCole {
     // frequency the D exponentials, then the D reciprocals -- FAST: one per group of modes; safe: one per
     // mode, exponents clamped -- then the modes accumulated in ascending order.  Same operations per
     // frequency for every F, so the same bits.
+    // the D exponentials of one frequency are 2^(exp_a(i) ln w + exp_b(i))   (see GridSteps below)
+    static constexpr int NEXP = D;
+    __device__ static __forceinline__ double exp_a(const Setup &s, int i) { return s.c2[i]; }
+    __device__ static __forceinline__ double exp_b(const Setup &s, int i) { return s.clt2[i]; }
     template <int F, bool FAST>
     __device__ static __forceinline__ void residual_n(const Setup &s, const double *const (&rec)[F],
                                                       double (&rr)[F], double (&ri)[F])
     {
         constexpr int K = F * D;     // value k = (frequency k / D, mode k % D)
-        double y[K], e[K], dr[F][D], di[F][D], den[F][D], inv[F][D];
+        double y[K], e[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             y[k] = fma(s.c2[k % D], rec[k / D][5], s.clt2[k % D]);
             if constexpr (!FAST) y[k] = fmin(y[k], EXP2_CLAMP);
         }
         exp2_finite_n<K>(y, e);
+        residual_from_exp<F, FAST>(s, rec, e, rr, ri);
+    }
+    // everything after the exponentials e[f * D + i] = (w_f tau_i)^c_i
+    template <int F, bool FAST>
+    __device__ static __forceinline__ void residual_from_exp(const Setup &s, const double *const (&rec)[F],
+                                                             const double (&e)[F * D], double (&rr)[F],
+                                                             double (&ri)[F])
+    {
+        constexpr int K = F * D;
+        double dr[F][D], di[F][D], den[F][D], inv[F][D];
 #pragma unroll
         for (int f = 0; f < F; ++f)
 #pragma unroll
@@ -588,18 +608,31 @@ struct Shin {
     // Q (iw)^n = 2^(n log2e ln w + log_Q log2e) (cs + i sn);  Z = sum_i conj(y_i)/|y_i|^2.
     // F frequencies in lockstep; FAST: per frequency the two elements' reciprocals come from one
     // reciprocal of the product of the |y_i|^2; safe: one each, exponents clamped.
+    static constexpr int NEXP = 2;
+    __device__ static __forceinline__ double exp_a(const Setup &s, int i) { return s.n2[i]; }
+    __device__ static __forceinline__ double exp_b(const Setup &s, int i) { return s.lq2[i]; }
     template <int F, bool FAST>
     __device__ static __forceinline__ void residual_n(const Setup &s, const double *const (&rec)[F],
                                                       double (&rr)[F], double (&ri)[F])
     {
         constexpr int K = 2 * F;     // value k = (frequency k / 2, element k % 2)
-        double y[K], p[K], yr[F][2], yi[F][2], den[F][2], inv[F][2];
+        double y[K], p[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             y[k] = fma(s.n2[k % 2], rec[k / 2][5], s.lq2[k % 2]);
             if constexpr (!FAST) y[k] = fmin(y[k], EXP2_CLAMP);
         }
         exp2_finite_n<K>(y, p);
+        residual_from_exp<F, FAST>(s, rec, p, rr, ri);
+    }
+    // everything after the exponentials p[f * 2 + i] = Q_i w_f^n_i
+    template <int F, bool FAST>
+    __device__ static __forceinline__ void residual_from_exp(const Setup &s, const double *const (&rec)[F],
+                                                             const double (&p)[F * 2], double (&rr)[F],
+                                                             double (&ri)[F])
+    {
+        constexpr int K = 2 * F;
+        double yr[F][2], yi[F][2], den[F][2], inv[F][2];
 #pragma unroll
         for (int f = 0; f < F; ++f)
 #pragma unroll
@@ -665,6 +698,58 @@ struct Shin {
         }
     }
 };
+
+// Geometric frequency grids (BOUNDS_GRID).  The exponentials of ColeCole / Shin at frequency f are
+// 2^(a_i ln w_f + b_i) with per-walker a_i, b_i: sixteen of their ~33 instructions per (frequency, term).
+// On a grid ln w_{4k+q} = ln w_{4k} + q dlnw they are, for the block of four frequencies that starts at 4k,
+//   base_i = 2^(a_i ln w_{4k} + b_i)             one exponential per block and term,
+//   base_i,  base_i S1_i,  base_i S2_i,  base_i S3_i        for q = 0..3,
+// with the per-walker steps S1 = 2^(a_i dlnw), S2 = S1 S1, S3 = S2 S1 -- a quarter of the exponentials plus
+// three multiplications.  The value at frequency f is defined by THIS formula (block start 4*(f/4), step
+// f%4) in every kernel, whichever lane evaluates it and in whatever order: the same bits everywhere, as for
+// the other paths.  Rounding: base as before; a step adds <= 4 ulp; the grid's own deviation <= 4e-15 in the
+// exponent's ln w, the size of the rounding of ln w itself.
+template <class M>
+struct GridSteps {
+    double S[3][M::NEXP];
+};
+
+template <class M>
+__device__ __forceinline__ GridSteps<M> grid_steps(const typename M::Setup &s, double dlnw)
+{
+    GridSteps<M> g;
+    double y[M::NEXP], r[M::NEXP];
+#pragma unroll
+    for (int i = 0; i < M::NEXP; ++i) y[i] = M::exp_a(s, i) * dlnw;
+    exp2_finite_n<M::NEXP>(y, r);
+#pragma unroll
+    for (int i = 0; i < M::NEXP; ++i) {
+        g.S[0][i] = r[i];
+        g.S[1][i] = r[i] * r[i];
+        g.S[2][i] = g.S[1][i] * r[i];
+    }
+    return g;
+}
+
+template <class M>
+__device__ __forceinline__ void grid_base(const typename M::Setup &s, double lnw0, double (&base)[M::NEXP])
+{
+    double y[M::NEXP];
+#pragma unroll
+    for (int i = 0; i < M::NEXP; ++i) y[i] = fma(M::exp_a(s, i), lnw0, M::exp_b(s, i));
+    exp2_finite_n<M::NEXP>(y, base);
+}
+
+// exponentials of step Q (compile time) of a block
+template <class M, int Q>
+__device__ __forceinline__ void grid_at(const GridSteps<M> &g, const double (&base)[M::NEXP], double *e)
+{
+#pragma unroll
+    for (int i = 0; i < M::NEXP; ++i) {
+        if constexpr (Q == 0) e[i] = base[i];
+        else e[i] = base[i] * g.S[Q - 1][i];
+    }
+}
 
 // ---------------------------------------------------------------------------------
 // log-probability of ONE row held in registers -- shared by the batch kernels below and
@@ -820,6 +905,124 @@ __device__ __forceinline__ void logprob_sums(const typename M::Setup &s, const M
     }
 }
 
+// The same sums on a geometric frequency grid (BOUNDS_GRID; the host guarantees N >= 8 and BOUNDS_FAST):
+// one loop per lane layout as above, the exponentials from grid_base / grid_at instead of one exp2 each.
+template <class M, int L, bool LDSREC>
+__device__ __forceinline__ void logprob_sums_grid(const typename M::Setup &s, const ModelOperands &o, const int g,
+                                                  double &acc0, double &acc1)
+{
+    static_assert(M::REC == 8 && !M::WEIGHTED, "per-frequency models with 8-double records");
+    constexpr int NE = M::NEXP, REC = M::REC;
+    if constexpr (L == 1 && LDSREC) {
+        // pairs of frequencies from LDS, the next pair in flight (see logprob_sums): a block of four
+        // frequencies is two pairs, the first takes the block's exponential
+        const double *__restrict__ rec = o.cb;
+        constexpr int R2 = 2 * REC;
+        double cur[R2], base[NE];
+        dbl2 buf[8];
+        lds_pair_issue(rec, buf, acc0);
+        lds_pair_wait(buf);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { cur[2 * q] = buf[q].x; cur[2 * q + 1] = buf[q].y; }
+        const GridSteps<M> gs = grid_steps<M>(s, cur[7]);
+        int j = 0;
+        auto pair = [&](auto second) {
+            lds_pair_issue((j + 3 < o.N) ? rec + R2 : rec, buf, cur[5]);   // last pair: a harmless re-read
+            double e[2 * NE], rr[2], ri[2];
+            if constexpr (!decltype(second)::value) {
+                grid_base<M>(s, cur[5], base);
+                grid_at<M, 0>(gs, base, e);
+                grid_at<M, 1>(gs, base, e + NE);
+            } else {
+                grid_at<M, 2>(gs, base, e);
+                grid_at<M, 3>(gs, base, e + NE);
+            }
+            const double *const r2[2] = {cur, cur + REC};
+            M::template residual_from_exp<2, true>(s, r2, e, rr, ri);
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                acc0 = fma(rr[f] * rr[f], cur[f * REC + 2], acc0);
+                acc1 = fma(ri[f] * ri[f], cur[f * REC + 3], acc1);
+            }
+            asm volatile("" : "+v"(acc0), "+v"(acc1));
+            lds_pair_wait(buf);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { cur[2 * q] = buf[q].x; cur[2 * q + 1] = buf[q].y; }
+            j += 2;
+            rec += R2;
+        };
+        for (; j + 3 < o.N;) {
+            pair(std::false_type{});
+            pair(std::true_type{});
+        }
+        const bool tail_pair = j + 1 < o.N;
+        if (tail_pair) pair(std::false_type{});
+        if (j < o.N) {                          // one frequency left: step 0 or step 2 of its block
+            double e[NE], rr[1], ri[1];
+            if (tail_pair) grid_at<M, 2>(gs, base, e);
+            else { grid_base<M>(s, rec[5], base); grid_at<M, 0>(gs, base, e); }
+            const double *const r1[1] = {rec};
+            M::template residual_from_exp<1, true>(s, r1, e, rr, ri);
+            acc0 = fma(rr[0] * rr[0], rec[2], acc0);
+            acc1 = fma(ri[0] * ri[0], rec[3], acc1);
+        }
+    } else if constexpr (L == 1) {
+        const double *__restrict__ rec = o.cb;
+        const GridSteps<M> gs = grid_steps<M>(s, rec[7]);
+        double base[NE];
+        auto one = [&](auto Q, const double *__restrict__ r) {
+            double e[NE], rr[1], ri[1];
+            grid_at<M, decltype(Q)::value>(gs, base, e);
+            const double *const r1[1] = {r};
+            M::template residual_from_exp<1, true>(s, r1, e, rr, ri);
+            acc0 = fma(rr[0] * rr[0], r[2], acc0);
+            acc1 = fma(ri[0] * ri[0], r[3], acc1);
+        };
+        int j = 0;
+        for (; j + 3 < o.N; j += 4, rec += 4 * REC) {
+            grid_base<M>(s, rec[5], base);
+            one(std::integral_constant<int, 0>{}, rec);
+            one(std::integral_constant<int, 1>{}, rec + REC);
+            one(std::integral_constant<int, 2>{}, rec + 2 * REC);
+            one(std::integral_constant<int, 3>{}, rec + 3 * REC);
+        }
+        if (j < o.N) {
+            grid_base<M>(s, rec[5], base);
+            one(std::integral_constant<int, 0>{}, rec);
+            if (j + 1 < o.N) one(std::integral_constant<int, 1>{}, rec + REC);
+            if (j + 2 < o.N) one(std::integral_constant<int, 2>{}, rec + 2 * REC);
+        }
+    } else {
+        // L lanes per walker: lane g takes frequency j0 + g.  Its step inside the block of four is g (L = 4),
+        // or g and 2 + g in turn (L = 2); the block's exponential is taken by every lane (as before: one
+        // exponential per lane and round), the step is one more multiplication -- by 1.0 at step 0, exact.
+        const GridSteps<M> gs = grid_steps<M>(s, o.cb[7]);
+        double mul_a[NE], mul_b[NE];
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            if constexpr (L == 4) {
+                mul_a[i] = g == 0 ? 1.0 : (g == 1 ? gs.S[0][i] : (g == 2 ? gs.S[1][i] : gs.S[2][i]));
+                mul_b[i] = mul_a[i];
+            } else {
+                mul_a[i] = g == 0 ? 1.0 : gs.S[0][i];
+                mul_b[i] = g == 0 ? gs.S[1][i] : gs.S[2][i];
+            }
+        }
+        for (int j0 = 0; j0 < o.N; j0 += L) {
+            const int j = (j0 + g < o.N) ? j0 + g : o.N - 1;   // clamp: its result is never adopted
+            const double *__restrict__ rec = o.cb + (long long)j * REC;
+            double base[NE], e[NE], rr[1], ri[1];
+            grid_base<M>(s, o.cb[(long long)(j0 & ~3) * REC + 5], base);
+            const bool second = (L == 2) && (j0 & 2);
+#pragma unroll
+            for (int i = 0; i < NE; ++i) e[i] = base[i] * (second ? mul_b[i] : mul_a[i]);
+            const double *const r1[1] = {rec};
+            M::template residual_from_exp<1, true>(s, r1, e, rr, ri);
+            rotate_sums<M, L, 0>(rr[0], ri[0], rec, j0, o.N, acc0, acc1);
+        }
+    }
+}
+
 template <class M, int L = 1, bool LDSREC = false>
 __device__ __forceinline__ double logprob_row(const double (&th)[M::NDIM], const ModelOperands &o,
                                               const Bounds &b, const int g = 0)
@@ -829,7 +1032,8 @@ __device__ __forceinline__ double logprob_row(const double (&th)[M::NDIM], const
     const typename M::Setup s = M::setup(th);
     double acc0 = 0.0, acc1 = 0.0;
     if constexpr (M::HAS_FAST) {
-        if (b.flags & BOUNDS_FAST) logprob_sums<M, L, LDSREC, true>(s, o, g, acc0, acc1);
+        if (b.flags & BOUNDS_GRID) logprob_sums_grid<M, L, LDSREC>(s, o, g, acc0, acc1);
+        else if (b.flags & BOUNDS_FAST) logprob_sums<M, L, LDSREC, true>(s, o, g, acc0, acc1);
         else logprob_sums<M, L, LDSREC, false>(s, o, g, acc0, acc1);
     } else {
         logprob_sums<M, L, LDSREC, false>(s, o, g, acc0, acc1);

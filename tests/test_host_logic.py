@@ -327,6 +327,20 @@ def test_reduced_kernel_tiers_estimates_on_the_host():
     assert needs_comp >= 3
 
 
+def test_estimate_finds_a_shell_patch_that_random_draws_miss():
+    """A prior box may cut the shell log-probability = 0 in a patch so small that none of 1,500 random
+    shell rows falls inside (this design -- problem 1558 of `fuzz_parity.py --seed 308 --valley`, degree 6,
+    80 frequencies, c = 0.22 -- keeps 9 of 200,000).  The estimate then bisects segments between probes of
+    positive and of negative log-probability inside the box, finds the patch, and reads what the plain
+    kernel does there (2e-8 absolute; before, 1.8e-13 from the other probes: AUTO kept the plain kernel and
+    one row of a 20,000-row batch was 1.1e-10 off)."""
+    from bisip_amd import _hip
+    z = np.load(os.path.join(ROOT, 'tests', 'golden', 'design_shell_patch_fuzz308_1558.npz'))
+    plain, comp = _hip.polydecomp_reduced_estimates(z['w'], z['zn'], z['zn_err'], z['taus'], z['log_taus'],
+                                                    float(z['c_exp']), z['bounds'])
+    assert plain > 1e-11 and comp < 1e-13, (plain, comp)
+
+
 def test_reduced_yardstick_is_pinned_by_fifty_digit_arithmetic():
     """bisip_polydecomp_reduced_reference -- what the reduced kernels' estimates, checks and guard measure
     against -- equals a 50-digit evaluation of the reference's own per-frequency formula
