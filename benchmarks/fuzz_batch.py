@@ -47,6 +47,10 @@ def main():
             kw = dict(n_modes=int(rng.randint(1, 4)))
         first = int(rng.randint(0, 300))
         tables = [synthetic_columns(N, first + i) for i in range(E)]
+        if model in ('PeltonColeCole', 'Shin2015'):
+            from fuzz_parity import frequencies_as_in_a_file
+            # per spectrum: a batch mixes grids, rounded grids and irregular frequencies, and runs ONE loop
+            tables = [frequencies_as_in_a_file(t, (first + i) * 131 + N + case) for i, t in enumerate(tables)]
         ndim = len(bisip_amd.batch.default_params(model, n_modes=kw.get('n_modes', 1), poly_deg=kw.get('poly_deg', 5)))
         Wp = int(rng.choice([2 * ndim + (2 * ndim) % 2, 30, 64, 100, 128, 256]))
         Wp += Wp % 2

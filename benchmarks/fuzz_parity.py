@@ -51,6 +51,22 @@ def valley_rows(ops, bounds, rng, n_rows):
     return t[np.all((bounds[0] < t) & (t < bounds[1]), axis=1)]
 
 
+def frequencies_as_in_a_file(cols, key):
+    """ColeCole / Shin run one of three loops, chosen by the frequencies (kernels.h: BOUNDS_GRID*): a third of
+    their problems keep the generator's exact geometric grid, a third hold it rounded to 4-6 digits as a data
+    file would (the stepped-and-corrected loop), a third have frequencies moved by up to 3 % (no grid: one
+    exponential per frequency).  Decided from `key`, not from the campaign's random stream: every problem of
+    every earlier campaign keeps its number and, for the other models, its content."""
+    sub = np.random.RandomState(key % (1 << 31))
+    mode = sub.randint(3)
+    if mode == 1:
+        digits = int(sub.randint(4, 7))
+        cols[:, 0] = np.array([float('%.*g' % (digits, f)) for f in cols[:, 0]])
+    elif mode == 2:
+        cols[:, 0] *= 1.0 + 0.03 * sub.uniform(-1, 1, len(cols))
+    return cols
+
+
 def draw_case(rng, widen=1.0, valley=False):
     """One random problem: model, shape, spectrum, prior box, theta batch, rows to check."""
     from bisip_amd.batch import default_params
@@ -59,7 +75,10 @@ def draw_case(rng, widen=1.0, valley=False):
     names = NAMES
     model = names[rng.randint(4)]
     N = int(rng.choice([1, 2, 3, 5, 16, 20, 21, 24, 30, 32, 33, 48, 64, 80]))
-    cols = synthetic_columns(N, int(rng.randint(0, 4096)))
+    idx = int(rng.randint(0, 4096))
+    cols = synthetic_columns(N, idx)
+    if model in ('PeltonColeCole', 'Shin2015'):
+        cols = frequencies_as_in_a_file(cols, idx * 131 + N)
     cols[:, 3] *= 10.0 ** rng.uniform(-1, 1)          # amplitude errors x0.1 .. x10
     cols[:, 4] *= 10.0 ** rng.uniform(-1, 1)          # phase errors
     d = columns_to_data(cols, 'mrad')

@@ -41,7 +41,12 @@ def main():
     for case in range(args.cases):
         model = names[rng.randint(4)]
         N = int(rng.choice([3, 16, 20, 21, 32, 45]))
-        d = columns_to_data(synthetic_columns(N, int(rng.randint(0, 500))), 'mrad')
+        idx = int(rng.randint(0, 500))
+        cols = synthetic_columns(N, idx)
+        if model in ('PeltonColeCole', 'Shin2015'):
+            from fuzz_parity import frequencies_as_in_a_file
+            cols = frequencies_as_in_a_file(cols, idx * 131 + N)
+        d = columns_to_data(cols, 'mrad')
         kw, okw, variant = {}, {}, 'auto'
         if model == 'PolynomialDecomposition':
             P = int(rng.randint(0, 8))

@@ -13,8 +13,16 @@ from bisip_amd.utils import columns_to_data
 MODELS = [('PeltonColeCole', 1, dict(n_modes=1)), ('PeltonColeCole', 1, dict(n_modes=2)), ('PeltonColeCole', 1, dict(n_modes=3)),
           ('Shin2015', 3, {})]
 W = 1 << 22
+import bisip_amd
+from bisip_amd.utils import load_data
+CASES = []
 for N in (32, 30, 21):
-    d = columns_to_data(synthetic_columns(N, 0), 'mrad')
+    CASES.append((f'N={N} geometric grid', columns_to_data(synthetic_columns(N, 0), 'mrad'), 3))
+cols = synthetic_columns(32, 0)
+cols[:, 0] = np.array([float('%.6g' % f) for f in cols[:, 0]])
+CASES.append(('N=32 grid rounded to 6 digits', columns_to_data(cols, 'mrad'), 5))
+CASES.append(('N=20 bundled SIP-K389175', load_data(bisip_amd.DataFiles()['SIP-K389175']), 5))
+for label, d, flags in CASES:
     for name, mid, kw in MODELS:
         bounds = np.array(list(default_params(name, **kw).values()), float).T
         rng = np.random.RandomState(1)
@@ -25,6 +33,7 @@ for N in (32, 30, 21):
             if grid: os.environ.pop('BISIP_NO_GRID', None)
             else: os.environ['BISIP_NO_GRID'] = '1'
             ctx = _hip.HipContext(mid, d['w'], d['zn'], d['zn_err'], bounds, **kw)
+            assert ctx.loop_flags == (flags if grid else 1)
             lp = torch.empty(W, dtype=torch.float64, device='cuda')
             for _ in range(3): ctx.logprob_dev(th.data_ptr(), W, lp.data_ptr(), torch.cuda.current_stream().cuda_stream)
             torch.cuda.synchronize(); t = time.perf_counter()
@@ -38,4 +47,4 @@ for N in (32, 30, 21):
             ctx.close()
         a, b = out[True][0], out[False][0]
         rel = np.max(np.abs(a - b) / np.maximum(1, np.abs(b)))
-        print(f'N={N} {name} {kw}: grid {out[True][1]:.3e} evals/s, direct {out[False][1]:.3e} evals/s, ratio {out[True][1]/out[False][1]:.2f}, max rel diff {rel:.2e}', flush=True)
+        print(f'{label} {name} {kw}: grid {out[True][1]:.3e} evals/s, direct {out[False][1]:.3e} evals/s, ratio {out[True][1]/out[False][1]:.2f}, max rel diff {rel:.2e}', flush=True)

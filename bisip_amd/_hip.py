@@ -122,6 +122,8 @@ SYMBOLS = {
     'bisip_ctx_ndim': (ctypes.c_int, [ctypes.c_void_p]),
     'bisip_ctx_nfreq': (ctypes.c_int, [ctypes.c_void_p]),
     'bisip_ctx_device': (ctypes.c_int, [ctypes.c_void_p]),
+    'bisip_ctx_loop_flags': (ctypes.c_int, [ctypes.c_void_p]),
+    'bisip_frequency_grid_step': (ctypes.c_int, [ctypes.c_int, _dp, _dp]),
     'bisip_ctx_loglike_const': (ctypes.c_double, [ctypes.c_void_p]),
     'bisip_ctx_kernel_name': (ctypes.c_char_p, [ctypes.c_void_p]),
     'bisip_ctx_reduced_error': (ctypes.c_double, [ctypes.c_void_p]),
@@ -228,6 +230,18 @@ def polydecomp_reduced_estimates(w, zn, zn_err, taus, log_taus, c_exp, bounds):
     est = np.empty(2)
     _check(lib.bisip_polydecomp_reduced_estimates(w.size, _p(w), _p(zn), _p(zn_err), ctypes.byref(desc), _p(lo), _p(hi), _p(est)))
     return float(est[0]), float(est[1])
+
+
+def frequency_grid_step(w):
+    """Host only: (tier, step of ln w) of bisip_frequency_grid_step (include/bisip_hip.h): tier 1 = ``w`` is a
+    geometric grid to rounding, 2 = to 0.012 in ln w (an instrument grid rounded in a file), 0 = neither."""
+    lib = load_library()
+    w = _c(w).ravel()
+    step = ctypes.c_double(0.0)
+    rc = lib.bisip_frequency_grid_step(int(w.size), w.ctypes.data_as(_dp), ctypes.cast(ctypes.byref(step), _dp))
+    if rc < 0:
+        _check(rc)
+    return int(rc), float(step.value)
 
 
 def polydecomp_reduced_reference(w, zn, zn_err, taus, log_taus, c_exp, theta):
@@ -348,6 +362,13 @@ class HipContext:
     @property
     def kernel_name(self):
         return self._lib.bisip_ctx_kernel_name(self._h).decode()
+
+    @property
+    def loop_flags(self):
+        """ColeCole / Shin: 1 = shared reciprocals (the prior box keeps the products normal), 3 = that and
+        exponentials stepped along a geometric frequency grid, 5 = along a grid rounded in the file (stepped
+        and corrected); 0 = safe loop or another model."""
+        return int(self._lib.bisip_ctx_loop_flags(self._h))
 
     @property
     def persistent_walkers(self):

@@ -153,6 +153,36 @@ def test_batch_persistent_equals_launch_path():
                 assert np.array_equal(x, y)
 
 
+@pytest.mark.parametrize('n_freq', [8, 9, 10, 11, 21])
+def test_persistent_kernel_steps_a_geometric_grid_like_the_launches_do(n_freq):
+    """The persistent kernel reads a spectrum's records from LDS two frequencies at a time; on a geometric
+    grid a block of four frequencies is two such pairs (kernels.h: logprob_sums_grid).  Every block tail --
+    a single frequency after a full block, a pair, a pair and a single -- gives the bits of the launch path."""
+    import bisip_amd
+    from bisip_amd.sampler import DeviceEnsembleSampler
+    for model, kw, centre in [('PeltonColeCole', dict(n_modes=2), [1.0, 0.15, 0.5, -1.5, -12.0, 0.45, 0.6]),
+                              ('PeltonColeCole', dict(n_modes=1), [1.0, 0.3, -3.0, 0.5]),
+                              ('Shin2015', {}, [0.5, 0.5, -14.0, -6.0, 0.5, 0.5])]:
+        for rounded in (False, True):
+            E, Wp, ndim = 3, 64, len(centre)
+            tables = _tables(E, n_freq)
+            if rounded:          # frequencies as a file would hold them: the stepped-and-corrected loop
+                for t in tables:
+                    t[:, 0] = np.array([float('%.4g' % f) for f in t[:, 0]])
+            batch = bisip_amd.SpectraBatch(model, tables, nwalkers=Wp, nsteps=8, **kw)
+            assert batch.ctx.loop_flags == (5 if rounded else 3)
+            rng = np.random.RandomState(n_freq)
+            p0 = (np.array(centre) + 1e-4 * rng.randn(E, Wp, ndim)).reshape(E * Wp, ndim)
+            chains = []
+            for persistent in (True, False):
+                s = DeviceEnsembleSampler(Wp, ndim, batch.ctx, rng='philox', seed=5, n_ensembles=E, persistent=persistent)
+                s.run_mcmc(p0, 8)
+                chains.append((s.get_chain(), s.get_log_prob(), s.last_path))
+            assert chains[0][2] == 'persistent' and chains[1][2] == 'launch-per-half-step'
+            assert np.array_equal(chains[0][0], chains[1][0]) and np.array_equal(chains[0][1], chains[1][1])
+            assert np.isfinite(chains[0][1]).all()
+
+
 # ----------------------------------------------------------------------------------
 # chain kept in HBM + posterior moments on the device (get_param_mean / get_param_std,
 # src/bisip/utils.py:55-85, per spectrum)

@@ -1165,3 +1165,117 @@ def test_bench_two_ranks_on_one_device():
     assert sc['n_gpus'] == 2 and sc['walkers'] == 32768 and sc['driver'] == 'sharded'
     assert sc['state_identical_on_every_rank'] is True and sc['equals_single_gpu_fused_chain'] is True
 
+
+
+@pytest.mark.parametrize('n_freq', [8, 9, 10, 11, 12, 30, 32, 33])
+def test_grid_stepped_exponentials_agree_with_direct_ones_and_with_the_oracle(n_freq, monkeypatch):
+    """On a geometric frequency grid (kernels.h: BOUNDS_GRID) ColeCole and Shin take one exponential per
+    block of four frequencies and term and step it by multiplication.  Same answer as one exponential per
+    (frequency, term) -- the loop BISIP_NO_GRID=1 and every off-grid spectrum run -- to rounding, both
+    within the parity tolerance of the oracle; and, as for every other loop, the same BITS whether one,
+    two or four lanes evaluate a walker (launches of 100, 6,000 and 200,000 rows), for every block tail
+    (N mod 4 = 0..3)."""
+    import oracle
+    from bisip_amd import _hip
+    from bisip_amd.batch import default_params
+    d = _synthetic_problem(n_freq, 2)
+    assert _hip.frequency_grid_step(d['w'])[0] == 1
+    rng = np.random.RandomState(n_freq)
+    for name, mid, kw in (('PeltonColeCole', 1, dict(n_modes=1)), ('PeltonColeCole', 1, dict(n_modes=2)),
+                          ('PeltonColeCole', 1, dict(n_modes=5)), ('Shin2015', 3, {})):
+        bounds = np.array(list(default_params(name, **kw).values()), float).T
+        theta = rng.uniform(bounds[0], bounds[1], (200000, bounds.shape[1]))
+        got = {}
+        for grid in (True, False):
+            if grid:
+                monkeypatch.delenv('BISIP_NO_GRID', raising=False)
+            else:
+                monkeypatch.setenv('BISIP_NO_GRID', '1')
+            ctx = _hip.HipContext(mid, d['w'], d['zn'], d['zn_err'], bounds, **kw)
+            assert ctx.loop_flags == (3 if grid else 1)
+            got[grid] = ctx.logprob(theta)
+            for rows in (100, 6000):
+                assert np.array_equal(ctx.logprob(theta[:rows]), got[grid][:rows]), (name, kw, rows, grid)
+            ctx.close()
+        monkeypatch.delenv('BISIP_NO_GRID', raising=False)
+        prob = oracle.OracleProblem(name, d['w'], d['zn'], d['zn_err'], bounds, **kw)
+        want = oracle.logprob(prob, theta[:3000], n_threads=4)
+        scale = np.maximum(1.0, np.abs(want))
+        assert np.max(np.abs(got[True][:3000] - want) / scale) <= 1e-10
+        assert np.max(np.abs(got[False][:3000] - want) / scale) <= 1e-10
+        assert np.max(np.abs(got[True] - got[False]) / np.maximum(1.0, np.abs(got[False]))) <= 2e-11
+
+
+def test_grid_loops_follow_the_frequencies_and_the_box(monkeypatch):
+    """The stepped loops run only where their premises hold.  Exact geometric grids: flags 3.  The bundled
+    spectra (frequencies halved from 6 kHz and then rounded in the files: 188.9 Hz for 187.5) and a jittered
+    grid: the stepped-and-corrected loop, flags 5, within the parity tolerance of the oracle like the loop
+    with one exponential per frequency (BISIP_NO_GRID=1), and the same bits from launches of every size.
+    A 1-2-5 sequence: one exponential per frequency.  A box widened past the shared-reciprocal limits: the
+    safe loop, and set_bounds switches with the box.  A batch runs the exact loop only if every spectrum is
+    on an exact grid."""
+    import bisip_amd
+    import oracle
+    from bisip_amd import _hip
+    from bisip_amd.batch import default_params
+    from bisip_amd.synthetic import synthetic_columns
+    from bisip_amd.utils import columns_to_data, load_data
+    rng = np.random.RandomState(3)
+    rounded = synthetic_columns(30, 4)
+    rounded[:, 0] = np.array([float('%.4g' % f) for f in rounded[:, 0]])
+    for d in [load_data(bisip_amd.DataFiles()[name]) for name in ('SIP-K389175', 'SIP-K389172')] + [columns_to_data(rounded, 'mrad')]:
+        for name, mid, kw in (('PeltonColeCole', 1, dict(n_modes=1)), ('PeltonColeCole', 1, dict(n_modes=2)),
+                              ('PeltonColeCole', 1, dict(n_modes=3)), ('Shin2015', 3, {})):
+            bounds = np.array(list(default_params(name, **kw).values()), float).T
+            theta = rng.uniform(bounds[0], bounds[1], (100000, bounds.shape[1]))
+            got = {}
+            for grid in (True, False):
+                if grid:
+                    monkeypatch.delenv('BISIP_NO_GRID', raising=False)
+                else:
+                    monkeypatch.setenv('BISIP_NO_GRID', '1')
+                ctx = _hip.HipContext(mid, d['w'], d['zn'], d['zn_err'], bounds, **kw)
+                assert ctx.loop_flags == (5 if grid else 1)
+                got[grid] = ctx.logprob(theta)
+                for rows in (100, 6000):
+                    assert np.array_equal(ctx.logprob(theta[:rows]), got[grid][:rows]), (name, kw, rows, grid)
+                ctx.close()
+            monkeypatch.delenv('BISIP_NO_GRID', raising=False)
+            prob = oracle.OracleProblem(name, d['w'], d['zn'], d['zn_err'], bounds, **kw)
+            want = oracle.logprob(prob, theta[:3000], n_threads=4)
+            scale = np.maximum(1.0, np.abs(want))
+            assert np.max(np.abs(got[True][:3000] - want) / scale) <= 1e-10
+            assert np.max(np.abs(got[False][:3000] - want) / scale) <= 1e-10
+            assert np.max(np.abs(got[True] - got[False]) / np.maximum(1.0, np.abs(got[False]))) <= 2e-11
+    bounds = np.array(list(default_params('PeltonColeCole', n_modes=2).values()), float).T
+    d = _synthetic_problem(32, 0)
+    w = d['w'].copy()
+    w[17] *= 1.0 + 3e-14
+    ctx = _hip.HipContext(1, w, d['zn'], d['zn_err'], bounds, n_modes=2)
+    assert ctx.loop_flags == 5
+    ctx.close()
+    w125 = 2 * np.pi * np.outer(10.0 ** np.arange(-2, 6), [1.0, 2.0, 5.0]).ravel()
+    d125 = _synthetic_problem(24, 0)
+    ctx = _hip.HipContext(1, w125, d125['zn'], d125['zn_err'], bounds, n_modes=2)
+    assert ctx.loop_flags == 1
+    ctx.close()
+    ctx = _hip.HipContext(1, d['w'], d['zn'], d['zn_err'], bounds, n_modes=2)
+    assert ctx.loop_flags == 3
+    wide = bounds.copy()
+    wide[1, 5:] = 30.0
+    ctx.set_bounds(wide)
+    assert ctx.loop_flags == 0
+    ctx.set_bounds(bounds)
+    assert ctx.loop_flags == 3
+    ctx.close()
+    tables = [synthetic_columns(32, i) for i in range(3)]
+    batch = bisip_amd.SpectraBatch('PeltonColeCole', tables, nwalkers=32, nsteps=2, n_modes=2)
+    assert batch.ctx.loop_flags == 3
+    tables[1] = tables[1].copy()
+    tables[1][5, 0] *= 1.0 + 1e-9
+    batch = bisip_amd.SpectraBatch('PeltonColeCole', tables, nwalkers=32, nsteps=2, n_modes=2)
+    assert batch.ctx.loop_flags == 5
+    tables[2] = tables[2].copy()
+    tables[2][9, 0] *= 1.05
+    batch = bisip_amd.SpectraBatch('PeltonColeCole', tables, nwalkers=32, nsteps=2, n_modes=2)
+    assert batch.ctx.loop_flags == 1
