@@ -52,9 +52,9 @@ def valley_rows(ops, bounds, rng, n_rows):
 
 
 def frequencies_as_in_a_file(cols, key):
-    """ColeCole / Shin run one of three loops, chosen by the frequencies (kernels.h: BOUNDS_GRID*): a third of
-    their problems keep the generator's exact geometric grid, a third hold it rounded to 4-6 digits as a data
-    file would (the stepped-and-corrected loop), a third have frequencies moved by up to 3 % (no grid: one
+    """ColeCole / Shin choose their loop by the frequencies (kernels.h: BOUNDS_GRID): a third of their problems
+    keep the generator's exact geometric grid (exponentials stepped by multiplication), a third hold it
+    rounded to 4-6 digits as a data file would, a third have frequencies moved by up to 3 % (both: one
     exponential per frequency).  Decided from `key`, not from the campaign's random stream: every problem of
     every earlier campaign keeps its number and, for the other models, its content."""
     sub = np.random.RandomState(key % (1 << 31))

@@ -18,10 +18,12 @@ from bisip_amd.utils import load_data
 CASES = []
 for N in (32, 30, 21):
     CASES.append((f'N={N} geometric grid', columns_to_data(synthetic_columns(N, 0), 'mrad'), 3))
+# off any grid (frequencies as a data file rounds them, the bundled field spectrum): both columns run the
+# same loop -- the control
 cols = synthetic_columns(32, 0)
 cols[:, 0] = np.array([float('%.6g' % f) for f in cols[:, 0]])
-CASES.append(('N=32 grid rounded to 6 digits', columns_to_data(cols, 'mrad'), 5))
-CASES.append(('N=20 bundled SIP-K389175', load_data(bisip_amd.DataFiles()['SIP-K389175']), 5))
+CASES.append(('N=32 grid rounded to 6 digits (no grid: control)', columns_to_data(cols, 'mrad'), 1))
+CASES.append(('N=20 bundled SIP-K389175 (no grid: control)', load_data(bisip_amd.DataFiles()['SIP-K389175']), 1))
 for label, d, flags in CASES:
     for name, mid, kw in MODELS:
         bounds = np.array(list(default_params(name, **kw).values()), float).T

@@ -233,15 +233,15 @@ def polydecomp_reduced_estimates(w, zn, zn_err, taus, log_taus, c_exp, bounds):
 
 
 def frequency_grid_step(w):
-    """Host only: (tier, step of ln w) of bisip_frequency_grid_step (include/bisip_hip.h): tier 1 = ``w`` is a
-    geometric grid to rounding, 2 = to 0.012 in ln w (an instrument grid rounded in a file), 0 = neither."""
+    """Host only: the common step of ln w if ``w`` is a geometric grid in the sense of
+    bisip_frequency_grid_step (include/bisip_hip.h), else None."""
     lib = load_library()
     w = _c(w).ravel()
     step = ctypes.c_double(0.0)
     rc = lib.bisip_frequency_grid_step(int(w.size), w.ctypes.data_as(_dp), ctypes.cast(ctypes.byref(step), _dp))
     if rc < 0:
         _check(rc)
-    return int(rc), float(step.value)
+    return float(step.value) if rc == 1 else None
 
 
 def polydecomp_reduced_reference(w, zn, zn_err, taus, log_taus, c_exp, theta):
@@ -366,8 +366,7 @@ class HipContext:
     @property
     def loop_flags(self):
         """ColeCole / Shin: 1 = shared reciprocals (the prior box keeps the products normal), 3 = that and
-        exponentials stepped along a geometric frequency grid, 5 = along a grid rounded in the file (stepped
-        and corrected); 0 = safe loop or another model."""
+        exponentials stepped along a geometric frequency grid; 0 = safe loop or another model."""
         return int(self._lib.bisip_ctx_loop_flags(self._h))
 
     @property

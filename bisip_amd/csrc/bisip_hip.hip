@@ -155,7 +155,7 @@ static int bound_flags(const bisip_ctx *c)
         return 0;
     }
     if (!(ok && ymax <= YMAX)) return 0;
-    return BOUNDS_FAST | (c->grid_tier == 1 ? BOUNDS_GRID : (c->grid_tier == 2 ? BOUNDS_GRID_FIX : 0));
+    return c->grid_ok ? (BOUNDS_FAST | BOUNDS_GRID) : BOUNDS_FAST;
 }
 
 // PolynomialDecomposition, reduced form: (re)choose the expansion point bhat for the current
@@ -425,7 +425,7 @@ static int build_context(bisip_ctx **out, int device, int model_id, int E, int N
     // per-spectrum operands, blocks of spectra on host threads (each writes its own slots).  The
     // kernel sums K, G depend on the frequencies only: a block reuses them while consecutive
     // spectra share their frequency list, as the spectra of a survey usually do.
-    std::atomic<int> off_grid{0}, fix_grid{0};
+    std::atomic<int> off_grid{0};
     parallel_blocks(E, 8, [&](int64_t e_lo, int64_t e_hi) {
         PolyDecompOperands o;
         const double *w_of_o = nullptr;
@@ -442,11 +442,8 @@ static int build_context(bisip_ctx **out, int device, int model_id, int E, int N
             }
             if (model_id != BISIP_MODEL_POLYDECOMP) {
                 double dlnw = 0.0;
-                std::vector<double> off((size_t)N);
-                const int tier = grid_step(N, we, lnw.data(), &dlnw, off.data());
-                if (tier == 0) off_grid.store(1);
-                if (tier == 2) fix_grid.store(1);
-                for (int j = 0; j < N; ++j) base[(size_t)j * rec + 7] = (j & 3) ? off[(size_t)j] : dlnw;
+                if (!grid_step(N, we, lnw.data(), &dlnw)) off_grid.store(1);
+                for (int j = 0; j < N; ++j) base[(size_t)j * rec + 7] = dlnw;
             }
             if (model_id != BISIP_MODEL_POLYDECOMP) continue;
             if (!w_of_o || std::memcmp(w_of_o, we, sizeof(double) * (size_t)N) != 0) {
@@ -492,9 +489,8 @@ static int build_context(bisip_ctx **out, int device, int model_id, int E, int N
             }
         }
     });
-    // a batch runs ONE loop: the exact-grid one only if every spectrum is on an exact grid
-    c->grid_tier = (model_id == BISIP_MODEL_POLYDECOMP || off_grid.load() || std::getenv("BISIP_NO_GRID")) ? 0
-                   : (fix_grid.load() ? 2 : 1);
+    // a batch runs ONE loop: the stepped one only if every spectrum is on a grid (each on its own)
+    c->grid_ok = model_id != BISIP_MODEL_POLYDECOMP && off_grid.load() == 0 && std::getenv("BISIP_NO_GRID") == nullptr;
     c->bounds.flags = bound_flags(c);
     if (!fb.empty() && P < 8) rc = upload(&c->d_cb_faithful, fb);
     c->lconst = lconsts[0];
@@ -591,8 +587,7 @@ int bisip_frequency_grid_step(int N, const double *w, double *step)
     return guarded([&] {
         std::vector<double> lnw((size_t)N);
         for (int j = 0; j < N; ++j) lnw[(size_t)j] = (double)logl((long double)w[j]);
-        std::vector<double> off((size_t)N);
-        return grid_step(N, w, lnw.data(), step, off.data());
+        return grid_step(N, w, lnw.data(), step) ? 1 : 0;
     });
 }
 double bisip_ctx_loglike_const(const bisip_ctx *c) { return c ? c->lconst : NAN; }

@@ -536,39 +536,21 @@ double reduced_logp_reference(int n, const std::vector<long double> &Rl, const s
     return (double)(-0.5L * reduced_chi2_exact(n, Rl, qty, rest, theta) + (ld)lconst);
 }
 
-int grid_step(int N, const double *w, const double *lnw, double *dlnw, double *off)
+bool grid_step(int N, const double *w, const double *lnw, double *dlnw)
 {
     *dlnw = 0.0;
-    for (int j = 0; j < N; ++j) off[j] = 0.0;
-    if (N < 8) return 0;
+    if (N < 8) return false;
     for (int j = 0; j < N; ++j)
-        if (!(w[j] > 0.0) || !std::isfinite(w[j])) return 0;
-    std::vector<ld> lw((size_t)N);
-    for (int j = 0; j < N; ++j) lw[(size_t)j] = logl((ld)w[j]);
-    // worst distance of a frequency from the grid of step d whose blocks start at the rounded ln w_{4k}
-    auto worst = [&](double d) {
-        ld m = 0.0L;
-        for (int j = 0; j < N; ++j) {
-            const ld dist = fabsl(lw[(size_t)j] - ((ld)lnw[j & ~3] + (ld)(j & 3) * (ld)d));
-            if (!(dist <= m)) m = dist;
-        }
-        return m;
-    };
-    const double ends = (double)((lw[(size_t)N - 1] - lw[0]) / (ld)(N - 1));
-    if (std::isfinite(ends) && ends != 0.0 && worst(ends) <= 4e-15L) {
-        *dlnw = ends;
-        return 1;
+        if (!(w[j] > 0.0) || !std::isfinite(w[j])) return false;
+    const ld first = logl((ld)w[0]), step = (logl((ld)w[N - 1]) - first) / (ld)(N - 1);
+    const double d = (double)step;
+    if (!std::isfinite(d) || d == 0.0) return false;
+    for (int j = 0; j < N; ++j) {
+        const ld want = logl((ld)w[j]), got = (ld)lnw[j & ~3] + (ld)(j & 3) * (ld)d;
+        if (!(fabsl(want - got) <= 4e-15L)) return false;
     }
-    // rounded files: the median step is the instrument's, whatever a few entries do
-    std::vector<double> steps((size_t)N - 1);
-    for (int j = 0; j + 1 < N; ++j) steps[(size_t)j] = (double)(lw[(size_t)j + 1] - lw[(size_t)j]);
-    std::nth_element(steps.begin(), steps.begin() + (N - 1) / 2, steps.end());
-    const double med = steps[(size_t)(N - 1) / 2];
-    if (!std::isfinite(med) || med == 0.0 || !(worst(med) <= 0.012L)) return 0;
-    *dlnw = med;
-    for (int j = 0; j < N; ++j)
-        if (j & 3) off[j] = (double)(lw[(size_t)j] - ((ld)lnw[j & ~3] + (ld)(j & 3) * (ld)med));
-    return 2;
+    *dlnw = d;
+    return true;
 }
 
 int host_threads()

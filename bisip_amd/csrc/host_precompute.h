@@ -84,13 +84,11 @@ double reduced_logp_reference(int n, const std::vector<long double> &Rl, const s
 // -0.5 * sum_i 2*ln(zn_err_i^2), the walker-independent term of src/bisip/models.py:62
 double loglike_const(int n2, const double *zn_err);
 
-// Geometric frequency grid (kernels.h: BOUNDS_GRID, BOUNDS_GRID_FIX), N >= 8, in blocks of four frequencies
-// that start at the ROUNDED values lnw[4k] the kernels hold (ln w_f itself taken in long double):
-//   1  ln w_{4k+q} = lnw[4k] + q * dlnw to 4e-15, dlnw = (ln w_{N-1} - ln w_0)/(N-1)         (off[] = 0)
-//   2  the same to 0.012 with dlnw = the median step; off[4k+q] = the frequency's distance from its grid
-//      point in ln w (q = 1..3; 0 at q = 0)                       -- rounded instrument grids
-//   0  neither (*dlnw = 0, off[] = 0)
-int grid_step(int N, const double *w, const double *lnw, double *dlnw, double *off);
+// Geometric frequency grid (kernels.h: BOUNDS_GRID): true when, in blocks of four frequencies,
+// ln w_{4k+q} = lnw[4k] + q * dlnw to 4e-15 -- lnw[] the ROUNDED values the kernels hold, ln w_f on the left
+// in long double -- for the common step dlnw = (ln w_{N-1} - ln w_0)/(N-1); N >= 8.  *dlnw is set either way
+// (0 when there is no such grid).
+bool grid_step(int N, const double *w, const double *lnw, double *dlnw);
 
 // ln(w_j) and 1/sigma^2 rounded from long double
 void common_operands(int N, const double *w, const double *zn_err, std::vector<double> &lnw,

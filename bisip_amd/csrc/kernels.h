@@ -41,11 +41,6 @@ constexpr int BOUNDS_FAST = 1;
 // every record holds dlnw).  The exponentials of the per-frequency models are then taken once per block of
 // four frequencies and stepped by multiplication (GridSteps below).
 constexpr int BOUNDS_GRID = 2;
-// BOUNDS_GRID_FIX (instead of BOUNDS_GRID): a grid to 0.012 only -- field instruments step their frequencies
-// geometrically and the files round them (the bundled spectra: 6 kHz halved nineteen times, to six digits,
-// 188.9 Hz for 187.5).  rec[7] of the records 4k+1..4k+3 then holds their distance from the grid in ln w and
-// the stepped exponentials are corrected by 2^(a off) (exp2_small); rec[7] of the records 4k holds dlnw.
-constexpr int BOUNDS_GRID_FIX = 4;
 // The safe loop clamps the exponent y of 2^y = |(i w tau)^c| (ColeCole) or Q w^n (Shin) at 500: beyond,
 // 2^y squared would overflow, the denominator become inf and rcp_nr(inf) NaN where the reference's term
 // quietly vanishes (a round-2 defect that boxes with c up to 22 and more exposed).  It takes one
@@ -745,30 +740,14 @@ __device__ __forceinline__ void grid_base(const typename M::Setup &s, double lnw
     exp2_finite_n<M::NEXP>(y, base);
 }
 
-// 2^u for |u ln 2| <= 0.012: the Taylor polynomial of degree 6 (next term 2e-18)
-__device__ __forceinline__ double exp2_small(double u)
-{
-    double p = 0x1.430912f86c786p-13;
-    p = fma(p, u, 0x1.5d87fe78a6730p-10);
-    p = fma(p, u, 0x1.3b2ab6fba4e77p-7);
-    p = fma(p, u, 0x1.c6b08d704a0bfp-5);
-    p = fma(p, u, 0x1.ebfbdff82c58ep-3);
-    p = fma(p, u, 0x1.62e42fefa39efp-1);
-    return fma(p, u, 1.0);
-}
-
-// exponentials of step Q (compile time) of a block.  FIX (BOUNDS_GRID_FIX): the frequency lies `off` away
-// from the grid in ln w (|off| <= 0.012; rec[7] of its record), a factor 2^(a_i off) by exp2_small: nine
-// instructions instead of the sixteen of a full exponential.  Step 0 is the block's own exponential.
-template <class M, int Q, bool FIX>
-__device__ __forceinline__ void grid_at(const typename M::Setup &s, const GridSteps<M> &g,
-                                        const double (&base)[M::NEXP], double off, double *e)
+// exponentials of step Q (compile time) of a block
+template <class M, int Q>
+__device__ __forceinline__ void grid_at(const GridSteps<M> &g, const double (&base)[M::NEXP], double *e)
 {
 #pragma unroll
     for (int i = 0; i < M::NEXP; ++i) {
         if constexpr (Q == 0) e[i] = base[i];
-        else if constexpr (!FIX) e[i] = base[i] * g.S[Q - 1][i];
-        else e[i] = (base[i] * g.S[Q - 1][i]) * exp2_small(M::exp_a(s, i) * off);
+        else e[i] = base[i] * g.S[Q - 1][i];
     }
 }
 
@@ -926,9 +905,27 @@ __device__ __forceinline__ void logprob_sums(const typename M::Setup &s, const M
     }
 }
 
+// One step of the travelling sums for a lane that holds FOUR residuals (a block): as rotate_sums, term by
+// term -- lane STEP's four terms are added in ascending frequency and every lane adopts the result.
+template <int L, int STEP>
+__device__ __forceinline__ void rotate_block_sums(const double (&rr)[4], const double (&ri)[4],
+                                                  const double (&iv)[4][2], int jb, int N, double &acc0,
+                                                  double &acc1)
+{
+    if constexpr (STEP < L) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const double c0 = fma(rr[q] * rr[q], iv[q][0], acc0), c1 = fma(ri[q] * ri[q], iv[q][1], acc1);
+            const double n0 = group_broadcast<STEP, L>(c0), n1 = group_broadcast<STEP, L>(c1);
+            if (jb + 4 * STEP + q < N) { acc0 = n0; acc1 = n1; }   // uniform inside the group
+        }
+        rotate_block_sums<L, STEP + 1>(rr, ri, iv, jb, N, acc0, acc1);
+    }
+}
+
 // The same sums on a geometric frequency grid (BOUNDS_GRID; the host guarantees N >= 8 and BOUNDS_FAST):
 // one loop per lane layout as above, the exponentials from grid_base / grid_at instead of one exp2 each.
-template <class M, int L, bool LDSREC, bool FIX>
+template <class M, int L, bool LDSREC>
 __device__ __forceinline__ void logprob_sums_grid(const typename M::Setup &s, const ModelOperands &o, const int g,
                                                   double &acc0, double &acc1)
 {
@@ -952,11 +949,11 @@ __device__ __forceinline__ void logprob_sums_grid(const typename M::Setup &s, co
             double e[2 * NE], rr[2], ri[2];
             if constexpr (!decltype(second)::value) {
                 grid_base<M>(s, cur[5], base);
-                grid_at<M, 0, FIX>(s, gs, base, 0.0, e);
-                grid_at<M, 1, FIX>(s, gs, base, cur[REC + 7], e + NE);
+                grid_at<M, 0>(gs, base, e);
+                grid_at<M, 1>(gs, base, e + NE);
             } else {
-                grid_at<M, 2, FIX>(s, gs, base, cur[7], e);
-                grid_at<M, 3, FIX>(s, gs, base, cur[REC + 7], e + NE);
+                grid_at<M, 2>(gs, base, e);
+                grid_at<M, 3>(gs, base, e + NE);
             }
             const double *const r2[2] = {cur, cur + REC};
             M::template residual_from_exp<2, true>(s, r2, e, rr, ri);
@@ -980,8 +977,8 @@ __device__ __forceinline__ void logprob_sums_grid(const typename M::Setup &s, co
         if (tail_pair) pair(std::false_type{});
         if (j < o.N) {                          // one frequency left: step 0 or step 2 of its block
             double e[NE], rr[1], ri[1];
-            if (tail_pair) grid_at<M, 2, FIX>(s, gs, base, rec[7], e);
-            else { grid_base<M>(s, rec[5], base); grid_at<M, 0, FIX>(s, gs, base, 0.0, e); }
+            if (tail_pair) grid_at<M, 2>(gs, base, e);
+            else { grid_base<M>(s, rec[5], base); grid_at<M, 0>(gs, base, e); }
             const double *const r1[1] = {rec};
             M::template residual_from_exp<1, true>(s, r1, e, rr, ri);
             acc0 = fma(rr[0] * rr[0], rec[2], acc0);
@@ -993,7 +990,7 @@ __device__ __forceinline__ void logprob_sums_grid(const typename M::Setup &s, co
         double base[NE];
         auto one = [&](auto Q, const double *__restrict__ r) {
             double e[NE], rr[1], ri[1];
-            grid_at<M, decltype(Q)::value, FIX>(s, gs, base, r[7], e);
+            grid_at<M, decltype(Q)::value>(gs, base, e);
             const double *const r1[1] = {r};
             M::template residual_from_exp<1, true>(s, r1, e, rr, ri);
             acc0 = fma(rr[0] * rr[0], r[2], acc0);
@@ -1014,37 +1011,33 @@ __device__ __forceinline__ void logprob_sums_grid(const typename M::Setup &s, co
             if (j + 2 < o.N) one(std::integral_constant<int, 2>{}, rec + 2 * REC);
         }
     } else {
-        // L lanes per walker: lane g takes frequency j0 + g.  Its step inside the block of four is g (L = 4),
-        // or g and 2 + g in turn (L = 2); the block's exponential is taken by every lane (as before: one
-        // exponential per lane and round), the step is one more multiplication -- by 1.0 at step 0, exact.
+        // L lanes per walker: lane g takes BLOCK jb/4 + g of every group of L blocks -- its own exponential,
+        // three steps, four residuals with independent dependency chains (these launches run one wave per
+        // SIMD or less: chains, not instruction counts, are what they wait for) -- and the sums then travel
+        // through the group block by block, term by term: the additions of the L = 1 loop in its order.
+        // (One frequency per lane and round, as logprob_sums does it, would have every lane take the block's
+        // exponential AND the step: slower than no grid at all -- measured, micro/grid_small_ensembles.py.)
         const GridSteps<M> gs = grid_steps<M>(s, o.cb[7]);
-        double mul_a[NE], mul_b[NE];
-#pragma unroll
-        for (int i = 0; i < NE; ++i) {
-            if constexpr (L == 4) {
-                mul_a[i] = g == 0 ? 1.0 : (g == 1 ? gs.S[0][i] : (g == 2 ? gs.S[1][i] : gs.S[2][i]));
-                mul_b[i] = mul_a[i];
-            } else {
-                mul_a[i] = g == 0 ? 1.0 : gs.S[0][i];
-                mul_b[i] = g == 0 ? gs.S[1][i] : gs.S[2][i];
-            }
-        }
-        for (int j0 = 0; j0 < o.N; j0 += L) {
-            const int j = (j0 + g < o.N) ? j0 + g : o.N - 1;   // clamp: its result is never adopted
-            const double *__restrict__ rec = o.cb + (long long)j * REC;
-            double base[NE], e[NE], rr[1], ri[1];
-            grid_base<M>(s, o.cb[(long long)(j0 & ~3) * REC + 5], base);
-            const bool second = (L == 2) && (j0 & 2);
-#pragma unroll
-            for (int i = 0; i < NE; ++i) e[i] = base[i] * (second ? mul_b[i] : mul_a[i]);
-            if constexpr (FIX) {
-                const double off = (g == 0 && !second) ? 0.0 : rec[7];     // step 0 holds the grid's step there
-#pragma unroll
-                for (int i = 0; i < NE; ++i) e[i] *= exp2_small(M::exp_a(s, i) * off);
-            }
-            const double *const r1[1] = {rec};
-            M::template residual_from_exp<1, true>(s, r1, e, rr, ri);
-            rotate_sums<M, L, 0>(rr[0], ri[0], rec, j0, o.N, acc0, acc1);
+        const int last = o.N - 1;
+        for (int jb = 0; jb < o.N; jb += 4 * L) {
+            const int j4 = (jb + 4 * g < o.N) ? jb + 4 * g : (last & ~3);   // clamp: its results are never adopted
+            double base[NE], rr[4], ri[4], iv[4][2];
+            grid_base<M>(s, o.cb[(long long)j4 * REC + 5], base);
+            auto one = [&](auto Q) {
+                constexpr int q = decltype(Q)::value;
+                const int j = (j4 + q <= last) ? j4 + q : last;
+                const double *__restrict__ rec = o.cb + (long long)j * REC;
+                double e[NE], r1r[1], r1i[1];
+                grid_at<M, q>(gs, base, e);
+                const double *const r1[1] = {rec};
+                M::template residual_from_exp<1, true>(s, r1, e, r1r, r1i);
+                rr[q] = r1r[0]; ri[q] = r1i[0]; iv[q][0] = rec[2]; iv[q][1] = rec[3];
+            };
+            one(std::integral_constant<int, 0>{});
+            one(std::integral_constant<int, 1>{});
+            one(std::integral_constant<int, 2>{});
+            one(std::integral_constant<int, 3>{});
+            rotate_block_sums<L, 0>(rr, ri, iv, jb, o.N, acc0, acc1);
         }
     }
 }
@@ -1058,8 +1051,7 @@ __device__ __forceinline__ double logprob_row(const double (&th)[M::NDIM], const
     const typename M::Setup s = M::setup(th);
     double acc0 = 0.0, acc1 = 0.0;
     if constexpr (M::HAS_FAST) {
-        if (b.flags & BOUNDS_GRID_FIX) logprob_sums_grid<M, L, LDSREC, true>(s, o, g, acc0, acc1);
-        else if (b.flags & BOUNDS_GRID) logprob_sums_grid<M, L, LDSREC, false>(s, o, g, acc0, acc1);
+        if (b.flags & BOUNDS_GRID) logprob_sums_grid<M, L, LDSREC>(s, o, g, acc0, acc1);
         else if (b.flags & BOUNDS_FAST) logprob_sums<M, L, LDSREC, true>(s, o, g, acc0, acc1);
         else logprob_sums<M, L, LDSREC, false>(s, o, g, acc0, acc1);
     } else {

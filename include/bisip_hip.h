@@ -382,15 +382,13 @@ int bisip_ctx_nfreq(const bisip_ctx *ctx);
 int bisip_ctx_device(const bisip_ctx *ctx);
 /* Which loop the per-frequency models (ColeCole, Shin) run for the current prior box and frequencies; bits:
  *   1  shared reciprocals, exponents unclamped: the box keeps every denominator product normal;
- *   2  (with 1) geometric frequency grid: every spectrum's ln w_{4k+q} = ln w_{4k} + q*step to 4e-15, so the
- *      exponentials are taken once per block of four frequencies and stepped by multiplication;
- *   4  (with 1, instead of 2) a grid to 0.012 only -- instrument grids rounded in the files, like the bundled
- *      spectra: the stepped exponentials are corrected by a short series in the distance from the grid.
- * The environment variable BISIP_NO_GRID, read when a context is created, switches bits 2 and 4 off
- * (measurement aid).  0 for the other models and for boxes widened past the limits. */
+ *   2  (only with 1) geometric frequency grid: every spectrum's ln w_{4k+q} = ln w_{4k} + q*step to 4e-15
+ *      (bisip_frequency_grid_step), so the exponentials are taken once per block of four frequencies and
+ *      stepped by multiplication.  The environment variable BISIP_NO_GRID, read when a context is created,
+ *      switches bit 2 off (measurement aid).
+ * 0 for the other models and for boxes widened past the limits. */
 int bisip_ctx_loop_flags(const bisip_ctx *ctx);
-/* Host-only: which of the two w[0..N) is (N >= 8): 1 = a grid to 4e-15, 2 = to 0.012, 0 = neither;
- * *step = the step of ln w (0 when neither). */
+/* Host-only: 1 and *step = the common step of ln w when w[0..N) is such a grid (N >= 8), else 0 and *step = 0. */
 int bisip_frequency_grid_step(int N, const double *w, double *step);
 /* Walker-independent part of the log-likelihood, -0.5*sum(2*ln(sigma^2)). */
 double bisip_ctx_loglike_const(const bisip_ctx *ctx);

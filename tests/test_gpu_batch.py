@@ -156,21 +156,19 @@ def test_batch_persistent_equals_launch_path():
 @pytest.mark.parametrize('n_freq', [8, 9, 10, 11, 21])
 def test_persistent_kernel_steps_a_geometric_grid_like_the_launches_do(n_freq):
     """The persistent kernel reads a spectrum's records from LDS two frequencies at a time; on a geometric
-    grid a block of four frequencies is two such pairs (kernels.h: logprob_sums_grid).  Every block tail --
-    a single frequency after a full block, a pair, a pair and a single -- gives the bits of the launch path."""
+    grid a block of four frequencies is two such pairs, and with several lanes per walker each lane takes
+    whole blocks (kernels.h: logprob_sums_grid).  Every block tail -- a single frequency after a full block,
+    a pair, a pair and a single -- and every ensemble size (1, 2, 4 lanes per walker) gives the bits of the
+    launch path."""
     import bisip_amd
     from bisip_amd.sampler import DeviceEnsembleSampler
     for model, kw, centre in [('PeltonColeCole', dict(n_modes=2), [1.0, 0.15, 0.5, -1.5, -12.0, 0.45, 0.6]),
                               ('PeltonColeCole', dict(n_modes=1), [1.0, 0.3, -3.0, 0.5]),
                               ('Shin2015', {}, [0.5, 0.5, -14.0, -6.0, 0.5, 0.5])]:
-        for rounded in (False, True):
-            E, Wp, ndim = 3, 64, len(centre)
-            tables = _tables(E, n_freq)
-            if rounded:          # frequencies as a file would hold them: the stepped-and-corrected loop
-                for t in tables:
-                    t[:, 0] = np.array([float('%.4g' % f) for f in t[:, 0]])
-            batch = bisip_amd.SpectraBatch(model, tables, nwalkers=Wp, nsteps=8, **kw)
-            assert batch.ctx.loop_flags == (5 if rounded else 3)
+        for E, Wp in ((3, 64), (2, 256), (1, 32), (1, 512)):
+            ndim = len(centre)
+            batch = bisip_amd.SpectraBatch(model, _tables(E, n_freq), nwalkers=Wp, nsteps=8, **kw)
+            assert batch.ctx.loop_flags == 3
             rng = np.random.RandomState(n_freq)
             p0 = (np.array(centre) + 1e-4 * rng.randn(E, Wp, ndim)).reshape(E * Wp, ndim)
             chains = []
@@ -181,6 +179,10 @@ def test_persistent_kernel_steps_a_geometric_grid_like_the_launches_do(n_freq):
             assert chains[0][2] == 'persistent' and chains[1][2] == 'launch-per-half-step'
             assert np.array_equal(chains[0][0], chains[1][0]) and np.array_equal(chains[0][1], chains[1][1])
             assert np.isfinite(chains[0][1]).all()
+            # and the bulk launch (one lane per walker) gives those bits too
+            last = chains[0][0][-1].reshape(E * Wp, ndim)
+            lp = batch.ctx.logprob(np.tile(last.reshape(E, Wp, ndim), (1, 40, 1)).reshape(-1, ndim))
+            assert np.array_equal(lp.reshape(E, -1)[:, :Wp].ravel(), chains[0][1][-1].ravel())
 
 
 # ----------------------------------------------------------------------------------

@@ -1179,7 +1179,7 @@ def test_grid_stepped_exponentials_agree_with_direct_ones_and_with_the_oracle(n_
     from bisip_amd import _hip
     from bisip_amd.batch import default_params
     d = _synthetic_problem(n_freq, 2)
-    assert _hip.frequency_grid_step(d['w'])[0] == 1
+    assert _hip.frequency_grid_step(d['w']) is not None
     rng = np.random.RandomState(n_freq)
     for name, mid, kw in (('PeltonColeCole', 1, dict(n_modes=1)), ('PeltonColeCole', 1, dict(n_modes=2)),
                           ('PeltonColeCole', 1, dict(n_modes=5)), ('Shin2015', 3, {})):
@@ -1206,53 +1206,28 @@ def test_grid_stepped_exponentials_agree_with_direct_ones_and_with_the_oracle(n_
         assert np.max(np.abs(got[True] - got[False]) / np.maximum(1.0, np.abs(got[False]))) <= 2e-11
 
 
-def test_grid_loops_follow_the_frequencies_and_the_box(monkeypatch):
-    """The stepped loops run only where their premises hold.  Exact geometric grids: flags 3.  The bundled
-    spectra (frequencies halved from 6 kHz and then rounded in the files: 188.9 Hz for 187.5) and a jittered
-    grid: the stepped-and-corrected loop, flags 5, within the parity tolerance of the oracle like the loop
-    with one exponential per frequency (BISIP_NO_GRID=1), and the same bits from launches of every size.
-    A 1-2-5 sequence: one exponential per frequency.  A box widened past the shared-reciprocal limits: the
-    safe loop, and set_bounds switches with the box.  A batch runs the exact loop only if every spectrum is
-    on an exact grid."""
+def test_grid_loop_needs_the_grid_and_the_default_box():
+    """The stepped loop runs only where its premises hold: the bundled spectra (frequencies halved from
+    6 kHz and then rounded in the files: 188.9 Hz for 187.5), a jittered grid and a 1-2-5 sequence keep one
+    exponential per frequency (a series correction for rounded grids was built and measured: 1.1x in bulk
+    launches, 0.7-0.9x on the ensembles of 32-256 walkers such spectra are fitted with -- not kept); so
+    does a box widened past the shared-reciprocal limits, and set_bounds switches with the box.  A batch
+    runs the stepped loop only if every spectrum is on a grid (each on its own)."""
     import bisip_amd
-    import oracle
     from bisip_amd import _hip
     from bisip_amd.batch import default_params
     from bisip_amd.synthetic import synthetic_columns
-    from bisip_amd.utils import columns_to_data, load_data
-    rng = np.random.RandomState(3)
-    rounded = synthetic_columns(30, 4)
-    rounded[:, 0] = np.array([float('%.4g' % f) for f in rounded[:, 0]])
-    for d in [load_data(bisip_amd.DataFiles()[name]) for name in ('SIP-K389175', 'SIP-K389172')] + [columns_to_data(rounded, 'mrad')]:
-        for name, mid, kw in (('PeltonColeCole', 1, dict(n_modes=1)), ('PeltonColeCole', 1, dict(n_modes=2)),
-                              ('PeltonColeCole', 1, dict(n_modes=3)), ('Shin2015', 3, {})):
-            bounds = np.array(list(default_params(name, **kw).values()), float).T
-            theta = rng.uniform(bounds[0], bounds[1], (100000, bounds.shape[1]))
-            got = {}
-            for grid in (True, False):
-                if grid:
-                    monkeypatch.delenv('BISIP_NO_GRID', raising=False)
-                else:
-                    monkeypatch.setenv('BISIP_NO_GRID', '1')
-                ctx = _hip.HipContext(mid, d['w'], d['zn'], d['zn_err'], bounds, **kw)
-                assert ctx.loop_flags == (5 if grid else 1)
-                got[grid] = ctx.logprob(theta)
-                for rows in (100, 6000):
-                    assert np.array_equal(ctx.logprob(theta[:rows]), got[grid][:rows]), (name, kw, rows, grid)
-                ctx.close()
-            monkeypatch.delenv('BISIP_NO_GRID', raising=False)
-            prob = oracle.OracleProblem(name, d['w'], d['zn'], d['zn_err'], bounds, **kw)
-            want = oracle.logprob(prob, theta[:3000], n_threads=4)
-            scale = np.maximum(1.0, np.abs(want))
-            assert np.max(np.abs(got[True][:3000] - want) / scale) <= 1e-10
-            assert np.max(np.abs(got[False][:3000] - want) / scale) <= 1e-10
-            assert np.max(np.abs(got[True] - got[False]) / np.maximum(1.0, np.abs(got[False]))) <= 2e-11
+    from bisip_amd.utils import load_data
     bounds = np.array(list(default_params('PeltonColeCole', n_modes=2).values()), float).T
+    real = load_data(bisip_amd.DataFiles()['SIP-K389175'])
+    ctx = _hip.HipContext(1, real['w'], real['zn'], real['zn_err'], bounds, n_modes=2)
+    assert ctx.loop_flags == 1
+    ctx.close()
     d = _synthetic_problem(32, 0)
     w = d['w'].copy()
     w[17] *= 1.0 + 3e-14
     ctx = _hip.HipContext(1, w, d['zn'], d['zn_err'], bounds, n_modes=2)
-    assert ctx.loop_flags == 5
+    assert ctx.loop_flags == 1
     ctx.close()
     w125 = 2 * np.pi * np.outer(10.0 ** np.arange(-2, 6), [1.0, 2.0, 5.0]).ravel()
     d125 = _synthetic_problem(24, 0)
@@ -1273,9 +1248,5 @@ def test_grid_loops_follow_the_frequencies_and_the_box(monkeypatch):
     assert batch.ctx.loop_flags == 3
     tables[1] = tables[1].copy()
     tables[1][5, 0] *= 1.0 + 1e-9
-    batch = bisip_amd.SpectraBatch('PeltonColeCole', tables, nwalkers=32, nsteps=2, n_modes=2)
-    assert batch.ctx.loop_flags == 5
-    tables[2] = tables[2].copy()
-    tables[2][9, 0] *= 1.05
     batch = bisip_amd.SpectraBatch('PeltonColeCole', tables, nwalkers=32, nsteps=2, n_modes=2)
     assert batch.ctx.loop_flags == 1

@@ -343,35 +343,27 @@ def test_estimate_finds_a_shell_patch_that_random_draws_miss():
 
 def test_geometric_frequency_grids_are_recognised():
     """bisip_frequency_grid_step: the premise of the stepped exponentials of ColeCole / Shin (kernels.h:
-    BOUNDS_GRID, BOUNDS_GRID_FIX).  np.logspace grids of any direction and exact halvings are grids to
-    rounding (tier 1), with the step of ln w; a frequency moved by 1e-14 ... 1e-2 of itself leaves a grid to
-    0.012 (tier 2, the median step) -- as the bundled field spectra are, halved from 6 kHz and rounded in the
-    files; fewer than 8 frequencies, a 1-2-5 sequence, equal or non-positive frequencies are neither."""
+    BOUNDS_GRID).  np.logspace grids of any direction and exact halvings qualify, with the step of ln w;
+    fewer than 8 frequencies, a frequency moved by 1e-14 of itself, a 1-2-5 sequence and the bundled field
+    spectra (halved from 6 kHz, then rounded in the files) do not."""
     import bisip_amd
     from bisip_amd import _hip
     from bisip_amd.utils import load_data
     for n in (8, 9, 20, 32, 33, 64, 200):
         w = 2 * np.pi * np.logspace(-2, 4, n)
-        tier, step = _hip.frequency_grid_step(w)
-        assert tier == 1 and abs(step - np.log(1e6) / (n - 1)) < 1e-14
-        tier, back = _hip.frequency_grid_step(w[::-1].copy())
-        assert tier == 1 and abs(back + step) < 1e-14
-        for rel in (1e-14, 1e-6, 1e-2):
-            moved = w.copy()
-            moved[n // 2] *= 1.0 + rel
-            tier, med = _hip.frequency_grid_step(moved)
-            assert tier == 2 and abs(med - step) < 1e-13
-        moved[n // 2] = w[n // 2] * 1.02
-        assert _hip.frequency_grid_step(moved)[0] == 0
-    tier, step = _hip.frequency_grid_step(2 * np.pi * 6000.0 / 2.0 ** np.arange(20))
-    assert tier == 1 and abs(step + np.log(2.0)) < 1e-15
-    assert _hip.frequency_grid_step(2 * np.pi * np.logspace(-2, 4, 7)) == (0, 0.0)
-    assert _hip.frequency_grid_step(np.ones(16))[0] == 0                   # step 0: not a grid
-    assert _hip.frequency_grid_step(np.r_[np.logspace(0, 3, 15), -1.0])[0] == 0
-    assert _hip.frequency_grid_step(np.outer(10.0 ** np.arange(4), [1.0, 2.0, 5.0]).ravel())[0] == 0
+        step = _hip.frequency_grid_step(w)
+        assert step is not None and abs(step - np.log(1e6) / (n - 1)) < 1e-14
+        assert abs(_hip.frequency_grid_step(w[::-1].copy()) + step) < 1e-14
+        moved = w.copy()
+        moved[n // 2] *= 1.0 + 1e-14
+        assert _hip.frequency_grid_step(moved) is None
+    assert abs(_hip.frequency_grid_step(2 * np.pi * 6000.0 / 2.0 ** np.arange(20)) + np.log(2.0)) < 1e-15
+    assert _hip.frequency_grid_step(2 * np.pi * np.logspace(-2, 4, 7)) is None
+    assert _hip.frequency_grid_step(np.ones(16)) is None                   # step 0: not a grid
+    assert _hip.frequency_grid_step(np.r_[np.logspace(0, 3, 15), -1.0]) is None
+    assert _hip.frequency_grid_step(np.outer(10.0 ** np.arange(4), [1.0, 2.0, 5.0]).ravel()) is None
     for name, path in bisip_amd.DataFiles().items():
-        tier, step = _hip.frequency_grid_step(load_data(path)['w'])
-        assert tier == 2 and abs(step + np.log(2.0)) < 1e-5, name
+        assert _hip.frequency_grid_step(load_data(path)['w']) is None, name
 
 
 def test_reduced_yardstick_is_pinned_by_fifty_digit_arithmetic():
