@@ -40,6 +40,21 @@ static void operands(int N, int S, int D, double c_exp)
     bisip::common_operands(N, w.data(), err.data(), lnw, iv);
     EXPECT((int)lnw.size() == N && (int)iv.size() == 2 * N);
     EXPECT(std::isfinite(bisip::loglike_const(2 * N, err.data())));
+    // geometric-grid detection (kernels.h: BOUNDS_GRID): whatever w is, dlnw is set; a log-spaced list of
+    // >= 8 frequencies qualifies, the same list with one entry moved or fewer entries does not
+    double dlnw = -1.0;
+    const bool as_given = bisip::grid_step(N, w.data(), lnw.data(), &dlnw);
+    EXPECT(std::isfinite(dlnw) && (as_given || dlnw == 0.0));
+    std::vector<double> geo((size_t)(N > 0 ? N : 1)), lg;
+    for (int j = 0; j < N; ++j) geo[(size_t)j] = 0.07 * std::pow(1.7, j);
+    bisip::common_operands(N, geo.data(), err.data(), lg, iv);
+    EXPECT(bisip::grid_step(N, geo.data(), lg.data(), &dlnw) == (N >= 8));
+    if (N >= 8) {
+        EXPECT(std::fabs(dlnw - std::log(1.7)) < 1e-14);
+        geo[(size_t)N / 2] *= 1.0001;
+        bisip::common_operands(N, geo.data(), err.data(), lg, iv);
+        EXPECT(!bisip::grid_step(N, geo.data(), lg.data(), &dlnw) && dlnw == 0.0);
+    }
 }
 
 static void stream(int64_t W, int64_t n_steps)
