@@ -171,16 +171,16 @@ __device__ __forceinline__ double exp2_finite(double y)
 
 constexpr double LOG2E = 0x1.71547652b82fep+0;
 
-// 1/x for normal x with a normal reciprocal: hardware estimate + two Newton steps
-// (5 instructions instead of the 10 of an IEEE division; <= 1 ulp).  Every caller's
-// argument is |1 + z|^2-like and bounded away from 0 (see the model comments).
+// 1/x for normal x with a normal reciprocal: hardware estimate r (2^-24.4 on gfx950) and ONE cubic step,
+// 1/x = r (1 + e + e^2 + ...) with e = 1 - x r: three FMAs, the neglected e^3 is 1e-22.  <= 1.00 ulp over 4M
+// doubles, the same as two Newton steps (four FMAs, a chain one longer): benchmarks/micro/rcp_accuracy.hip.
+// 4 instructions instead of the 10 of an IEEE division.  Every caller's argument is |1 + z|^2-like and
+// bounded away from 0 (see the model comments).
 __device__ __forceinline__ double rcp_nr(double x)
 {
-    double r = __builtin_amdgcn_rcp(x);
-    double e = fma(-x, r, 1.0);
-    r = fma(r, e, r);
-    e = fma(-x, r, 1.0);
-    return fma(r, e, r);
+    const double r = __builtin_amdgcn_rcp(x);
+    const double e = fma(-x, r, 1.0);
+    return fma(r, fma(e, e, e), r);
 }
 
 // K independent values in lockstep: every Horner / Newton step is issued for all K before the
@@ -214,16 +214,14 @@ __device__ __forceinline__ void rcp_nr_n(const double (&x)[K], double (&r)[K])
 #pragma unroll
     for (int k = 0; k < K; ++k) e[k] = fma(-x[k], r[k], 1.0);
 #pragma unroll
-    for (int k = 0; k < K; ++k) r[k] = fma(r[k], e[k], r[k]);
-#pragma unroll
-    for (int k = 0; k < K; ++k) e[k] = fma(-x[k], r[k], 1.0);
+    for (int k = 0; k < K; ++k) e[k] = fma(e[k], e[k], e[k]);
 #pragma unroll
     for (int k = 0; k < K; ++k) r[k] = fma(r[k], e[k], r[k]);
 }
 
 // 1/x_k for K values from ONE reciprocal of their product (Montgomery's trick): 3(K-1)
 // multiplications + rcp_nr instead of K rcp_nr.  v_rcp_f64 issues at a quarter of the FMA rate, so a
-// reciprocal costs 8 issue slots and a pair by this route 11 instead of 16.  F independent groups
+// reciprocal costs 7 issue slots and a pair by this route 10 instead of 14.  F independent groups
 // (one per frequency) run in lockstep.  The caller guarantees that products of K arguments stay
 // normal (BOUNDS_FAST).  Groups are always formed WITHIN one frequency, in every kernel, so a
 // walker's value does not depend on which kernel evaluated it.
