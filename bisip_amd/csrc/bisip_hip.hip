@@ -155,7 +155,8 @@ static int bound_flags(const bisip_ctx *c)
         return 0;
     }
     if (!(ok && ymax <= YMAX)) return 0;
-    return c->grid_ok ? (BOUNDS_FAST | BOUNDS_GRID) : BOUNDS_FAST;
+    const int terms = c->model_id == BISIP_MODEL_COLECOLE ? c->D : 2;
+    return c->grid_ok && terms <= GRID_MAX_TERMS ? (BOUNDS_FAST | BOUNDS_GRID) : BOUNDS_FAST;
 }
 
 // PolynomialDecomposition, reduced form: (re)choose the expansion point bhat for the current

@@ -41,6 +41,7 @@ constexpr int BOUNDS_FAST = 1;
 // every record holds dlnw).  The exponentials of the per-frequency models are then taken once per block of
 // four frequencies and stepped by multiplication (GridSteps below).
 constexpr int BOUNDS_GRID = 2;
+constexpr int GRID_MAX_TERMS = 3;     // ColeCole with up to three modes, Shin (two elements)
 // The safe loop clamps the exponent y of 2^y = |(i w tau)^c| (ColeCole) or Q w^n (Shin) at 500: beyond,
 // 2^y squared would overflow, the denominator become inf and rcp_nr(inf) NaN where the reference's term
 // quietly vanishes (a round-2 defect that boxes with c up to 22 and more exposed).  It takes one
@@ -1049,8 +1050,16 @@ __device__ __forceinline__ double logprob_row(const double (&th)[M::NDIM], const
     const typename M::Setup s = M::setup(th);
     double acc0 = 0.0, acc1 = 0.0;
     if constexpr (M::HAS_FAST) {
-        if (b.flags & BOUNDS_GRID) logprob_sums_grid<M, L, LDSREC>(s, o, g, acc0, acc1);
-        else if (b.flags & BOUNDS_FAST) logprob_sums<M, L, LDSREC, true>(s, o, g, acc0, acc1);
+        // (up to three exponentials per frequency: with four or five the steps' registers push the
+        // persistent kernels into scratch -- for every loop of the kernel, not only this one; bound_flags
+        // never sets the bit for those)
+        if constexpr (M::NEXP <= GRID_MAX_TERMS) {
+            if (b.flags & BOUNDS_GRID) {
+                logprob_sums_grid<M, L, LDSREC>(s, o, g, acc0, acc1);
+                return fma(-0.5, acc0 + acc1, o.lconst);
+            }
+        }
+        if (b.flags & BOUNDS_FAST) logprob_sums<M, L, LDSREC, true>(s, o, g, acc0, acc1);
         else logprob_sums<M, L, LDSREC, false>(s, o, g, acc0, acc1);
     } else {
         logprob_sums<M, L, LDSREC, false>(s, o, g, acc0, acc1);

@@ -1182,7 +1182,7 @@ def test_grid_stepped_exponentials_agree_with_direct_ones_and_with_the_oracle(n_
     assert _hip.frequency_grid_step(d['w']) is not None
     rng = np.random.RandomState(n_freq)
     for name, mid, kw in (('PeltonColeCole', 1, dict(n_modes=1)), ('PeltonColeCole', 1, dict(n_modes=2)),
-                          ('PeltonColeCole', 1, dict(n_modes=5)), ('Shin2015', 3, {})):
+                          ('PeltonColeCole', 1, dict(n_modes=3)), ('PeltonColeCole', 1, dict(n_modes=5)), ('Shin2015', 3, {})):
         bounds = np.array(list(default_params(name, **kw).values()), float).T
         theta = rng.uniform(bounds[0], bounds[1], (200000, bounds.shape[1]))
         got = {}
@@ -1192,7 +1192,8 @@ def test_grid_stepped_exponentials_agree_with_direct_ones_and_with_the_oracle(n_
             else:
                 monkeypatch.setenv('BISIP_NO_GRID', '1')
             ctx = _hip.HipContext(mid, d['w'], d['zn'], d['zn_err'], bounds, **kw)
-            assert ctx.loop_flags == (3 if grid else 1)
+            # five modes: the steps' registers would spill in the persistent kernels; such models keep the direct loop
+            assert ctx.loop_flags == (3 if grid and kw.get('n_modes', 2) <= 3 else 1)
             got[grid] = ctx.logprob(theta)
             for rows in (100, 6000):
                 assert np.array_equal(ctx.logprob(theta[:rows]), got[grid][:rows]), (name, kw, rows, grid)
