@@ -1244,6 +1244,23 @@ def test_grid_loop_needs_the_grid_and_the_default_box():
     ctx.set_bounds(bounds)
     assert ctx.loop_flags == 3
     ctx.close()
+    # frequencies in either order (instruments write them descending: a negative step), and a sparse grid
+    # (8 frequencies over 6 decades: steps of 2 in ln w): same value as in ascending order, to rounding
+    import oracle
+    rng = np.random.RandomState(12)
+    theta = rng.uniform(bounds[0], bounds[1], (4000, 7))
+    for dd in (d, _synthetic_problem(8, 1)):
+        rev = dict(w=dd['w'][::-1].copy(), zn=dd['zn'][:, ::-1].copy(), zn_err=dd['zn_err'][:, ::-1].copy())
+        assert _hip.frequency_grid_step(rev['w']) * _hip.frequency_grid_step(dd['w']) < 0     # one of them descends
+        got = []
+        for x in (dd, rev):
+            ctx = _hip.HipContext(1, x['w'], x['zn'], x['zn_err'], bounds, n_modes=2)
+            assert ctx.loop_flags == 3
+            got.append(ctx.logprob(theta))
+            ctx.close()
+        want = oracle.logprob(oracle.OracleProblem('PeltonColeCole', rev['w'], rev['zn'], rev['zn_err'], bounds, n_modes=2), theta, n_threads=4)
+        for g in got:
+            assert np.max(np.abs(g - want) / np.maximum(1.0, np.abs(want))) <= 1e-10
     tables = [synthetic_columns(32, i) for i in range(3)]
     batch = bisip_amd.SpectraBatch('PeltonColeCole', tables, nwalkers=32, nsteps=2, n_modes=2)
     assert batch.ctx.loop_flags == 3
