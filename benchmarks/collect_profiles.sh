@@ -79,7 +79,7 @@ if [ "$what" = micro ] || [ "$what" = all ]; then
   for m in issue_latency row_latency half_step_phases forward_rows_variants grid_barrier; do
     [ -x benchmarks/micro/$m ] && step $m timeout -k 5 200 benchmarks/micro/$m > "$out/micro_$m.txt" 2>&1
   done
-  for m in collapsed_r3 exp2_variants; do
+  for m in collapsed_r3 exp2_variants rcp_accuracy; do
     [ -x benchmarks/micro/$m ] && step $m timeout -k 5 200 benchmarks/micro/$m > "$out/micro_$m.txt" 2>&1
   done
   step post_run_stall bash -c 'python3 benchmarks/micro/post_run_stall.py kernel 2>/dev/null | grep after' > "$out/micro_post_run_stall.txt"
