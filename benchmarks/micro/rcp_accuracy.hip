@@ -1,5 +1,6 @@
 // Accuracy of v_rcp_f64 on gfx950 and of the refinements built on it (kernels.h: rcp_nr), over 4M doubles
 // with exponents -200..200, against long double.
+//   hipcc -O2 --offload-arch=gfx950 -ffp-contract=off -o rcp_accuracy rcp_accuracy.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cmath>
