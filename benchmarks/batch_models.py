@@ -41,7 +41,8 @@ for model, kw, centre in MODELS:
     nd = len(centre)
     p0 = np.asarray(centre) + 1e-4 * np.random.RandomState(0).randn(E * Wp, nd)
     row = {'model': model + (f" D={kw['n_modes']}" if 'n_modes' in kw else ''), 'kernel': b.ctx.kernel_name,
-           'spectra': E, 'walkers_per_spectrum': Wp, 'iterations': stored * thin}
+           'spectra': E, 'walkers_per_spectrum': Wp, 'iterations': stored * thin,
+           'spectra_plain_comp': list(b.ctx.reduced_tiers)}
     for name, persistent in (('persistent', True), ('launch_per_half_step', False)):
         best = None
         for rep in range(3):

@@ -59,6 +59,7 @@ try:
         assert mean.shape == (E, len(centre)) and pct.shape == (3, E, len(centre)) and band.shape == (3, E, 2, 32)
         assert np.isfinite(band).all() and (band[0] <= band[2]).all()
         b_check, b_acc, b_path = b.reduced_check_, round(float(b.acceptance_fraction.mean()), 3), b._sampler.last_path
+        b_tiers = list(b.ctx.reduced_tiers)      # PolynomialDecomposition: spectra on the plain / compensated kernel
         b.close()
         if rep == 0:
             continue
@@ -68,7 +69,7 @@ try:
         out.update(ingest_and_context_s=round(t[1] - t[0], 4), fit_s=round(t[2] - t[1], 4),
                    parameter_summaries_s=round(t[3] - t[2], 4), model_bands_s=round(t[4] - t[3], 4),
                    total_s=round(t[4] - t[0], 4), walker_steps=E * Wp * stored * args.thin_by,
-                   acceptance=b_acc, path=b_path, reduced_check=b_check)
+                   acceptance=b_acc, path=b_path, reduced_check=b_check, spectra_plain_comp=b_tiers)
     out['total_s_all_passes'] = totals
     out['walker_steps_per_s_end_to_end'] = float('%.4g' % (out['walker_steps'] / out['total_s']))
     print(json.dumps(out))

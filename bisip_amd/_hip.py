@@ -123,6 +123,7 @@ SYMBOLS = {
     'bisip_ctx_nfreq': (ctypes.c_int, [ctypes.c_void_p]),
     'bisip_ctx_device': (ctypes.c_int, [ctypes.c_void_p]),
     'bisip_ctx_loop_flags': (ctypes.c_int, [ctypes.c_void_p]),
+    'bisip_ctx_reduced_tiers': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
     'bisip_frequency_grid_step': (ctypes.c_int, [ctypes.c_int, _dp, _dp]),
     'bisip_ctx_loglike_const': (ctypes.c_double, [ctypes.c_void_p]),
     'bisip_ctx_kernel_name': (ctypes.c_char_p, [ctypes.c_void_p]),
@@ -362,6 +363,14 @@ class HipContext:
     @property
     def kernel_name(self):
         return self._lib.bisip_ctx_kernel_name(self._h).decode()
+
+    @property
+    def reduced_tiers(self):
+        """PolynomialDecomposition: (spectra on the plain, spectra on the compensated QR-reduced kernel); a
+        batch on 'auto' decides per spectrum, inside one launch."""
+        a, b = ctypes.c_int64(0), ctypes.c_int64(0)
+        _check(self._lib.bisip_ctx_reduced_tiers(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return int(a.value), int(b.value)
 
     @property
     def loop_flags(self):

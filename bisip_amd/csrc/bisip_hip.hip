@@ -63,7 +63,10 @@ BatchArgs make_batch_args(const bisip_ctx *c, const double *theta, double *out, 
     BatchArgs a;
     a.theta = theta; a.out = out; a.W = W; a.Wp = W / c->E;
     a.cb = c->d_cb; a.cb_stride = c->cb_stride; a.lconst = c->d_lconst;
-    a.red = c->red[effective_variant(c) == BISIP_VARIANT_REDUCED_COMP ? 1 : 0].d_red;
+    const bool comp = effective_variant(c) == BISIP_VARIANT_REDUCED_COMP;
+    a.red = c->red[comp ? 1 : 0].d_red;
+    a.red_plain = c->red[0].d_red;
+    a.tier = comp && c->mixed ? c->d_tier : nullptr;
     a.N = c->N; a.b = c->bounds;
     return a;
 }
@@ -175,6 +178,28 @@ static bool in_prior_host(const double *th, const bisip_ctx *c)
 // the plain tier passes and the compensated one is never looked at: AUTO / REDUCED need tier 0, and
 // tier 1 when tier 0's estimate is too large; REDUCED_COMP needs tier 1.  set_variant and set_bounds come
 // back here.
+// Which spectra of a batch take the plain tier inside a compensated launch (host.h: tier_of, mixed).
+static int update_tiers(bisip_ctx *c)
+{
+    c->mixed = false;
+    if (c->E <= 1 || c->variant != BISIP_VARIANT_AUTO || c->mix_off || c->demoted[0]) return BISIP_OK;
+    if (!c->red[0].valid || !c->red[1].valid || !c->red[0].d_red || !c->red[1].d_red) return BISIP_OK;
+    if (effective_variant(c) != BISIP_VARIANT_REDUCED_COMP) return BISIP_OK;
+    const size_t E = (size_t)c->E;
+    if (c->red[0].est.size() != E) return BISIP_OK;
+    c->tier_of.assign(E, 1);
+    size_t plain = 0;
+    for (size_t e = 0; e < E; ++e)
+        if (c->red[0].est[e] <= BISIP_REDUCED_ERR_MAX) { c->tier_of[e] = 0; ++plain; }
+    if (plain == 0) return BISIP_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->d_tier) HIP_TRY(hipMalloc((void **)&c->d_tier, E));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(c->d_tier, c->tier_of.data(), E, hipMemcpyHostToDevice));
+    c->mixed = true;
+    return BISIP_OK;
+}
+
 static int recenter_reduced(bisip_ctx *c)
 {
     if (c->model_id != BISIP_MODEL_POLYDECOMP || c->reduced.empty()) return BISIP_OK;
@@ -225,6 +250,7 @@ static int recenter_reduced(bisip_ctx *c)
         T.err = 0.0;
         for (double v : est)
             if (!(v <= T.err)) T.err = v;
+        T.est = est;
         T.valid = true;
         if (c->E > 1) {
             if (red.size() != red_doubles * (size_t)c->E) return fail(BISIP_EHIP, "internal: reduced operand size mismatch");
@@ -235,7 +261,7 @@ static int recenter_reduced(bisip_ctx *c)
             HIP_TRY(hipMemcpy(T.d_red, red.data(), red.size() * sizeof(double), hipMemcpyHostToDevice));
         }
     }
-    return BISIP_OK;
+    return update_tiers(c);
 }
 
 // no C++ exception may cross the C ABI: the host-side precompute allocates (std::vector)
@@ -534,6 +560,7 @@ void bisip_ctx_destroy(bisip_ctx *c)
     if (c->d_cb_faithful) (void)hipFree(c->d_cb_faithful);
     if (c->d_lconst) (void)hipFree(c->d_lconst);
     for (auto &t : c->red) if (t.d_red) (void)hipFree(t.d_red);
+    if (c->d_tier) (void)hipFree(c->d_tier);
     if (c->d_ws) (void)hipFree(c->d_ws);
     if (c->d_gather) (void)hipFree(c->d_gather);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
@@ -550,6 +577,7 @@ int bisip_ctx_set_bounds(bisip_ctx *c, const double *lo, const double *hi)
     for (int q = 0; q < c->ndim; ++q) { c->bounds.lo[q] = lo[q]; c->bounds.hi[q] = hi[q]; }
     c->bounds.flags = bound_flags(c);
     c->demoted[0] = c->demoted[1] = false;                            // observed on the old box
+    c->mix_off = false;
     for (auto &t : c->red) { t.valid = false; t.err = INFINITY; }     // estimates and expansion points belong to the old box
     const int rc = guarded([&] { return recenter_reduced(c); });   // the reduced form expands about a point of the box
     c->kernel_name = name_for(c);                                  // AUTO may change formulation with the box
@@ -598,8 +626,31 @@ double bisip_ctx_reduced_error(const bisip_ctx *c)
     if (!c) return NAN;
     const int v = effective_variant(c);
     if (v == BISIP_VARIANT_REDUCED) return c->red[0].err;
+    if (v == BISIP_VARIANT_REDUCED_COMP && c->mixed) {           // each spectrum under the tier it runs
+        double worst = 0.0;
+        for (size_t e = 0; e < c->tier_of.size(); ++e) {
+            const double x = c->red[c->tier_of[e]].est[e];
+            if (!(x <= worst)) worst = x;
+        }
+        return worst;
+    }
     if (v == BISIP_VARIANT_REDUCED_COMP) return c->red[1].err;
     return c->red[0].err <= c->red[1].err ? c->red[0].err : c->red[1].err;
+}
+
+int bisip_ctx_reduced_tiers(const bisip_ctx *c, int64_t *n_plain, int64_t *n_comp)
+{
+    if (!c || !n_plain || !n_comp) return fail(BISIP_EINVAL, "null argument");
+    *n_plain = *n_comp = 0;
+    const int v = effective_variant(c);
+    if (c->model_id != BISIP_MODEL_POLYDECOMP) return BISIP_OK;
+    if (v == BISIP_VARIANT_REDUCED) *n_plain = c->E;
+    else if (v == BISIP_VARIANT_REDUCED_COMP) {
+        if (c->mixed)
+            for (unsigned char t : c->tier_of) ++*(t ? n_comp : n_plain);
+        else *n_comp = c->E;
+    }
+    return BISIP_OK;
 }
 
 int bisip_logprob_dev(bisip_ctx *c, const double *d_theta, int64_t W, double *d_logp, void *stream)
@@ -938,7 +989,7 @@ static int guard_after_logprob(bisip_ctx *c, const double *theta, int64_t W, dou
     if (c->E > 1 && W % c->E) return BISIP_OK;
     const int64_t call = ++c->guard_calls;
     if (call & (call - 1)) return BISIP_OK;                       // 1, 2, 4, 8, ...
-    for (int round = 0; round < 2; ++round) {
+    for (int round = 0; round < 3; ++round) {
         const int v = effective_variant(c);
         if (v != BISIP_VARIANT_REDUCED && v != BISIP_VARIANT_REDUCED_COMP) return BISIP_OK;
         const int64_t stride = W > 256 ? W / 256 : 1;
@@ -946,7 +997,8 @@ static int guard_after_logprob(bisip_ctx *c, const double *theta, int64_t W, dou
         ++c->guard_checks;
         if (!(worst <= c->guard_worst)) c->guard_worst = worst;
         if (worst <= GUARD_TOL || c->variant != BISIP_VARIANT_AUTO) return BISIP_OK;
-        c->demoted[v == BISIP_VARIANT_REDUCED ? 0 : 1] = true;
+        if (v == BISIP_VARIANT_REDUCED_COMP && c->mixed) c->mix_off = true;   // first every spectrum compensated
+        else c->demoted[v == BISIP_VARIANT_REDUCED ? 0 : 1] = true;
         ++c->guard_escalations;
         int rc = guarded([&] { return recenter_reduced(c); });    // the next tier may not have been estimated yet
         if (rc != BISIP_OK) return rc;

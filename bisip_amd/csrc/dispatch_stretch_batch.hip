@@ -33,6 +33,8 @@ int stretch_reduced_batch(const bisip_ctx *c, const StretchWork &a, long long Wp
 {
     BatchReducedLP<P, U, COMP> lp;
     lp.red = reinterpret_cast<const ReducedArgs<P, COMP> *>(c->red[COMP ? 1 : 0].d_red); lp.Wp = Wp; lp.lconst = c->d_lconst;
+    lp.red_plain = reinterpret_cast<const ReducedArgs<P, false> *>(c->red[0].d_red);
+    lp.tier = COMP && c->mixed ? c->d_tier : nullptr;
     lp.b = c->bounds;
     return launch_stretch(a, lp, st);
 }

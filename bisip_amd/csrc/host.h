@@ -62,11 +62,18 @@ struct bisip_ctx {
         double err = INFINITY;                  // worst estimated relative log-prob error (all spectra); INFINITY: not estimated
         bool valid = false;                     // estimated for the current prior box
         void *d_red = nullptr;                  // (E,) ReducedArgs<P>  batch only
+        std::vector<double> est;                // the estimate of every spectrum (err = their maximum)
     };
     ReducedTier red[2];
     // bisip_logprob measures the reduced kernel it ran on rows of its own batches (first call, then
     // every 2^n-th); a tier found wanting is closed to BISIP_VARIANT_AUTO until the box changes
     bool demoted[2] = {false, false};
+    // A batch on BISIP_VARIANT_AUTO whose spectra do not all pass the plain tier launches the compensated
+    // kernels with a tier per spectrum (BatchArgs::tier): tier_of[e] = 0 where the plain estimate of spectrum e
+    // passes -- every spectrum runs what a context of its own would run.  mix_off: the guard closed the mix.
+    std::vector<unsigned char> tier_of;
+    unsigned char *d_tier = nullptr;
+    bool mixed = false, mix_off = false;
     bool guard_on = true;
     int64_t guard_calls = 0, guard_checks = 0;
     double guard_worst = 0.0;

@@ -1194,9 +1194,10 @@ __device__ __forceinline__ void two_diff(double a, double b, double &s, double &
 // measured on posterior-valley probes 1e-13 .. 1e-16 relative where the plain form AND the
 // per-frequency form (the reference's own kind of sum) give 1e-12 .. 7e-11.  ~11 flops per
 // matrix entry instead of 1, still independent of the number of frequencies.
-template <int P, bool COMP = false>
-__device__ __forceinline__ double logprob_row_reduced(const double (&th)[P + 2],
-                                                      const ReducedArgs<P, COMP> &r, double lconst,
+// RA: the operand struct -- ReducedArgs<P, COMP>, or, for COMP = false, any struct with R, bhat, e and rest
+// (a batch whose spectra run different tiers keeps one register copy of the larger layout: BatchReducedLP).
+template <int P, bool COMP = false, class RA = ReducedArgs<P, COMP>>
+__device__ __forceinline__ double logprob_row_reduced(const double (&th)[P + 2], const RA &r, double lconst,
                                                       const Bounds &b)
 {
     constexpr int n = P + 2;
@@ -1431,7 +1432,12 @@ struct BatchArgs {
     const double *__restrict__ cb;
     long long cb_stride;      // doubles between two spectra's records
     const double *__restrict__ lconst;  // (E,)
-    const void *__restrict__ red;       // (E,) ReducedArgs<P> (reduced variant only)
+    const void *__restrict__ red;       // (E,) ReducedArgs<P, COMP> (reduced variants only)
+    // compensated launch of a batch whose spectra need different tiers (BISIP_VARIANT_AUTO): tier[e] = 0
+    // sends spectrum e through the plain arithmetic on its plain operands -- every spectrum runs what a
+    // context of its own would run.  tier == nullptr: every spectrum compensated.
+    const void *__restrict__ red_plain; // (E,) ReducedArgs<P, false>
+    const unsigned char *__restrict__ tier;
     int N;
     Bounds b;
 };
@@ -1469,6 +1475,13 @@ __global__ __launch_bounds__(64) void k_logprob_batch_reduced(const BatchArgs a)
 #pragma unroll
     for (int q = 0; q < NDIM; ++q) th[q] = a.theta[row * NDIM + q];
     const long long e = spectrum_of<UNIFORM>(row, a.Wp);
+    if constexpr (COMP) {
+        if (a.tier && !a.tier[e]) {
+            const ReducedArgs<P, false> *__restrict__ rp = reinterpret_cast<const ReducedArgs<P, false> *>(a.red_plain) + e;
+            a.out[row] = logprob_row_reduced<P, false>(th, *rp, a.lconst[e], a.b);
+            return;
+        }
+    }
     const ReducedArgs<P, COMP> *__restrict__ r = reinterpret_cast<const ReducedArgs<P, COMP> *>(a.red) + e;
     a.out[row] = logprob_row_reduced<P, COMP>(th, *r, a.lconst[e], a.b);
 }
@@ -1490,6 +1503,13 @@ __global__ __launch_bounds__(BLK) void k_logprob_batch_reduced_stream(const Batc
 #pragma unroll
     for (int q = 0; q < NDIM; ++q) th[q] = lds[threadIdx.x * NDIM + q];
     const unsigned e = (unsigned)row0 / (unsigned)a.Wp;          // one spectrum per workgroup (Wp % BLK == 0)
+    if constexpr (COMP) {
+        if (a.tier && !a.tier[e]) {                              // uniform: the whole workgroup takes the plain tier
+            const ReducedArgs<P, false> *__restrict__ rp = reinterpret_cast<const ReducedArgs<P, false> *>(a.red_plain) + e;
+            a.out[row] = logprob_row_reduced<P, false>(th, *rp, a.lconst[e], a.b);
+            return;
+        }
+    }
     const ReducedArgs<P, COMP> *__restrict__ r = reinterpret_cast<const ReducedArgs<P, COMP> *>(a.red) + e;
     a.out[row] = logprob_row_reduced<P, COMP>(th, *r, a.lconst[e], a.b);
 }

@@ -146,28 +146,59 @@ struct BatchReducedLP {
     static constexpr int L = 1;
     static constexpr bool CAN_STAGE = false;
     const ReducedArgs<P, COMP> *red;
+    // COMP only: spectra whose tier[e] is 0 take the plain arithmetic on their plain operands (see BatchArgs)
+    const ReducedArgs<P, false> *red_plain;
+    const unsigned char *tier;
     long long Wp;
     const double *lconst;
     Bounds b;
+    __device__ __forceinline__ bool plain_tier(long long e) const
+    {
+        if constexpr (COMP) return tier && !tier[e];
+        else return false;
+    }
     __device__ __forceinline__ double operator()(const double (&th)[NDIM], int walker, int) const
     {
         const long long e = spectrum_of<UNIFORM>(walker, Wp);
+        if constexpr (COMP) {
+            if (plain_tier(e)) return logprob_row_reduced<P, false>(th, red_plain[e], lconst[e], b);
+        }
         return logprob_row_reduced<P, COMP>(th, red[e], lconst[e], b);
     }
     // The spectrum's triangle, expansion point and residual vector (50 doubles at P = 5) are read
     // ONCE per launch into registers: read where they lie they were ~25 vector loads per half-step,
     // each a trip to memory that the 130 instructions of a half-step cannot hide (SQ counters of the
     // 512 x 256 batch: 4,300 cycles per half-step, 1,900 of them waiting; benchmarks/micro/batch_pd_pmc.sh).
-    struct Local { ReducedArgs<P, COMP> r; double lconst; };
+    // A spectrum on the plain tier of a compensated launch fills the same registers from its plain operands
+    // (its expansion point differs) and leaves the low words unused.
+    struct Local { ReducedArgs<P, COMP> r; double lconst; bool plain; };
     __device__ __forceinline__ Local local(long long e) const
     {
         // through the vector path on purpose: as wave-uniform values the 100 dwords would overflow the
         // scalar registers and come back lane by lane (v_readlane) in every half-step
-        return {red[e], lconst[e]};
+        if constexpr (COMP) {
+            if (plain_tier(e)) {
+                Local loc;
+                const ReducedArgs<P, false> &p = red_plain[e];
+                constexpr int n = P + 2;
+#pragma unroll
+                for (int k = 0; k < n * (n + 1) / 2; ++k) { loc.r.R[k] = p.R[k]; loc.r.Rlo[k] = 0.0f; }
+#pragma unroll
+                for (int k = 0; k < n; ++k) { loc.r.bhat[k] = p.bhat[k]; loc.r.e[k] = p.e[k]; loc.r.elo[k] = 0.0; }
+                loc.r.rest = p.rest;
+                loc.lconst = lconst[e];
+                loc.plain = true;
+                return loc;
+            }
+        }
+        return {red[e], lconst[e], false};
     }
     template <bool STAGED>
     __device__ __forceinline__ double eval_ens(const double (&th)[NDIM], const Local &loc, int, const double *) const
     {
+        if constexpr (COMP) {
+            if (loc.plain) return logprob_row_reduced<P, false, ReducedArgs<P, true>>(th, loc.r, loc.lconst, b);
+        }
         return logprob_row_reduced<P, COMP>(th, loc.r, loc.lconst, b);
     }
 };

@@ -405,6 +405,12 @@ const char *bisip_ctx_kernel_name(const bisip_ctx *ctx);
  * of the two). */
 double bisip_ctx_reduced_error(const bisip_ctx *ctx);
 
+/* PolynomialDecomposition: how many spectra of the context run the plain (*n_plain) and the compensated
+ * (*n_comp) QR-reduced kernel at the moment; both 0 when the per-frequency form runs.  A batch on
+ * BISIP_VARIANT_AUTO decides per spectrum -- every spectrum runs what a context of its own would run, inside
+ * one launch; a forced variant, and a batch whose mix bisip_logprob's guard closed, run one tier for all. */
+int bisip_ctx_reduced_tiers(const bisip_ctx *ctx, int64_t *n_plain, int64_t *n_comp);
+
 /* Host-only inspection of the walker-independent PolynomialDecomposition operands the
  * context precomputes (no GPU needed; used by the CPU-side tests).  Outputs:
  * G_re/G_im (N, P+1);  R (n,n) upper triangle row-major, bhat (n,), e (n,), rest (1,)

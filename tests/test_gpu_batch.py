@@ -63,9 +63,7 @@ def test_batch_logprob_and_forward(model, kw, E, Wp):
         okw = dict(poly_deg=batch.poly_deg, c_exp=batch.c_exp, taus=batch.taus, log_taus=batch.log_taus)
     e = E - 1
     model_id = {'PolynomialDecomposition': 0, 'PeltonColeCole': 1, 'Dias2000': 2, 'Shin2015': 3}[model]
-    # (same formulation: a batch runs the kernel its least accurate spectrum needs)
-    if model == 'PolynomialDecomposition':
-        okw['variant'] = batch.ctx.variant
+    # (on 'auto' every spectrum of a batch runs the kernel a context of its own would run)
     single = _hip.HipContext(model_id, batch.w[e], batch.zn[e], batch.zn_err[e], batch.param_bounds, **okw)
     assert np.array_equal(single.logprob(theta[e]), got[e])
     assert_Z_close(Z[e], single.forward(theta[e, :5]), 1e-15)
@@ -151,6 +149,102 @@ def test_batch_persistent_equals_launch_path():
             assert chains[0][3] == 'persistent' and chains[1][3] == 'launch-per-half-step'
             for x, y in zip(chains[0][:3], chains[1][:3]):
                 assert np.array_equal(x, y)
+
+
+def test_every_spectrum_of_a_batch_runs_the_tier_its_own_context_would(monkeypatch):
+    """A PolynomialDecomposition batch on 'auto' decides plain / compensated PER SPECTRUM inside one launch
+    (BatchArgs::tier): the spectra that pass the plain estimate -- most of a survey at the headline's shape --
+    no longer pay for the few that do not.  Each spectrum's log-probabilities are the bits of a single-spectrum context on 'auto'
+    -- from the bulk batch kernels (whole workgroups per spectrum or not), from the launch-per-half-step
+    sampler and from the persistent one; a forced variant still runs one tier for all; and when
+    bisip_logprob's guard finds the batch wanting it first closes the mix (every spectrum compensated)."""
+    import warnings
+    import bisip_amd
+    from bisip_amd import _hip
+    from bisip_amd.sampler import DeviceEnsembleSampler
+    E = 24
+    tables = _tables(E, 20)                    # degree 5, c = 0.5, 20 frequencies: 4 of these 24 pass the plain estimate
+    for Wp in (128, 40):                       # 128: the streaming kernel (one spectrum per workgroup); 40: rows of two spectra in a wave
+        batch = bisip_amd.SpectraBatch('PolynomialDecomposition', tables, nwalkers=Wp, nsteps=8, poly_deg=5, c_exp=0.5)
+        n_plain, n_comp = batch.ctx.reduced_tiers
+        assert n_plain + n_comp == E and n_plain >= 2 and n_comp >= 2, (n_plain, n_comp)
+        assert batch.ctx.variant == 'reduced_comp' and batch.ctx.reduced_error <= 1e-12
+        lo, hi = batch.param_bounds
+        rng = np.random.RandomState(Wp)
+        theta = rng.uniform(lo, hi, (E, Wp, lo.size))
+        theta[:, : Wp // 2, 1:] *= 1e-2
+        got = batch.log_prob(theta)
+        tiers = []
+        for e in range(E):
+            single = _hip.HipContext(0, batch.w[e], batch.zn[e], batch.zn_err[e], batch.param_bounds, poly_deg=5,
+                                     c_exp=batch.c_exp, taus=batch.taus, log_taus=batch.log_taus)
+            tiers.append(single.variant)
+            assert np.array_equal(single.logprob(theta[e]), got[e]), (e, single.variant)
+            single.close()
+        assert tiers.count('reduced') == n_plain and tiers.count('reduced_comp') == n_comp
+        # the samplers: persistent == launches, and the stored log-probabilities are the bulk kernel's bits
+        centre = np.array([1.0, 0.005, -0.003, -0.001, 0.0005, 0.0002, 0.00001])
+        p0 = (centre + 1e-4 * rng.randn(E, Wp, 7)).reshape(E * Wp, 7)
+        chains = []
+        for persistent in (True, False):
+            s = DeviceEnsembleSampler(Wp, 7, batch.ctx, rng='philox', seed=2, n_ensembles=E, persistent=persistent)
+            s.run_mcmc(p0, 8)
+            chains.append((s.get_chain(), s.get_log_prob(), s.last_path))
+        assert chains[0][2] == 'persistent' and chains[1][2] == 'launch-per-half-step'
+        assert np.array_equal(chains[0][0], chains[1][0]) and np.array_equal(chains[0][1], chains[1][1])
+        last = chains[0][0][-1].reshape(E, Wp, 7)
+        assert np.array_equal(batch.ctx.logprob(last.reshape(-1, 7)), chains[0][1][-1].ravel())
+        # a forced variant: one tier for all
+        batch.ctx.set_variant('reduced_comp')
+        assert batch.ctx.reduced_tiers == (0, E)
+        comp_all = batch.ctx.logprob(theta.reshape(-1, 7)).reshape(E, Wp)
+        plain_spectra = [e for e in range(E) if tiers[e] == 'reduced']
+        assert any(not np.array_equal(comp_all[e], got[e]) for e in plain_spectra)      # different arithmetic ...
+        assert np.max(np.abs(comp_all - got) / np.maximum(1.0, np.abs(got))) <= 1e-11  # ... the same number
+        batch.ctx.set_variant('auto')
+        assert batch.ctx.reduced_tiers == (n_plain, n_comp)
+        assert np.array_equal(batch.ctx.logprob(theta.reshape(-1, 7)).reshape(E, Wp), got)
+
+
+def test_guard_closes_a_batch_mix_before_it_closes_a_tier(monkeypatch):
+    """A batch whose spectra run different tiers and whose plain spectra are then measured > 2e-11 off on the
+    caller's rows: bisip_logprob's guard first sends EVERY spectrum through the compensated kernel (one
+    escalation), re-evaluates, and is satisfied.  The batch is built with the estimate's shell probes at a
+    fifth of their weight (BISIP_SHELL_WEIGHT=0.01), so that 15 of 16 degree-6 designs keep the plain tier
+    although they read 4-8e-11 on the shell; the rows: each spectrum's own shell logp = 0."""
+    import bisip_amd
+    from bisip_amd import _hip
+    from test_gpu_parity import _shell_rows
+    E, Wp = 16, 256
+    tables = _tables(E, 64)
+    monkeypatch.setenv('BISIP_SHELL_WEIGHT', '0.01')
+    batch = bisip_amd.SpectraBatch('PolynomialDecomposition', tables, nwalkers=Wp, nsteps=4, poly_deg=6)
+    monkeypatch.delenv('BISIP_SHELL_WEIGHT')
+    n_plain, n_comp = batch.ctx.reduced_tiers
+    assert n_plain >= 4 and n_comp >= 1 and batch.ctx.variant == 'reduced_comp', (n_plain, n_comp)
+    bounds = np.array(batch.param_bounds)
+    theta = np.empty((E, Wp, 8))
+    for e in range(E):
+        ops = _hip.polydecomp_operands(batch.w[e], batch.zn[e], batch.zn_err[e], batch.taus, batch.log_taus, batch.c_exp)
+        rows = _shell_rows(ops, bounds, 4000, e)
+        assert len(rows) >= Wp
+        theta[e] = rows[:Wp]
+    with pytest.warns(RuntimeWarning, match='k_logprob_pd_reduced_comp'):
+        got = batch.ctx.logprob(theta.reshape(-1, 8))
+    checks, worst, moves = batch.ctx.reduced_guard()
+    assert moves == 1 and checks == 2 and worst > 2e-11
+    assert batch.ctx.reduced_tiers == (0, E) and batch.ctx.variant == 'reduced_comp'
+    assert batch.ctx.reduced_check(theta.reshape(-1, 8), got) <= 2e-12
+    forced = bisip_amd.SpectraBatch('PolynomialDecomposition', tables, nwalkers=Wp, nsteps=4, poly_deg=6)
+    forced.ctx.set_variant('reduced_comp')
+    assert np.array_equal(forced.ctx.logprob(theta.reshape(-1, 8)), got)
+    # a new prior box starts over: the mix is back
+    wide = bounds.copy()
+    wide[:, 1:] *= 1.01
+    monkeypatch.setenv('BISIP_SHELL_WEIGHT', '0.01')
+    batch.ctx.set_bounds(wide)
+    monkeypatch.delenv('BISIP_SHELL_WEIGHT')
+    assert batch.ctx.reduced_tiers[0] >= 1
 
 
 @pytest.mark.parametrize('n_freq', [8, 9, 10, 11, 21])
@@ -404,12 +498,12 @@ def test_batch_operands_do_not_depend_on_threads_or_on_shared_frequencies(monkey
         lo, hi = batch.param_bounds
         theta = np.random.RandomState(8).uniform(lo, hi, (E, Wp, lo.size))
         got[threads] = batch.log_prob(theta)
-        v_default = batch.ctx.variant             # a batch runs the formulation its least accurate spectrum needs
+        v_default = 'auto'                        # every spectrum of a batch runs what a context of its own would run
         # a wider box re-centres every spectrum's reduced form (the other threaded loop)
         wide = batch.param_bounds.copy()
         wide[:, 1:] *= 1.5
         batch.ctx.set_bounds(wide)
-        v_wide = batch.ctx.variant
+        v_wide = 'auto'
         got[threads, 'wide'] = batch.ctx.logprob(theta.reshape(-1, lo.size)).reshape(E, Wp)
         if threads is None:
             assert_logp_close(got[threads], _oracle_logp(batch, theta))
