@@ -386,10 +386,11 @@ class HipContext:
         walker, the longer one CU keeps up with launches that spread over the chip."""
         name = self.kernel_name
         if 'reduced_comp' in name:
-            # the compensated triangle keeps ~12 live doubles per matrix entry in flight: from degree 6-7 the
-            # persistent kernel spills and the launch path is 30-70 % faster at every ensemble size
-            # (profiles/r03_micro_persistent_comp_by_degree.txt); 0 = never persistent
-            return 1024 if self.poly_deg <= 5 else (64 if self.poly_deg == 6 else 0)
+            # the compensated triangle (kept in scalar registers, its low words and the other operands in
+            # vector registers) wins in the persistent kernel up to degree 8 and 512 walkers -- 1.2-1.9x at 32
+            # walkers -- ties at degree 9 and loses at 10, where it spills (profiles/
+            # r03_micro_persistent_comp_by_degree.txt); 0 = never persistent
+            return 1024 if self.poly_deg <= 5 else (512 if self.poly_deg <= 8 else 0)
         if 'reduced' in name:
             return 1024
         if 'Dias' in name:
@@ -397,6 +398,15 @@ class HipContext:
         if 'ColeCole' in name:
             return {1: 768, 2: 512}.get(self.n_modes, 256)
         return 512          # Shin, per-frequency PolynomialDecomposition
+
+    @property
+    def persistent_in_big_batches(self):
+        """A batch that fills the chip (>= 65,536 walkers in all) runs its launches in the bulk regime; the
+        persistent kernel -- one workgroup per ensemble, waiting on dependency chains -- then only wins with
+        the cheaper kernels: every one except the compensated triangle above degree 5 (512 x 256: 9.6 against
+        10.5 us per half-step of a whole fit at degree 5, 16 against 12 at degree 6, 32 against 15 at degree 8;
+        benchmarks/micro/batch_comp_by_degree.py)."""
+        return not ('reduced_comp' in self.kernel_name and self.poly_deg > 5)
 
     @property
     def reduced_error(self):

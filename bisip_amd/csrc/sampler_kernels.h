@@ -88,14 +88,21 @@ struct ReducedLP {
         return logprob_row_reduced<P, COMP>(th, r, lconst, b);
     }
     // a copy of the kernarg operands in VECTOR registers (see BatchReducedLP::Local: as scalars
-    // they do not fit and return lane by lane in every half-step)
+    // they do not fit and return lane by lane in every half-step).  The compensated tier holds 2.5x the
+    // operands (low words) and ran out of vector registers instead (256 + 192 bytes of scratch per lane at
+    // degree 5): its triangle R -- every use is one operand of a product -- stays in SCALAR registers, the
+    // rest goes to vector registers: 225 VGPRs at degree 5, and the persistent sampler 1.2-1.8x faster at
+    // degrees 5-8 (benchmarks/micro/persistent_comp_by_degree.py).
     struct Local { ReducedArgs<P, COMP> r; };
     __device__ __forceinline__ Local local(long long) const
     {
         Local loc{r};
         double *v = reinterpret_cast<double *>(&loc.r);
+        constexpr int n = P + 2, TRI = n * (n + 1) / 2;
+        constexpr int R0 = COMP ? ((TRI + 1) & ~1) / 2 : 0, R1 = R0 + TRI;     // where R lies in the struct, in doubles
 #pragma unroll
-        for (int i = 0; i < (int)(sizeof(ReducedArgs<P, COMP>) / sizeof(double)); ++i) asm volatile("" : "+v"(v[i]));
+        for (int i = 0; i < (int)(sizeof(ReducedArgs<P, COMP>) / sizeof(double)); ++i)
+            if (!COMP || i < R0 || i >= R1) asm volatile("" : "+v"(v[i]));
         return loc;
     }
     template <bool STAGED>
@@ -191,6 +198,9 @@ struct BatchReducedLP {
                 return loc;
             }
         }
+        // (the single-spectrum kernel keeps the compensated tier's triangle in scalar registers,
+        // ReducedLP::local; here, with the batch's own scalar state, the same 56 values were spilled to
+        // vector lanes and read back in the loop: measured no faster, left in vector registers)
         return {red[e], lconst[e], false};
     }
     template <bool STAGED>

@@ -732,9 +732,12 @@ class DeviceEnsembleSampler(_SamplerBase):
         # half-step (512 spectra x 256 walkers: 6.5 vs 12.4 us per half-step).
         # None = that rule; True / False force it.
         if persistent is None:
-            limit = getattr(getattr(self.backend, 'ctx', None), 'persistent_walkers', 128)
-            persistent = int(nwalkers) <= limit or (limit > 0 and int(nwalkers) <= 1024 and
-                                                    int(nwalkers) * self.n_ensembles >= 65536)
+            ctx = getattr(self.backend, 'ctx', None)
+            limit = getattr(ctx, 'persistent_walkers', 128)
+            if int(nwalkers) * self.n_ensembles >= 65536 and self.n_ensembles > 1:      # a batch that fills the chip
+                persistent = limit > 0 and int(nwalkers) <= 1024 and getattr(ctx, 'persistent_in_big_batches', True)
+            else:
+                persistent = int(nwalkers) <= limit
         self.persistent = bool(persistent)
         # keep the stored samples in HBM: nothing is copied to the host until get_chain() /
         # get_log_prob() ask for it, and param_moments() summarises the chain where it lies
