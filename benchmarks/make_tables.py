@@ -282,7 +282,7 @@ FILES = [
     (f'{ROUND}_micro_grid_vs_direct.txt', '`python benchmarks/micro/grid_vs_direct.py`', 'ColeCole (1-3 modes) and Shin bulk launches on geometric frequency grids (exponentials stepped by multiplication: 1.3-1.45x) against one exponential per frequency (`BISIP_NO_GRID=1`), with the largest difference between the two; rounded grid and bundled field spectrum as controls (no grid: the same loop twice)'),
     (f'{ROUND}_micro_grid_small_ensembles.txt', '`python benchmarks/micro/grid_small_ensembles.py`', '`fit()` of one spectrum with 32-1024 walkers and emcee-sized calls, stepped against direct: 1.11-1.24x on an exact grid (lanes that share a walker take whole blocks), 1.0 on the bundled spectrum (no grid)'),
     (f'{ROUND}_micro_grid_small_ensembles_before.txt', 'the same script on two designs that were taken out', 'one frequency per lane and round on a grid: 0.92-1.0x; a series-corrected tier for grids rounded in data files: 0.71-0.94x on the bundled spectrum (1.09-1.16x in bulk launches) -- why field data keeps the direct loop'),
-    (f'{ROUND}_micro_persistent_comp_by_degree.txt', '`python benchmarks/micro/persistent_comp_by_degree.py`, `batch_comp_by_degree.py`', 'the compensated kernel in the persistent sampler against one launch per half-step, by degree, with its triangle in scalar registers: single ensembles -- persistent wins up to degree 8 and 512 walkers (1.2-1.9x at 32 walkers), ties at 9, loses at 10; 512 x 256 batches -- persistent wins at degree 5 only; the automatic rules follow'),
+    (f'{ROUND}_micro_persistent_comp_by_degree.txt', '`python benchmarks/micro/persistent_comp_by_degree.py`, `batch_comp_by_degree.py`', 'the compensated kernel in the persistent sampler against one launch per half-step, by degree, with its triangle in scalar registers (single spectrum) and its low words staged in LDS: single ensembles -- persistent wins at every degree up to 512 walkers (1.6-2.3x at 32 walkers); 512 x 256 batches -- persistent wins up to degree 8, ties at 9; the automatic rules follow'),
     (f'{ROUND}_micro_small_call_latency.jsonl', '`python benchmarks/micro/small_call_latency.py`', 'one emcee-sized log-probability call with host buffers, every model, 16 ... 4096 rows'),
     (f'{ROUND}_micro_issue_latency.txt', '`benchmarks/micro/issue_latency`', 'cycles per fp64 FMA for 1/2/4/8 independent chains at 1, 2, 4 waves per SIMD; placement of 1-, 2-, 4-, 8-, 16-wave workgroups'),
     (f'{ROUND}_micro_row_latency.txt', '`benchmarks/micro/row_latency`', 'cycles of one log-probability row at one wave per SIMD, records from the scalar cache vs staged in LDS'),

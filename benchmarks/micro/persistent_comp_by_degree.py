@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The compensated QR-reduced kernel in the persistent sampler against one launch per half-step, by polynomial
 degree and ensemble size (bundled spectrum SIP-K389175, 1000 iterations, best of three): the measurement behind
-HipContext.persistent_walkers for 'reduced_comp' (persistent up to 1024 walkers at degree <= 5, up to 512 at degrees 6-8, never from 9)."""
+HipContext.persistent_walkers for 'reduced_comp' (persistent up to 1024 walkers at degree <= 5, up to 512 above)."""
 import os
 import sys, time, numpy as np, warnings
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))

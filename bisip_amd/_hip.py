@@ -386,11 +386,10 @@ class HipContext:
         walker, the longer one CU keeps up with launches that spread over the chip."""
         name = self.kernel_name
         if 'reduced_comp' in name:
-            # the compensated triangle (kept in scalar registers, its low words and the other operands in
-            # vector registers) wins in the persistent kernel up to degree 8 and 512 walkers -- 1.2-1.9x at 32
-            # walkers -- ties at degree 9 and loses at 10, where it spills (profiles/
-            # r03_micro_persistent_comp_by_degree.txt); 0 = never persistent
-            return 1024 if self.poly_deg <= 5 else (512 if self.poly_deg <= 8 else 0)
+            # the compensated tier with its triangle in scalar registers and its low words in LDS wins in the
+            # persistent kernel at every degree up to 512 walkers (1.6-2.3x the launch path at 32 walkers,
+            # degrees 5-10; profiles/r03_micro_persistent_comp_by_degree.txt), up to 1024 at degree <= 5
+            return 1024 if self.poly_deg <= 5 else 512
         if 'reduced' in name:
             return 1024
         if 'Dias' in name:
@@ -402,11 +401,11 @@ class HipContext:
     @property
     def persistent_in_big_batches(self):
         """A batch that fills the chip (>= 65,536 walkers in all) runs its launches in the bulk regime; the
-        persistent kernel -- one workgroup per ensemble, waiting on dependency chains -- then only wins with
-        the cheaper kernels: every one except the compensated triangle above degree 5 (512 x 256: 9.6 against
-        10.5 us per half-step of a whole fit at degree 5, 16 against 12 at degree 6, 32 against 15 at degree 8;
-        benchmarks/micro/batch_comp_by_degree.py)."""
-        return not ('reduced_comp' in self.kernel_name and self.poly_deg > 5)
+        persistent kernel -- one workgroup per ensemble, waiting on dependency chains -- still wins with every
+        kernel except the compensated triangle from degree 9, where the two tie (512 x 256, whole fits: 5.9
+        against 10.7 us per half-step at degree 5, 11.3 against 15.2 at degree 6, 10.4 against 13.5 at degree
+        7, 15.0 against 16.4 at degree 8, 24.2 against 23.8 at degree 9; benchmarks/micro/batch_comp_by_degree.py)."""
+        return not ('reduced_comp' in self.kernel_name and self.poly_deg > 8)
 
     @property
     def reduced_error(self):

@@ -15,6 +15,7 @@
 // The log-probability of q is evaluated by the same device functions as the batch
 // kernels (kernels.h: logprob_row / logprob_row_reduced) -- identical bits.
 #pragma once
+#include <type_traits>
 #include "kernels.h"
 #include "philox.h"
 
@@ -75,11 +76,67 @@ struct GenericLP {
     }
 };
 
+// ReducedArgs<P, true> with the low words (Rlo, elo) read where they lie -- LDS, in the persistent kernels --
+// instead of held in registers: what logprob_row_reduced needs of an operand struct, nothing else
+template <int P>
+struct ReducedLowInLds {
+    static constexpr int n = P + 2;
+    double R[n * (n + 1) / 2];
+    double bhat[n];
+    double e[n];
+    double rest;
+    const float *Rlo;
+    const double *elo;
+};
+
+// the compensated row sums of the persistent kernels: R, bhat, e, rest from the register copy, the low words from
+// the operand image staged in LDS (layout of ReducedArgs<P, true>: Rlo floats | R | bhat | e | elo | rest)
+template <int P>
+__device__ __forceinline__ double logprob_row_reduced_staged(const double (&th)[P + 2], const ReducedArgs<P, true> &r,
+                                                              const double *lds, double lconst, const Bounds &b)
+{
+    constexpr int n = P + 2, TRI = n * (n + 1) / 2, LO = ((TRI + 1) & ~1) / 2;
+    ReducedLowInLds<P> v;
+#pragma unroll
+    for (int k = 0; k < TRI; ++k) v.R[k] = r.R[k];
+#pragma unroll
+    for (int k = 0; k < n; ++k) { v.bhat[k] = r.bhat[k]; v.e[k] = r.e[k]; }
+    v.rest = r.rest;
+    v.Rlo = reinterpret_cast<const float *>(lds);
+    v.elo = lds + LO + TRI + 2 * n;
+    return logprob_row_reduced<P, true, ReducedLowInLds<P>>(th, v, lconst, b);
+}
+
+// does the functor write its LDS image itself (from kernel arguments) instead of naming a source in memory?
+template <class LP, class = void>
+struct StagesFromArgs : std::false_type {};
+template <class LP>
+struct StagesFromArgs<LP, std::void_t<decltype(LP::STAGE_FROM_ARGS)>> : std::bool_constant<LP::STAGE_FROM_ARGS> {};
+
 template <int P, bool COMP = false>
 struct ReducedLP {
     static constexpr int NDIM = P + 2;
     static constexpr int L = 1;
-    static constexpr bool CAN_STAGE = false;
+    // compensated tier: the low words live in LDS (see BatchReducedLP); the operands are kernel arguments here,
+    // so lane 0 writes the two arrays itself
+    static constexpr bool CAN_STAGE = COMP;
+    static constexpr bool STAGE_FROM_ARGS = true;
+    static constexpr int REC_DOUBLES = (int)(sizeof(ReducedArgs<P, COMP>) / sizeof(double));
+    __host__ __device__ __forceinline__ int n_freq() const { return 1; }
+    __device__ __forceinline__ const double *records(long long) const { return nullptr; }
+    __device__ __forceinline__ void stage_from_args(double *mine, int lane) const
+    {
+        if constexpr (COMP) {
+            constexpr int n = P + 2, TRI = n * (n + 1) / 2, LO = ((TRI + 1) & ~1) / 2;
+            if (lane == 0) {
+                float *lo = reinterpret_cast<float *>(mine);
+#pragma unroll
+                for (int k = 0; k < TRI; ++k) lo[k] = r.Rlo[k];
+#pragma unroll
+                for (int k = 0; k < n; ++k) mine[LO + TRI + 2 * n + k] = r.elo[k];
+            }
+        }
+    }
     ReducedArgs<P, COMP> r;
     double lconst;
     Bounds b;
@@ -106,9 +163,10 @@ struct ReducedLP {
         return loc;
     }
     template <bool STAGED>
-    __device__ __forceinline__ double eval_ens(const double (&th)[NDIM], const Local &loc, int, const double *) const
+    __device__ __forceinline__ double eval_ens(const double (&th)[NDIM], const Local &loc, int, const double *lds) const
     {
-        return logprob_row_reduced<P, COMP>(th, loc.r, lconst, b);
+        if constexpr (COMP && STAGED) return logprob_row_reduced_staged<P>(th, loc.r, lds, lconst, b);
+        else return logprob_row_reduced<P, COMP>(th, loc.r, lconst, b);
     }
 };
 
@@ -151,7 +209,15 @@ template <int P, bool UNIFORM, bool COMP = false>
 struct BatchReducedLP {
     static constexpr int NDIM = P + 2;
     static constexpr int L = 1;
-    static constexpr bool CAN_STAGE = false;
+    // The compensated tier's register copy of a spectrum's operands (Local) is 130 dwords: with the rest of
+    // the kernel 256 VGPRs and 108 bytes of scratch per lane at degree 5.  Its low words -- Rlo as floats and
+    // elo, 42 dwords, each read once per evaluation -- are therefore STAGED: the persistent kernel copies the
+    // spectrum's operand image into LDS once per launch (the mechanism of the per-frequency models' records)
+    // and the row sums read them there, every lane the same address.
+    static constexpr bool CAN_STAGE = COMP;
+    static constexpr int REC_DOUBLES = (int)(sizeof(ReducedArgs<P, COMP>) / sizeof(double));
+    __device__ __forceinline__ const double *records(long long e) const { return reinterpret_cast<const double *>(red + e); }
+    __host__ __device__ __forceinline__ int n_freq() const { return 1; }
     const ReducedArgs<P, COMP> *red;
     // COMP only: spectra whose tier[e] is 0 take the plain arithmetic on their plain operands (see BatchArgs)
     const ReducedArgs<P, false> *red_plain;
@@ -204,10 +270,11 @@ struct BatchReducedLP {
         return {red[e], lconst[e], false};
     }
     template <bool STAGED>
-    __device__ __forceinline__ double eval_ens(const double (&th)[NDIM], const Local &loc, int, const double *) const
+    __device__ __forceinline__ double eval_ens(const double (&th)[NDIM], const Local &loc, int, const double *lds) const
     {
         if constexpr (COMP) {
             if (loc.plain) return logprob_row_reduced<P, false, ReducedArgs<P, true>>(th, loc.r, loc.lconst, b);
+            if constexpr (STAGED) return logprob_row_reduced_staged<P>(th, loc.r, lds, loc.lconst, b);
         }
         return logprob_row_reduced<P, COMP>(th, loc.r, loc.lconst, b);
     }
@@ -519,9 +586,12 @@ __global__ __launch_bounds__(512) void k_stretch_persistent(const PersistArgs a,
     const double *recs = nullptr;
     if constexpr (STAGED) {
         double *mine = lds_state + ((a.epw * state_doubles + 1) & ~1LL) + ens_local * a.rec_stride;
-        const double *__restrict__ src = lp.records(e);
-        const int n = lp.n_freq() * LP::REC_DOUBLES;
-        for (int i = lane; i < n; i += a.lanes_per_ens) mine[i] = src[i];
+        if constexpr (StagesFromArgs<LP>::value) lp.stage_from_args(mine, lane);
+        else {
+            const double *__restrict__ src = lp.records(e);
+            const int n = lp.n_freq() * LP::REC_DOUBLES;
+            for (int i = lane; i < n; i += a.lanes_per_ens) mine[i] = src[i];
+        }
         recs = mine;
     }
     __syncthreads();
