@@ -1,6 +1,7 @@
-"""What the stepped exponentials (kernels.h: BOUNDS_GRID, BOUNDS_GRID_FIX) do to SMALL work, where several lanes
-share a walker and every lane takes the block's exponential itself: fit() of one spectrum and emcee-sized
-calls, each against BISIP_NO_GRID=1 on the same box.  Prints iterations/s and microseconds per call."""
+"""What the stepped exponentials (kernels.h: BOUNDS_GRID) do to SMALL work, where several lanes share a walker:
+fit() of one spectrum and emcee-sized calls, each against BISIP_NO_GRID=1 on the same box.  Prints iterations/s
+and microseconds per call.  (profiles/r03_micro_grid_small_ensembles_before.txt holds the same script on two
+designs that were taken out: one frequency per lane and round, and a series-corrected tier for rounded grids.)"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', '..'))
@@ -13,7 +14,7 @@ from bisip_amd.utils import columns_to_data, load_data
 
 real = load_data(bisip_amd.DataFiles()['SIP-K389175'])
 synth = columns_to_data(synthetic_columns(32, 0), 'mrad')
-for label, d in (('bundled SIP-K389175 (N=20, rounded grid)', real), ('synthetic N=32 (exact grid)', synth)):
+for label, d in (('bundled SIP-K389175 (N=20, no grid: control)', real), ('synthetic N=32 (exact grid)', synth)):
     for name, mid, kw, centre in (('PeltonColeCole', 1, dict(n_modes=2), [1.0, 0.15, 0.5, -1.5, -12.0, 0.45, 0.6]),
                                   ('PeltonColeCole', 1, dict(n_modes=1), [1.0, 0.3, -3.0, 0.5]),
                                   ('Shin2015', 3, {}, [0.5, 0.5, -14.0, -6.0, 0.5, 0.5])):
