@@ -390,6 +390,69 @@ def test_lanes_per_slot_and_record_staging_do_not_change_the_chain(prefix, model
     ctx.close()
 
 
+@pytest.mark.parametrize('poly_deg', [2, 5, 7, 9, 10])
+def test_compensated_persistent_kernel_with_and_without_staged_low_words(poly_deg, monkeypatch):
+    """The compensated tier in the persistent kernel keeps its triangle in scalar registers and reads its low
+    words (Rlo, elo) from LDS, where lane 0 put them (single spectrum) or the operand image was copied (a
+    batch).  Same arithmetic as the launch path and as the bulk kernel: the chains are bit-equal with the
+    staging on, with it off (BISIP_NO_LDS_STAGING=1: low words in registers) and from one launch per
+    half-step; the stored log-probabilities are the bulk kernel's; ensembles of 1, 2 and 4 waves."""
+    import bisip_amd
+    from bisip_amd import _hip
+    from bisip_amd.sampler import DeviceEnsembleSampler
+    from bisip_amd.synthetic import synthetic_columns
+    from bisip_amd.utils import columns_to_data
+    d = columns_to_data(synthetic_columns(32, 3), 'mrad')
+    per = np.log10(1. / d['w'])
+    lt = np.linspace(np.floor(per.min() - 1), np.floor(per.max() + 1), 64)
+    ndim = poly_deg + 2
+    bounds = np.array([[0.9] + [-1.0] * (poly_deg + 1), [1.1] + [1.0] * (poly_deg + 1)])
+    ctx = _hip.HipContext(0, d['w'], d['zn'], d['zn_err'], bounds, poly_deg=poly_deg, c_exp=1.0, taus=10 ** lt,
+                          log_taus=np.array([lt ** i for i in range(poly_deg + 1)]), variant='reduced_comp')
+    assert ctx.kernel_name == 'k_logprob_pd_reduced_comp'
+    rng = np.random.RandomState(poly_deg)
+    centre = np.r_[1.0, 0.005 * rng.randn(poly_deg + 1) / (1.0 + np.arange(poly_deg + 1)) ** 2]
+    for W in (32, 200, 512):
+        p0 = centre + 1e-4 * rng.randn(W, ndim)
+        chains = {}
+        for key, persistent, staging in (('staged', True, True), ('registers', True, False), ('launches', False, True)):
+            if staging:
+                monkeypatch.delenv('BISIP_NO_LDS_STAGING', raising=False)
+            else:
+                monkeypatch.setenv('BISIP_NO_LDS_STAGING', '1')
+            s = DeviceEnsembleSampler(W, ndim, ctx, rng='philox', seed=7, persistent=persistent)
+            s.run_mcmc(p0, 12, thin_by=2)
+            chains[key] = (s.get_chain(), s.get_log_prob(), s.last_path)
+        monkeypatch.delenv('BISIP_NO_LDS_STAGING', raising=False)
+        assert chains['staged'][2] == 'persistent' and chains['registers'][2] == 'persistent'
+        assert chains['launches'][2] == 'launch-per-half-step'
+        for key in ('registers', 'launches'):
+            assert np.array_equal(chains['staged'][0], chains[key][0]), (poly_deg, W, key)
+            assert np.array_equal(chains['staged'][1], chains[key][1]), (poly_deg, W, key)
+        last = chains['staged'][0][-1]
+        assert np.array_equal(ctx.logprob(np.tile(last, (40, 1)))[:W], chains['staged'][1][-1])
+        assert np.isfinite(chains['staged'][1]).all()
+    ctx.close()
+    # a batch: the image of every spectrum staged by its workgroup
+    tables = [synthetic_columns(32, i) for i in range(5)]
+    batch = bisip_amd.SpectraBatch('PolynomialDecomposition', tables, nwalkers=64, nsteps=6, poly_deg=poly_deg)
+    batch.ctx.set_variant('reduced_comp')
+    p0 = (centre + 1e-4 * rng.randn(5, 64, ndim)).reshape(-1, ndim)
+    chains = {}
+    for key, persistent, staging in (('staged', True, True), ('registers', True, False), ('launches', False, True)):
+        if staging:
+            monkeypatch.delenv('BISIP_NO_LDS_STAGING', raising=False)
+        else:
+            monkeypatch.setenv('BISIP_NO_LDS_STAGING', '1')
+        s = DeviceEnsembleSampler(64, ndim, batch.ctx, rng='philox', seed=8, n_ensembles=5, persistent=persistent)
+        s.run_mcmc(p0, 6)
+        chains[key] = (s.get_chain(), s.get_log_prob())
+    monkeypatch.delenv('BISIP_NO_LDS_STAGING', raising=False)
+    for key in ('registers', 'launches'):
+        assert np.array_equal(chains['staged'][0], chains[key][0]) and np.array_equal(chains['staged'][1], chains[key][1])
+    batch.close()
+
+
 def test_persistent_falls_back_when_ensemble_too_large():
     from bisip_amd.sampler import DeviceEnsembleSampler
     g = np.load(_case('case15_'))
