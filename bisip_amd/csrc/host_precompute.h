@@ -84,8 +84,8 @@ double reduced_logp_reference(int n, const std::vector<long double> &Rl, const s
 // -0.5 * sum_i 2*ln(zn_err_i^2), the walker-independent term of src/bisip/models.py:62
 double loglike_const(int n2, const double *zn_err);
 
-// Geometric frequency grid (kernels.h: BOUNDS_GRID): true when, in blocks of four frequencies,
-// ln w_{4k+q} = lnw[4k] + q * dlnw to 4e-15 -- lnw[] the ROUNDED values the kernels hold, ln w_f on the left
+// Geometric frequency grid (kernels.h: BOUNDS_GRID): true when, in blocks of eight frequencies,
+// ln w_{8k+q} = lnw[8k] + q * dlnw to 4e-15 -- lnw[] the ROUNDED values the kernels hold, ln w_f on the left
 // in long double -- for the common step dlnw = (ln w_{N-1} - ln w_0)/(N-1); N >= 8.  *dlnw is set either way
 // (0 when there is no such grid).
 bool grid_step(int N, const double *w, const double *lnw, double *dlnw);

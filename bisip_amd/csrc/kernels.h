@@ -37,9 +37,9 @@ struct Bounds {
 };
 constexpr int BOUNDS_FAST = 1;
 // BOUNDS_GRID (only together with BOUNDS_FAST): the frequencies of every spectrum of the context lie on a
-// geometric grid, ln w_{4k+q} = ln w_{4k} + q * dlnw to 4e-15 (grid_step in host_precompute.cpp; rec[7] of
+// geometric grid, ln w_{8k+q} = ln w_{8k} + q * dlnw to 4e-15 (grid_step in host_precompute.cpp; rec[7] of
 // every record holds dlnw).  The exponentials of the per-frequency models are then taken once per block of
-// four frequencies and stepped by multiplication (GridSteps below).
+// eight frequencies and stepped by multiplication (GridSteps below).
 constexpr int BOUNDS_GRID = 2;
 constexpr int GRID_MAX_TERMS = 3;     // ColeCole with up to three modes, Shin (two elements)
 // The safe loop clamps the exponent y of 2^y = |(i w tau)^c| (ColeCole) or Q w^n (Shin) at 500: beyond,
@@ -700,17 +700,18 @@ struct Shin {
 
 // Geometric frequency grids (BOUNDS_GRID).  The exponentials of ColeCole / Shin at frequency f are
 // 2^(a_i ln w_f + b_i) with per-walker a_i, b_i: sixteen of their ~33 instructions per (frequency, term).
-// On a grid ln w_{4k+q} = ln w_{4k} + q dlnw they are, for the block of four frequencies that starts at 4k,
-//   base_i = 2^(a_i ln w_{4k} + b_i)             one exponential per block and term,
-//   base_i,  base_i S1_i,  base_i S2_i,  base_i S3_i        for q = 0..3,
-// with the per-walker steps S1 = 2^(a_i dlnw), S2 = S1 S1, S3 = S2 S1 -- a quarter of the exponentials plus
-// three multiplications.  The value at frequency f is defined by THIS formula (block start 4*(f/4), step
-// f%4) in every kernel, whichever lane evaluates it and in whatever order: the same bits everywhere, as for
-// the other paths.  Rounding: base as before; a step adds <= 4 ulp; the grid's own deviation <= 4e-15 in the
-// exponent's ln w, the size of the rounding of ln w itself.
+// On a grid ln w_{8k+q} = ln w_{8k} + q dlnw they are, for the block of eight frequencies that starts at 8k,
+//   base_i = 2^(a_i ln w_{8k} + b_i)             one exponential per block and term,
+//   half_i = base_i  (q < 4)   or   base_i S4_i  (q >= 4),
+//   half_i,  half_i S1_i,  half_i S2_i,  half_i S3_i        for q mod 4 = 0..3,
+// with the per-walker steps S1 = 2^(a_i dlnw), S2 = S1 S1, S3 = S2 S1, S4 = S2 S2 -- an eighth of the
+// exponentials plus seven multiplications.  The value at frequency f is defined by THIS formula (block start
+// 8*(f/8), half (f/4)%2, step f%4, in that order) in every kernel, whichever lane evaluates it and in whatever
+// order: the same bits everywhere, as for the other paths.  Rounding: base as before; the half and the step
+// add <= 6 ulp; the grid's own deviation <= 4e-15 in the exponent's ln w, the size of the rounding of ln w.
 template <class M>
 struct GridSteps {
-    double S[3][M::NEXP];
+    double S[4][M::NEXP];     // 2^(a dlnw) to the powers 1, 2, 3 and 4
 };
 
 template <class M>
@@ -726,6 +727,7 @@ __device__ __forceinline__ GridSteps<M> grid_steps(const typename M::Setup &s, d
         g.S[0][i] = r[i];
         g.S[1][i] = r[i] * r[i];
         g.S[2][i] = g.S[1][i] * r[i];
+        g.S[3][i] = g.S[1][i] * g.S[1][i];
     }
     return g;
 }
@@ -739,7 +741,15 @@ __device__ __forceinline__ void grid_base(const typename M::Setup &s, double lnw
     exp2_finite_n<M::NEXP>(y, base);
 }
 
-// exponentials of step Q (compile time) of a block
+// the second half of a block of eight frequencies starts from the first half's exponential times S4
+template <class M>
+__device__ __forceinline__ void grid_half(const GridSteps<M> &g, double (&base)[M::NEXP])
+{
+#pragma unroll
+    for (int i = 0; i < M::NEXP; ++i) base[i] = base[i] * g.S[3][i];
+}
+
+// exponentials of step Q (compile time) of a half-block
 template <class M, int Q>
 __device__ __forceinline__ void grid_at(const GridSteps<M> &g, const double (&base)[M::NEXP], double *e)
 {
@@ -943,11 +953,15 @@ __device__ __forceinline__ void logprob_sums_grid(const typename M::Setup &s, co
         for (int q = 0; q < 8; ++q) { cur[2 * q] = buf[q].x; cur[2 * q + 1] = buf[q].y; }
         const GridSteps<M> gs = grid_steps<M>(s, cur[7]);
         int j = 0;
-        auto pair = [&](auto second) {
+        // KIND 0: first pair of a block of eight (takes the block's exponential); 2: first pair of its second
+        // half (the exponential times S4); 1: the second pair of either half
+        auto pair = [&](auto kind) {
+            constexpr int KIND = decltype(kind)::value;
             lds_pair_issue((j + 3 < o.N) ? rec + R2 : rec, buf, cur[5]);   // last pair: a harmless re-read
             double e[2 * NE], rr[2], ri[2];
-            if constexpr (!decltype(second)::value) {
-                grid_base<M>(s, cur[5], base);
+            if constexpr (KIND != 1) {
+                if constexpr (KIND == 0) grid_base<M>(s, cur[5], base);
+                else grid_half<M>(gs, base);
                 grid_at<M, 0>(gs, base, e);
                 grid_at<M, 1>(gs, base, e + NE);
             } else {
@@ -968,16 +982,25 @@ __device__ __forceinline__ void logprob_sums_grid(const typename M::Setup &s, co
             j += 2;
             rec += R2;
         };
-        for (; j + 3 < o.N;) {
-            pair(std::false_type{});
-            pair(std::true_type{});
+        using K0 = std::integral_constant<int, 0>;
+        using K1 = std::integral_constant<int, 1>;
+        using K2 = std::integral_constant<int, 2>;
+        for (; j + 7 < o.N;) {
+            pair(K0{});
+            pair(K1{});
+            pair(K2{});
+            pair(K1{});
         }
-        const bool tail_pair = j + 1 < o.N;
-        if (tail_pair) pair(std::false_type{});
-        if (j < o.N) {                          // one frequency left: step 0 or step 2 of its block
+        // fewer than eight left: up to three pairs and a single frequency, in the block's order
+        int done = 0;                           // pairs of the last, partial block
+        if (j + 1 < o.N) { pair(K0{}); done = 1; }
+        if (j + 1 < o.N) { pair(K1{}); done = 2; }
+        if (j + 1 < o.N) { pair(K2{}); done = 3; }
+        if (j < o.N) {                          // one frequency left: step 0 or 2 of the half it falls in
             double e[NE], rr[1], ri[1];
-            if (tail_pair) grid_at<M, 2>(gs, base, e);
-            else { grid_base<M>(s, rec[5], base); grid_at<M, 0>(gs, base, e); }
+            if (done == 0) { grid_base<M>(s, rec[5], base); grid_at<M, 0>(gs, base, e); }
+            else if (done == 2) { grid_half<M>(gs, base); grid_at<M, 0>(gs, base, e); }
+            else grid_at<M, 2>(gs, base, e);
             const double *const r1[1] = {rec};
             M::template residual_from_exp<1, true>(s, r1, e, rr, ri);
             acc0 = fma(rr[0] * rr[0], rec[2], acc0);
@@ -995,19 +1018,34 @@ __device__ __forceinline__ void logprob_sums_grid(const typename M::Setup &s, co
             acc0 = fma(rr[0] * rr[0], r[2], acc0);
             acc1 = fma(ri[0] * ri[0], r[3], acc1);
         };
+        auto four = [&](const double *__restrict__ r) {
+            one(std::integral_constant<int, 0>{}, r);
+            one(std::integral_constant<int, 1>{}, r + REC);
+            one(std::integral_constant<int, 2>{}, r + 2 * REC);
+            one(std::integral_constant<int, 3>{}, r + 3 * REC);
+        };
+        auto upto3 = [&](const double *__restrict__ r, int left) {
+            one(std::integral_constant<int, 0>{}, r);
+            if (left > 1) one(std::integral_constant<int, 1>{}, r + REC);
+            if (left > 2) one(std::integral_constant<int, 2>{}, r + 2 * REC);
+        };
         int j = 0;
-        for (; j + 3 < o.N; j += 4, rec += 4 * REC) {
+        for (; j + 7 < o.N; j += 8, rec += 8 * REC) {
             grid_base<M>(s, rec[5], base);
-            one(std::integral_constant<int, 0>{}, rec);
-            one(std::integral_constant<int, 1>{}, rec + REC);
-            one(std::integral_constant<int, 2>{}, rec + 2 * REC);
-            one(std::integral_constant<int, 3>{}, rec + 3 * REC);
+            four(rec);
+            grid_half<M>(gs, base);
+            four(rec + 4 * REC);
         }
-        if (j < o.N) {
+        if (j < o.N) {                           // a partial block of eight
             grid_base<M>(s, rec[5], base);
-            one(std::integral_constant<int, 0>{}, rec);
-            if (j + 1 < o.N) one(std::integral_constant<int, 1>{}, rec + REC);
-            if (j + 2 < o.N) one(std::integral_constant<int, 2>{}, rec + 2 * REC);
+            if (j + 3 < o.N) {
+                four(rec);
+                j += 4;
+                rec += 4 * REC;
+                if (j < o.N) { grid_half<M>(gs, base); upto3(rec, o.N - j); }
+            } else {
+                upto3(rec, o.N - j);
+            }
         }
     } else {
         // L lanes per walker: lane g takes BLOCK jb/4 + g of every group of L blocks -- its own exponential,
@@ -1021,7 +1059,9 @@ __device__ __forceinline__ void logprob_sums_grid(const typename M::Setup &s, co
         for (int jb = 0; jb < o.N; jb += 4 * L) {
             const int j4 = (jb + 4 * g < o.N) ? jb + 4 * g : (last & ~3);   // clamp: its results are never adopted
             double base[NE], rr[4], ri[4], iv[4][2];
-            grid_base<M>(s, o.cb[(long long)j4 * REC + 5], base);
+            grid_base<M>(s, o.cb[(long long)(j4 & ~7) * REC + 5], base);
+#pragma unroll
+            for (int i = 0; i < NE; ++i) base[i] = base[i] * ((j4 & 4) ? gs.S[3][i] : 1.0);    // second half: times S4
             auto one = [&](auto Q) {
                 constexpr int q = decltype(Q)::value;
                 const int j = (j4 + q <= last) ? j4 + q : last;

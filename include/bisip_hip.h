@@ -382,8 +382,8 @@ int bisip_ctx_nfreq(const bisip_ctx *ctx);
 int bisip_ctx_device(const bisip_ctx *ctx);
 /* Which loop the per-frequency models (ColeCole, Shin) run for the current prior box and frequencies; bits:
  *   1  shared reciprocals, exponents unclamped: the box keeps every denominator product normal;
- *   2  (only with 1) geometric frequency grid: every spectrum's ln w_{4k+q} = ln w_{4k} + q*step to 4e-15
- *      (bisip_frequency_grid_step), so the exponentials are taken once per block of four frequencies and
+ *   2  (only with 1) geometric frequency grid: every spectrum's ln w_{8k+q} = ln w_{8k} + q*step to 4e-15
+ *      (bisip_frequency_grid_step), so the exponentials are taken once per block of eight frequencies and
  *      stepped by multiplication.  The environment variable BISIP_NO_GRID, read when a context is created,
  *      switches bit 2 off (measurement aid).
  * 0 for the other models and for boxes widened past the limits. */
