@@ -272,15 +272,15 @@ FILES = [
     (f'{ROUND}_survey.jsonl', '`python benchmarks/survey.py [--model PeltonColeCole]`', 'a 4096-spectrum survey end to end: files to posterior summaries and model bands'),
     (f'{ROUND}_batch_setup.jsonl', '`python benchmarks/batch_setup.py`', 'what surrounds a survey run: batch context creation (host precompute on threads), a short fit, the summaries'),
     (f'{ROUND}_soak.json', '`python benchmarks/soak.py`', 'twenty 100,000-iteration fits and twenty 10,000-iteration batch fits in one process: device memory constant, posterior means within 0.02 sigma of each other, identical summaries for identical seeds'),
-    (f'{ROUND}_fuzz_*_summary.jsonl', '`python benchmarks/fuzz_parity.py --cases 3000 --seed S` (S = 41..44, 47, 48; 4000 at S = 49..51; 1500 cases at S = 45, 46 with `--widen 1.5`, `--widen 3`; S = 52..57 -- 2000, 3000, 1500 with `--widen 1.5`, 3000, 3000, 1500 with `--widen 3`, 8000 each at S = 58, 59 and 10000 each at S = 60, 61 -- with the ColeCole / Shin frequencies on exact grids, rounded grids and off any grid by thirds), `fuzz_sampler.py --cases 1500 --seed 2` (and 5, 6; 3000 at 8; 10, 2000 at 12, 4000 at 14, 2000 / 2500 / 6000 at 17, 19, 21 with the three kinds of frequencies), `fuzz_batch.py --cases 500 --seed 1` (and 4, 7; 1000 at 9; 600 each at 11, 13 and 1200 at 15 with the three kinds mixed inside a batch; 1000 at 16, 600 / 800 / 2000 at 18, 20, 22 with a reduced tier per spectrum)', 'randomised campaigns of this round (earlier rounds: `r02_fuzz_*`, 41,000 problems): violations, worst errors, which kernel AUTO ran'),
+    (f'{ROUND}_fuzz_*_summary.jsonl', '`python benchmarks/fuzz_parity.py --cases 3000 --seed S` (S = 41..44, 47, 48; 4000 at S = 49..51; 1500 cases at S = 45, 46 with `--widen 1.5`, `--widen 3`; S = 52..57 -- 2000, 3000, 1500 with `--widen 1.5`, 3000, 3000, 1500 with `--widen 3`, 8000 each at S = 58, 59, 10000 each at S = 60, 61, 6000 and 2000 with `--widen 1.5` at S = 62, 63 (blocks of eight) -- with the ColeCole / Shin frequencies on exact grids, rounded grids and off any grid by thirds), `fuzz_sampler.py --cases 1500 --seed 2` (and 5, 6; 3000 at 8; 10, 2000 at 12, 4000 at 14, 2000 / 2500 / 6000 at 17, 19, 21 with the three kinds of frequencies), `fuzz_batch.py --cases 500 --seed 1` (and 4, 7; 1000 at 9; 600 each at 11, 13 and 1200 at 15 with the three kinds mixed inside a batch; 1000 at 16, 600 / 800 / 2000 at 18, 20, 22 with a reduced tier per spectrum)', 'randomised campaigns of this round (earlier rounds: `r02_fuzz_*`, 41,000 problems): violations, worst errors, which kernel AUTO ran'),
     (f'{ROUND}_fuzz_valley_summary.jsonl', '`python benchmarks/fuzz_parity.py --cases 1500 --seed S --valley` (S = 301..303; 3000 cases each at S = 304..306, 4000 at S = 307..309, 6000 at S = 310; all re-run under the bisecting estimate)', 'half of the checked PolynomialDecomposition rows along the valley of chi^2 / on the shell logp = 0: distances of every formulation AND of the reference from the exact value'),
     (f'{ROUND}_valley_rows.jsonl, {ROUND}_valley_rows_before.jsonl', '`python benchmarks/valley_rows.py`', 'the kernel AUTO picks, measured on 3000 valley rows per scale (1 ... 1000 sigma) of 216 designs of degree 5-10 (designs above 1e-11 are listed): with this round\'s estimate, and -- `_before` -- with round 2\'s, against plain long double'),
     (f'{ROUND}_micro_collapsed_r3.txt', '`benchmarks/micro/collapsed_r3`', 'PDCollapsed: the shipped kernel against LDS-staged records, 4 rows per lane, single-wave workgroups and persistent waves, each with the engine clock it ran at and cycles per VALU instruction'),
     (f'{ROUND}_micro_exp2_variants.txt', '`benchmarks/micro/exp2_variants`', 'a table-driven exp2 (16 / 32 entries in LDS) against the shipped degree-11 polynomial: cycles per exp2 per SIMD, clock, worst ulp -- not adopted'),
     (f'{ROUND}_micro_fit_speed_by_tier.txt', '`python benchmarks/micro/fit_speed_by_tier.py`', 'fit() iterations/s on the plain and on the compensated reduced kernel (32 / 256 / 4096 walkers), with fit()\'s own measurement of the kernel'),
     (f'{ROUND}_micro_rcp_accuracy.txt', '`benchmarks/micro/rcp_accuracy` (hipcc from `rcp_accuracy.hip`)', '`v_rcp_f64` is good to 2^-24.4 on gfx950; one Newton step leaves 20 ulp, two 1.00 ulp, ONE cubic step `r(1 + e + e^2)` 1.00 ulp with one instruction less and a shorter chain: what `rcp_nr` does'),
-    (f'{ROUND}_micro_grid_vs_direct.txt', '`python benchmarks/micro/grid_vs_direct.py`', 'ColeCole (1-3 modes) and Shin bulk launches on geometric frequency grids (exponentials stepped by multiplication: 1.3-1.45x) against one exponential per frequency (`BISIP_NO_GRID=1`), with the largest difference between the two; rounded grid and bundled field spectrum as controls (no grid: the same loop twice)'),
-    (f'{ROUND}_micro_grid_small_ensembles.txt', '`python benchmarks/micro/grid_small_ensembles.py`', '`fit()` of one spectrum with 32-1024 walkers and emcee-sized calls, stepped against direct: 1.11-1.24x on an exact grid (lanes that share a walker take whole blocks), 1.0 on the bundled spectrum (no grid)'),
+    (f'{ROUND}_micro_grid_vs_direct.txt', '`python benchmarks/micro/grid_vs_direct.py`', 'ColeCole (1-3 modes) and Shin bulk launches on geometric frequency grids (exponentials stepped by multiplication in blocks of eight: 1.38-1.65x) against one exponential per frequency (`BISIP_NO_GRID=1`), with the largest difference between the two; rounded grid and bundled field spectrum as controls (no grid: the same loop twice)'),
+    (f'{ROUND}_micro_grid_small_ensembles.txt', '`python benchmarks/micro/grid_small_ensembles.py`', '`fit()` of one spectrum with 32-1024 walkers and emcee-sized calls, stepped against direct: 1.08-1.31x on an exact grid (lanes that share a walker take whole half-blocks), 1.0 on the bundled spectrum (no grid)'),
     (f'{ROUND}_micro_grid_small_ensembles_before.txt', 'the same script on two designs that were taken out', 'one frequency per lane and round on a grid: 0.92-1.0x; a series-corrected tier for grids rounded in data files: 0.71-0.94x on the bundled spectrum (1.09-1.16x in bulk launches) -- why field data keeps the direct loop'),
     (f'{ROUND}_micro_persistent_comp_by_degree.txt', '`python benchmarks/micro/persistent_comp_by_degree.py`, `batch_comp_by_degree.py`', 'the compensated kernel in the persistent sampler against one launch per half-step, by degree, with its triangle in scalar registers (single spectrum) and its low words staged in LDS: single ensembles -- persistent wins at every degree up to 512 walkers (1.6-2.3x at 32 walkers); 512 x 256 batches -- persistent wins up to degree 8, ties at 9; the automatic rules follow'),
     (f'{ROUND}_micro_small_call_latency.jsonl', '`python benchmarks/micro/small_call_latency.py`', 'one emcee-sized log-probability call with host buffers, every model, 16 ... 4096 rows'),
