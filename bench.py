@@ -82,6 +82,32 @@ def load_json(name):
         return None
 
 
+# The PMC counters this file replays (profiles/pmc_traffic.json, valu_counts.json) were collected from a
+# particular build of the log-probability kernels: the files carry the SHA-256 of these sources as they were
+# on the GPU box, and a line printed from other sources reports the counters as stale instead of quoting them.
+KERNEL_SOURCES = ('bisip_amd/csrc/kernels.h', 'bisip_amd/csrc/sampler_kernels.h', 'bisip_amd/csrc/dispatch_logprob.hip')
+
+
+def kernel_sources_sha256():
+    import hashlib
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, rel), 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def load_counters(name):
+    """A counter file of profiles/ if it was collected from the kernel sources of this tree, else None;
+    second value: True when the file exists but belongs to other sources."""
+    rec = load_json(name)
+    if rec is None:
+        return None, False
+    if rec.get('kernel_sources_sha256') != kernel_sources_sha256():
+        return None, True
+    return rec, False
+
+
 def valu_roofline(label, W, kernel_ms, counts):
     """fp64 VALU-issue roofline of one launch from the PMC-measured instruction count
     (profiles/valu_counts.json, written by benchmarks/summarize_pmc.py from a
@@ -525,7 +551,7 @@ def main():
             bytes_per_eval = 8 * (ndim + 1)            # read one theta row, write one logp
             achieved = bytes_per_eval * W / (kern_ms * 1e-3) / 1e9    # per GPU, slowest rank
             traffic = None
-            rec = load_json('pmc_traffic.json')
+            rec, traffic_stale = load_counters('pmc_traffic.json')
             if rec and rec.get('walkers') == W and rec.get('kernel') == ctx.kernel_name:
                 traffic = rec.get('hbm_bytes_per_launch')
             result.update({
@@ -546,11 +572,16 @@ def main():
                                                'WRITE_SIZE passes of this command (FETCH_SIZE x2, gfx950)'
                                                if traffic is not None else None},
             })
+            result['kernel_sources_sha256'] = kernel_sources_sha256()
+            if traffic_stale:
+                result['roofline']['counters_stale'] = True     # collected from other kernel sources: not quoted
             if parity is not None:
                 result['parity'] = parity
             if world == 1:
                 result['roofline']['clock_ghz'] = engine_clock_ghz(step, kern_ms, torch)
-                counts = load_json('valu_counts.json')
+                counts, counts_stale = load_counters('valu_counts.json')
+                if counts_stale:
+                    result['valu_counters_stale'] = True        # no roofline_valu below
                 gpu_logp = out_t.cpu().numpy()
                 if not args.no_variants:
                     result['variants'] = time_variants(ctx, args, step, W, torch, stream, counts)
@@ -773,7 +804,7 @@ def pmc_pass(ctx, step, theta_t, out_t, data, torch):
         torch.cuda.synchronize()
         order.append({'label': label, 'kernel': zctx.kernel_name, 'walkers': ZOO_WALKERS})
         zctx.close()
-    print(json.dumps({'pmc_pass': order}))
+    print(json.dumps({'pmc_pass': order, 'kernel_sources_sha256': kernel_sources_sha256()}))
 
 
 if __name__ == '__main__':

@@ -18,7 +18,10 @@ repo=$PWD
 trap 'rm -rf "$scratch"' EXIT
 step() {   # step <name> <command...>: run, log a failure, carry on
   local name=$1; shift
-  if ! "$@"; then echo "!! step $name failed (status $?)" | tee -a "$out/progress.log"; fi
+  "$@"
+  local rc=$?
+  # to stderr and the log only: every caller redirects stdout into the evidence file itself
+  if [ $rc -ne 0 ]; then echo "!! step $name failed (status $rc)" >&2; echo "!! step $name failed (status $rc)" >> "$out/progress.log"; fi
 }
 
 if [ "$what" = bench ] || [ "$what" = all ]; then

@@ -7,6 +7,11 @@ tag=${1:?round tag, e.g. r02}
 src=gpurun_out
 dst=profiles
 newest() { ls -t "$1"/*"$2" 2>/dev/null | head -1; }   # earlier calls leave their PID-named files behind
+if grep -q '^!!' "$src/progress.log" 2>/dev/null; then
+  echo "gpurun_out/progress.log records failed steps; look at them (and remove the log) before importing:" >&2
+  grep '^!!' "$src/progress.log" >&2
+  exit 1
+fi
 cpy() { [ -s "$1" ] && cp "$1" "$2" || echo "missing or empty: $1" >&2; }
 cpy $src/bench.json                    $dst/${tag}_bench.json
 cpy $src/bench_under_rocprof.json      $dst/${tag}_bench_under_rocprof.json

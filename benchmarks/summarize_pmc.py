@@ -23,6 +23,17 @@ import sys
 src, dst, tag = sys.argv[1:4]
 
 
+def sources_hash(path, key):
+    """The SHA-256 of the kernel sources as the profiled run on the GPU box reported it (bench.py prints it
+    in its result line and in the --pmc-pass line): what bench.py compares with the tree it runs from."""
+    for line in open(path):
+        if line.startswith('{"' + key + '"'):
+            h = json.loads(line).get('kernel_sources_sha256')
+            if h:
+                return h
+    sys.exit(f'{path}: no {key} line with kernel_sources_sha256 (collected by an older bench.py?)')
+
+
 def newest_run(pattern):
     """The counter CSV of the LAST run only: gpurun merges every call's files into the same local
     directory under PID-derived names, so earlier runs' files sit next to the new one."""
@@ -53,7 +64,11 @@ with open(os.path.join(dst, f'{tag}_bench_pmc_summary.csv'), 'w', newline='') as
 fetch = 2.0 * mean['FETCH_SIZE'] * 1024.0
 write = mean['WRITE_SIZE'] * 1024.0
 W = grid
+hashes = {sources_hash(os.path.join(src, f'pmc_{c}.json'), 'metric') for c in ('FETCH_SIZE', 'WRITE_SIZE')}
+if len(hashes) != 1:
+    sys.exit('the FETCH_SIZE and WRITE_SIZE passes ran different kernel sources')
 rec = {
+    'kernel_sources_sha256': hashes.pop(),
     'walkers': W, 'kernel': KERNEL, 'hbm_bytes_per_launch': fetch + write,
     'fetch_bytes_corrected': fetch, 'write_bytes': write,
     'FETCH_SIZE_KB_raw': mean['FETCH_SIZE'], 'WRITE_SIZE_KB_raw': mean['WRITE_SIZE'],
@@ -100,6 +115,7 @@ def valu_counts():
             sys.exit(f'dispatch order mismatch: expected {o["kernel"]}, saw {name}')
         out[o['label']] = {'kernel': name, 'walkers': o['walkers'], 'SQ_INSTS_VALU_per_launch': val,
                            'valu_wave_instr_per_eval': val / o['walkers']}
+    out['kernel_sources_sha256'] = sources_hash(order_file, 'pmc_pass')
     out['_note'] = (f'rocprofv3 --pmc SQ_INSTS_VALU on `python3 bench.py --pmc-pass` ({tag}); one launch per kernel; '
                     'wave-instructions summed over all waves of the launch')
     json.dump(out, open(os.path.join(dst, 'valu_counts.json'), 'w'), indent=1)

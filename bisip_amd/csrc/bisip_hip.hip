@@ -123,7 +123,7 @@ const char *name_for(const bisip_ctx *c)
 
 }  // namespace
 
-// May ColeCole<D> / Shin run their FAST frequency loop -- ONE reciprocal per group of denominators
+// May ColeCole<D> / Shin / Dias run their FAST frequency loop -- ONE reciprocal per group of denominators
 // (kernels.h: rcp_batch_n), no exponent clamp?  Only if, everywhere inside the prior box, every denominator of
 // a frequency lies in [1, 2^225], so that a product of four is a normal number: exponents
 // y = c log2e (ln w + log_tau) (ColeCole) or log2e (n ln w + log_Q) (Shin) bounded by 110, cos(c pi/2) >= 0
@@ -154,6 +154,21 @@ static int bound_flags(const bisip_ctx *c)
             ymax = y <= ymax ? ymax : y;
             ok = ok && rlo >= 0.0 && rhi <= 1.0 && nlo >= 0.0 && nhi <= 1.0;
         }
+    } else if (c->model_id == BISIP_MODEL_DIAS2000) {
+        // Dias shares ONE reciprocal between frequencies 2k and 2k+1 (kernels.h: Dias::residual2<true>): the
+        // product of two D = X^2 + Y^2 must be a normal number with a normal reciprocal everywhere in the box.
+        // Bounds of D over the box (parameters r0, m, log_tau, eta, delta; tau' >= 0 needs m, delta within
+        // [0, 1] and is clamped at 1e50 in the kernel; u = sqrt(w)):
+        //   D >= n2^2 >= (u tau)^4,   D <= (n2 + b g)^2 + (b (u n2 + teh))^2 at the upper ends.
+        const double u_max = std::exp(0.5 * c->lnw_max), u_min = std::exp(0.5 * c->lnw_min);
+        const double tau_max = std::exp(hi[2]), tau_min = std::exp(lo[2]);
+        const double teh = tau_max * mag(lo[3], hi[3]) * 0.70710678118654752440;
+        const double g = u_max * tau_max + teh, n2 = teh * teh + g * g, b = 1e50 * u_max;
+        const double X = n2 + b * g, Y = b * (u_max * n2 + teh);
+        const double d_max = X * X + Y * Y, d_min = std::pow(u_min * tau_min, 4.0);
+        ok = lo[1] >= 0.0 && hi[1] <= 1.0 && lo[4] >= 0.0 && hi[4] <= 1.0 && mag(lo[0], hi[0]) <= 1e10 &&
+             d_max <= 1e140 && d_min >= 1e-140;          // false for NaN / inf anywhere
+        return ok ? BOUNDS_FAST : 0;
     } else {
         return 0;
     }
@@ -173,11 +188,12 @@ static bool in_prior_host(const double *th, const bisip_ctx *c)
     return true;
 }
 
-// Only the tiers the current variant can run are (re)computed -- the probing is most of what a batch
-// context costs to build, and on well-conditioned designs (every bundled spectrum, the headline shape)
-// the plain tier passes and the compensated one is never looked at: AUTO / REDUCED need tier 0, and
-// tier 1 when tier 0's estimate is too large; REDUCED_COMP needs tier 1.  set_variant and set_bounds come
-// back here.
+// Only what the current variant can run is (re)computed -- the probing is most of what a batch context costs
+// to build.  Tier 0 (plain) for every spectrum under AUTO / REDUCED.  Tier 1 (compensated: operands from a QR
+// in binary128, built on demand) for every spectrum under REDUCED_COMP, and under AUTO for exactly the spectra
+// whose plain estimate fails (all of them once the guard has closed the plain tier or the mix): on
+// well-conditioned designs -- every bundled spectrum, the headline shape -- the compensated tier is never looked
+// at.  A spectrum's probe rows serve both tiers.  set_variant, set_bounds and the guard come back here.
 // Which spectra of a batch take the plain tier inside a compensated launch (host.h: tier_of, mixed).
 static int update_tiers(bisip_ctx *c)
 {
@@ -200,65 +216,160 @@ static int update_tiers(bisip_ctx *c)
     return BISIP_OK;
 }
 
+// does spectrum e run the compensated tier under the context's present variant and history?
+static bool needs_comp(const bisip_ctx *c, size_t e)
+{
+    if (c->variant == BISIP_VARIANT_REDUCED_COMP) return true;
+    if (c->variant != BISIP_VARIANT_AUTO) return false;
+    if (c->demoted[0] || c->mix_off) return true;
+    return c->red[0].done.size() > e && c->red[0].done[e] && !(c->red[0].est[e] <= BISIP_REDUCED_ERR_MAX);
+}
+
+// binary128 operands of the spectra in `need` that lack them: the kernel sums once per distinct frequency list
+// (the spectra of a survey usually share one), then one QR per spectrum on the host threads
+static void make_quad_operands(bisip_ctx *c, const std::vector<int64_t> &need)
+{
+    const int N = c->N, S = c->S, D = c->P + 1;
+    std::vector<int64_t> todo;
+    for (int64_t e : need)
+        if (!c->reduced[(size_t)e].has_quad()) todo.push_back(e);
+    if (todo.empty()) return;
+    // group by frequency list
+    std::vector<int64_t> rep;                       // a representative spectrum of every distinct list
+    std::vector<int> group(todo.size());
+    for (size_t i = 0; i < todo.size(); ++i) {
+        const double *we = &c->h_w[(size_t)todo[i] * N];
+        int g = -1;
+        for (size_t k = rep.size(); k-- > 0 && g < 0;)      // the latest list first: consecutive spectra share theirs
+            if (std::memcmp(&c->h_w[(size_t)rep[k] * N], we, sizeof(double) * (size_t)N) == 0) g = (int)k;
+        if (g < 0) { g = (int)rep.size(); rep.push_back(todo[i]); }
+        group[i] = g;
+    }
+    std::vector<std::shared_ptr<const QuadKernelSums>> ks(rep.size());
+    parallel_blocks((int64_t)rep.size(), 1, [&](int64_t lo, int64_t hi) {
+        for (int64_t k = lo; k < hi; ++k)
+            ks[(size_t)k] = polydecomp_kernel_sums_quad(N, &c->h_w[(size_t)rep[(size_t)k] * N], S, c->h_taus.data(), D,
+                                                        c->h_log_taus.data(), c->c_exp);
+    });
+    parallel_blocks((int64_t)todo.size(), 1, [&](int64_t lo, int64_t hi) {
+        for (int64_t i = lo; i < hi; ++i) {
+            const size_t e = (size_t)todo[(size_t)i];
+            reduced_make_quad(*ks[(size_t)group[(size_t)i]], &c->h_zn[e * 2 * N], &c->h_err[e * 2 * N], c->reduced[e]);
+        }
+    });
+}
+
 static int recenter_reduced(bisip_ctx *c)
 {
     if (c->model_id != BISIP_MODEL_POLYDECOMP || c->reduced.empty()) return BISIP_OK;
     const int n = c->P + 2;
     const size_t tri = (size_t)n * (n + 1) / 2;
+    const size_t E = c->reduced.size();
+    const double w_shell = reduced_shell_weight();          // read once, on this thread
+    // == sizeof(ReducedArgs<P, COMP>)/8: the compensated tier's image starts with the triangle's low word
+    // as floats, an even number of them
+    const size_t lo_floats = (tri + 1) & ~(size_t)1;
+    const size_t red_doubles[2] = {tri + 3 * (size_t)n + 1, tri + 3 * (size_t)n + 1 + lo_floats / 2};
     for (int tier = 0; tier < 2; ++tier) {
         bisip_ctx::ReducedTier &T = c->red[tier];
-        const bool wanted = tier == 0 ? (c->variant == BISIP_VARIANT_AUTO || c->variant == BISIP_VARIANT_REDUCED)
-                                      : (c->variant == BISIP_VARIANT_REDUCED_COMP ||
-                                         (c->variant == BISIP_VARIANT_AUTO &&
-                                          (!(c->red[0].err <= BISIP_REDUCED_ERR_MAX) || c->demoted[0])));
-        if (T.valid || !wanted) continue;
-        const size_t E = c->reduced.size();
-        // == sizeof(ReducedArgs<P, COMP>)/8: the compensated tier's image starts with the triangle's low word
-        // as floats, an even number of them
-        const size_t lo_floats = (tri + 1) & ~(size_t)1;
-        const size_t red_doubles = tri + 3 * (size_t)n + 1 + (tier == 1 ? lo_floats / 2 : 0);
-        std::vector<double> red(c->E > 1 ? red_doubles * E : 0), est(E);
-        // the probing of every spectrum (reduced_center emulates the kernel on ~200 rows per
-        // candidate) is independent of the others: blocks of spectra on host threads
-        parallel_blocks((int64_t)E, 4, [&](int64_t e_lo, int64_t e_hi) {
-            std::vector<double> bh(n), ev(n), el(n), Rp;
-            std::vector<float> Rlo;
-            for (int64_t e = e_lo; e < e_hi; ++e) {
-                const bisip_ctx::ReducedHost &rh = c->reduced[(size_t)e];
-                est[(size_t)e] = reduced_center(n, rh.R, rh.Rl, rh.qty, rh.bhat_ls, rh.rest, rh.lconst, c->bounds.lo,
-                                                c->bounds.hi, tier == 1, bh.data(), ev.data(), el.data());
-                Rp.clear();
-                Rlo.clear();
-                for (int i = 0; i < n; ++i)
-                    for (int j = i; j < n; ++j) {
-                        Rp.push_back(rh.R[(size_t)i * n + j]);
-                        Rlo.push_back((float)(rh.Rl[(size_t)i * n + j] - (long double)rh.R[(size_t)i * n + j]));
-                    }
-                Rlo.resize(lo_floats, 0.0f);
-                if (e == 0) { c->Rpacked = Rp; c->Rlo_packed = Rlo; T.bhat = bh; T.evec = ev; T.elo = el; c->rest = rh.rest; }
-                if (c->E > 1) {  // ReducedArgs<P, COMP> image: [Rlo |] R | bhat | e | elo | rest
-                    double *dst = &red[red_doubles * (size_t)e];
-                    if (tier == 1) { std::memcpy(dst, Rlo.data(), lo_floats * sizeof(float)); dst += lo_floats / 2; }
-                    dst = std::copy(Rp.begin(), Rp.end(), dst);
-                    dst = std::copy(bh.begin(), bh.end(), dst);
-                    dst = std::copy(ev.begin(), ev.end(), dst);
-                    dst = std::copy(el.begin(), el.end(), dst);
-                    *dst = rh.rest;
+        if (T.done.size() != E) { T.done.assign(E, 0); T.est.assign(E, 0.0); }
+        if (c->E > 1 && T.image.size() != red_doubles[tier] * E) T.image.assign(red_doubles[tier] * E, 0.0);
+    }
+    // one spectrum's entry of a tier: its image (batch) and, for spectrum 0, the kernarg copy
+    auto store = [&](int tier, size_t e, const double *Rfull, const float *Rlo_full, double rest, const double *bh,
+                     const double *ev, const double *el) {
+        bisip_ctx::ReducedTier &T = c->red[tier];
+        std::vector<double> Rp;
+        std::vector<float> Rlo;
+        for (int i = 0; i < n; ++i)
+            for (int j = i; j < n; ++j) {
+                Rp.push_back(Rfull[(size_t)i * n + j]);
+                if (tier == 1) Rlo.push_back(Rlo_full[(size_t)i * n + j]);
+            }
+        if (tier == 1) Rlo.resize(lo_floats, 0.0f);
+        if (e == 0) {
+            T.Rpacked = Rp; T.Rlo_packed = Rlo; T.rest = rest;
+            T.bhat.assign(bh, bh + n); T.evec.assign(ev, ev + n); T.elo.assign(el, el + n);
+        }
+        if (c->E > 1) {  // ReducedArgs<P, COMP> image: [Rlo |] R | bhat | e | elo | rest
+            double *dst = &T.image[red_doubles[tier] * e];
+            if (tier == 1) { std::memcpy(dst, Rlo.data(), lo_floats * sizeof(float)); dst += lo_floats / 2; }
+            dst = std::copy(Rp.begin(), Rp.end(), dst);
+            dst = std::copy(bh, bh + n, dst);
+            dst = std::copy(ev, ev + n, dst);
+            dst = std::copy(el, el + n, dst);
+            *dst = rest;
+        }
+    };
+    bool changed[2] = {false, false};
+    // ---- tier 0, and tier 1 of the spectra known to need it, in one pass over the spectra (shared probes)
+    const bool want0 = (c->variant == BISIP_VARIANT_AUTO || c->variant == BISIP_VARIANT_REDUCED) && !c->red[0].valid;
+    auto pass = [&](const std::vector<int64_t> &which, bool do0) {
+        // the binary128 operands of the spectra already known to need tier 1 (under AUTO a spectrum is known
+        // to once its plain estimate has failed: those come back in a second pass)
+        std::vector<int64_t> need;
+        for (int64_t e : which)
+            if (needs_comp(c, (size_t)e) && !c->red[1].done[(size_t)e]) need.push_back(e);
+        make_quad_operands(c, need);
+        parallel_blocks((int64_t)which.size(), 4, [&](int64_t i_lo, int64_t i_hi) {
+            std::vector<double> bh(n), ev(n), el(n);
+            ReducedProbes probes;
+            for (int64_t i = i_lo; i < i_hi; ++i) {
+                const size_t e = (size_t)which[(size_t)i];
+                bisip::ReducedProblem &rp = c->reduced[e];
+                reduced_probes(rp, c->bounds.lo, c->bounds.hi, probes);
+                if (do0 && !c->red[0].done[e]) {
+                    c->red[0].est[e] = reduced_center_plain(rp, probes, c->bounds.lo, c->bounds.hi, w_shell, bh.data(), ev.data(), el.data());
+                    store(0, e, rp.R.data(), nullptr, rp.rest, bh.data(), ev.data(), el.data());
+                    c->red[0].done[e] = 1;
+                }
+                if (rp.has_quad() && needs_comp(c, e) && !c->red[1].done[e]) {
+                    c->red[1].est[e] = reduced_center_comp(rp, probes, c->bounds.lo, c->bounds.hi, w_shell, bh.data(), ev.data(), el.data());
+                    store(1, e, rp.Rc.data(), rp.Rc_lo.data(), rp.rest_c, bh.data(), ev.data(), el.data());
+                    c->red[1].done[e] = 1;
                 }
             }
         });
-        T.err = 0.0;
-        for (double v : est)
-            if (!(v <= T.err)) T.err = v;
-        T.est = est;
-        T.valid = true;
-        if (c->E > 1) {
-            if (red.size() != red_doubles * (size_t)c->E) return fail(BISIP_EHIP, "internal: reduced operand size mismatch");
-            HIP_TRY(hipSetDevice(c->device));
-            if (!T.d_red) HIP_TRY(hipMalloc(&T.d_red, red.size() * sizeof(double)));
+    };
+    std::vector<int64_t> all(E);
+    for (size_t e = 0; e < E; ++e) all[e] = (int64_t)e;
+    if (want0) {
+        pass(all, true);
+        changed[0] = true;
+        c->red[0].valid = true;
+        c->red[0].err = 0.0;
+        for (double v : c->red[0].est)
+            if (!(v <= c->red[0].err)) c->red[0].err = v;
+    }
+    // ---- tier 1 for the spectra that turned out to need it (their plain estimate failed just now, or the
+    // variant / the guard asks for it)
+    bool any_comp = false;
+    std::vector<int64_t> late;
+    for (size_t e = 0; e < E; ++e)
+        if (needs_comp(c, e)) {
+            any_comp = true;
+            if (!c->red[1].done[e]) late.push_back((int64_t)e);
+        }
+    if (!late.empty()) pass(late, false);
+    if (any_comp) {
+        changed[1] = changed[1] || !late.empty() || !c->red[1].valid;
+        c->red[1].valid = true;
+        c->red[1].err = 0.0;
+        for (size_t e = 0; e < E; ++e)
+            if (needs_comp(c, e) && !(c->red[1].est[e] <= c->red[1].err)) c->red[1].err = c->red[1].est[e];
+        if (c->E == 1 && c->red[1].Rpacked.empty()) return fail(BISIP_EHIP, "internal: compensated operands missing");
+    }
+    // a batch's compensated image needs an entry for EVERY spectrum the kernel may index: spectra on the plain
+    // tier of a mixed launch read their plain operands (BatchArgs::red_plain) and leave theirs at zero
+    if (c->E > 1) {
+        HIP_TRY(hipSetDevice(c->device));
+        for (int tier = 0; tier < 2; ++tier) {
+            bisip_ctx::ReducedTier &T = c->red[tier];
+            if (!changed[tier]) continue;
+            if (!T.d_red) HIP_TRY(hipMalloc(&T.d_red, T.image.size() * sizeof(double)));
             // set_bounds between launches: the copy is ordered after earlier work by the sync
             HIP_TRY(hipDeviceSynchronize());
-            HIP_TRY(hipMemcpy(T.d_red, red.data(), red.size() * sizeof(double), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(T.d_red, T.image.data(), T.image.size() * sizeof(double), hipMemcpyHostToDevice));
         }
     }
     return update_tiers(c);
@@ -355,10 +466,16 @@ int bisip_polydecomp_reduced_estimates(int N, const double *w, const double *zn,
         PolyDecompOperands o;
         const int D = desc->poly_deg + 1, n = D + 1;
         polydecomp_operands(N, w, desc->n_taus, desc->taus, D, desc->log_taus, desc->c_exp, zn, zn_err, o);
-        const double lconst = loglike_const(2 * N, zn_err);
+        ReducedProblem p;
+        reduced_from_operands(o, loglike_const(2 * N, zn_err), p);
+        if (2 * N >= n)     // a design with a triangle: the compensated tier's operands in binary128
+            reduced_make_quad(*polydecomp_kernel_sums_quad(N, w, desc->n_taus, desc->taus, D, desc->log_taus, desc->c_exp), zn, zn_err, p);
+        ReducedProbes probes;
+        reduced_probes(p, lo, hi, probes);
+        const double w_shell = reduced_shell_weight();
         std::vector<double> bh(n), ev(n), el(n);
-        for (int tier = 0; tier < 2; ++tier)
-            est[tier] = reduced_center(n, o.R, o.Rl, o.qty, o.bhat_ls, o.rest, lconst, lo, hi, tier == 1, bh.data(), ev.data(), el.data());
+        est[0] = reduced_center_plain(p, probes, lo, hi, w_shell, bh.data(), ev.data(), el.data());
+        est[1] = reduced_center_comp(p, probes, lo, hi, w_shell, bh.data(), ev.data(), el.data());
         return (int)BISIP_OK;
     });
 }
@@ -372,13 +489,14 @@ int bisip_polydecomp_reduced_reference(int N, const double *w, const double *zn,
         return fail(BISIP_EINVAL, "bad shape");
     if (2 * N < desc->poly_deg + 2) return fail(BISIP_EUNSUPPORTED, "2N < poly_deg + 2: the design has no triangle");
     return guarded([&] {
-        PolyDecompOperands o;
-        const int D = desc->poly_deg + 1, n = D + 1;
-        polydecomp_operands(N, w, desc->n_taus, desc->taus, D, desc->log_taus, desc->c_exp, zn, zn_err, o);
-        const double lconst = loglike_const(2 * N, zn_err);
-        parallel_blocks(W, 512, [&](int64_t lo, int64_t hi) {
-            for (int64_t i = lo; i < hi; ++i)
-                logp[i] = reduced_logp_reference(n, o.Rl, o.qty, o.rest, lconst, theta + i * n);
+        // the reduced form with operands from a QR in binary128, evaluated in binary128
+        const int D = desc->poly_deg + 1;
+        ReducedProblem p;
+        p.n = D + 1;
+        p.lconst = loglike_const(2 * N, zn_err);
+        reduced_make_quad(*polydecomp_kernel_sums_quad(N, w, desc->n_taus, desc->taus, D, desc->log_taus, desc->c_exp), zn, zn_err, p);
+        parallel_blocks(W, 256, [&](int64_t lo, int64_t hi) {
+            for (int64_t i = lo; i < hi; ++i) logp[i] = reduced_logp_reference(p, theta + i * p.n);
         });
         return (int)BISIP_OK;
     });
@@ -447,7 +565,16 @@ static int build_context(bisip_ctx **out, int device, int model_id, int E, int N
     std::vector<double> cb((size_t)E * N * rec, 0.0), lconsts(E), cb_lp;
     if (model_id == BISIP_MODEL_POLYDECOMP) cb_lp.assign((size_t)E * N * rec, 0.0);
     int rc = BISIP_OK;
-    if (model_id == BISIP_MODEL_POLYDECOMP) { c->c_exp = desc->c_exp; c->reduced.resize((size_t)E); }
+    if (model_id == BISIP_MODEL_POLYDECOMP) {
+        c->c_exp = desc->c_exp;
+        c->reduced.resize((size_t)E);
+        // what the compensated tier's binary128 operands are built from, if a spectrum ever needs them
+        c->h_w.assign(w, w + (size_t)E * N);
+        c->h_zn.assign(zn, zn + (size_t)E * 2 * N);
+        c->h_err.assign(zn_err, zn_err + (size_t)E * 2 * N);
+        c->h_taus.assign(desc->taus, desc->taus + S);
+        c->h_log_taus.assign(desc->log_taus, desc->log_taus + (size_t)(P + 1) * S);
+    }
     std::vector<double> fb;       // E == 1: loop-faithful records (see k_logprob_pd_faithful)
     // per-spectrum operands, blocks of spectra on host threads (each writes its own slots).  The
     // kernel sums K, G depend on the frequencies only: a block reuses them while consecutive
@@ -495,8 +622,7 @@ static int build_context(bisip_ctx **out, int device, int model_id, int E, int N
                     r[4 + P + 1 + p] = (double)(si * (long double)o.G_im[(size_t)j * (P + 1) + p]);
                 }
             }
-            bisip_ctx::ReducedHost &rh = c->reduced[(size_t)e];
-            rh.R = o.R; rh.Rl = o.Rl; rh.qty = o.qty; rh.bhat_ls = o.bhat_ls; rh.rest = o.rest; rh.lconst = lconsts[e];
+            reduced_from_operands(o, lconsts[e], c->reduced[(size_t)e]);
             if (E == 1) {
                 const int JB = 16, nb = (N + JB - 1) / JB;
                 const size_t blk_stride = 4 * (size_t)JB + (size_t)S * 2 * JB;
@@ -578,7 +704,7 @@ int bisip_ctx_set_bounds(bisip_ctx *c, const double *lo, const double *hi)
     c->bounds.flags = bound_flags(c);
     c->demoted[0] = c->demoted[1] = false;                            // observed on the old box
     c->mix_off = false;
-    for (auto &t : c->red) { t.valid = false; t.err = INFINITY; }     // estimates and expansion points belong to the old box
+    for (auto &t : c->red) { t.valid = false; t.err = INFINITY; t.done.assign(t.done.size(), 0); }     // estimates and expansion points belong to the old box
     const int rc = guarded([&] { return recenter_reduced(c); });   // the reduced form expands about a point of the box
     c->kernel_name = name_for(c);                                  // AUTO may change formulation with the box
     return rc;
@@ -805,14 +931,13 @@ int bisip_stretch_run_dev(bisip_ctx *c, const bisip_stretch_args *first, int64_t
 static double reduced_check_rows(const bisip_ctx *c, const double *theta, int64_t W, const double *logp,
                                  int64_t lo, int64_t hi, int64_t stride)
 {
-    const int n = c->P + 2;
     const int64_t per = c->E > 1 ? W / c->E : W;
     double w = 0.0;
     for (int64_t i = lo; i < hi; i += stride) {
         const double *th = theta + i * c->ndim;
         if (!in_prior_host(th, c)) continue;                  // the prior decides those rows, exactly
-        const bisip_ctx::ReducedHost &rh = c->reduced[(size_t)(per ? i / per : 0)];
-        const double want = reduced_logp_reference(n, rh.Rl, rh.qty, rh.rest, rh.lconst, th);
+        // from the spectrum's binary128 operands where it has them (the spectra on the compensated tier do)
+        const double want = reduced_logp_reference(c->reduced[(size_t)(per ? i / per : 0)], th);
         const double scale = std::fabs(want) > 1.0 ? std::fabs(want) : 1.0;
         const double rel = std::fabs(logp[i] - want) / scale;
         if (!(rel <= w)) w = rel;                              // NaN counts as worst

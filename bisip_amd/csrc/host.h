@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/bisip_hip.h"
+#include "host_precompute.h"
 #include "kernels.h"
 #include "sampler_kernels.h"
 
@@ -56,13 +57,19 @@ struct bisip_ctx {
     double *d_lconst = nullptr;    // (E,)  batch only
     long long cb_stride = 0;
     // QR-reduced form, two arithmetic tiers: [0] plain, [1] compensated (kernels.h:
-    // logprob_row_reduced<P, COMP>); each has its own expansion point
+    // logprob_row_reduced<P, COMP>); each has its own expansion point, and the compensated tier its own
+    // operands (triangle, rest) from the QR carried out in binary128 (host_precompute.h: ReducedProblem)
     struct ReducedTier {
         std::vector<double> bhat, evec, elo;   // spectrum 0, for the kernarg segment
-        double err = INFINITY;                  // worst estimated relative log-prob error (all spectra); INFINITY: not estimated
-        bool valid = false;                     // estimated for the current prior box
+        std::vector<double> Rpacked;            // spectrum 0, packed upper triangle as this tier's kernel holds it
+        std::vector<float> Rlo_packed;          // tier 1: its low word (even count)
+        double rest = 0.0;                      // spectrum 0
+        double err = INFINITY;                  // worst estimated relative log-prob error over the spectra that RUN this tier; INFINITY: not estimated
+        bool valid = false;                     // estimated for the current prior box (every spectrum that needs it)
         void *d_red = nullptr;                  // (E,) ReducedArgs<P>  batch only
-        std::vector<double> est;                // the estimate of every spectrum (err = their maximum)
+        std::vector<double> image;              // batch only: host copy of d_red (entries are rewritten spectrum by spectrum)
+        std::vector<double> est;                // the estimate of every spectrum (tier 1: 0 where the spectrum does not run it)
+        std::vector<unsigned char> done;        // per spectrum: estimated for the current box
     };
     ReducedTier red[2];
     // bisip_logprob measures the reduced kernel it ran on rows of its own batches (first call, then
@@ -70,7 +77,8 @@ struct bisip_ctx {
     bool demoted[2] = {false, false};
     // A batch on BISIP_VARIANT_AUTO whose spectra do not all pass the plain tier launches the compensated
     // kernels with a tier per spectrum (BatchArgs::tier): tier_of[e] = 0 where the plain estimate of spectrum e
-    // passes -- every spectrum runs what a context of its own would run.  mix_off: the guard closed the mix.
+    // passes -- every spectrum runs what a context of its own would run, and only the others pay for the
+    // compensated tier's operands and estimate.  mix_off: the guard closed the mix.
     std::vector<unsigned char> tier_of;
     unsigned char *d_tier = nullptr;
     bool mixed = false, mix_off = false;
@@ -78,17 +86,11 @@ struct bisip_ctx {
     int64_t guard_calls = 0, guard_checks = 0;
     double guard_worst = 0.0;
     int guard_escalations = 0;
-    std::vector<double> Rpacked;   // spectrum 0, packed upper triangle
-    std::vector<float> Rlo_packed;    // ... and its low word (R = Rpacked + Rlo_packed to 64 bits: exact in a float), even count
-    double rest = 0.0;
     // per spectrum, for re-centring the reduced form when the prior box changes
-    struct ReducedHost {
-        std::vector<double> R;                  // (n,n)
-        std::vector<long double> Rl;            // (n,n) the same, unrounded (R = (double)Rl)
-        std::vector<long double> qty, bhat_ls;  // (n,)
-        double rest = 0.0, lconst = 0.0;
-    };
-    std::vector<ReducedHost> reduced;
+    std::vector<bisip::ReducedProblem> reduced;
+    // PolynomialDecomposition: host copies of what the compensated tier's binary128 operands are built from, on
+    // demand (a spectrum that passes the plain tier never needs them)
+    std::vector<double> h_w, h_zn, h_err, h_taus, h_log_taus;
     // workspace of the host-pointer entry points
     double *d_ws = nullptr;
     size_t ws_bytes = 0;
@@ -114,12 +116,12 @@ template <int P, bool COMP>
 inline void fill_reduced(const bisip_ctx *c, ReducedArgs<P, COMP> &r)
 {
     const bisip_ctx::ReducedTier &t = c->red[COMP ? 1 : 0];
-    if constexpr (COMP) std::memcpy(r.Rlo, c->Rlo_packed.data(), sizeof(float) * c->Rlo_packed.size());
-    std::memcpy(r.R, c->Rpacked.data(), sizeof(r.R));
+    if constexpr (COMP) std::memcpy(r.Rlo, t.Rlo_packed.data(), sizeof(float) * t.Rlo_packed.size());
+    std::memcpy(r.R, t.Rpacked.data(), sizeof(r.R));
     std::memcpy(r.bhat, t.bhat.data(), sizeof(r.bhat));
     std::memcpy(r.e, t.evec.data(), sizeof(r.e));
     std::memcpy(r.elo, t.elo.data(), sizeof(r.elo));
-    r.rest = c->rest;
+    r.rest = t.rest;
 }
 LaunchArgs make_args(const bisip_ctx *c, const double *theta, double *out, int64_t W, const double *cb);
 BatchArgs make_batch_args(const bisip_ctx *c, const double *theta, double *out, int64_t W);

@@ -2,6 +2,7 @@
 // context, never per walker.
 #include "host_precompute.h"
 
+#include <quadmath.h>
 #include <sched.h>
 
 #include <algorithm>
@@ -15,9 +16,156 @@
 namespace bisip {
 
 typedef long double ld;
+typedef __float128 qd;
 constexpr int BISIP_HOST_MAXN = 32;    // unknowns of the reduced form: poly_deg + 2 <= 12
 
-static const ld PI_L = 3.141592653589793238462643383279502884L;
+// ---------------------------------------------------------------------------------------------
+// the two working precisions of the precompute: the same algorithms, written once
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+inline ld x_sqrt(ld x) { return sqrtl(x); }
+inline qd x_sqrt(qd x) { return sqrtq(x); }
+inline ld x_abs(ld x) { return fabsl(x); }
+inline qd x_abs(qd x) { return fabsq(x); }
+inline ld x_pow(ld x, ld y) { return powl(x, y); }
+inline qd x_pow(qd x, qd y) { return powq(x, y); }
+inline void x_sincos_half_pi(ld c, ld &sn, ld &cs)
+{
+    const ld ang = c * 3.141592653589793238462643383279502884L / 2;
+    cs = cosl(ang);
+    sn = sinl(ang);
+}
+inline void x_sincos_half_pi(qd c, qd &sn, qd &cs)
+{
+    const qd ang = c * M_PIq / 2;
+    cs = cosq(ang);
+    sn = sinq(ang);
+}
+
+// K[j,k] = 1 - 1/(1 + (i w_j tau_k)^c) and G[j,p] = sum_k log_taus[p,k] K[j,k] in the working precision T.
+// (i*w*tau)^c = (w*tau)^c * (cos(c*pi/2) + i sin(c*pi/2)); the base is purely imaginary and positive so its
+// argument is exactly pi/2.
+template <class T>
+void kernel_sums_T(int N, const double *w, int S, const double *taus, int D, const double *log_taus, double c_exp,
+                   std::vector<T> &Kr, std::vector<T> &Ki, std::vector<T> &Gr, std::vector<T> &Gi)
+{
+    Kr.assign((size_t)N * S, T(0));
+    Ki.assign((size_t)N * S, T(0));
+    T ca, sa;
+    x_sincos_half_pi((T)c_exp, sa, ca);
+    // long double: (w tau)^c of the product rounded to 64 bits, one power per (j, k) -- as in every earlier round,
+    // bit for bit.  binary128: the product of two doubles is exact there, and w^c tau^c needs N + S powers
+    // instead of N S (a power in binary128 is a microsecond); c = 1 needs none.
+    std::vector<T> wc, tc;
+    if constexpr (!std::is_same<T, ld>::value) {
+        wc.resize((size_t)N);
+        tc.resize((size_t)S);
+        for (int j = 0; j < N; ++j) wc[(size_t)j] = c_exp == 1.0 ? (T)w[j] : x_pow((T)w[j], (T)c_exp);
+        for (int k = 0; k < S; ++k) tc[(size_t)k] = c_exp == 1.0 ? (T)taus[k] : x_pow((T)taus[k], (T)c_exp);
+    }
+    for (int j = 0; j < N; ++j)
+        for (int k = 0; k < S; ++k) {
+            T x;
+            if constexpr (std::is_same<T, ld>::value) x = x_pow((T)w[j] * (T)taus[k], (T)c_exp);
+            else x = wc[(size_t)j] * tc[(size_t)k];
+            const T xr = x * ca, xi = x * sa;
+            const T dr = 1 + xr;
+            const T den = dr * dr + xi * xi;
+            // 1 - 1/(1+x) = x/(1+x) = x*conj(1+x)/|1+x|^2
+            Kr[(size_t)j * S + k] = (xr * dr + xi * xi) / den;
+            Ki[(size_t)j * S + k] = xi / den;
+        }
+    Gr.assign((size_t)N * D, T(0));
+    Gi.assign((size_t)N * D, T(0));
+    for (int j = 0; j < N; ++j)
+        for (int p = 0; p < D; ++p) {
+            T sr = 0, si = 0;
+            for (int k = 0; k < S; ++k) {
+                const T L = (T)log_taus[(size_t)p * S + k];
+                sr += L * Kr[(size_t)j * S + k];
+                si += L * Ki[(size_t)j * S + k];
+            }
+            Gr[(size_t)j * D + p] = sr;
+            Gi[(size_t)j * D + p] = si;
+        }
+}
+
+// Weighted design matrix of the linear model Z = R0 - sum_p (R0 a_p) G_p, rows = (real j..., imag j...), built
+// from the UNROUNDED kernel sums (the reduced form stands for the reference's formula, not for the per-frequency
+// kernel's rounded operands: rounding G to double moves a log-probability on the shell logp = 0 of a degree-9
+// design by 1e-9, like rounding R does); Householder QR, applied to y as well (column-wise backward stable);
+// the least-squares solution where the triangle is well conditioned, 0 elsewhere.
+// Rl: (n,n) upper triangle; qty: first n entries of Q^T y; rest = sum of the squares of the others.
+template <class T>
+void reduce_T(int N, int D, const std::vector<T> &Gr, const std::vector<T> &Gi, const double *zn, const double *zn_err,
+              std::vector<T> &Rl, std::vector<T> &qty, std::vector<T> &bhat_ls, T &rest_out)
+{
+    const int n = D + 1, m = 2 * N;
+    std::vector<T> A((size_t)m * n), y(m), v((size_t)m);
+    for (int i = 0; i < m; ++i) {
+        const int j = i % N;
+        const bool im = i >= N;
+        const T s = T(1) / (T)zn_err[i];
+        y[i] = (T)zn[i] * s;
+        A[(size_t)i * n + 0] = im ? T(0) : s;
+        for (int p = 0; p < D; ++p)
+            A[(size_t)i * n + 1 + p] = -s * (im ? Gi[(size_t)j * D + p] : Gr[(size_t)j * D + p]);
+    }
+    const int steps = n < m ? n : m;
+    for (int c = 0; c < steps; ++c) {
+        T nrm = 0;
+        for (int i = c; i < m; ++i) nrm += A[(size_t)i * n + c] * A[(size_t)i * n + c];
+        nrm = x_sqrt(nrm);
+        if (nrm == 0) continue;
+        const T alpha = A[(size_t)c * n + c] > 0 ? -nrm : nrm;
+        for (int i = c; i < m; ++i) v[(size_t)(i - c)] = A[(size_t)i * n + c];
+        v[0] -= alpha;
+        T vv = 0;
+        for (int i = 0; i < m - c; ++i) vv += v[(size_t)i] * v[(size_t)i];
+        if (vv == 0) continue;
+        for (int cc = c; cc < n; ++cc) {
+            T dot = 0;
+            for (int i = c; i < m; ++i) dot += v[(size_t)(i - c)] * A[(size_t)i * n + cc];
+            const T f = 2 * dot / vv;
+            for (int i = c; i < m; ++i) A[(size_t)i * n + cc] -= f * v[(size_t)(i - c)];
+        }
+        T dot = 0;
+        for (int i = c; i < m; ++i) dot += v[(size_t)(i - c)] * y[i];
+        const T f = 2 * dot / vv;
+        for (int i = c; i < m; ++i) y[i] -= f * v[(size_t)(i - c)];
+    }
+    Rl.assign((size_t)n * n, T(0));
+    for (int i = 0; i < n && i < m; ++i)
+        for (int j = i; j < n; ++j) Rl[(size_t)i * n + j] = A[(size_t)i * n + j];
+    T rest = 0;
+    for (int i = n; i < m; ++i) rest += y[i] * y[i];
+    rest_out = rest;
+    bhat_ls.assign((size_t)n, T(0));
+    T rmax = 0;
+    for (int i = 0; i < n && i < m; ++i) { const T a = x_abs(Rl[(size_t)i * n + i]); if (a > rmax) rmax = a; }
+    for (int i = (n < m ? n : m) - 1; i >= 0; --i) {
+        const T rii = Rl[(size_t)i * n + i];
+        if (x_abs(rii) <= T(1e-13L) * rmax) { bhat_ls[(size_t)i] = 0; continue; }
+        T s = y[i];
+        for (int j = i + 1; j < n; ++j) s -= Rl[(size_t)i * n + j] * bhat_ls[(size_t)j];
+        bhat_ls[(size_t)i] = s / rii;
+    }
+    qty.assign((size_t)n, T(0));
+    for (int i = 0; i < n && i < m; ++i) qty[(size_t)i] = y[i];
+}
+
+}  // namespace
+
+struct QuadKernelSums {
+    int N = 0, D = 0;
+    std::vector<qd> Gr, Gi;
+};
+
+struct QuadReduced {
+    std::vector<qd> Rq, qty;     // (n,n), (n,)
+    qd rest = 0;
+};
 
 double loglike_const(int n2, const double *zn_err)
 {
@@ -53,180 +201,80 @@ void polydecomp_kernel_sums(int N, const double *w, int S, const double *taus, i
                             const double *log_taus, double c_exp, PolyDecompOperands &o)
 {
     o.N = N; o.S = S; o.D = D;
-    std::vector<ld> Kr((size_t)N * S), Ki((size_t)N * S);
-    // (i*w*tau)^c = (w*tau)^c * (cos(c*pi/2) + i sin(c*pi/2)); the base is purely
-    // imaginary and positive so its argument is exactly pi/2.
-    const ld ang = (ld)c_exp * PI_L / 2;
-    const ld ca = cosl(ang), sa = sinl(ang);
-    for (int j = 0; j < N; ++j)
-        for (int k = 0; k < S; ++k) {
-            ld x = powl((ld)w[j] * (ld)taus[k], (ld)c_exp);
-            ld xr = x * ca, xi = x * sa;
-            ld dr = 1 + xr;
-            ld den = dr * dr + xi * xi;
-            // 1 - 1/(1+x) = x/(1+x) = x*conj(1+x)/|1+x|^2
-            Kr[(size_t)j * S + k] = (xr * dr + xi * xi) / den;
-            Ki[(size_t)j * S + k] = xi / den;
-        }
+    std::vector<ld> Kr, Ki;
+    kernel_sums_T<ld>(N, w, S, taus, D, log_taus, c_exp, Kr, Ki, o.Gl_re, o.Gl_im);
     o.K_re.resize((size_t)N * S); o.K_im.resize((size_t)N * S);
     for (size_t i = 0; i < (size_t)N * S; ++i) { o.K_re[i] = (double)Kr[i]; o.K_im[i] = (double)Ki[i]; }
-
-    std::vector<ld> Gr((size_t)N * D), Gi((size_t)N * D);
-    for (int j = 0; j < N; ++j)
-        for (int p = 0; p < D; ++p) {
-            ld sr = 0, si = 0;
-            for (int k = 0; k < S; ++k) {
-                ld L = (ld)log_taus[(size_t)p * S + k];
-                sr += L * Kr[(size_t)j * S + k];
-                si += L * Ki[(size_t)j * S + k];
-            }
-            Gr[(size_t)j * D + p] = sr;
-            Gi[(size_t)j * D + p] = si;
-        }
     o.G_re.resize((size_t)N * D); o.G_im.resize((size_t)N * D);
-    for (size_t i = 0; i < (size_t)N * D; ++i) { o.G_re[i] = (double)Gr[i]; o.G_im[i] = (double)Gi[i]; }
-    o.Gl_re = Gr;
-    o.Gl_im = Gi;
+    for (size_t i = 0; i < (size_t)N * D; ++i) { o.G_re[i] = (double)o.Gl_re[i]; o.G_im[i] = (double)o.Gl_im[i]; }
 }
 
 void polydecomp_reduce(const double *zn, const double *zn_err, PolyDecompOperands &o)
 {
-    const int N = o.N, D = o.D;
-    // Weighted design matrix of the linear model Z = R0 - sum_p (R0 a_p) G_p, rows = (real j..., imag
-    // j...), built from the UNROUNDED kernel sums: the reduced form stands for the reference's formula,
-    // not for the per-frequency kernel's rounded operands (rounding G to double moves a log-probability
-    // on the shell logp = 0 of a degree-9 design by 1e-9, like rounding R does).
-    const int n = D + 1, m = 2 * N;
-    std::vector<ld> A((size_t)m * n), y(m);
-    for (int i = 0; i < m; ++i) {
-        const int j = i % N;
-        const bool im = i >= N;
-        ld s = 1.0L / (ld)zn_err[i];
-        y[i] = (ld)zn[i] * s;
-        A[(size_t)i * n + 0] = im ? 0.0L : s;
-        for (int p = 0; p < D; ++p)
-            A[(size_t)i * n + 1 + p] = -s * (im ? o.Gl_im[(size_t)j * D + p] : o.Gl_re[(size_t)j * D + p]);
-    }
-    // Householder QR, applied to y as well (column-wise backward stable).
-    const int steps = n < m ? n : m;
-    for (int c = 0; c < steps; ++c) {
-        ld nrm = 0;
-        for (int i = c; i < m; ++i) nrm += A[(size_t)i * n + c] * A[(size_t)i * n + c];
-        nrm = sqrtl(nrm);
-        if (nrm == 0) continue;
-        ld alpha = A[(size_t)c * n + c] > 0 ? -nrm : nrm;
-        std::vector<ld> v(m - c);
-        for (int i = c; i < m; ++i) v[i - c] = A[(size_t)i * n + c];
-        v[0] -= alpha;
-        ld vv = 0;
-        for (int i = 0; i < m - c; ++i) vv += v[i] * v[i];
-        if (vv == 0) continue;
-        for (int cc = c; cc < n; ++cc) {
-            ld dot = 0;
-            for (int i = c; i < m; ++i) dot += v[i - c] * A[(size_t)i * n + cc];
-            ld f = 2 * dot / vv;
-            for (int i = c; i < m; ++i) A[(size_t)i * n + cc] -= f * v[i - c];
-        }
-        ld dot = 0;
-        for (int i = c; i < m; ++i) dot += v[i - c] * y[i];
-        ld f = 2 * dot / vv;
-        for (int i = c; i < m; ++i) y[i] -= f * v[i - c];
-    }
-    o.R.assign((size_t)n * n, 0.0);
-    o.Rl.assign((size_t)n * n, 0.0L);
-    for (int i = 0; i < n && i < m; ++i)
-        for (int j = i; j < n; ++j) {
-            o.Rl[(size_t)i * n + j] = A[(size_t)i * n + j];
-            o.R[(size_t)i * n + j] = (double)A[(size_t)i * n + j];
-        }
+    const int N = o.N, D = o.D, n = D + 1, m = 2 * N;
     ld rest = 0;
-    for (int i = n; i < m; ++i) rest += y[i] * y[i];
+    reduce_T<ld>(N, D, o.Gl_re, o.Gl_im, zn, zn_err, o.Rl, o.qty, o.bhat_ls, rest);
     o.rest = (double)rest;
-    // Any bhat gives an exact identity once e = c - R_d*bhat_d is carried; take the
-    // least-squares solution where the triangle is well conditioned, 0 elsewhere.
-    std::vector<ld> bh(n, 0.0L);
-    ld rmax = 0;
-    for (int i = 0; i < n && i < m; ++i) { ld a = fabsl(o.Rl[(size_t)i * n + i]); if (a > rmax) rmax = a; }
-    for (int i = (n < m ? n : m) - 1; i >= 0; --i) {
-        ld rii = o.Rl[(size_t)i * n + i];
-        if (fabsl(rii) <= 1e-13L * rmax) { bh[i] = 0; continue; }
-        ld s = y[i];
-        for (int j = i + 1; j < n; ++j) s -= o.Rl[(size_t)i * n + j] * bh[j];
-        bh[i] = s / rii;
-    }
+    o.R.assign((size_t)n * n, 0.0);
+    for (size_t i = 0; i < (size_t)n * n; ++i) o.R[i] = (double)o.Rl[i];
+    // Any bhat gives an exact identity once e = c - R_d*bhat_d is carried; the least-squares solution here
+    // (reduced_center_* choose the one a context runs with)
     o.bhat.resize(n);
-    for (int i = 0; i < n; ++i) o.bhat[i] = (double)bh[i];
+    for (int i = 0; i < n; ++i) o.bhat[i] = (double)o.bhat_ls[i];
     o.e.assign(n, 0.0);
     for (int i = 0; i < n && i < m; ++i) {
-        ld s = y[i];
+        ld s = o.qty[i];
         for (int j = i; j < n; ++j) s -= (ld)o.R[(size_t)i * n + j] * (ld)o.bhat[j];
         o.e[i] = (double)s;
     }
-    o.qty.assign(n, 0.0L);
-    for (int i = 0; i < n && i < m; ++i) o.qty[i] = y[i];
-    o.bhat_ls = bh;
+}
+
+void reduced_from_operands(const PolyDecompOperands &o, double lconst, ReducedProblem &p)
+{
+    p.n = o.D + 1;
+    p.R = o.R; p.Rl = o.Rl; p.qty = o.qty; p.bhat_ls = o.bhat_ls;
+    p.rest = o.rest;
+    p.lconst = lconst;
+    p.Rc.clear(); p.Rc_lo.clear(); p.rest_c = 0.0; p.quad.reset();
+}
+
+std::shared_ptr<const QuadKernelSums> polydecomp_kernel_sums_quad(int N, const double *w, int S, const double *taus, int D,
+                                                                  const double *log_taus, double c_exp)
+{
+    auto ks = std::make_shared<QuadKernelSums>();
+    ks->N = N; ks->D = D;
+    std::vector<qd> Kr, Ki;
+    kernel_sums_T<qd>(N, w, S, taus, D, log_taus, c_exp, Kr, Ki, ks->Gr, ks->Gi);
+    return ks;
+}
+
+void reduced_make_quad(const QuadKernelSums &ks, const double *zn, const double *zn_err, ReducedProblem &p)
+{
+    auto q = std::make_shared<QuadReduced>();
+    std::vector<qd> bls;
+    reduce_T<qd>(ks.N, ks.D, ks.Gr, ks.Gi, zn, zn_err, q->Rq, q->qty, bls, q->rest);
+    const int n = ks.D + 1;
+    p.n = n;
+    p.Rc.assign((size_t)n * n, 0.0);
+    p.Rc_lo.assign((size_t)n * n, 0.0f);
+    for (size_t i = 0; i < (size_t)n * n; ++i) {
+        p.Rc[i] = (double)q->Rq[i];
+        p.Rc_lo[i] = (float)(q->Rq[i] - (qd)p.Rc[i]);
+    }
+    p.rest_c = (double)q->rest;
+    p.quad = q;
 }
 
 namespace {
 
-// logprob_row_reduced<P, COMP> (kernels.h) in the same double arithmetic, operation for operation
-double reduced_chi2_double(int n, const std::vector<double> &R, const std::vector<ld> &Rl, const double *bhat,
-                           const double *e, const double *elo, double rest, const double *th, bool comp)
-{
-    double chi2 = rest;
-    std::vector<double> d(n), dl(n);
-    auto two_diff = [](double a, double b, double &s, double &err) {
-        s = a - b;
-        const double bb = s - a;
-        err = (a - (s - bb)) + ((-b) - bb);
-    };
-    if (!comp) {
-        d[0] = bhat[0] - th[0];
-        for (int q = 1; q < n; ++q) {
-            const double prod = th[0] * th[q];
-            d[q] = bhat[q] - prod;
-        }
-        for (int i = 0; i < n; ++i) {
-            double u = e[i];
-            for (int j = i; j < n; ++j) u = std::fma(R[(size_t)i * n + j], d[j], u);
-            chi2 = std::fma(u, u, chi2);
-        }
-        return chi2;
-    }
-    two_diff(bhat[0], th[0], d[0], dl[0]);
-    for (int q = 1; q < n; ++q) {
-        const double p = th[0] * th[q];
-        const double pe = std::fma(th[0], th[q], -p);
-        double err;
-        two_diff(bhat[q], p, d[q], err);
-        dl[q] = err - pe;
-    }
-    for (int i = 0; i < n; ++i) {
-        double s = e[i], c = elo[i];
-        for (int j = i; j < n; ++j) {
-            const double Rk = R[(size_t)i * n + j];
-            const double h = Rk * d[j];
-            const double l = std::fma(Rk, d[j], -h);
-            const double t = s + h;
-            const double bb = t - s;
-            const double er = (s - (t - bb)) + (h - bb);
-            s = t;
-            c += er + l;
-            c = std::fma(Rk, dl[j], c);
-            c = std::fma((double)(float)(Rl[(size_t)i * n + j] - (ld)Rk), d[j], c);     // Rlo, as the kernel holds it (a float: <= 11 bits)
-        }
-        const double u = s + c;
-        chi2 = std::fma(u, u, chi2);
-    }
-    return chi2;
-}
-
-// the same quantity from the unrounded operands, to about twice the precision of long double: every row
-// qty_i - sum_j R_ij b_j is accumulated as an unevaluated sum of two long doubles (TwoProduct by fmal,
-// TwoSum; Ogita-Rump-Oishi Dot2, b_j = R0 a_j split the same way).  Plain long double is NOT enough to
+// ---------------------------------------------------------------------------------------------
+// yardsticks
+// ---------------------------------------------------------------------------------------------
+// the reduced form from long-double operands, to about twice the precision of long double: every row
+// qty_i - sum_j R_ij b_j is accumulated as an unevaluated sum of two long doubles (TwoProduct, TwoSum;
+// Ogita-Rump-Oishi Dot2, b_j = R0 a_j split the same way).  Plain long double is NOT enough to
 // judge the compensated kernel: on degree 9-10 designs the terms reach 1e8 against a row sum of ~10 and
-// a 64-bit mantissa leaves 1e-10 of error in a log-probability on the shell logp = 0 -- more than the
-// kernel being judged (whose double-double rows are good to ~1e-30).
+// a 64-bit mantissa leaves 1e-10 of error in a log-probability on the shell logp = 0.
 static inline void two_sum(ld a, ld b, ld &s, ld &err)
 {
     s = a + b;
@@ -235,7 +283,7 @@ static inline void two_sum(ld a, ld b, ld &s, ld &err)
 }
 
 // a*b = p + err exactly, by Dekker's splitting of the 64-bit mantissas into 32 + 32 bits (glibc's fmal is a
-// software routine on x86: ~350 ns a call, which made a context's estimate take 60 ms)
+// software routine on x86: ~350 ns a call)
 static inline void split32(ld a, ld &hi, ld &lo)
 {
     const ld c = 4294967297.0L * a;      // 2^32 + 1
@@ -256,7 +304,7 @@ ld reduced_chi2_exact(int n, const std::vector<ld> &R, const std::vector<ld> &qt
                       const double *th)
 {
     ld chi2 = rest;
-    // b = b_h + b_l exactly: R0 and a_j are doubles, their product two doubles (one hardware fma)
+    // b = b_h + b_l exactly: R0 and a_j are doubles, their product two doubles (one fma)
     ld bh[BISIP_HOST_MAXN], bl[BISIP_HOST_MAXN];
     bh[0] = (ld)th[0];
     bl[0] = 0.0L;
@@ -281,34 +329,61 @@ ld reduced_chi2_exact(int n, const std::vector<ld> &R, const std::vector<ld> &qt
     return chi2;
 }
 
+// the same from binary128 operands, in binary128: 113 bits against terms 1e8 times the row sums
+qd reduced_chi2_quad(int n, const QuadReduced &q, const double *th)
+{
+    qd b[BISIP_HOST_MAXN];
+    b[0] = (qd)th[0];
+    for (int j = 1; j < n; ++j) b[j] = (qd)th[0] * (qd)th[j];      // exact: 106 bits
+    qd chi2 = q.rest;
+    for (int i = 0; i < n; ++i) {
+        qd u = q.qty[(size_t)i];
+        for (int j = i; j < n; ++j) u -= q.Rq[(size_t)i * n + j] * b[j];
+        chi2 += u * u;
+    }
+    return chi2;
+}
+
+// the kernels' arithmetic and the plain tier's yardstick, as plain x86-64 code and with hardware fma
+#define EMU(name) name##_base
+#define EMU_ATTR
+#include "host_emulate.inc"
+#undef EMU
+#undef EMU_ATTR
+#define EMU(name) name##_fma
+#define EMU_ATTR __attribute__((target("fma")))
+#include "host_emulate.inc"
+#undef EMU
+#undef EMU_ATTR
+
+bool have_fma()
+{
+    static const bool yes = __builtin_cpu_supports("fma");
+    return yes;
+}
+
+long double chi2_dd(int n, const double *Rhi, const double *Rlo, const double *qhi, const double *qlo, double rest,
+                    const double *th)
+{
+    return have_fma() ? chi2_dd_fma(n, Rhi, Rlo, qhi, qlo, rest, th) : chi2_dd_base(n, Rhi, Rlo, qhi, qlo, rest, th);
+}
+
+double worst_error(int n, const double *R, const float *Rlo, const double *bhat, const double *e, const double *elo,
+                   double rest, bool comp, const ReducedProbes &pr, const long double *exact, double lconst, double w_shell)
+{
+    return have_fma() ? worst_error_fma(n, R, Rlo, bhat, e, elo, rest, comp, pr.rows.data(), pr.count(), pr.n_regular, exact, lconst, w_shell)
+                      : worst_error_base(n, R, Rlo, bhat, e, elo, rest, comp, pr.rows.data(), pr.count(), pr.n_regular, exact, lconst, w_shell);
+}
+
 struct Lcg {   // deterministic probe points, no <random>
     unsigned long long s = 0x9E3779B97F4A7C15ull;
     double uni() { s = s * 6364136223846793005ull + 1442695040888963407ull; return (double)(s >> 11) / 9007199254740992.0; }
     double sym() { return 2.0 * uni() - 1.0; }
 };
 
-}  // namespace
-
-// Weight of the shell probes in the estimate (see reduced_center).  BISIP_SHELL_WEIGHT=0 reproduces the
-// round-2 estimate that never looked at the shell: tests use it to build a context whose estimate passes
-// and whose batch then does not (the guard of bisip_logprob).  Read when a context is created.
-static double shell_weight()
+// image of the theta box under b = R0 * (1, a)
+void box_image(int n, const double *lo, const double *hi, double *blo, double *bhi)
 {
-    const char *s = std::getenv("BISIP_SHELL_WEIGHT");
-    const double w = s ? std::atof(s) : 0.05;
-    return w >= 0.0 && w <= 1.0 ? w : 0.05;
-}
-
-double reduced_center(int n, const std::vector<double> &R, const std::vector<long double> &Rl,
-                      const std::vector<long double> &qty,
-                      const std::vector<long double> &bhat_ls, double rest, double lconst,
-                      const double *lo, const double *hi, bool comp, double *out_bhat, double *out_e,
-                      double *out_elo)
-{
-    bool finite_box = true;
-    for (int j = 0; j < n; ++j) finite_box = finite_box && std::isfinite(lo[j]) && std::isfinite(hi[j]);
-    // image of the theta box under b = R0 * (1, a)
-    std::vector<double> blo(n), bhi(n);
     blo[0] = lo[0]; bhi[0] = hi[0];
     for (int j = 1; j < n; ++j) {
         const double c[4] = {lo[0] * lo[j], lo[0] * hi[j], hi[0] * lo[j], hi[0] * hi[j]};
@@ -318,42 +393,83 @@ double reduced_center(int n, const std::vector<double> &R, const std::vector<lon
         if (nan || !(a <= b)) { a = -INFINITY; b = INFINITY; }
         blo[j] = a; bhi[j] = b;
     }
-    // probe rows: where walkers are going to be evaluated
-    std::vector<std::vector<double>> probes;
+}
+
+// candidates for the expansion point: least squares, centre of the box's image, zero
+int candidates(int n, const std::vector<ld> &bhat_ls, const double *lo, const double *hi, double (*cand)[BISIP_HOST_MAXN])
+{
+    int k = 0;
+    bool finite_box = true;
+    for (int j = 0; j < n; ++j) finite_box = finite_box && std::isfinite(lo[j]) && std::isfinite(hi[j]);
+    {
+        bool ok = true;
+        for (int j = 0; j < n; ++j) { cand[k][j] = (double)bhat_ls[(size_t)j]; ok = ok && std::isfinite(cand[k][j]) && std::fabs(cand[k][j]) <= 1e6; }
+        if (ok) ++k;
+    }
+    if (finite_box) {
+        double blo[BISIP_HOST_MAXN], bhi[BISIP_HOST_MAXN];
+        box_image(n, lo, hi, blo, bhi);
+        bool ok = true;
+        for (int j = 0; j < n; ++j) { cand[k][j] = 0.5 * (blo[j] + bhi[j]); ok = ok && std::isfinite(cand[k][j]); }
+        if (ok) ++k;
+    }
+    for (int j = 0; j < n; ++j) cand[k][j] = 0.0;
+    return k + 1;
+}
+
+}  // namespace
+
+double reduced_shell_weight()
+{
+    const char *s = std::getenv("BISIP_SHELL_WEIGHT");
+    const double w = s ? std::atof(s) : 0.05;
+    return w >= 0.0 && w <= 1.0 ? w : 0.05;
+}
+
+void reduced_probes(const ReducedProblem &p, const double *lo, const double *hi, ReducedProbes &out)
+{
+    const int n = p.n;
+    const std::vector<double> &R = p.R;
+    const std::vector<ld> &qty = p.qty, &bhat_ls = p.bhat_ls;
+    const double rest = p.rest, lconst = p.lconst;
+    out.n = n;
+    out.rows.clear();
+    out.rows.reserve((size_t)n * 260);
+    auto push = [&](const double *t) { out.rows.insert(out.rows.end(), t, t + n); };
+    bool finite_box = true;
+    for (int j = 0; j < n; ++j) finite_box = finite_box && std::isfinite(lo[j]) && std::isfinite(hi[j]);
     Lcg rng;
-    auto inside = [&](const std::vector<double> &t) {
+    auto inside = [&](const double *t) {
         for (int j = 0; j < n; ++j) if (!(lo[j] < t[j] && t[j] < hi[j])) return false;
         return true;
     };
+    double t[BISIP_HOST_MAXN];
     const bool ls_ok = std::isfinite((double)bhat_ls[0]) && bhat_ls[0] != 0.0L;
     if (finite_box) {
         for (int k = 0; k < 32; ++k) {   // uniform in the prior box
-            std::vector<double> t(n);
             for (int j = 0; j < n; ++j) t[j] = lo[j] + (hi[j] - lo[j]) * rng.uni();
-            probes.push_back(t);
+            push(t);
         }
         for (int k = 0; k < 16; ++k) {   // small coefficients: where a decent fit usually lies
-            std::vector<double> t(n);
             t[0] = lo[0] + (hi[0] - lo[0]) * rng.uni();
             for (int j = 1; j < n; ++j) {
                 double v = 1e-3 * rng.sym();
                 v = v < lo[j] ? lo[j] : (v > hi[j] ? hi[j] : v);
                 t[j] = v;
             }
-            if (inside(t)) probes.push_back(t);
+            if (inside(t)) push(t);
         }
     }
     if (ls_ok)
         for (int k = 0; k < 16; ++k) {   // around the least-squares solution (the posterior mode)
             const double s = k < 8 ? 1e-3 : 1e-2;
-            std::vector<double> t(n);
             t[0] = (double)bhat_ls[0] * (1.0 + s * rng.sym());
             bool fin = std::isfinite(t[0]);
             for (int j = 1; j < n; ++j) {
-                t[j] = (double)(bhat_ls[j] / bhat_ls[0]) * (1.0 + s * rng.sym());
+                t[j] = (double)(bhat_ls[(size_t)j] / bhat_ls[0]) * (1.0 + s * rng.sym());
                 fin = fin && std::isfinite(t[j]);
             }
-            if (fin && (!finite_box || inside(t))) probes.push_back(t);
+            if (fin && (!finite_box || inside(t))) push(t);
         }
     // theta of b = b_ls + s R^-1 z for a random direction z (unit variance per component: four uniforms; the
     // shape of the distribution does not matter), s = `scale`, or, for scale < 0, such that the row lies ON
@@ -362,9 +478,8 @@ double reduced_center(int n, const std::vector<double> &R, const std::vector<lon
     bool solvable = ls_ok;
     for (int i = 0; i < n; ++i) solvable = solvable && R[(size_t)i * n + i] != 0.0;
     double bls_d[BISIP_HOST_MAXN];
-    for (int j = 0; j < n; ++j) bls_d[j] = (double)bhat_ls[j];
-    std::vector<double> tpt(n);
-    auto valley_point = [&](double scale, std::vector<double> &t) {
+    for (int j = 0; j < n; ++j) bls_d[j] = (double)bhat_ls[(size_t)j];
+    auto valley_point = [&](double scale, double *tp) {
         double z[BISIP_HOST_MAXN], db[BISIP_HOST_MAXN], zz = 0.0;
         for (int j = 0; j < n; ++j) {
             z[j] = 1.7320508075688772 * (rng.uni() + rng.uni() + rng.uni() + rng.uni() - 2.0);
@@ -378,13 +493,13 @@ double reduced_center(int n, const std::vector<double> &R, const std::vector<lon
             db[i] = acc / R[(size_t)i * n + i];
         }
         const double b0 = bls_d[0] + db[0];
-        t[0] = b0;
+        tp[0] = b0;
         if (!std::isfinite(b0) || b0 == 0.0) return false;
         for (int j = 1; j < n; ++j) {
-            t[j] = (bls_d[j] + db[j]) / b0;
-            if (!std::isfinite(t[j])) return false;
+            tp[j] = (bls_d[j] + db[j]) / b0;
+            if (!std::isfinite(tp[j])) return false;
         }
-        return !finite_box || inside(t);
+        return !finite_box || inside(tp);
     };
     if (ls_ok) {
         // where an ensemble sampler's walkers actually are: draws from the Gaussian posterior of the
@@ -392,142 +507,212 @@ double reduced_center(int n, const std::vector<double> &R, const std::vector<lon
         // ensemble, and the same ensemble on its way in during burn-in.  On nearly collinear
         // designs these spread far along the flat directions of chi^2 -- the rows of R (bhat - b)
         // then cancel by many orders of magnitude although chi^2 stays within a few units (a few
-        // hundred, at 10-30 sigma) of its minimum.  Round 2 probed 1x and 3x only: a NumPy emulation of
-        // the plain kernel on 10-sigma rows of degree 8-10 designs it had passed read 1e-10 ... 2e-8.
+        // hundred, at 10-30 sigma) of its minimum.
         // 16 probes INSIDE the box per scale (a narrowed box keeps few of the draws: up to 300 tries each)
         for (int scale_i = 0; solvable && scale_i < 4; ++scale_i) {
             const double sc = scale_i == 0 ? 1.0 : (scale_i == 1 ? 3.0 : (scale_i == 2 ? 10.0 : 30.0));
             int kept = 0;
             for (int k = 0; k < 300 && kept < 16; ++k)
-                if (valley_point(sc, tpt)) { probes.push_back(tpt); ++kept; }
+                if (valley_point(sc, t)) { push(t); ++kept; }
         }
     }
     // The shell log-probability = 0.  The parity tolerance is |d logp| <= 1e-10 max(1, |logp|): where the
     // log-probability crosses zero -- chi^2 = 2 lconst, ten or so posterior sigmas out on a typical
     // spectrum, where burn-in passes -- the denominator is 1 and the ABSOLUTE error of a chi^2 of several
     // hundred counts.  Random valley rows land within |logp| < 1 one time in a few hundred, so the probes
-    // above practically never see it (measured on the GPU, benchmarks/valley_rows.py: 3000 rows per scale
-    // found 1e-11 ... 2.5e-10 on degree 7-9 designs whose 32 probes per scale had read < 1e-12).  These
-    // probes are ON the shell: b = b_ls + s R^-1 z with s such that rest + s^2 |z|^2 = 2 lconst.  No double
-    // formulation gets below ~1e-12 there (one rounding of chi^2 ~ 1e3 is 1e-13; the plain triangle of the
-    // headline's degree-5 design reads 9e-12, of which 5e-12 is the rounding of R itself), so they count
-    // at a twentieth: the gate 1e-12 then reads "2e-11 on the shell" -- a fifth of the tolerance, where
-    // the region is sampled directly -- the same bar bisip_logprob's guard applies to real batches.
-    size_t n_regular = probes.size();
+    // above practically never see it.  These probes are ON the shell: b = b_ls + s R^-1 z with s such that
+    // rest + s^2 |z|^2 = 2 lconst.  No double formulation gets below ~1e-12 there (one rounding of chi^2 ~ 1e3
+    // is 1e-13; the plain triangle of the headline's degree-5 design reads 9e-12, of which 5e-12 is the rounding
+    // of R itself), so they count at a twentieth (reduced_shell_weight): the gate 1e-12 then reads "2e-11 on the
+    // shell" -- a fifth of the tolerance, where the region is sampled directly -- the same bar bisip_logprob's
+    // guard applies to real batches.
+    out.n_regular = out.count();
     if (ls_ok && 2.0 * lconst - rest > 0.0) {
         int kept = 0;     // 64 probes inside the box, up to 1500 tries (a narrowed box keeps few of the draws)
         for (int k = 0; solvable && k < 1500 && kept < 64; ++k)
-            if (valley_point(-1.0, tpt)) { probes.push_back(tpt); ++kept; }
+            if (valley_point(-1.0, t)) { push(t); ++kept; }
         // A box that cuts the shell in a small patch keeps none of those draws (a degree-6 design of the
-        // fuzz campaign: 9 of 200,000; its estimate then never saw the shell and passed a kernel that read
-        // 1.1e-10 on the one row of a 20,000-row batch that lay there).  The box is convex in theta: between
-        // a probe with log-probability > 0 and one with < 0, both inside, the segment stays inside and
-        // crosses the shell -- found by bisection (plain double: where the probe lies need not be exact).
+        // fuzz campaign: 9 of 200,000).  The box is convex in theta: between a probe with log-probability > 0 and
+        // one with < 0, both inside, the segment stays inside and crosses the shell -- found by bisection (plain
+        // double: where the probe lies need not be exact).
         if (kept < 64 && finite_box) {
-            auto logp_of = [&](const std::vector<double> &t) {
+            auto logp_of = [&](const double *tt) {
                 double chi2 = rest;
                 for (int i = 0; i < n; ++i) {
-                    double u = (double)qty[i];
-                    for (int j = i; j < n; ++j) u -= R[(size_t)i * n + j] * (j ? t[0] * t[j] : t[0]);
+                    double u = (double)qty[(size_t)i];
+                    for (int j = i; j < n; ++j) u -= R[(size_t)i * n + j] * (j ? tt[0] * tt[j] : tt[0]);
                     chi2 += u * u;
                 }
                 return lconst - 0.5 * chi2;
             };
             std::vector<size_t> pos, neg;
-            std::vector<std::vector<double>> ends(probes.begin(), probes.begin() + (long)n_regular);
+            std::vector<double> ends(out.rows.begin(), out.rows.begin() + (long)(out.n_regular * (size_t)n));
             for (int k = 0; k < 32; ++k) {       // more of the box, as far ends of the segments only
-                std::vector<double> t(n);
                 for (int j = 0; j < n; ++j) t[j] = lo[j] + (hi[j] - lo[j]) * rng.uni();
-                ends.push_back(t);
+                ends.insert(ends.end(), t, t + n);
             }
-            for (size_t ip = 0; ip < ends.size(); ++ip) {
-                if (!inside(ends[ip])) continue;
-                const double lp = logp_of(ends[ip]);
+            const size_t n_ends = ends.size() / (size_t)n;
+            for (size_t ip = 0; ip < n_ends; ++ip) {
+                const double *ep = &ends[ip * (size_t)n];
+                if (!inside(ep)) continue;
+                const double lp = logp_of(ep);
                 if (lp > 0.0) pos.push_back(ip);
                 else if (lp < 0.0) neg.push_back(ip);
             }
             for (int k = 0; !pos.empty() && !neg.empty() && kept < 64 && k < 128; ++k) {
-                const std::vector<double> &a = ends[pos[(size_t)(rng.uni() * (double)pos.size()) % pos.size()]];
-                const std::vector<double> &b = ends[neg[(size_t)(rng.uni() * (double)neg.size()) % neg.size()]];
+                const double *a = &ends[pos[(size_t)(rng.uni() * (double)pos.size()) % pos.size()] * (size_t)n];
+                const double *b = &ends[neg[(size_t)(rng.uni() * (double)neg.size()) % neg.size()] * (size_t)n];
                 double t0 = 0.0, t1 = 1.0;
                 for (int it = 0; it < 60; ++it) {
                     const double tm = 0.5 * (t0 + t1);
-                    for (int j = 0; j < n; ++j) tpt[j] = a[j] + tm * (b[j] - a[j]);
-                    if (logp_of(tpt) > 0.0) t0 = tm; else t1 = tm;
+                    for (int j = 0; j < n; ++j) t[j] = a[j] + tm * (b[j] - a[j]);
+                    if (logp_of(t) > 0.0) t0 = tm; else t1 = tm;
                 }
-                for (int j = 0; j < n; ++j) tpt[j] = a[j] + t0 * (b[j] - a[j]);
-                if (inside(tpt) && std::fabs(logp_of(tpt)) < 1.0) { probes.push_back(tpt); ++kept; }
+                for (int j = 0; j < n; ++j) t[j] = a[j] + t0 * (b[j] - a[j]);
+                if (inside(t) && std::fabs(logp_of(t)) < 1.0) { push(t); ++kept; }
             }
         }
     }
-    // candidates for the expansion point
-    std::vector<std::vector<double>> cand;
-    {
-        bool ok = true;
-        std::vector<double> c(n);
-        for (int j = 0; j < n; ++j) { c[j] = (double)bhat_ls[j]; ok = ok && std::isfinite(c[j]) && std::fabs(c[j]) <= 1e6; }
-        if (ok) cand.push_back(c);
-    }
-    if (finite_box) {
-        std::vector<double> c(n);
-        bool ok = true;
-        for (int j = 0; j < n; ++j) { c[j] = 0.5 * (blo[j] + bhi[j]); ok = ok && std::isfinite(c[j]); }
-        if (ok) cand.push_back(c);
-    }
-    cand.push_back(std::vector<double>(n, 0.0));
-    double best = INFINITY;
-    std::vector<double> e(n), elo(n);
-    // The compensated kernel's rows are double-doubles: its estimate reads 1e-14 on every design ever probed
-    // (TABLE:auto_by_degree); a third of the probes is plenty to notice if that ever stopped being true.
-    if (comp) {
-        std::vector<std::vector<double>> some;
-        size_t shell_from = 0;
-        for (size_t ip = 0; ip < probes.size(); ip += 3) {
-            if (ip < n_regular) shell_from = some.size() + 1;
-            some.push_back(probes[ip]);
-        }
-        probes.swap(some);
-        n_regular = shell_from;
-    }
-    std::vector<ld> exact_of(probes.size());
-    for (size_t ip = 0; ip < probes.size(); ++ip) exact_of[ip] = reduced_chi2_exact(n, Rl, qty, rest, probes[ip].data());
-    if (probes.empty()) {
+}
+
+double reduced_center_plain(const ReducedProblem &p, const ReducedProbes &probes, const double *lo, const double *hi,
+                            double shell_weight, double *out_bhat, double *out_e, double *out_elo)
+{
+    const int n = p.n;
+    if (probes.count() == 0) {
         // nothing to measure the kernel against (a non-finite box with no usable least-squares
         // solution): expand about zero and report "unknown", so AUTO takes the per-frequency form
         for (int j = 0; j < n; ++j) {
             out_bhat[j] = 0.0;
-            out_e[j] = (double)qty[j];
-            out_elo[j] = (double)(qty[j] - (ld)out_e[j]);
+            out_e[j] = (double)p.qty[(size_t)j];
+            out_elo[j] = (double)(p.qty[(size_t)j] - (ld)out_e[j]);
         }
         return INFINITY;
     }
-    for (const auto &c : cand) {
+    // yardstick: the reduced form with the UNROUNDED triangle, rows as double-doubles (exact splits of Rl, qty)
+    std::vector<double> Rhi((size_t)n * n), Rlo((size_t)n * n), qhi((size_t)n), qlo((size_t)n);
+    for (size_t i = 0; i < (size_t)n * n; ++i) { Rhi[i] = (double)p.Rl[i]; Rlo[i] = (double)(p.Rl[i] - (ld)Rhi[i]); }
+    for (size_t i = 0; i < (size_t)n; ++i) { qhi[i] = (double)p.qty[i]; qlo[i] = (double)(p.qty[i] - (ld)qhi[i]); }
+    std::vector<ld> exact(probes.count());
+    for (size_t ip = 0; ip < probes.count(); ++ip)
+        exact[ip] = chi2_dd(n, Rhi.data(), Rlo.data(), qhi.data(), qlo.data(), p.rest, &probes.rows[ip * (size_t)n]);
+    double cand[3][BISIP_HOST_MAXN];
+    const int nc = candidates(n, p.bhat_ls, lo, hi, cand);
+    double best = INFINITY, e[BISIP_HOST_MAXN], elo[BISIP_HOST_MAXN];
+    for (int ic = 0; ic < nc; ++ic) {
+        const double *c = cand[ic];
         for (int i = 0; i < n; ++i) {
-            // plain: with the triangle the kernel holds, so that its identity is exact for THAT triangle;
-            // compensated: with the unrounded one, which R + Rlo stands for
-            ld s = qty[i];
-            for (int j = i; j < n; ++j) s -= (comp ? Rl[(size_t)i * n + j] : (ld)R[(size_t)i * n + j]) * (ld)c[j];
+            // with the triangle the kernel holds, so that its identity is exact for THAT triangle
+            ld s = p.qty[(size_t)i];
+            for (int j = i; j < n; ++j) s -= (ld)p.R[(size_t)i * n + j] * (ld)c[j];
             e[i] = (double)s;
             elo[i] = (double)(s - (ld)e[i]);
         }
-        double worst = 0.0;
-        const double w_shell = shell_weight();
-        for (size_t ip = 0; ip < probes.size(); ++ip) {
-            const auto &t = probes[ip];
-            const ld exact = exact_of[ip];
-            const double got = reduced_chi2_double(n, R, Rl, c.data(), e.data(), elo.data(), rest, t.data(), comp);
-            const ld lp = -0.5L * exact + (ld)lconst;
-            const ld scale = fabsl(lp) > 1.0L ? fabsl(lp) : 1.0L;
-            double rel = (double)(fabsl(-0.5L * ((ld)got - exact)) / scale);
-            if (ip >= n_regular) rel *= w_shell;    // shell probes (above)
-            if (!(rel <= worst)) worst = rel;   // NaN counts as worst
-        }
+        const double worst = worst_error(n, p.R.data(), nullptr, c, e, elo, p.rest, false, probes, exact.data(), p.lconst, shell_weight);
         if (worst < best || best == INFINITY) {
             best = worst;
             for (int j = 0; j < n; ++j) { out_bhat[j] = c[j]; out_e[j] = e[j]; out_elo[j] = elo[j]; }
         }
     }
     return best;
+}
+
+namespace {
+
+// The compensated kernel's rows are double-doubles: its estimate reads 1e-14 on every design ever probed; a
+// third of the probes is plenty to notice if that ever stopped being true.
+void every_third(const ReducedProbes &all, ReducedProbes &some)
+{
+    const size_t n = (size_t)all.n;
+    some.n = all.n;
+    some.rows.clear();
+    size_t shell_from = 0;
+    for (size_t ip = 0; ip < all.count(); ip += 3) {
+        if (ip < all.n_regular) shell_from = some.count() + 1;
+        some.rows.insert(some.rows.end(), all.rows.begin() + (long)(ip * n), all.rows.begin() + (long)((ip + 1) * n));
+    }
+    some.n_regular = shell_from;
+}
+
+// compensated tier, operands R = Rc + Rlo (as the kernel holds them), e + elo formed with the unrounded triangle
+// RT / qtyT of precision T, yardstick `exact` (chi^2 per probe) from the same unrounded operands
+template <class T>
+double center_comp_T(int n, const double *Rc, const float *Rlo, const std::vector<T> &RT, const std::vector<T> &qtyT,
+                     const std::vector<ld> &bhat_ls, double rest, double lconst, const ReducedProbes &some,
+                     const std::vector<ld> &exact, const double *lo, const double *hi, double shell_weight,
+                     double *out_bhat, double *out_e, double *out_elo)
+{
+    double cand[3][BISIP_HOST_MAXN];
+    const int nc = candidates(n, bhat_ls, lo, hi, cand);
+    double best = INFINITY, e[BISIP_HOST_MAXN], elo[BISIP_HOST_MAXN];
+    for (int ic = 0; ic < nc; ++ic) {
+        const double *c = cand[ic];
+        for (int i = 0; i < n; ++i) {
+            T s = qtyT[(size_t)i];
+            for (int j = i; j < n; ++j) s -= RT[(size_t)i * n + j] * (T)c[j];
+            e[i] = (double)s;
+            elo[i] = (double)(s - (T)e[i]);
+        }
+        const double worst = worst_error(n, Rc, Rlo, c, e, elo, rest, true, some, exact.data(), lconst, shell_weight);
+        if (worst < best || best == INFINITY) {
+            best = worst;
+            for (int j = 0; j < n; ++j) { out_bhat[j] = c[j]; out_e[j] = e[j]; out_elo[j] = elo[j]; }
+        }
+    }
+    return best;
+}
+
+}  // namespace
+
+double reduced_center_comp(const ReducedProblem &p, const ReducedProbes &probes, const double *lo, const double *hi,
+                           double shell_weight, double *out_bhat, double *out_e, double *out_elo)
+{
+    const int n = p.n;
+    if (probes.count() == 0) {
+        for (int j = 0; j < n; ++j) {
+            out_bhat[j] = 0.0;
+            out_e[j] = (double)p.qty[(size_t)j];
+            out_elo[j] = (double)(p.qty[(size_t)j] - (ld)out_e[j]);
+        }
+        return INFINITY;
+    }
+    ReducedProbes some;
+    every_third(probes, some);
+    std::vector<ld> exact(some.count());
+    if (p.has_quad()) {
+        const QuadReduced &q = *p.quad;
+        for (size_t ip = 0; ip < some.count(); ++ip) exact[ip] = (ld)reduced_chi2_quad(n, q, &some.rows[ip * (size_t)n]);
+        // (the yardstick's chi^2 is rounded to long double: 64 bits of a number of a few hundred, 1e-17)
+        return center_comp_T<qd>(n, p.Rc.data(), p.Rc_lo.data(), q.Rq, q.qty, p.bhat_ls, p.rest_c, p.lconst, some, exact,
+                                 lo, hi, shell_weight, out_bhat, out_e, out_elo);
+    }
+    // no binary128 operands (reduced_center's old signature): the long-double triangle and its 11-bit low word
+    std::vector<float> Rlo((size_t)n * n);
+    for (size_t i = 0; i < (size_t)n * n; ++i) Rlo[i] = (float)(p.Rl[i] - (ld)p.R[i]);
+    for (size_t ip = 0; ip < some.count(); ++ip) exact[ip] = reduced_chi2_exact(n, p.Rl, p.qty, p.rest, &some.rows[ip * (size_t)n]);
+    return center_comp_T<ld>(n, p.R.data(), Rlo.data(), p.Rl, p.qty, p.bhat_ls, p.rest, p.lconst, some, exact, lo, hi,
+                             shell_weight, out_bhat, out_e, out_elo);
+}
+
+double reduced_center(int n, const std::vector<double> &R, const std::vector<long double> &Rl,
+                      const std::vector<long double> &qty,
+                      const std::vector<long double> &bhat_ls, double rest, double lconst,
+                      const double *lo, const double *hi, bool comp, double *out_bhat, double *out_e,
+                      double *out_elo)
+{
+    ReducedProblem p;
+    p.n = n; p.R = R; p.Rl = Rl; p.qty = qty; p.bhat_ls = bhat_ls; p.rest = rest; p.lconst = lconst;
+    ReducedProbes probes;
+    reduced_probes(p, lo, hi, probes);
+    const double w = reduced_shell_weight();
+    return comp ? reduced_center_comp(p, probes, lo, hi, w, out_bhat, out_e, out_elo)
+                : reduced_center_plain(p, probes, lo, hi, w, out_bhat, out_e, out_elo);
+}
+
+double reduced_logp_reference(const ReducedProblem &p, const double *theta)
+{
+    if (p.has_quad()) return (double)(-0.5Q * reduced_chi2_quad(p.n, *p.quad, theta) + (qd)p.lconst);
+    return (double)(-0.5L * reduced_chi2_exact(p.n, p.Rl, p.qty, p.rest, theta) + (ld)p.lconst);
 }
 
 double reduced_logp_reference(int n, const std::vector<long double> &Rl, const std::vector<long double> &qty,

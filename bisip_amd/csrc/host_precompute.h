@@ -1,8 +1,10 @@
 // host_precompute.h -- walker-independent operands, computed once per context in
-// x87 80-bit long double and rounded once to binary64.
+// x87 80-bit long double (and, for the compensated tier of the QR-reduced form, in IEEE binary128)
+// and rounded once to binary64.
 #pragma once
 #include <cstdint>
 #include <functional>
+#include <memory>
 #include <vector>
 
 namespace bisip {
@@ -30,6 +32,62 @@ void polydecomp_operands(int N, const double *w, int S, const double *taus, int 
                          const double *log_taus, double c_exp, const double *zn,
                          const double *zn_err, PolyDecompOperands &out);
 
+// The part of polydecomp_operands that depends on the frequencies and the tau grid only (K, G):
+// the spectra of a survey usually share one frequency list, and the N*S long-double powers are
+// most of the cost of a spectrum's operands.
+void polydecomp_kernel_sums(int N, const double *w, int S, const double *taus, int D,
+                            const double *log_taus, double c_exp, PolyDecompOperands &out);
+// The rest (weighted design matrix from out's unrounded G, Householder QR, least squares).
+void polydecomp_reduce(const double *zn, const double *zn_err, PolyDecompOperands &out);
+
+// ---------------------------------------------------------------------------------------------
+// The reduced form of ONE spectrum as the host keeps it (per spectrum of a context).
+//
+// Plain tier: R = (double)Rl from the long-double QR above.
+// Compensated tier: its operands come from the SAME computation carried out in IEEE binary128
+// (__float128: kernel sums G, weighted design matrix, Householder QR, Q^T y), because on nearly
+// collinear designs (degree 9, 64 frequencies, c = 0.5: terms 6e7 times the row sums) a 64-bit
+// mantissa leaves 2e-10 in a log-probability on the shell logp = 0 -- in the OPERANDS, where no
+// arithmetic of the kernel can undo it.  The kernel holds Rc = (double)Rq and Rc_lo = (float)(Rq - Rc)
+// (77 bits of the triangle) and e + elo formed with Rq.  Built on demand (reduced_make_quad): a spectrum
+// that passes the plain tier never pays for it.
+// ---------------------------------------------------------------------------------------------
+struct QuadKernelSums;     // kernel sums G of one frequency list in binary128 (opaque: host_precompute.cpp)
+struct QuadReduced;        // Rq, Q^T y, least squares of one spectrum in binary128 (opaque)
+
+struct ReducedProblem {
+    int n = 0;
+    std::vector<double> R;                          // (n,n) plain tier's triangle
+    std::vector<long double> Rl, qty, bhat_ls;      // long-double QR
+    double rest = 0.0, lconst = 0.0;
+    std::vector<double> Rc;                         // (n,n) compensated tier's triangle, empty until reduced_make_quad
+    std::vector<float> Rc_lo;                       // (n,n) its low word
+    double rest_c = 0.0;
+    std::shared_ptr<const QuadReduced> quad;
+    bool has_quad() const { return (bool)quad; }
+};
+
+std::shared_ptr<const QuadKernelSums> polydecomp_kernel_sums_quad(int N, const double *w, int S, const double *taus, int D,
+                                                                  const double *log_taus, double c_exp);
+// fills p.Rc, p.Rc_lo, p.rest_c, p.quad (p.n must be set; zn, zn_err: the spectrum's (2N,) rows)
+void reduced_make_quad(const QuadKernelSums &ks, const double *zn, const double *zn_err, ReducedProblem &p);
+// a ReducedProblem's long-double part from operands computed by polydecomp_reduce
+void reduced_from_operands(const PolyDecompOperands &o, double lconst, ReducedProblem &p);
+
+// Probe rows of one spectrum for one prior box: where walkers are going to be evaluated -- uniform in the
+// box, clouds of small coefficients, clouds around the least-squares solution, draws from the Gaussian
+// posterior b_ls + s R^-1 z at 1, 3, 10 and 30 sigma (the flat valley of an ill-conditioned design), and rows
+// ON the shell log-probability = 0 (rows [n_regular, count)), found by scaling random directions or, where the
+// box cuts the shell in a small patch, by bisection.  Deterministic (a fixed LCG): the same rows for both
+// tiers and for every call with the same operands and box.
+struct ReducedProbes {
+    int n = 0;
+    std::vector<double> rows;      // count x n, theta space
+    size_t n_regular = 0;
+    size_t count() const { return n ? rows.size() / (size_t)n : 0; }
+};
+void reduced_probes(const ReducedProblem &p, const double *lo, const double *hi, ReducedProbes &out);
+
 // Chooses the expansion point of the reduced form and says how far the kernel can be trusted.
 // The identity
 //   chi2(b) = rest + | e + R (bhat - b) |^2,  e = Q^T y - R bhat
@@ -38,32 +96,40 @@ void polydecomp_operands(int N, const double *w, int S, const double *taus, int 
 // orders of magnitude, and forming bhat - b in double discards the low bits of a small b when
 // bhat is O(1).  No single rule is best everywhere (measured: least squares 2e-10 .. 8.6e-3
 // when it lies far outside the prior box; box centre 2.5e-10 where zero gives 4e-14; zero 3x
-// worse than least squares around a well-determined mode), so this function EMULATES the
-// kernel's double arithmetic on the host -- the plain form (comp = false) or the compensated
-// one (comp = true; kernels.h: logprob_row_reduced<P, COMP>) -- for ~200 probe rows: uniform in
-// the prior box [lo, hi] (theta space), clouds of small coefficients, clouds around the
-// least-squares solution, and draws from the Gaussian posterior b_ls + R^-1 z (where a
-// sampler's walkers sit: the flat valley of an ill-conditioned design) -- against long double,
-// for each candidate (least squares, centre of the box's image, zero), keeps the best, and
-// returns its worst relative log-probability error.  out_e + out_elo = Q^T y - R bhat to twice
-// the working precision.  The caller (AUTO variant) takes the plain kernel while its estimate
-// is <= 1e-12, else the compensated one, else the per-frequency form.
-// R is the triangle as the kernels hold it (double); Rl the unrounded one: the yardstick is the reduced
-// form with Rl, so the plain kernel's estimate includes what rounding R costs; the compensated kernel
-// carries Rlo = Rl - R and its e + elo is formed with Rl.
+// worse than least squares around a well-determined mode), so these functions EMULATE the
+// kernel's double arithmetic on the host -- the plain form or the compensated one (kernels.h:
+// logprob_row_reduced<P, COMP>) -- on the probe rows against a yardstick of about twice the precision,
+// for each candidate (least squares, centre of the box's image, zero), keep the best, and
+// return its worst relative log-probability error (shell probes weighted by shell_weight: see the .cpp).
+// out_e + out_elo = Q^T y - R bhat to twice the working precision.  The caller (AUTO variant) takes the
+// plain kernel while its estimate is <= 1e-12, else the compensated one, else the per-frequency form.
+//   plain: the kernel's triangle is p.R; the yardstick is the reduced form with the unrounded p.Rl (so the
+//          estimate includes what rounding R costs), rows accumulated as double-doubles.
+//   comp : needs p.has_quad(); the kernel holds p.Rc + p.Rc_lo, the yardstick is the reduced form in
+//          binary128; a third of the probes (the compensated rows read 1e-14 on every design ever probed).
+double reduced_center_plain(const ReducedProblem &p, const ReducedProbes &probes, const double *lo, const double *hi,
+                            double shell_weight, double *out_bhat, double *out_e, double *out_elo);
+double reduced_center_comp(const ReducedProblem &p, const ReducedProbes &probes, const double *lo, const double *hi,
+                           double shell_weight, double *out_bhat, double *out_e, double *out_elo);
+// Weight of the shell probes: BISIP_SHELL_WEIGHT (a test hook: 0 reproduces an estimate that never looks at
+// the shell) or 0.05.  Read by the caller ONCE per (re)estimation, on its own thread.
+double reduced_shell_weight();
+
+// One call for a lone spectrum, the signature of earlier rounds (tests/native/sanitize_host.cpp): probes +
+// centre of one tier from long-double operands; comp = true builds nothing in binary128 (its yardstick is then
+// the long-double one).
 double reduced_center(int n, const std::vector<double> &R, const std::vector<long double> &Rl,
                       const std::vector<long double> &qty,
                       const std::vector<long double> &bhat_ls, double rest, double lconst,
                       const double *lo, const double *hi, bool comp, double *out_bhat, double *out_e,
                       double *out_elo);
 
-// The part of polydecomp_operands that depends on the frequencies and the tau grid only (K, G):
-// the spectra of a survey usually share one frequency list, and the N*S long-double powers are
-// most of the cost of a spectrum's operands.
-void polydecomp_kernel_sums(int N, const double *w, int S, const double *taus, int D,
-                            const double *log_taus, double c_exp, PolyDecompOperands &out);
-// The rest (weighted design matrix from out's rounded G, Householder QR, least squares).
-void polydecomp_reduce(const double *zn, const double *zn_err, PolyDecompOperands &out);
+// The reduced form's log-likelihood of one theta row from the unrounded operands: what the reduced kernels
+// compute, without their rounding.  From the binary128 operands when the spectrum has them, else from the
+// long-double ones with rows accumulated as pairs of long doubles.
+double reduced_logp_reference(const ReducedProblem &p, const double *theta);
+double reduced_logp_reference(int n, const std::vector<long double> &Rl, const std::vector<long double> &qty,
+                              double rest, double lconst, const double *theta);
 
 // Host threads for per-spectrum work (batch contexts, file ingest): BISIP_HOST_THREADS, else the
 // CPUs this process may use -- affinity mask and cgroup CPU quota -- capped at 16.
@@ -75,11 +141,6 @@ void parallel_blocks(int64_t n, int64_t min_per_thread, const std::function<void
 // host_ingest.cpp: the body of bisip_read_tables (include/bisip_hip.h)
 void read_tables(const char *const *paths, int64_t n_files, int headers, int64_t n_rows, double *tables,
                  int32_t *status, int threads);
-
-// The reduced form's log-likelihood of one theta row from the unrounded operands, in long double:
-// what the reduced kernels compute, without their rounding (reduced_center's yardstick).
-double reduced_logp_reference(int n, const std::vector<long double> &Rl, const std::vector<long double> &qty,
-                              double rest, double lconst, const double *theta);
 
 // -0.5 * sum_i 2*ln(zn_err_i^2), the walker-independent term of src/bisip/models.py:62
 double loglike_const(int n2, const double *zn_err);

@@ -33,6 +33,8 @@ struct Bounds {
     // group of <= 4 neither overflows nor underflows, so ONE reciprocal serves the group (rcp_batch_n) --
     // and no exponent needs clamping.  Wave-uniform (kernel argument): logprob_row picks, once per row,
     // between two instantiations of the frequency loop (FAST / safe); the loop itself has no branch.
+    // Dias: the bit says that the product of two frequencies' denominators is a normal number everywhere in
+    // the box, so frequencies 2k and 2k+1 share one reciprocal.
     int flags = 0;
 };
 constexpr int BOUNDS_FAST = 1;
@@ -320,6 +322,8 @@ struct PDCollapsed {
         return s;
     }
     static constexpr bool HAS_FAST = false;
+    static constexpr bool HAS_GRID = false;
+    static constexpr bool PAIRED = false;
     // Log-prob records are pre-weighted by 1/sigma (rows of the weighted design matrix):
     //   rec = ys_re, ys_im, -s_re, pad | s_re*G_re[0..P] | s_im*G_im[0..P]
     // so (y - Z)/sigma = ys + r0*(-s) + sum_p b_p (s G_p): 2(P+1)+1 FMAs, and the caller
@@ -364,6 +368,8 @@ struct ColeCole {
         double A[D], c2[D], clt2[D], C;  // residual(): m r0, c log2e, c log2e lt, r0 - sum A
     };
     static constexpr bool HAS_FAST = true;
+    static constexpr bool HAS_GRID = true;
+    static constexpr bool PAIRED = false;
     __device__ static __forceinline__ Setup setup(const double (&th)[NDIM])
     {
         Setup s;
@@ -490,87 +496,104 @@ struct Dias {
     static constexpr int REC = 8;
     static constexpr bool WEIGHTED = false;
     struct Setup {
-        double r0, m, tau, taup, taupp;
-        double A, C, teh;  // residual(): r0 m, r0 - A, tau |eta| / sqrt(2)
+        double r0, m, tau, taup;
+        double A, C, teh, teh2;  // r0 m, r0 - A, tau |eta| / sqrt(2) and its square
     };
+    // tau' is clamped at 1e50: delta = 0 or m = 1 (prior bounds; forward() may be asked for them) make it
+    // infinite and the reference's complex arithmetic then gives Z = r0 (1 - m).  A huge finite tau' reaches
+    // the same limit without inf * 0 (NaN, from 0/0, is kept): beyond 1e50 the term r0 m / den is below
+    // 1e-45 in absolute terms.  1e50 (not 1e100) so that the PRODUCT of two frequencies' X^2 + Y^2 stays
+    // finite inside the reference's box (the shared reciprocal below; bound_flags in bisip_hip.hip checks it).
+    static constexpr double TAUP_MAX = 1e50;
     __device__ static __forceinline__ Setup setup(const double (&th)[NDIM])
     {
         Setup s;
         s.r0 = th[0];
         s.m = th[1];
         s.tau = exp_finite(th[2]);
-        // delta = 0 or m = 1 (prior bounds; forward() may be asked for them) make tau' infinite;
-        // the reference's complex arithmetic then gives Z = r0 (1 - m).  A huge finite tau'
-        // reaches the same limit without inf * 0 (NaN, from 0/0, is kept); 1e100 leaves X^2 + Y^2 of
-        // den() finite for |mu|^2 up to 1e45.
         double taup = s.tau * (1.0 / th[4] - 1.0) / (1.0 - s.m);
-        if (fabs(taup) > 1e100) taup = copysign(1e100, taup);
+        if (fabs(taup) > TAUP_MAX) taup = copysign(TAUP_MAX, taup);
         s.taup = taup;
-        s.taupp = (s.tau * s.tau) * (th[3] * th[3]);
         s.A = th[0] * th[1];
         s.C = th[0] - s.A;
         s.teh = s.tau * fabs(th[3]) * 0.70710678118654752440;
+        s.teh2 = s.teh * s.teh;
         return s;
     }
-    // Z = r0 (1-m) + r0 m / den,  den = 1 + i a (1 + 1/mu),  a = w tau',  mu = i w tau + (i w tau'')^0.5.
-    // (i w tau'')^0.5 = sqrt(w) tau |eta| (1+i)/sqrt(2) with sqrt(w_j) precomputed per frequency, so no
-    // square root per (walker, frequency); and with m2 = |mu|^2 the inner division disappears:
-    //   1 + 1/mu = (m2 + conj(mu))/m2   =>   den = (X + iY)/m2,  X = m2 + a Im(mu),  Y = a (m2 + Re(mu)),
-    //   1/den = m2 (X - iY)/(X^2 + Y^2):  ONE reciprocal per frequency instead of two (v_rcp_f64 issues
-    // at a quarter of the FMA rate: 21 instructions / 24 issue slots per frequency instead of 26 / 32).
-    // Inside the prior a > 0, mu has non-negative parts and |mu| >= w tau > 0: X, Y > 0, nothing cancels.
-    static constexpr bool HAS_FAST = false;
-    struct Den { double X, Y, t; };   // t = A m2 / (X^2 + Y^2)
-    __device__ static __forceinline__ Den den(const Setup &s, double w, double sqrtw)
+    // Z = r0 (1-m) + r0 m / den,  den = 1 + i a (1 + 1/mu),  a = w tau',  mu = i w tau + (i w tau'')^0.5,
+    // tau'' = tau^2 eta^2.  With u = sqrt(w_j) (precomputed per frequency: no square root per (walker,
+    // frequency)), (i w tau'')^0.5 = u teh (1 + i), so mu = u (teh + i g) with g = u tau + teh, and
+    // |mu|^2 = w n2, n2 = teh^2 + g^2.  The inner division goes (1 + 1/mu = (|mu|^2 + conj mu)/|mu|^2) and the
+    // common factor w cancels between numerator and denominator:
+    //   1/den = n2 (X - iY)/(X^2 + Y^2),   X = n2 + b g,   Y = b (u n2 + teh),   b = tau' u
+    // -- 8 instructions up to D = X^2 + Y^2, ONE reciprocal per frequency.  Inside the prior b > 0 and every
+    // term is positive: nothing cancels.
+    static constexpr bool HAS_FAST = true;
+    static constexpr bool HAS_GRID = false;
+    // FAST (bound_flags: everywhere in the box D lies in [1e-145, 1e145]): the reciprocals of frequencies 2k and
+    // 2k+1 come from ONE reciprocal of D_2k D_2k+1 (v_rcp_f64 issues at a quarter of the FMA rate).  The pairs
+    // are (2k, 2k+1) in every kernel, a last unpaired frequency takes its own reciprocal: a walker's value does
+    // not depend on which kernel evaluated it.
+    static constexpr bool PAIRED = true;
+    struct Den { double X, Y, n2, D; };
+    __device__ static __forceinline__ Den den(const Setup &s, double u)
     {
-        const double mur = sqrtw * s.teh, mui = fma(w, s.tau, mur);
-        const double m2 = fma(mur, mur, mui * mui);
-        const double a = w * s.taup;
         Den d;
-        d.X = fma(a, mui, m2);
-        d.Y = a * (m2 + mur);
-        d.t = (s.A * m2) * rcp_nr(fma(d.X, d.X, d.Y * d.Y));
+        const double b = s.taup * u;
+        const double g = fma(u, s.tau, s.teh);
+        d.n2 = fma(g, g, s.teh2);
+        d.X = fma(b, g, d.n2);
+        d.Y = b * fma(u, d.n2, s.teh);
+        d.D = fma(d.X, d.X, d.Y * d.Y);
         return d;
     }
     template <bool FAST = false>
     __device__ static __forceinline__ void residual(const Setup &s, const double *__restrict__ rec,
                                                     double &rr, double &ri)
     {
-        const Den d = den(s, rec[4], rec[6]);
-        rr = fma(-d.t, d.X, rec[0] - s.C);
-        ri = fma(d.t, d.Y, rec[1]);
+        const Den d = den(s, rec[6]);
+        const double t = d.n2 * (s.A * rcp_nr(d.D));
+        rr = fma(-t, d.X, rec[0] - s.C);
+        ri = fma(t, d.Y, rec[1]);
     }
+    // two frequencies with their dependency chains interleaved; FAST: one reciprocal for the pair
     template <bool FAST = false>
     __device__ static __forceinline__ void residual2(const Setup &s, const double *__restrict__ ra,
                                                      const double *__restrict__ rb, double (&rr)[2],
                                                      double (&ri)[2])
     {
         const double *__restrict__ rec[2] = {ra, rb};
-        double X[2], Y[2], m2[2], D[2], inv[2];
+        Den d[2];
+        double Ainv[2];
 #pragma unroll
-        for (int f = 0; f < 2; ++f) {
-            const double mur = rec[f][6] * s.teh, mui = fma(rec[f][4], s.tau, mur);
-            m2[f] = fma(mur, mur, mui * mui);
-            const double a = rec[f][4] * s.taup;
-            X[f] = fma(a, mui, m2[f]);
-            Y[f] = a * (m2[f] + mur);
-            D[f] = fma(X[f], X[f], Y[f] * Y[f]);
+        for (int f = 0; f < 2; ++f) d[f] = den(s, rec[f][6]);
+        if constexpr (FAST) {
+            const double Ar = s.A * rcp_nr(d[0].D * d[1].D);
+            Ainv[0] = Ar * d[1].D;
+            Ainv[1] = Ar * d[0].D;
+        } else {
+            const double D[2] = {d[0].D, d[1].D};
+            double inv[2];
+            rcp_nr_n<2>(D, inv);
+            Ainv[0] = s.A * inv[0];
+            Ainv[1] = s.A * inv[1];
         }
-        rcp_nr_n<2>(D, inv);
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
-            const double t = (s.A * m2[f]) * inv[f];
-            rr[f] = fma(-t, X[f], rec[f][0] - s.C);
-            ri[f] = fma(t, Y[f], rec[f][1]);
+            const double t = d[f].n2 * Ainv[f];
+            rr[f] = fma(-t, d[f].X, rec[f][0] - s.C);
+            ri[f] = fma(t, d[f].Y, rec[f][1]);
         }
     }
-    // Z = r0 (1-m) + r0 m m2 (X - iY)/(X^2 + Y^2)   (m = w, ln w, sqrt w)
+    // Z = r0 (1-m) + r0 m n2 (X - iY)/(X^2 + Y^2)   (m = w, ln w, sqrt w); its own reciprocal: any theta may
+    // be asked of forward()
     __device__ static __forceinline__ void eval(const Setup &s, const double *__restrict__ m,
                                                 double &zr, double &zi)
     {
-        const Den d = den(s, m[0], m[2]);
-        zr = fma(d.t, d.X, s.C);
-        zi = -(d.t * d.Y);
+        const Den d = den(s, m[2]);
+        const double t = d.n2 * (s.A * rcp_nr(d.D));
+        zr = fma(t, d.X, s.C);
+        zi = -(t * d.Y);
     }
 };
 
@@ -584,6 +607,8 @@ struct Shin {
         double n2[2], lq2[2];  // residual(): n log2e, log_Q log2e
     };
     static constexpr bool HAS_FAST = true;
+    static constexpr bool HAS_GRID = true;
+    static constexpr bool PAIRED = false;
     __device__ static __forceinline__ Setup setup(const double (&th)[NDIM])
     {
         Setup s;
@@ -596,7 +621,7 @@ struct Shin {
             double ir = 1.0 / th[i];
             if (fabs(ir) > 1e70) ir = copysign(1e70, ir);
             s.invR[i] = ir;
-            s.Q[i] = exp_finite(th[2 + i]);
+            s.Q[i] = exp_finite(th[2 + i] > 700.0 ? 700.0 : th[2 + i]);     // finite (forward() only; NaN stays NaN)
             s.n[i] = th[4 + i];
             sincospi(0.5 * s.n[i], &s.sn[i], &s.cs[i]);
             s.n2[i] = s.n[i] * LOG2E;
@@ -679,17 +704,23 @@ struct Shin {
         residual_n<2, FAST>(s, r2, rr, ri);
     }
     // Z = sum_i conj(y_i)/|y_i|^2,  y_i = Q (iw)^n + 1/R   (m = w, ln w, sqrt w)
+    // forward() may be asked for any theta.  With R < 0 and n > 1 (boxes widened beyond the reference's) the
+    // two terms of Re y can cancel -- Z then amplifies the rounding of Q w^n a thousandfold -- so the power is
+    // taken with the REFERENCE'S roundings: e^(n ln w), the product n ln w rounded as its cpow rounds it, times
+    // Q = e^logQ (a walker constant), instead of one exponential of the fused exponent.
     __device__ static __forceinline__ void eval(const Setup &s, const double *__restrict__ m,
                                                 double &zr, double &zi)
     {
         const double lnw = m[1];
+        constexpr double PMAX = 0x1p500;          // beyond, |y|^2 would overflow (EXP2_CLAMP)
         zr = 0.0;
         zi = 0.0;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            double y = fma(s.n2[i], lnw, s.lq2[i]);
-            y = y > EXP2_CLAMP ? EXP2_CLAMP : y;     // any theta may be asked of forward(); NaN stays NaN
-            const double p = exp2_finite(y);
+            double t = s.n[i] * lnw;
+            t = t > 350.0 ? 350.0 : t;               // NaN stays NaN
+            double p = s.Q[i] * exp_finite(t);
+            p = p > PMAX ? PMAX : p;
             const double yr = fma(p, s.cs[i], s.invR[i]), yi = p * s.sn[i];  // yr >= 1/R > 1
             const double inv = rcp_nr(fma(yr, yr, yi * yi));
             zr = fma(yr, inv, zr);
@@ -815,6 +846,24 @@ __device__ __forceinline__ void rotate_sums(double rr, double ri, const double *
     }
 }
 
+// One step of the travelling sums for a lane that holds TWO residuals (a pair of Dias's shared reciprocal): as
+// rotate_sums, term by term -- lane STEP's two terms are added in ascending frequency and every lane adopts the result.
+template <int L, int STEP>
+__device__ __forceinline__ void rotate_pair_sums(const double (&rr)[2], const double (&ri)[2],
+                                                 const double (&iv)[2][2], int jb, int N, double &acc0,
+                                                 double &acc1)
+{
+    if constexpr (STEP < L) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const double c0 = fma(rr[q] * rr[q], iv[q][0], acc0), c1 = fma(ri[q] * ri[q], iv[q][1], acc1);
+            const double n0 = group_broadcast<STEP, L>(c0), n1 = group_broadcast<STEP, L>(c1);
+            if (jb + 2 * STEP + q < N) { acc0 = n0; acc1 = n1; }   // uniform inside the group
+        }
+        rotate_pair_sums<L, STEP + 1>(rr, ri, iv, jb, N, acc0, acc1);
+    }
+}
+
 // Two 8-double frequency records (128 B) from LDS into registers, asynchronously: the ds_reads
 // are issued here, and lds_pair_wait() -- an s_waitcnt that names the same registers, so every
 // use is ordered after it -- is placed by the CALLER after the arithmetic of the current pair.
@@ -889,6 +938,25 @@ __device__ __forceinline__ void logprob_sums(const typename M::Setup &s, const M
             acc0 = fma(rr * rr, rec[2], acc0);
             acc1 = fma(ri * ri, rec[3], acc1);
         }
+    } else if constexpr (L == 1 && FAST && M::PAIRED) {
+        // pairs (2k, 2k+1) share a reciprocal (Dias); the sums still take their terms one by one
+        const double *__restrict__ rec = o.cb;
+        int j = 0;
+        for (; j + 1 < o.N; j += 2, rec += 2 * M::REC) {
+            double rr[2], ri[2];
+            M::template residual2<true>(s, rec, rec + M::REC, rr, ri);
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                acc0 = fma(rr[f] * rr[f], rec[f * M::REC + 2], acc0);
+                acc1 = fma(ri[f] * ri[f], rec[f * M::REC + 3], acc1);
+            }
+        }
+        if (j < o.N) {
+            double rr, ri;
+            M::template residual<true>(s, rec, rr, ri);
+            acc0 = fma(rr * rr, rec[2], acc0);
+            acc1 = fma(ri * ri, rec[3], acc1);
+        }
     } else if constexpr (L == 1) {
         const double *__restrict__ rec = o.cb;
 #pragma unroll 2
@@ -902,6 +970,25 @@ __device__ __forceinline__ void logprob_sums(const typename M::Setup &s, const M
                 acc0 = fma(rr * rr, rec[2], acc0);
                 acc1 = fma(ri * ri, rec[3], acc1);
             }
+        }
+    } else if constexpr (FAST && M::PAIRED) {
+        // L lanes per walker: lane g takes PAIR j0/2 + g of every group of L pairs (the pairs of the L = 1 loop:
+        // 2k, 2k+1 with one reciprocal; a last unpaired frequency its own), then the sums travel through the
+        // group pair by pair, term by term
+        const int last = o.N - 1;
+        for (int j0 = 0; j0 < o.N; j0 += 2 * L) {
+            const int ja = (j0 + 2 * g < o.N) ? j0 + 2 * g : (last & ~1);    // clamp: its results are never adopted
+            const double *__restrict__ ra = o.cb + (long long)ja * M::REC;
+            double rr[2], ri[2], iv[2][2];
+            if (ja + 1 < o.N) {
+                M::template residual2<true>(s, ra, ra + M::REC, rr, ri);
+                iv[1][0] = ra[M::REC + 2]; iv[1][1] = ra[M::REC + 3];
+            } else {
+                M::template residual<true>(s, ra, rr[0], ri[0]);
+                rr[1] = 0.0; ri[1] = 0.0; iv[1][0] = 0.0; iv[1][1] = 0.0;
+            }
+            iv[0][0] = ra[2]; iv[0][1] = ra[3];
+            rotate_pair_sums<L, 0>(rr, ri, iv, j0, o.N, acc0, acc1);
         }
     } else {
         for (int j0 = 0; j0 < o.N; j0 += L) {
@@ -1093,10 +1180,12 @@ __device__ __forceinline__ double logprob_row(const double (&th)[M::NDIM], const
         // (up to three exponentials per frequency: with four or five the steps' registers push the
         // persistent kernels into scratch -- for every loop of the kernel, not only this one; bound_flags
         // never sets the bit for those)
-        if constexpr (M::NEXP <= GRID_MAX_TERMS) {
-            if (b.flags & BOUNDS_GRID) {
-                logprob_sums_grid<M, L, LDSREC>(s, o, g, acc0, acc1);
-                return fma(-0.5, acc0 + acc1, o.lconst);
+        if constexpr (M::HAS_GRID) {
+            if constexpr (M::NEXP <= GRID_MAX_TERMS) {
+                if (b.flags & BOUNDS_GRID) {
+                    logprob_sums_grid<M, L, LDSREC>(s, o, g, acc0, acc1);
+                    return fma(-0.5, acc0 + acc1, o.lconst);
+                }
             }
         }
         if (b.flags & BOUNDS_FAST) logprob_sums<M, L, LDSREC, true>(s, o, g, acc0, acc1);

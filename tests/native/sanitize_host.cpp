@@ -175,6 +175,24 @@ static void reduced(int N, int S, int D)
     std::vector<double> th(n, 0.01);
     th[0] = 1.0;
     EXPECT(std::isfinite(bisip::reduced_logp_reference(n, o.Rl, o.qty, o.rest, lconst, th.data())));
+    // the same spectrum as a context keeps it: shared probes, the plain tier, then the compensated tier on
+    // operands from the QR in binary128, and the yardstick from those operands
+    bisip::ReducedProblem p;
+    bisip::reduced_from_operands(o, lconst, p);
+    bisip::ReducedProbes probes;
+    bisip::reduced_probes(p, lo.data(), hi.data(), probes);
+    EXPECT(probes.n == n && probes.rows.size() == probes.count() * (size_t)n && probes.n_regular <= probes.count());
+    const double plain = bisip::reduced_center_plain(p, probes, lo.data(), hi.data(), 0.05, bh.data(), e.data(), el.data());
+    EXPECT(plain >= 0.0 || plain != plain);
+    const double ld_ref = bisip::reduced_logp_reference(p, th.data());
+    if (2 * N >= n) {
+        bisip::reduced_make_quad(*bisip::polydecomp_kernel_sums_quad(N, w.data(), S, taus.data(), D, lt.data(), 1.0), zn.data(), err.data(), p);
+        EXPECT(p.has_quad() && (int)p.Rc.size() == n * n && (int)p.Rc_lo.size() == n * n);
+        const double comp = bisip::reduced_center_comp(p, probes, lo.data(), hi.data(), 0.05, bh.data(), e.data(), el.data());
+        EXPECT(comp >= 0.0 || comp != comp);
+        const double q_ref = bisip::reduced_logp_reference(p, th.data());
+        EXPECT(std::isfinite(q_ref) && std::fabs(q_ref - ld_ref) <= 1e-6 * (1.0 + std::fabs(ld_ref)));
+    }
 }
 
 int main(int argc, char **argv)

@@ -109,7 +109,7 @@ def test_two_rank_gloo(tmp_path):
         assert np.array_equal(r[i]['survey'], np.arange(11.0)[:, None, None] * 100 + np.arange(6.0).reshape(2, 3))
 
 
-def _device_driver_worker(rank, world, port, case, outdir):
+def _device_driver_worker(rank, world, port, case, outdir, nwalkers=19):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     os.environ['MASTER_ADDR'] = '127.0.0.1'
@@ -124,9 +124,9 @@ def _device_driver_worker(rank, world, port, case, outdir):
     fn = lambda t: oracle.logprob(prob, t)  # noqa: E731
     lo, hi = g['bounds']
     np.random.seed(11)
-    p0 = np.random.uniform(lo, hi, (19, lo.size))   # odd ensemble: uneven halves and shards
+    p0 = np.random.uniform(lo, hi, (nwalkers, lo.size))   # odd ensemble: uneven halves and shards
     np.random.seed(12)
-    s = DeviceEnsembleSampler(19, lo.size, backend=NumpyStretchBackend(fn), distributed=True, chunk=6)
+    s = DeviceEnsembleSampler(nwalkers, lo.size, backend=NumpyStretchBackend(fn), distributed=True, chunk=6)
     s.run_mcmc(p0, 20)
     np.savez(os.path.join(outdir, f'dev_rank{rank}.npz'), chain=s.get_chain(), logp=s.get_log_prob(),
              acc=s.acceptance_fraction)
@@ -134,24 +134,25 @@ def _device_driver_worker(rank, world, port, case, outdir):
     dist.destroy_process_group()
 
 
-def test_sharded_device_driver_two_rank_gloo(tmp_path):
+@pytest.mark.parametrize('world,nwalkers', [(2, 19), (8, 15)])
+def test_sharded_device_driver_two_rank_gloo(tmp_path, world, nwalkers):
     """DeviceEnsembleSampler's multi-rank path (eval -> all_gather_into_tensor -> apply)
     over gloo with a NumPy stand-in for the kernels: every rank ends with the chain of
-    the single-rank host sampler."""
+    the single-rank host sampler.  Two ranks, and the eight of the scaling run with an ensemble whose halves
+    (8 and 7 slots) leave the last rank of the second half with nothing to evaluate."""
     import torch.multiprocessing as mp
     import oracle
     from bisip_amd.sampler import EnsembleSampler
     case = [p for p in golden_cases() if 'PeltonColeCole_SIP-K389175' in p][0]
-    world = 2
-    mp.spawn(_device_driver_worker, args=(world, _free_port(), case, str(tmp_path)), nprocs=world,
+    mp.spawn(_device_driver_worker, args=(world, _free_port(), case, str(tmp_path), nwalkers), nprocs=world,
              join=True)
     g = np.load(case)
     prob = oracle.OracleProblem.from_golden(g, 'PeltonColeCole')
     lo, hi = g['bounds']
     np.random.seed(11)
-    p0 = np.random.uniform(lo, hi, (19, lo.size))
+    p0 = np.random.uniform(lo, hi, (nwalkers, lo.size))
     np.random.seed(12)
-    s = EnsembleSampler(19, lo.size, lambda t: oracle.logprob(prob, t))
+    s = EnsembleSampler(nwalkers, lo.size, lambda t: oracle.logprob(prob, t))
     s.run_mcmc(p0, 20)
     for i in range(world):
         r = np.load(tmp_path / f'dev_rank{i}.npz')

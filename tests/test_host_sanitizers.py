@@ -1,5 +1,5 @@
 """AddressSanitizer + UndefinedBehaviorSanitizer over the library's host-only C++ (the
-long-double operand precompute with its Householder QR and the probing that picks a reduced kernel, the
+long-double and binary128 operand precompute with its Householder QR and the probing that picks a reduced kernel, the
 NumPy-order random stream, the spectrum-file parser on well-formed and hostile files, the thread helper).
 GPU sanitizers are not available on the target pool; this is the CPU build the task's
 environment notes ask for."""
@@ -20,9 +20,9 @@ def test_host_code_under_asan_ubsan(tmp_path):
            os.path.join(ROOT, 'bisip_amd', 'csrc', 'host_precompute.cpp'),
            os.path.join(ROOT, 'bisip_amd', 'csrc', 'host_rng.cpp'),
            os.path.join(ROOT, 'bisip_amd', 'csrc', 'host_ingest.cpp')]
-    build = subprocess.run(['g++', '-std=c++17', '-O1', '-g', '-fno-omit-frame-pointer',
+    build = subprocess.run(['g++', '-std=gnu++17', '-O1', '-g', '-fno-omit-frame-pointer',
                             '-fsanitize=address,undefined', '-fno-sanitize-recover=all', '-pthread',
-                            '-o', str(exe)] + src, capture_output=True, text=True)
+                            '-o', str(exe)] + src + ['-lquadmath'], capture_output=True, text=True)
     assert build.returncode == 0, build.stderr
     env = dict(os.environ, ASAN_OPTIONS='detect_leaks=1:abort_on_error=0', UBSAN_OPTIONS='print_stacktrace=1')
     files = tmp_path / 'files'
@@ -41,7 +41,7 @@ def test_host_threads_under_tsan(tmp_path):
            os.path.join(ROOT, 'bisip_amd', 'csrc', 'host_precompute.cpp'),
            os.path.join(ROOT, 'bisip_amd', 'csrc', 'host_rng.cpp'),
            os.path.join(ROOT, 'bisip_amd', 'csrc', 'host_ingest.cpp')]
-    build = subprocess.run(['g++', '-std=c++17', '-O1', '-g', '-fsanitize=thread', '-pthread', '-o', str(exe)] + src,
+    build = subprocess.run(['g++', '-std=gnu++17', '-O1', '-g', '-fsanitize=thread', '-pthread', '-o', str(exe)] + src + ['-lquadmath'],
                            capture_output=True, text=True)
     if build.returncode != 0 and 'tsan' in build.stderr.lower():
         pytest.skip('no ThreadSanitizer runtime here')
