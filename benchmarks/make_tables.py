@@ -21,7 +21,21 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROF = os.path.join(ROOT, 'profiles')
-ROUND = 'r03'
+ROUNDS = ['r04', 'r03']     # a measurement is quoted from the newest round that repeated it
+
+
+def rn(suffix):
+    """profiles/<round>_<suffix> of the newest round that has it (globs allowed); several, comma separated, each on its own."""
+    import glob
+    if ', ' in suffix:
+        return ', '.join(rn(x) for x in suffix.split(', '))
+    for r in ROUNDS:
+        if glob.glob(os.path.join(PROF, f'{r}_{suffix}')):
+            return f'{r}_{suffix}'
+    return f'{ROUNDS[0]}_{suffix}'
+
+
+ROUND = ROUNDS[0]
 
 
 def jload(name):
@@ -54,25 +68,25 @@ def kernel_stats(name, needle):
 
 # ---------------------------------------------------------------------------------------
 def table_bench():
-    b = jload(f'{ROUND}_bench.json')
-    u = jload(f'{ROUND}_bench_under_rocprof.json')
-    ks = kernel_stats(f'{ROUND}_bench_kernel_stats.csv', 'k_logprob_pd_reduced')
+    b = jload(rn('bench.json'))
+    u = jload(rn('bench_under_rocprof.json'))
+    ks = kernel_stats(rn('bench_kernel_stats.csv'), 'k_logprob_pd_reduced')
     t = jload('pmc_traffic.json')
     r = b['roofline']
     cb = b['cpu_baseline']
     cal = cb.get('reference_calibration', {})
     rows = [
-        ['value (whole job, 1 GPU)', f"{sci(b['value'], 4)} evals/s", f"`{ROUND}_bench.json`"],
+        ['value (whole job, 1 GPU)', f"{sci(b['value'], 4)} evals/s", f"`{rn('bench.json')}`"],
         ['ms per step (W = 2^24 walkers per launch)', f"{b['ms_per_step']:.4f}", ''],
         ['kernel duration, HIP events on the launch stream', f"{r['kernel_ms'] * 1e3:.1f} us", 'un-profiled run'],
         ['achieved / peak', f"{r['achieved']:.0f} / {r['peak']:.0f} GB/s = **{r['frac']:.3f}**", '64 B per eval'],
         ['same command under `rocprofv3 --kernel-trace --stats`',
          f"{float(ks['AverageNs']) / 1e3:.2f} us average over {ks['Calls']} launches",
-         f"`{ROUND}_bench_kernel_stats.csv`"],
-        ['in-process HIP-event clock in that profiled run', f"{u['roofline']['kernel_ms'] * 1e3:.2f} us", f"`{ROUND}_bench_under_rocprof.json`"],
+         f"`{rn('bench_kernel_stats.csv')}`"],
+        ['in-process HIP-event clock in that profiled run', f"{u['roofline']['kernel_ms'] * 1e3:.2f} us", f"`{rn('bench_under_rocprof.json')}`"],
         ['HBM traffic per launch (PMC, FETCH_SIZE x2 + WRITE_SIZE)',
          f"{t['hbm_bytes_per_launch'] / 1e6:.2f} MB vs {t['algorithmic_bytes_per_launch'] / 1e6:.2f} MB algorithmic "
-         f"= x{t['hbm_bytes_per_launch'] / t['algorithmic_bytes_per_launch']:.5f}", f"`pmc_traffic.json`, `{ROUND}_bench_pmc_summary.csv`"],
+         f"= x{t['hbm_bytes_per_launch'] / t['algorithmic_bytes_per_launch']:.5f}", f"`pmc_traffic.json`, `{rn('bench_pmc_summary.csv')}`"],
         ['CPU baseline (oracle, kind "port")', f"{sci(cb['value'])} evals/s on {cb['cores']} threads; {sci(cb['value_1core'])} on one",
          f"quota {cb.get('cpu_quota')} of {cb['host_cpus_visible']} visible CPUs"],
     ]
@@ -85,7 +99,7 @@ def table_bench():
 
 
 def table_variants():
-    b = jload(f'{ROUND}_bench.json')
+    b = jload(rn('bench.json'))
     rows = []
     for group, title in (('variants', 'PolynomialDecomposition P=5, N=32, W=2^24'), ('kernels', 'N=32, W=2^22')):
         for label, v in b[group].items():
@@ -104,13 +118,13 @@ def table_variants():
 
 def table_sweep():
     rows = [[d['case'], f"`{d['kernel']}`", d['N'], d['W'], f"{d['us_per_launch']:.2f}", sci(d['evals_per_s']),
-             f"{d['hbm_frac']:.3f}"] for d in jlines(f'{ROUND}_sweep.jsonl')]
+             f"{d['hbm_frac']:.3f}"] for d in jlines(rn('sweep.jsonl'))]
     return md(rows, ['case', 'kernel', 'N', 'W', 'us per launch', 'evals/s', 'fraction of HBM peak'])
 
 
 def table_forward():
     rows = []
-    for d in jlines(f'{ROUND}_host_path.jsonl'):
+    for d in jlines(rn('host_path.jsonl')):
         if 'forward' in d['case']:
             rows.append([d['case'].replace(' bisip_forward_dev', ''), d['W'], d['us'], sci(d['rows_per_s']),
                          f"{d['write_GBs'] / 1e3:.2f}"])
@@ -119,12 +133,12 @@ def table_forward():
 
 def table_host_path():
     rows = [[d['case'].replace(' bisip_logprob (host buffers, pageable)', ''), d['W'], sci(d['evals_per_s']), d['GBs_over_pcie']]
-            for d in jlines(f'{ROUND}_host_path.jsonl') if 'host buffers' in d['case']]
+            for d in jlines(rn('host_path.jsonl')) if 'host buffers' in d['case']]
     return md(rows, ['`bisip_logprob`, host buffers (PCIe inclusive; never `value`)', 'W', 'evals/s', 'GB/s over the link'])
 
 
 def table_samplers():
-    data = jlines(f'{ROUND}_sampler_bench.jsonl')
+    data = jlines(rn('sampler_bench.jsonl'))
     cases, samplers = [], ['device-philox-persistent', 'device-philox', 'device', 'device-launches', 'host']
     for d in data:
         if d['case'] not in cases:
@@ -141,10 +155,10 @@ def table_samplers():
 
 def table_cfg4():
     rows = []
-    for f, label in ((f'{ROUND}_cfg4_fused_device_chain.json', 'fused half-step (one launch), single GPU'),
-                     (f'{ROUND}_cfg4_sharded_rccl.json', "sharded: C loop, eval -> ncclAllGather -> apply, torch's communicator"),
-                     (f'{ROUND}_cfg4_sharded_rccl-own.json', 'sharded: C loop, communicator from bisip_rccl_comm_create'),
-                     (f'{ROUND}_cfg4_sharded_python.json', 'sharded: Python loop over torch.distributed (round 1)')):
+    for f, label in ((rn('cfg4_fused_device_chain.json'), 'fused half-step (one launch), single GPU'),
+                     (rn('cfg4_sharded_rccl.json'), "sharded: C loop, eval -> ncclAllGather -> apply, torch's communicator"),
+                     (rn('cfg4_sharded_rccl-own.json'), 'sharded: C loop, communicator from bisip_rccl_comm_create'),
+                     (rn('cfg4_sharded_python.json'), 'sharded: Python loop over torch.distributed (round 1)')):
         d = jload(f)
         rows.append([label, d['n_gpus'], d['driver'], d['us_per_half_step'], sci(d['walker_steps_per_s']), d['acceptance']])
     return md(rows, ['cfg4: 32,768 walkers, Debye S=40, P=5', 'ranks', 'driver', 'us per half-step', 'walker-steps/s', 'acceptance'])
@@ -152,13 +166,13 @@ def table_cfg4():
 
 def table_cfg5():
     rows = []
-    for f, label in ((f'{ROUND}_cfg5_device_chain.json', 'persistent kernel (automatic for this shape), chain in HBM'),
-                     (f'{ROUND}_cfg5_device_chain_launches.json', 'one launch per half-step, chain in HBM'),
-                     (f'{ROUND}_cfg5_host_chain.json', 'persistent kernel, chain copied to pinned host memory')):
+    for f, label in ((rn('cfg5_device_chain.json'), 'persistent kernel (automatic for this shape), chain in HBM'),
+                     (rn('cfg5_device_chain_launches.json'), 'one launch per half-step, chain in HBM'),
+                     (rn('cfg5_host_chain.json'), 'persistent kernel, chain copied to pinned host memory')):
         d = jload(f)
         rows.append([label, d['path'], d['iterations'], d['seconds'], d.get('us_per_half_step', '-'), sci(d['walker_steps_per_s'])])
-    for f, label in ((f'{ROUND}_cfg5_4096_spectra.json', 'ALL 4096 spectra (1,048,576 walkers) on one GPU, persistent kernel'),
-                     (f'{ROUND}_cfg5_4096_spectra_launches.json', 'ALL 4096 spectra on one GPU, one launch per half-step')):
+    for f, label in ((rn('cfg5_4096_spectra.json'), 'ALL 4096 spectra (1,048,576 walkers) on one GPU, persistent kernel'),
+                     (rn('cfg5_4096_spectra_launches.json'), 'ALL 4096 spectra on one GPU, one launch per half-step')):
         if os.path.exists(os.path.join(PROF, f)):
             d = jload(f)
             rows.append([label, d['path'], d['iterations'], d['seconds'], d.get('us_per_half_step', '-'), sci(d['walker_steps_per_s'])])
@@ -167,7 +181,7 @@ def table_cfg5():
 
 
 def table_ingest():
-    d = jload(f'{ROUND}_ingest.json')
+    d = jload(rn('ingest.json'))
     th = max(int(k.split('_')[1]) for k in d if k.startswith('batch_') and k.endswith('_threads_s'))
     rows = [['np.loadtxt + per-file arithmetic, file after file (the reference\'s way)', d['per_file_numpy_s'], round(1e6 * d['per_file_numpy_s'] / d['spectra'], 1), '1'],
             ['`load_data_batch`, 1 thread', d['batch_1_threads_s'], round(1e6 * d['batch_1_threads_s'] / d['spectra'], 1), d['batch_1_threads_speedup']],
@@ -177,35 +191,35 @@ def table_ingest():
 
 def table_batch_models():
     rows = []
-    for d in jlines(f'{ROUND}_batch_models.jsonl'):
+    for d in jlines(rn('batch_models.jsonl')):
         a, b = d['persistent'], d['launch_per_half_step']
         rows.append([d['model'], a['us_per_half_step'], sci(a['walker_steps_per_s']), b['us_per_half_step'], sci(b['walker_steps_per_s']), a['acceptance']])
-    d0 = jlines(f'{ROUND}_batch_models.jsonl')[0]
+    d0 = jlines(rn('batch_models.jsonl'))[0]
     return md(rows, [f"{d0['spectra']} spectra x {d0['walkers_per_spectrum']} walkers, 32 frequencies, {d0['iterations']} iterations, chain in HBM: model",
                      'persistent kernel: us per half-step', 'walker-steps/s', 'launch per half-step: us per half-step', 'walker-steps/s', 'acceptance'])
 
 
 def table_survey():
     rows = [[d['model'], d['ingest_and_context_s'], d['fit_s'], d['parameter_summaries_s'], d['model_bands_s'], d['total_s'], sci(d['walker_steps_per_s_end_to_end'])]
-            for d in jlines(f'{ROUND}_survey.jsonl')]
-    d0 = jlines(f'{ROUND}_survey.jsonl')[0]
+            for d in jlines(rn('survey.jsonl'))]
+    d0 = jlines(rn('survey.jsonl'))[0]
     return md(rows, [f"a survey end to end on one GPU: {d0['spectra']} spectrum files, {d0['walkers_per_spectrum']} walkers x {d0['iterations']} iterations each; model",
                      'ingest + batch context, s', '`fit()`, s', 'mean, std, 3 percentiles of every parameter, s', 'model-space bands of every spectrum, s', 'total, s', 'walker-steps/s end to end'])
 
 
 def table_batch_setup():
-    rows = [[d['model'], d['kernel'], d['create_s'], d['fit_100_iterations_s'], d['summaries_s'], d.get('model_percentiles_s', '-')] for d in jlines(f'{ROUND}_batch_setup.jsonl')]
+    rows = [[d['model'], d['kernel'], d['create_s'], d['fit_100_iterations_s'], d['summaries_s'], d.get('model_percentiles_s', '-')] for d in jlines(rn('batch_setup.jsonl'))]
     return md(rows, ['512 spectra x 256 walkers: model', 'kernel', 'batch context creation, s', '`fit()` of 100 iterations, s', 'mean + std + 3 percentiles on the device, s',
                      'model-space percentile bands of every spectrum (50 x 256 samples each), s'])
 
 
 def table_fuzz():
     rows = []
-    for d in jlines(f'{ROUND}_fuzz_parity_summary.jsonl'):
+    for d in jlines(rn('fuzz_parity_summary.jsonl')):
         a = d['auto_on_polydecomp']
         rows.append([f"parity, seed {d['seed']}" + (f", prior boxes widened x{d['widen']}" if d.get('widen') else ''), d['cases'], d['violations'], f"{d['worst_logp_rel_err']:.1e}", f"{d['worst_Z_rel_err']:.1e}",
                      f"{a['reduced']} + {a['reduced_comp']} + {a['collapsed']} of {a['problems']} (reduced + compensated + collapsed)"])
-    for name, f in (('sampler', f'{ROUND}_fuzz_sampler_summary.jsonl'), ('batch of spectra', f'{ROUND}_fuzz_batch_summary.jsonl')):
+    for name, f in (('sampler', rn('fuzz_sampler_summary.jsonl')), ('batch of spectra', rn('fuzz_batch_summary.jsonl'))):
         for d in jlines(f):
             rows.append([f"{name}, seed {d['seed']}", d['cases'], d['failures'], '-', '-', '-'])
     return md(rows, ['campaign', 'cases', 'violations', 'worst log-prob rel. err (tol 1e-10)', 'worst Z rel. err (tol 1e-12)',
@@ -214,7 +228,7 @@ def table_fuzz():
 
 def table_valley():
     rows = []
-    for d in jlines(f'{ROUND}_fuzz_valley_summary.jsonl'):
+    for d in jlines(rn('fuzz_valley_summary.jsonl')):
         v, a = d['valley_rows'], d['auto_on_polydecomp']
         rows.append([d['seed'], d['cases'], v['cases'], d['violations'], f"{v['worst_auto_vs_exact']:.1e}", f"{v['worst_comp_vs_exact']:.1e}",
                      f"{v['worst_reference_vs_exact']:.1e}", v['cases_where_reference_is_off'], f"{v['worst_per_frequency_vs_exact']:.1e}",
@@ -227,7 +241,7 @@ def table_valley():
 
 def table_latency():
     rows = []
-    for d in jlines(f'{ROUND}_micro_small_call_latency.jsonl'):
+    for d in jlines(rn('micro_small_call_latency.jsonl')):
         u = d['us_per_call']
         rows.append([d['model'], f"`{d['kernel']}`"] + [f"{u[w]['ctx.logprob']:.1f} / {u[w]['model.log_prob']:.1f}" for w in ('16', '32', '64', '256', '4096')])
     return md(rows, ['one log-probability call, host buffers in and out: us per call, `ctx.logprob` / `model.log_prob`', 'kernel',
@@ -236,7 +250,7 @@ def table_latency():
 
 def table_auto_by_degree():
     tot = {}
-    for d in jlines(f'{ROUND}_fuzz_parity_summary.jsonl'):
+    for d in jlines(rn('fuzz_parity_summary.jsonl')):
         for deg, v in d['auto_on_polydecomp']['by_degree'].items():
             t = tot.setdefault(int(deg), dict(problems=0, reduced=0, reduced_comp=0, collapsed=0))
             for k in t:
@@ -255,47 +269,47 @@ TABLES = {
 }
 
 FILES = [
-    (f'{ROUND}_bench.json', '`python bench.py`', 'the headline line: value, roofline (HIP-event kernel time), variants and other kernels with `roofline_valu`, cpu_baseline + reference calibration, parity'),
-    (f'{ROUND}_bench_kernel_stats.csv', '`rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-variants`', 'average duration of the headline kernel under the profiler'),
-    (f'{ROUND}_bench_under_rocprof.json', 'stdout of that run', 'the in-process HIP-event clock under the profiler (agrees with the trace)'),
-    (f'{ROUND}_bench_pmc_summary.csv, pmc_traffic.json', 'two more runs with `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes), `benchmarks/summarize_pmc.py`', 'HBM bytes per launch; bench.py copies it into `roofline.traffic`'),
+    (rn('bench.json'), '`python bench.py`', 'the headline line: value, roofline (HIP-event kernel time), variants and other kernels with `roofline_valu`, cpu_baseline + reference calibration, parity'),
+    (rn('bench_kernel_stats.csv'), '`rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-variants`', 'average duration of the headline kernel under the profiler'),
+    (rn('bench_under_rocprof.json'), 'stdout of that run', 'the in-process HIP-event clock under the profiler (agrees with the trace)'),
+    (rn('bench_pmc_summary.csv, pmc_traffic.json'), 'two more runs with `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes), `benchmarks/summarize_pmc.py`', 'HBM bytes per launch; bench.py copies it into `roofline.traffic`'),
     ('valu_counts.json', '`rocprofv3 --pmc SQ_INSTS_VALU -- python3 bench.py --pmc-pass`, `benchmarks/summarize_pmc.py`', 'VALU wave-instructions per eval of every kernel bench.py times: the numerators of `roofline_valu`'),
     ('cpu_calibration.json', '`python benchmarks/cpu_calibration.py` (build container only: imports the real reference)', 'real reference vs oracle on one core, same rows: bit-identical values, rate ratio'),
-    (f'{ROUND}_sweep.jsonl, {ROUND}_sweep_kernel_stats.csv', '`python benchmarks/sweep.py` (and under `rocprofv3 --kernel-trace --stats`)', 'every log-probability kernel at the BASELINE config shapes'),
-    (f'{ROUND}_host_path.jsonl', '`python benchmarks/host_path.py`', 'PCIe-inclusive `bisip_logprob` rate; `bisip_forward_dev` store rate'),
-    (f'{ROUND}_sampler_bench.jsonl, {ROUND}_sampler_kernel_stats.csv', '`python benchmarks/sampler_bench.py`', 'end-to-end `fit()` iterations/s per sampler / stream mode'),
-    (f'{ROUND}_cfg4_*.json', '`python benchmarks/cfg4_sampler.py --steps 200 --chain device [--fused] [--loop rccl|rccl-own|python]`', 'BASELINE config 4 on one GPU: fused vs the sharded half-step driven from C over RCCL vs from Python'),
-    (f'{ROUND}_cfg5_*.json, {ROUND}_cfg5_kernel_stats.csv', '`python benchmarks/cfg5_batch.py --chain device --steps 500 --thin-by 40 [--no-persistent]`', "BASELINE config 5, one GPU's share (512 spectra x 256 walkers)"),
-    (f'{ROUND}_bench_2ranks_one_device*.json', '`python bench.py --gpus 2 --backend gloo --same-device --walkers 1048576 --steps 4`', 'the self-launched 2-rank run on one GPU (gloo): result line and the sharded-sampler extra (state identical on both ranks = single-GPU chain)'),
-    (f'{ROUND}_ingest.json', '`python benchmarks/ingest.py` (host only)', 'survey ingest: the C parser + batched arithmetic against np.loadtxt file after file, same bits'),
-    (f'{ROUND}_batch_models.jsonl, {ROUND}_batch_models_kernel_stats.csv', '`python benchmarks/batch_models.py` (and `--only Polynomial` under `rocprofv3 --kernel-trace --stats`)', 'the batch-of-spectra sampler for every model at the cfg5 shape; the trace shows the stream draw next to the sampler kernel'),
-    (f'{ROUND}_survey.jsonl', '`python benchmarks/survey.py [--model PeltonColeCole]`', 'a 4096-spectrum survey end to end: files to posterior summaries and model bands'),
-    (f'{ROUND}_batch_setup.jsonl', '`python benchmarks/batch_setup.py`', 'what surrounds a survey run: batch context creation (host precompute on threads), a short fit, the summaries'),
-    (f'{ROUND}_soak.json', '`python benchmarks/soak.py`', 'twenty 100,000-iteration fits and twenty 10,000-iteration batch fits in one process: device memory constant, posterior means within 0.02 sigma of each other, identical summaries for identical seeds'),
-    (f'{ROUND}_fuzz_*_summary.jsonl', '`python benchmarks/fuzz_parity.py --cases 3000 --seed S` (S = 41..44, 47, 48; 4000 at S = 49..51; 1500 cases at S = 45, 46 with `--widen 1.5`, `--widen 3`; S = 52..57 -- 2000, 3000, 1500 with `--widen 1.5`, 3000, 3000, 1500 with `--widen 3`, 8000 each at S = 58, 59, 10000 each at S = 60, 61, 6000 and 2000 with `--widen 1.5` at S = 62, 63 (blocks of eight) -- with the ColeCole / Shin frequencies on exact grids, rounded grids and off any grid by thirds), `fuzz_sampler.py --cases 1500 --seed 2` (and 5, 6; 3000 at 8; 10, 2000 at 12, 4000 at 14, 2000 / 2500 / 6000 at 17, 19, 21 with the three kinds of frequencies), `fuzz_batch.py --cases 500 --seed 1` (and 4, 7; 1000 at 9; 600 each at 11, 13 and 1200 at 15 with the three kinds mixed inside a batch; 1000 at 16, 600 / 800 / 2000 at 18, 20, 22 with a reduced tier per spectrum)', 'randomised campaigns of this round (earlier rounds: `r02_fuzz_*`, 41,000 problems): violations, worst errors, which kernel AUTO ran'),
-    (f'{ROUND}_fuzz_valley_summary.jsonl', '`python benchmarks/fuzz_parity.py --cases 1500 --seed S --valley` (S = 301..303; 3000 cases each at S = 304..306, 4000 at S = 307..309, 6000 at S = 310; all re-run under the bisecting estimate)', 'half of the checked PolynomialDecomposition rows along the valley of chi^2 / on the shell logp = 0: distances of every formulation AND of the reference from the exact value'),
-    (f'{ROUND}_valley_rows.jsonl, {ROUND}_valley_rows_before.jsonl', '`python benchmarks/valley_rows.py`', 'the kernel AUTO picks, measured on 3000 valley rows per scale (1 ... 1000 sigma) of 216 designs of degree 5-10 (designs above 1e-11 are listed): with this round\'s estimate, and -- `_before` -- with round 2\'s, against plain long double'),
-    (f'{ROUND}_micro_collapsed_r3.txt', '`benchmarks/micro/collapsed_r3`', 'PDCollapsed: the shipped kernel against LDS-staged records, 4 rows per lane, single-wave workgroups and persistent waves, each with the engine clock it ran at and cycles per VALU instruction'),
-    (f'{ROUND}_micro_exp2_variants.txt', '`benchmarks/micro/exp2_variants`', 'a table-driven exp2 (16 / 32 entries in LDS) against the shipped degree-11 polynomial: cycles per exp2 per SIMD, clock, worst ulp -- not adopted'),
-    (f'{ROUND}_micro_fit_speed_by_tier.txt', '`python benchmarks/micro/fit_speed_by_tier.py`', 'fit() iterations/s on the plain and on the compensated reduced kernel (32 / 256 / 4096 walkers), with fit()\'s own measurement of the kernel'),
-    (f'{ROUND}_micro_rcp_accuracy.txt', '`benchmarks/micro/rcp_accuracy` (hipcc from `rcp_accuracy.hip`)', '`v_rcp_f64` is good to 2^-24.4 on gfx950; one Newton step leaves 20 ulp, two 1.00 ulp, ONE cubic step `r(1 + e + e^2)` 1.00 ulp with one instruction less and a shorter chain: what `rcp_nr` does'),
-    (f'{ROUND}_micro_grid_vs_direct.txt', '`python benchmarks/micro/grid_vs_direct.py`', 'ColeCole (1-3 modes) and Shin bulk launches on geometric frequency grids (exponentials stepped by multiplication in blocks of eight: 1.38-1.65x) against one exponential per frequency (`BISIP_NO_GRID=1`), with the largest difference between the two; rounded grid and bundled field spectrum as controls (no grid: the same loop twice)'),
-    (f'{ROUND}_micro_grid_small_ensembles.txt', '`python benchmarks/micro/grid_small_ensembles.py`', '`fit()` of one spectrum with 32-1024 walkers and emcee-sized calls, stepped against direct: 1.08-1.31x on an exact grid (lanes that share a walker take whole half-blocks), 1.0 on the bundled spectrum (no grid)'),
-    (f'{ROUND}_micro_grid_small_ensembles_before.txt', 'the same script on two designs that were taken out', 'one frequency per lane and round on a grid: 0.92-1.0x; a series-corrected tier for grids rounded in data files: 0.71-0.94x on the bundled spectrum (1.09-1.16x in bulk launches) -- why field data keeps the direct loop'),
-    (f'{ROUND}_micro_persistent_comp_by_degree.txt', '`python benchmarks/micro/persistent_comp_by_degree.py`, `batch_comp_by_degree.py`', 'the compensated kernel in the persistent sampler against one launch per half-step, by degree, with its triangle in scalar registers (single spectrum) and its low words staged in LDS: single ensembles -- persistent wins at every degree up to 512 walkers (1.6-2.3x at 32 walkers); 512 x 256 batches -- persistent wins up to degree 8, ties at 9; the automatic rules follow'),
-    (f'{ROUND}_micro_small_call_latency.jsonl', '`python benchmarks/micro/small_call_latency.py`', 'one emcee-sized log-probability call with host buffers, every model, 16 ... 4096 rows'),
-    (f'{ROUND}_micro_issue_latency.txt', '`benchmarks/micro/issue_latency`', 'cycles per fp64 FMA for 1/2/4/8 independent chains at 1, 2, 4 waves per SIMD; placement of 1-, 2-, 4-, 8-, 16-wave workgroups'),
-    (f'{ROUND}_micro_row_latency.txt', '`benchmarks/micro/row_latency`', 'cycles of one log-probability row at one wave per SIMD, records from the scalar cache vs staged in LDS'),
-    (f'{ROUND}_micro_half_step_phases.txt', '`benchmarks/micro/half_step_phases`', 'phases of the cfg5 half-step launch by s_memtime'),
-    (f'{ROUND}_micro_cfg5_pmc.txt', '`bash benchmarks/micro/cfg5_pmc.sh`', 'SQ counters of the cfg5 sampler kernel (VALU busy vs waiting)'),
-    (f'{ROUND}_micro_batch_pd_pmc.txt', '`bash benchmarks/micro/batch_pd_pmc.sh`', 'SQ counters of the persistent kernel on a PolynomialDecomposition batch, per wave (divide by the half-steps of a launch)'),
-    (f'{ROUND}_micro_batch_logprob_rate.txt', '`python benchmarks/micro/batch_logprob_rate.py`', 'bulk log-probability of a 512-spectrum batch, every model: the single-spectrum kernels\' rates'),
-    (f'{ROUND}_micro_select_vs_sort.txt', '`python benchmarks/micro/select_vs_sort.py`', 'percentiles of 131,072 columns by radix selection and by the segmented sort: time, and that the doubles are the same'),
-    (f'{ROUND}_micro_model_percentile_single.txt', '`python benchmarks/micro/model_percentile_single.py`', 'get_model_percentile of one model over a 160,000-row chain: the device call against forward + np.percentile'),
-    (f'{ROUND}_micro_forward_rows_variants.txt', '`benchmarks/micro/forward_rows_variants`', 'output path of the batched forward kernels (whole rows at N = 20, 16-frequency tiles at N = 32 / 64)'),
-    (f'{ROUND}_micro_persistent_crossover.txt', '`python benchmarks/micro/persistent_crossover.py`', 'persistent kernel vs launch per half-step by ensemble size and model: the automatic rule'),
-    (f'{ROUND}_micro_grid_barrier.txt', '`benchmarks/micro/grid_barrier`', 'cost of a device-wide barrier (with and without a row exchange) for 64 / 128 / 256 workgroups'),
-    (f'{ROUND}_micro_post_run_stall.txt', '`python benchmarks/micro/post_run_stall.py kernel`, `upload_cost.py plain`', 'the sporadic 20-30 ms delay of the first device work after a synchronisation early in a process'),
+    (rn('sweep.jsonl, sweep_kernel_stats.csv'), '`python benchmarks/sweep.py` (and under `rocprofv3 --kernel-trace --stats`)', 'every log-probability kernel at the BASELINE config shapes'),
+    (rn('host_path.jsonl'), '`python benchmarks/host_path.py`', 'PCIe-inclusive `bisip_logprob` rate; `bisip_forward_dev` store rate'),
+    (rn('sampler_bench.jsonl, sampler_kernel_stats.csv'), '`python benchmarks/sampler_bench.py`', 'end-to-end `fit()` iterations/s per sampler / stream mode'),
+    (rn('cfg4_*.json'), '`python benchmarks/cfg4_sampler.py --steps 200 --chain device [--fused] [--loop rccl|rccl-own|python]`', 'BASELINE config 4 on one GPU: fused vs the sharded half-step driven from C over RCCL vs from Python'),
+    (rn('cfg5_*.json, cfg5_kernel_stats.csv'), '`python benchmarks/cfg5_batch.py --chain device --steps 500 --thin-by 40 [--no-persistent]`', "BASELINE config 5, one GPU's share (512 spectra x 256 walkers)"),
+    (rn('bench_2ranks_one_device*.json'), '`python bench.py --gpus 2 --backend gloo --same-device --walkers 1048576 --steps 4`', 'the self-launched 2-rank run on one GPU (gloo): result line and the sharded-sampler extra (state identical on both ranks = single-GPU chain)'),
+    (rn('ingest.json'), '`python benchmarks/ingest.py` (host only)', 'survey ingest: the C parser + batched arithmetic against np.loadtxt file after file, same bits'),
+    (rn('batch_models.jsonl, batch_models_kernel_stats.csv'), '`python benchmarks/batch_models.py` (and `--only Polynomial` under `rocprofv3 --kernel-trace --stats`)', 'the batch-of-spectra sampler for every model at the cfg5 shape; the trace shows the stream draw next to the sampler kernel'),
+    (rn('survey.jsonl'), '`python benchmarks/survey.py [--model PeltonColeCole]`', 'a 4096-spectrum survey end to end: files to posterior summaries and model bands'),
+    (rn('batch_setup.jsonl'), '`python benchmarks/batch_setup.py`', 'what surrounds a survey run: batch context creation (host precompute on threads), a short fit, the summaries'),
+    (rn('soak.json'), '`python benchmarks/soak.py`', 'twenty 100,000-iteration fits and twenty 10,000-iteration batch fits in one process: device memory constant, posterior means within 0.02 sigma of each other, identical summaries for identical seeds'),
+    (rn('fuzz_*_summary.jsonl'), '`python benchmarks/fuzz_parity.py --cases 3000 --seed S` (S = 41..44, 47, 48; 4000 at S = 49..51; 1500 cases at S = 45, 46 with `--widen 1.5`, `--widen 3`; S = 52..57 -- 2000, 3000, 1500 with `--widen 1.5`, 3000, 3000, 1500 with `--widen 3`, 8000 each at S = 58, 59, 10000 each at S = 60, 61, 6000 and 2000 with `--widen 1.5` at S = 62, 63 (blocks of eight) -- with the ColeCole / Shin frequencies on exact grids, rounded grids and off any grid by thirds), `fuzz_sampler.py --cases 1500 --seed 2` (and 5, 6; 3000 at 8; 10, 2000 at 12, 4000 at 14, 2000 / 2500 / 6000 at 17, 19, 21 with the three kinds of frequencies), `fuzz_batch.py --cases 500 --seed 1` (and 4, 7; 1000 at 9; 600 each at 11, 13 and 1200 at 15 with the three kinds mixed inside a batch; 1000 at 16, 600 / 800 / 2000 at 18, 20, 22 with a reduced tier per spectrum)', 'randomised campaigns of this round (earlier rounds: `r02_fuzz_*`, 41,000 problems): violations, worst errors, which kernel AUTO ran'),
+    (rn('fuzz_valley_summary.jsonl'), '`python benchmarks/fuzz_parity.py --cases 1500 --seed S --valley` (S = 301..303; 3000 cases each at S = 304..306, 4000 at S = 307..309, 6000 at S = 310; all re-run under the bisecting estimate)', 'half of the checked PolynomialDecomposition rows along the valley of chi^2 / on the shell logp = 0: distances of every formulation AND of the reference from the exact value'),
+    (rn('valley_rows.jsonl, valley_rows_before.jsonl'), '`python benchmarks/valley_rows.py`', 'the kernel AUTO picks, measured on 3000 valley rows per scale (1 ... 1000 sigma) of 216 designs of degree 5-10 (designs above 1e-11 are listed): with this round\'s estimate, and -- `_before` -- with round 2\'s, against plain long double'),
+    (rn('micro_collapsed_r3.txt'), '`benchmarks/micro/collapsed_r3`', 'PDCollapsed: the shipped kernel against LDS-staged records, 4 rows per lane, single-wave workgroups and persistent waves, each with the engine clock it ran at and cycles per VALU instruction'),
+    (rn('micro_exp2_variants.txt'), '`benchmarks/micro/exp2_variants`', 'a table-driven exp2 (16 / 32 entries in LDS) against the shipped degree-11 polynomial: cycles per exp2 per SIMD, clock, worst ulp -- not adopted'),
+    (rn('micro_fit_speed_by_tier.txt'), '`python benchmarks/micro/fit_speed_by_tier.py`', 'fit() iterations/s on the plain and on the compensated reduced kernel (32 / 256 / 4096 walkers), with fit()\'s own measurement of the kernel'),
+    (rn('micro_rcp_accuracy.txt'), '`benchmarks/micro/rcp_accuracy` (hipcc from `rcp_accuracy.hip`)', '`v_rcp_f64` is good to 2^-24.4 on gfx950; one Newton step leaves 20 ulp, two 1.00 ulp, ONE cubic step `r(1 + e + e^2)` 1.00 ulp with one instruction less and a shorter chain: what `rcp_nr` does'),
+    (rn('micro_grid_vs_direct.txt'), '`python benchmarks/micro/grid_vs_direct.py`', 'ColeCole (1-3 modes) and Shin bulk launches on geometric frequency grids (exponentials stepped by multiplication in blocks of eight: 1.38-1.65x) against one exponential per frequency (`BISIP_NO_GRID=1`), with the largest difference between the two; rounded grid and bundled field spectrum as controls (no grid: the same loop twice)'),
+    (rn('micro_grid_small_ensembles.txt'), '`python benchmarks/micro/grid_small_ensembles.py`', '`fit()` of one spectrum with 32-1024 walkers and emcee-sized calls, stepped against direct: 1.08-1.31x on an exact grid (lanes that share a walker take whole half-blocks), 1.0 on the bundled spectrum (no grid)'),
+    (rn('micro_grid_small_ensembles_before.txt'), 'the same script on two designs that were taken out', 'one frequency per lane and round on a grid: 0.92-1.0x; a series-corrected tier for grids rounded in data files: 0.71-0.94x on the bundled spectrum (1.09-1.16x in bulk launches) -- why field data keeps the direct loop'),
+    (rn('micro_persistent_comp_by_degree.txt'), '`python benchmarks/micro/persistent_comp_by_degree.py`, `batch_comp_by_degree.py`', 'the compensated kernel in the persistent sampler against one launch per half-step, by degree, with its triangle in scalar registers (single spectrum) and its low words staged in LDS: single ensembles -- persistent wins at every degree up to 512 walkers (1.6-2.3x at 32 walkers); 512 x 256 batches -- persistent wins up to degree 8, ties at 9; the automatic rules follow'),
+    (rn('micro_small_call_latency.jsonl'), '`python benchmarks/micro/small_call_latency.py`', 'one emcee-sized log-probability call with host buffers, every model, 16 ... 4096 rows'),
+    (rn('micro_issue_latency.txt'), '`benchmarks/micro/issue_latency`', 'cycles per fp64 FMA for 1/2/4/8 independent chains at 1, 2, 4 waves per SIMD; placement of 1-, 2-, 4-, 8-, 16-wave workgroups'),
+    (rn('micro_row_latency.txt'), '`benchmarks/micro/row_latency`', 'cycles of one log-probability row at one wave per SIMD, records from the scalar cache vs staged in LDS'),
+    (rn('micro_half_step_phases.txt'), '`benchmarks/micro/half_step_phases`', 'phases of the cfg5 half-step launch by s_memtime'),
+    (rn('micro_cfg5_pmc.txt'), '`bash benchmarks/micro/cfg5_pmc.sh`', 'SQ counters of the cfg5 sampler kernel (VALU busy vs waiting)'),
+    (rn('micro_batch_pd_pmc.txt'), '`bash benchmarks/micro/batch_pd_pmc.sh`', 'SQ counters of the persistent kernel on a PolynomialDecomposition batch, per wave (divide by the half-steps of a launch)'),
+    (rn('micro_batch_logprob_rate.txt'), '`python benchmarks/micro/batch_logprob_rate.py`', 'bulk log-probability of a 512-spectrum batch, every model: the single-spectrum kernels\' rates'),
+    (rn('micro_select_vs_sort.txt'), '`python benchmarks/micro/select_vs_sort.py`', 'percentiles of 131,072 columns by radix selection and by the segmented sort: time, and that the doubles are the same'),
+    (rn('micro_model_percentile_single.txt'), '`python benchmarks/micro/model_percentile_single.py`', 'get_model_percentile of one model over a 160,000-row chain: the device call against forward + np.percentile'),
+    (rn('micro_forward_rows_variants.txt'), '`benchmarks/micro/forward_rows_variants`', 'output path of the batched forward kernels (whole rows at N = 20, 16-frequency tiles at N = 32 / 64)'),
+    (rn('micro_persistent_crossover.txt'), '`python benchmarks/micro/persistent_crossover.py`', 'persistent kernel vs launch per half-step by ensemble size and model: the automatic rule'),
+    (rn('micro_grid_barrier.txt'), '`benchmarks/micro/grid_barrier`', 'cost of a device-wide barrier (with and without a row exchange) for 64 / 128 / 256 workgroups'),
+    (rn('micro_post_run_stall.txt'), '`python benchmarks/micro/post_run_stall.py kernel`, `upload_cost.py plain`', 'the sporadic 20-30 ms delay of the first device work after a synchronisation early in a process'),
 ]
 
 

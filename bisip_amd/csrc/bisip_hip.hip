@@ -579,7 +579,7 @@ static int build_context(bisip_ctx **out, int device, int model_id, int E, int N
     // per-spectrum operands, blocks of spectra on host threads (each writes its own slots).  The
     // kernel sums K, G depend on the frequencies only: a block reuses them while consecutive
     // spectra share their frequency list, as the spectra of a survey usually do.
-    std::atomic<int> off_grid{0};
+    std::atomic<int> on_grid{0};
     parallel_blocks(E, 8, [&](int64_t e_lo, int64_t e_hi) {
         PolyDecompOperands o;
         const double *w_of_o = nullptr;
@@ -596,7 +596,7 @@ static int build_context(bisip_ctx **out, int device, int model_id, int E, int N
             }
             if (model_id != BISIP_MODEL_POLYDECOMP) {
                 double dlnw = 0.0;
-                if (!grid_step(N, we, lnw.data(), &dlnw)) off_grid.store(1);
+                if (grid_step(N, we, lnw.data(), &dlnw)) on_grid.store(1);
                 for (int j = 0; j < N; ++j) base[(size_t)j * rec + 7] = dlnw;
             }
             if (model_id != BISIP_MODEL_POLYDECOMP) continue;
@@ -642,8 +642,10 @@ static int build_context(bisip_ctx **out, int device, int model_id, int E, int N
             }
         }
     });
-    // a batch runs ONE loop: the stepped one only if every spectrum is on a grid (each on its own)
-    c->grid_ok = model_id != BISIP_MODEL_POLYDECOMP && off_grid.load() == 0 && std::getenv("BISIP_NO_GRID") == nullptr;
+    // the stepped loop is chosen per spectrum (rec[7] = its step, 0 off any grid): the flag says that some
+    // spectrum of the context is on a grid.  (BOUNDS_FAST stays a property of the context: the box against the
+    // frequency range of ALL its spectra.)
+    c->grid_ok = model_id != BISIP_MODEL_POLYDECOMP && on_grid.load() != 0 && std::getenv("BISIP_NO_GRID") == nullptr;
     c->bounds.flags = bound_flags(c);
     if (!fb.empty() && P < 8) rc = upload(&c->d_cb_faithful, fb);
     c->lconst = lconsts[0];

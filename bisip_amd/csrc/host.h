@@ -49,7 +49,7 @@ struct bisip_ctx {
     double c_exp = 1.0, lconst = 0.0;
     bisip::Bounds bounds{};
     double lnw_min = 0.0, lnw_max = 0.0;   // over every frequency of every spectrum (bound_flags)
-    bool grid_ok = false;                  // every spectrum's frequencies on a geometric grid (grid_step; BOUNDS_GRID)
+    bool grid_ok = false;                  // some spectrum's frequencies lie on a geometric grid (grid_step; BOUNDS_GRID; the loop is chosen per spectrum)
     int E = 1;                      // spectra in the context (batch of spectra: E > 1)
     double *d_cb = nullptr;        // records for k_forward (and k_logprob of CC/Dias/Shin): (E, N, REC)
     double *d_cb_lp = nullptr;     // PolynomialDecomposition: 1/sigma-weighted log-prob records (E, N, REC)

@@ -38,9 +38,9 @@ struct Bounds {
     int flags = 0;
 };
 constexpr int BOUNDS_FAST = 1;
-// BOUNDS_GRID (only together with BOUNDS_FAST): the frequencies of every spectrum of the context lie on a
+// BOUNDS_GRID (only together with BOUNDS_FAST): the frequencies of at least one spectrum of the context lie on a
 // geometric grid, ln w_{8k+q} = ln w_{8k} + q * dlnw to 4e-15 (grid_step in host_precompute.cpp; rec[7] of
-// every record holds dlnw).  The exponentials of the per-frequency models are then taken once per block of
+// every record of a spectrum holds ITS dlnw, 0 for a spectrum on no grid: logprob_row looks there).  The exponentials of the per-frequency models are then taken once per block of
 // eight frequencies and stepped by multiplication (GridSteps below).
 constexpr int BOUNDS_GRID = 2;
 constexpr int GRID_MAX_TERMS = 3;     // ColeCole with up to three modes, Shin (two elements)
@@ -1182,7 +1182,9 @@ __device__ __forceinline__ double logprob_row(const double (&th)[M::NDIM], const
         // never sets the bit for those)
         if constexpr (M::HAS_GRID) {
             if constexpr (M::NEXP <= GRID_MAX_TERMS) {
-                if (b.flags & BOUNDS_GRID) {
+                // per SPECTRUM: rec[7] holds the spectrum's own step, 0 when its frequencies are on no grid -- in a
+                // batch every spectrum runs the loop a context of its own would run
+                if ((b.flags & BOUNDS_GRID) && o.cb[7] != 0.0) {
                     logprob_sums_grid<M, L, LDSREC>(s, o, g, acc0, acc1);
                     return fma(-0.5, acc0 + acc1, o.lconst);
                 }

@@ -343,7 +343,8 @@ int bisip_numpy_stretch_stream(uint32_t *mt_key, int32_t *mt_pos, int64_t W, dou
                                double *u);
 
 /* Host, after the fact: how far are log-probabilities that a QR-reduced kernel produced from the
- * reduced form evaluated in long double from the unrounded operands?  theta (W, ndim) and logp (W,)
+ * reduced form evaluated from the unrounded operands (in long double; in binary128 for a spectrum on the
+ * compensated tier, whose operands come from a QR in binary128)?  theta (W, ndim) and logp (W,)
  * are host arrays -- typically a sampler's final ensemble and its log-probabilities (batch context:
  * the (E*Wp, ndim) layout of bisip_logprob).  *worst_rel = max |logp - reference| / max(1, |reference|)
  * over the rows inside the prior.  BISIP_VARIANT_AUTO picks a formulation from an ESTIMATE made on
@@ -359,7 +360,14 @@ int bisip_ctx_reduced_check(bisip_ctx *ctx, const double *theta, int64_t W, cons
  * the guard on (default) / off, anything else leaves it; outputs (each may be NULL): checks made so far,
  * the worst relative error any of them saw, how many times the context changed formulation.
  * The device-pointer entry bisip_logprob_dev never synchronises and is not guarded: its callers hold
- * the rows and can call bisip_ctx_reduced_check (the device sampler's fit() does). */
+ * the rows and can call bisip_ctx_reduced_check (the device sampler's fit() does).
+ * The guard's findings are CONTEXT STATE: an escalation is remembered by the context, and every later launch on
+ * it -- bisip_logprob_dev and the stretch-move entries included -- runs the formulation the guard moved to.  A
+ * context that only ever sees device-pointer calls keeps the formulation its estimate chose; so a host-loop
+ * sampler (guarded) and a device sampler on two contexts of the same spectrum may, after an escalation, run
+ * different kernels (both within the tolerance the guard enforces; the chains then differ in the last bits).
+ * bisip_logprob updates that state and the context's workspace: like every entry that takes a context it is
+ * not re-entrant for ONE context (contexts are not shared across threads without locking). */
 int bisip_ctx_reduced_guard(bisip_ctx *ctx, int enable, int64_t *n_checks, double *worst_rel, int *escalations);
 
 /* Host: read n_files 5-column spectrum files (freq, amp, pha, amp_err, pha_err; comma separated,

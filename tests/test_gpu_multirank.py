@@ -4,8 +4,9 @@ RCCL has, on this pool, only ever seen one rank (the pool hands out one GPU per 
 on one device): the tests that need two GPUs are here and SKIP themselves -- decided from the KFD topology in
 sysfs, before anything touches a device -- so that they run the day a box has two.  What a one-GPU box can run
 runs: the same worker with every rank on cuda:0 over gloo (the Python half-step loop, exchange through host
-memory, the real kernels), and `bench.py` with five ranks on one device (with the test runner itself that is the
-six processes the pool allows on a card; eight ranks are rehearsed on the CPU in tests/test_dist.py).
+memory, the real kernels), and `bench.py` with four ranks on one device (with the test runner and the launcher --
+torch.distributed.run opens the device too -- that is the six processes the pool allows on a card; eight ranks
+are rehearsed on the CPU in tests/test_dist.py).
 
 What the sharded sampler replaces: fit(pool=...) -> emcee.EnsembleSampler(pool=pool),
 /root/reference/src/bisip/models.py:84,91-94,115."""
@@ -92,22 +93,22 @@ def test_three_ranks_on_one_device_sharded_chains_equal_the_fused_chain(tmp_path
     _check(_run_worker(3, tmp_path, '--backend', 'gloo', '--same-device'), 3, ['python'])
 
 
-def test_bench_five_ranks_on_one_device():
-    """`bench.py --gpus 5 --backend gloo --same-device`: the whole multi-rank control flow of the scaling run
+def test_bench_four_ranks_on_one_device():
+    """`bench.py --gpus 4 --backend gloo --same-device`: the whole multi-rank control flow of the scaling run
     (self-launch, rendezvous, barriers, the all-reduced timing, a parity check per rank, the extras in a second
-    group of ranks) with the real kernels and more than two ranks -- five, because the pool allows six
-    processes on a card and this test runner is one of them."""
-    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '5', '--backend', 'gloo',
+    group of ranks) with the real kernels and more than two ranks -- four, because the pool allows six
+    processes on a card and this test runner and the launcher are two of them (five ranks: the run is killed)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '4', '--backend', 'gloo',
                         '--same-device', '--walkers', str(1 << 20), '--steps', '4', '--warmup', '1',
                         '--prime-seconds', '0.05'], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1
     rec = json.loads(lines[0])
-    assert rec['n_gpus'] == 5 and rec['ranks_seen'] == 5 and rec['scaling'] == 'weak'
-    assert rec['config']['global_walkers'] == 5 << 20 and len(rec['roofline']['per_rank_kernel_ms']) == 5
-    assert rec['parity']['ranks_checked'] == 5 and rec['parity']['neg_inf_rows_match'] is True
+    assert rec['n_gpus'] == 4 and rec['ranks_seen'] == 4 and rec['scaling'] == 'weak'
+    assert rec['config']['global_walkers'] == 4 << 20 and len(rec['roofline']['per_rank_kernel_ms']) == 4
+    assert rec['parity']['ranks_checked'] == 4 and rec['parity']['neg_inf_rows_match'] is True
     assert rec['parity']['max_rel_err_vs_oracle'] <= 1e-10
     cfg4 = [json.loads(ln)['sampler_cfg4'] for ln in r.stderr.splitlines() if ln.startswith('{"sampler_cfg4"')]
-    assert len(cfg4) == 1 and cfg4[0]['n_gpus'] == 5 and cfg4[0]['sharded_loop'] == 'python', r.stderr[-3000:]
+    assert len(cfg4) == 1 and cfg4[0]['n_gpus'] == 4 and cfg4[0]['sharded_loop'] == 'python', r.stderr[-3000:]
     assert cfg4[0]['state_identical_on_every_rank'] is True and cfg4[0]['equals_single_gpu_fused_chain'] is True

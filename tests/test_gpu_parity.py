@@ -1313,7 +1313,19 @@ def test_grid_loop_needs_the_grid_and_the_default_box():
     tables = [synthetic_columns(32, i) for i in range(3)]
     batch = bisip_amd.SpectraBatch('PeltonColeCole', tables, nwalkers=32, nsteps=2, n_modes=2)
     assert batch.ctx.loop_flags == 3
+    # a batch that mixes spectra on a grid with one that is not: the loop is chosen per spectrum (its records
+    # carry its own step, 0 off any grid), so every spectrum gets the bits of a context of its own -- for
+    # whole-wave ensembles (64 rows per spectrum) and for ensembles that share waves (40 rows)
     tables[1] = tables[1].copy()
     tables[1][5, 0] *= 1.0 + 1e-9
     batch = bisip_amd.SpectraBatch('PeltonColeCole', tables, nwalkers=32, nsteps=2, n_modes=2)
-    assert batch.ctx.loop_flags == 1
+    assert batch.ctx.loop_flags == 3
+    for rows in (64, 40):
+        th = rng.uniform(bounds[0], bounds[1], (3, rows, 7))
+        got = batch.log_prob(th)
+        for e in range(3):
+            one = bisip_amd.SpectraBatch('PeltonColeCole', [tables[e]], nwalkers=32, nsteps=2, n_modes=2)
+            assert one.ctx.loop_flags == (1 if e == 1 else 3)
+            assert np.array_equal(one.log_prob(th[e:e + 1])[0], got[e]), (rows, e)
+            one.close()
+    batch.close()
