@@ -79,7 +79,7 @@ if [ "$what" = sampler ] || [ "$what" = all ]; then
 fi
 if [ "$what" = micro ] || [ "$what" = all ]; then
   echo "== micro-benchmarks" | tee -a "$out/progress.log"
-  for m in issue_latency row_latency half_step_phases forward_rows_variants grid_barrier; do
+  for m in issue_latency row_latency half_step_phases forward_rows_variants grid_barrier xcd_barrier; do
     [ -x benchmarks/micro/$m ] && step $m timeout -k 5 200 benchmarks/micro/$m > "$out/micro_$m.txt" 2>&1
   done
   for m in collapsed_r3 exp2_variants rcp_accuracy; do

@@ -38,6 +38,16 @@ def rn(suffix):
 ROUND = ROUNDS[0]
 
 
+def all_rounds(suffix):
+    """(round, record) of every line of profiles/<round>_<suffix>, oldest round first: campaigns add up over the
+    rounds (a later round re-runs a seed only where a kernel it exercises changed)."""
+    for r in reversed(ROUNDS):
+        path = os.path.join(PROF, f'{r}_{suffix}')
+        if os.path.exists(path):
+            for rec in jlines(f'{r}_{suffix}'):
+                yield r, rec
+
+
 def jload(name):
     with open(os.path.join(PROF, name)) as fh:
         return json.load(fh)
@@ -215,25 +225,25 @@ def table_batch_setup():
 
 def table_fuzz():
     rows = []
-    for d in jlines(rn('fuzz_parity_summary.jsonl')):
+    for r, d in all_rounds('fuzz_parity_summary.jsonl'):
         a = d['auto_on_polydecomp']
-        rows.append([f"parity, seed {d['seed']}" + (f", prior boxes widened x{d['widen']}" if d.get('widen') else ''), d['cases'], d['violations'], f"{d['worst_logp_rel_err']:.1e}", f"{d['worst_Z_rel_err']:.1e}",
+        rows.append([r, f"parity, seed {d['seed']}" + (f", prior boxes widened x{d['widen']}" if d.get('widen') else ''), d['cases'], d['violations'], f"{d['worst_logp_rel_err']:.1e}", f"{d['worst_Z_rel_err']:.1e}",
                      f"{a['reduced']} + {a['reduced_comp']} + {a['collapsed']} of {a['problems']} (reduced + compensated + collapsed)"])
-    for name, f in (('sampler', rn('fuzz_sampler_summary.jsonl')), ('batch of spectra', rn('fuzz_batch_summary.jsonl'))):
-        for d in jlines(f):
-            rows.append([f"{name}, seed {d['seed']}", d['cases'], d['failures'], '-', '-', '-'])
-    return md(rows, ['campaign', 'cases', 'violations', 'worst log-prob rel. err (tol 1e-10)', 'worst Z rel. err (tol 1e-12)',
+    for name, f in (('sampler', 'fuzz_sampler_summary.jsonl'), ('batch of spectra', 'fuzz_batch_summary.jsonl')):
+        for r, d in all_rounds(f):
+            rows.append([r, f"{name}, seed {d['seed']}", d['cases'], d['failures'], '-', '-', '-'])
+    return md(rows, ['round', 'campaign', 'cases', 'violations', 'worst log-prob rel. err (tol 1e-10)', 'worst Z rel. err (tol 1e-12)',
                      'AUTO on PolynomialDecomposition designs with 2N >= P+2'])
 
 
 def table_valley():
     rows = []
-    for d in jlines(rn('fuzz_valley_summary.jsonl')):
+    for r, d in all_rounds('fuzz_valley_summary.jsonl'):
         v, a = d['valley_rows'], d['auto_on_polydecomp']
-        rows.append([d['seed'], d['cases'], v['cases'], d['violations'], f"{v['worst_auto_vs_exact']:.1e}", f"{v['worst_comp_vs_exact']:.1e}",
+        rows.append([r, d['seed'], d['cases'], v['cases'], d['violations'], f"{v['worst_auto_vs_exact']:.1e}", f"{v['worst_comp_vs_exact']:.1e}",
                      f"{v['worst_reference_vs_exact']:.1e}", v['cases_where_reference_is_off'], f"{v['worst_per_frequency_vs_exact']:.1e}",
                      f"{a['reduced']} + {a['reduced_comp']} + {a['collapsed']}"])
-    return md(rows, ['seed', 'cases', 'PolynomialDecomposition cases with valley / shell rows', 'violations (more than 1e-10 from the reference AND from the exact value)',
+    return md(rows, ['round', 'seed', 'cases', 'PolynomialDecomposition cases with valley / shell rows', 'violations (more than 1e-10 from the reference AND from the exact value)',
                      'AUTO: worst distance from the exact value', 'compensated kernel: the same', "the REFERENCE's arithmetic (oracle): the same",
                      'cases where the reference is more than 1e-10 from the exact value', 'per-frequency forms (collapsed / faithful / wave): the same, not judged',
                      'AUTO ran plain + compensated + collapsed'])
@@ -250,7 +260,7 @@ def table_latency():
 
 def table_auto_by_degree():
     tot = {}
-    for d in jlines(rn('fuzz_parity_summary.jsonl')):
+    for _, d in all_rounds('fuzz_parity_summary.jsonl'):
         for deg, v in d['auto_on_polydecomp']['by_degree'].items():
             t = tot.setdefault(int(deg), dict(problems=0, reduced=0, reduced_comp=0, collapsed=0))
             for k in t:
@@ -286,8 +296,8 @@ FILES = [
     (rn('survey.jsonl'), '`python benchmarks/survey.py [--model PeltonColeCole]`', 'a 4096-spectrum survey end to end: files to posterior summaries and model bands'),
     (rn('batch_setup.jsonl'), '`python benchmarks/batch_setup.py`', 'what surrounds a survey run: batch context creation (host precompute on threads), a short fit, the summaries'),
     (rn('soak.json'), '`python benchmarks/soak.py`', 'twenty 100,000-iteration fits and twenty 10,000-iteration batch fits in one process: device memory constant, posterior means within 0.02 sigma of each other, identical summaries for identical seeds'),
-    (rn('fuzz_*_summary.jsonl'), '`python benchmarks/fuzz_parity.py --cases 3000 --seed S` (S = 41..44, 47, 48; 4000 at S = 49..51; 1500 cases at S = 45, 46 with `--widen 1.5`, `--widen 3`; S = 52..57 -- 2000, 3000, 1500 with `--widen 1.5`, 3000, 3000, 1500 with `--widen 3`, 8000 each at S = 58, 59, 10000 each at S = 60, 61, 6000 and 2000 with `--widen 1.5` at S = 62, 63 (blocks of eight) -- with the ColeCole / Shin frequencies on exact grids, rounded grids and off any grid by thirds), `fuzz_sampler.py --cases 1500 --seed 2` (and 5, 6; 3000 at 8; 10, 2000 at 12, 4000 at 14, 2000 / 2500 / 6000 at 17, 19, 21 with the three kinds of frequencies), `fuzz_batch.py --cases 500 --seed 1` (and 4, 7; 1000 at 9; 600 each at 11, 13 and 1200 at 15 with the three kinds mixed inside a batch; 1000 at 16, 600 / 800 / 2000 at 18, 20, 22 with a reduced tier per spectrum)', 'randomised campaigns of this round (earlier rounds: `r02_fuzz_*`, 41,000 problems): violations, worst errors, which kernel AUTO ran'),
-    (rn('fuzz_valley_summary.jsonl'), '`python benchmarks/fuzz_parity.py --cases 1500 --seed S --valley` (S = 301..303; 3000 cases each at S = 304..306, 4000 at S = 307..309, 6000 at S = 310; all re-run under the bisecting estimate)', 'half of the checked PolynomialDecomposition rows along the valley of chi^2 / on the shell logp = 0: distances of every formulation AND of the reference from the exact value'),
+    ('r03_fuzz_*_summary.jsonl, r04_fuzz_*_summary.jsonl', '`python benchmarks/fuzz_parity.py --cases N --seed S [--widen X] [--valley]`, `fuzz_sampler.py`, `fuzz_batch.py` (r03: parity seeds 41-63, valley 301-310, sampler 2-23, batch 1-24; r04, after Dias / Shin forward / the binary128 operands changed: parity 46 (`--widen 3`, the seed with round 3\'s one violation), 64, 65 (`--widen 1.5`), valley 311, sampler 25, batch 26; `benchmarks/collect_r04.sh`)', 'randomised campaigns (one line per seed in the tables below; earlier rounds: `r02_fuzz_*`, 41,000 problems): violations, worst errors, which kernel AUTO ran'),
+    ('r03_fuzz_valley_summary.jsonl, r04_fuzz_valley_summary.jsonl', '`python benchmarks/fuzz_parity.py --cases 1500 --seed S --valley` (S = 301..303; 3000 cases each at S = 304..306, 4000 at S = 307..309, 6000 at S = 310; r04: 3000 at S = 311 with the binary128 yardstick and operands)', 'half of the checked PolynomialDecomposition rows along the valley of chi^2 / on the shell logp = 0: distances of every formulation AND of the reference from the exact value'),
     (rn('valley_rows.jsonl, valley_rows_before.jsonl'), '`python benchmarks/valley_rows.py`', 'the kernel AUTO picks, measured on 3000 valley rows per scale (1 ... 1000 sigma) of 216 designs of degree 5-10 (designs above 1e-11 are listed): with this round\'s estimate, and -- `_before` -- with round 2\'s, against plain long double'),
     (rn('micro_collapsed_r3.txt'), '`benchmarks/micro/collapsed_r3`', 'PDCollapsed: the shipped kernel against LDS-staged records, 4 rows per lane, single-wave workgroups and persistent waves, each with the engine clock it ran at and cycles per VALU instruction'),
     (rn('micro_exp2_variants.txt'), '`benchmarks/micro/exp2_variants`', 'a table-driven exp2 (16 / 32 entries in LDS) against the shipped degree-11 polynomial: cycles per exp2 per SIMD, clock, worst ulp -- not adopted'),
@@ -309,6 +319,7 @@ FILES = [
     (rn('micro_forward_rows_variants.txt'), '`benchmarks/micro/forward_rows_variants`', 'output path of the batched forward kernels (whole rows at N = 20, 16-frequency tiles at N = 32 / 64)'),
     (rn('micro_persistent_crossover.txt'), '`python benchmarks/micro/persistent_crossover.py`', 'persistent kernel vs launch per half-step by ensemble size and model: the automatic rule'),
     (rn('micro_grid_barrier.txt'), '`benchmarks/micro/grid_barrier`', 'cost of a device-wide barrier (with and without a row exchange) for 64 / 128 / 256 workgroups'),
+    (rn('micro_xcd_barrier.txt'), '`benchmarks/micro/xcd_barrier`', 'round 4: a barrier among the workgroups of ONE XCD (0.7-0.9 us for 8-32 workgroups, no fences: the counter and the rows go through that XCD\'s L2 with sc1 loads; 0 stale rows) and what a stretch half-step\'s row exchange costs on top, naive (every lane writes and gathers 72-B rows) and laid out for it (one lane per walker, 64-B rows, 16-B accesses): 1.4 us at 2,048 walkers, 2.1 at 8,192, **6.1 at cfg4\'s 32,768** on one XCD, 5.2-5.9 spread over the chip with write-through rows -- no better than the 6.4 us kernel boundary it would replace: the persistent multi-workgroup sampler was not built (kill criterion of VERDICT r3 #3)'),
     (rn('micro_post_run_stall.txt'), '`python benchmarks/micro/post_run_stall.py kernel`, `upload_cost.py plain`', 'the sporadic 20-30 ms delay of the first device work after a synchronisation early in a process'),
 ]
 
