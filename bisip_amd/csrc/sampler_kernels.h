@@ -340,7 +340,9 @@ __device__ __forceinline__ void commit_row(const StretchArgs &a, int i, const do
         for (int k = 0; k < NDIM; ++k) a.chain_row[(long long)i * NDIM + k] = row[k];
     }
     if (a.logp_row) a.logp_row[i] = lp_row;
-    if (a.naccept && acc) a.naccept[i] += 1;
+    // a return-less atomic: `naccept[i] += 1` is a load the add and the store then wait for -- a third trip to
+    // memory at the tail of every half-step launch (one lane per walker touches i: no contention either way)
+    if (a.naccept && acc) atomicAdd(a.naccept + i, 1);
 }
 
 // single-rank half-step: evaluate every slot and update the state in place.
