@@ -219,6 +219,7 @@ static int update_tiers(bisip_ctx *c)
 // does spectrum e run the compensated tier under the context's present variant and history?
 static bool needs_comp(const bisip_ctx *c, size_t e)
 {
+    if (2 * c->N < c->P + 2 && c->variant == BISIP_VARIANT_AUTO) return false;   // no triangle: AUTO runs the per-frequency form
     if (c->variant == BISIP_VARIANT_REDUCED_COMP) return true;
     if (c->variant != BISIP_VARIANT_AUTO) return false;
     if (c->demoted[0] || c->mix_off) return true;
