@@ -206,6 +206,36 @@ def test_every_spectrum_of_a_batch_runs_the_tier_its_own_context_would(monkeypat
         assert np.array_equal(batch.ctx.logprob(theta.reshape(-1, 7)).reshape(E, Wp), got)
 
 
+def test_compensated_operands_follow_each_spectrum_s_own_frequency_list():
+    """The compensated tier's operands come from a QR in binary128 whose kernel sums are computed once per
+    DISTINCT frequency list of the spectra that need them (bisip_hip.hip: make_quad_operands).  A batch whose
+    spectra alternate between three lists -- all of degree 8, so every one needs the compensated kernel --
+    gives each spectrum the bits of a context of its own, and stays within 2e-11 of the yardstick."""
+    import bisip_amd
+    from bisip_amd import _hip
+    E = 9
+    tables = _tables(E, 24)
+    for e in range(E):
+        tables[e] = tables[e].copy()
+        tables[e][:, 0] *= (1.0, 1.013, 0.97)[e % 3]
+    batch = bisip_amd.SpectraBatch('PolynomialDecomposition', tables, nwalkers=64, nsteps=4, poly_deg=8, c_exp=0.5)
+    assert batch.ctx.variant == 'reduced_comp' and batch.ctx.reduced_tiers[1] >= E - 1
+    lo, hi = batch.param_bounds
+    rng = np.random.RandomState(3)
+    theta = rng.uniform(lo, hi, (E, 64, lo.size))
+    theta[:, :32, 1:] *= 1e-3
+    got = batch.log_prob(theta)
+    for e in range(E):
+        single = _hip.HipContext(0, batch.w[e], batch.zn[e], batch.zn_err[e], batch.param_bounds, poly_deg=8,
+                                 c_exp=batch.c_exp, taus=batch.taus, log_taus=batch.log_taus)
+        assert np.array_equal(single.logprob(theta[e]), got[e]), (e, single.variant)
+        exact = _hip.polydecomp_reduced_reference(batch.w[e], batch.zn[e], batch.zn_err[e], batch.taus, batch.log_taus,
+                                                  batch.c_exp, theta[e])
+        assert np.max(np.abs(got[e] - exact) / np.maximum(1.0, np.abs(exact))) <= 2e-11
+        single.close()
+    batch.close()
+
+
 def test_guard_closes_a_batch_mix_before_it_closes_a_tier(monkeypatch):
     """A batch whose spectra run different tiers and whose plain spectra are then measured > 2e-11 off on the
     caller's rows: bisip_logprob's guard first sends EVERY spectrum through the compensated kernel (one
