@@ -247,11 +247,14 @@ static void make_quad_operands(bisip_ctx *c, const std::vector<int64_t> &need)
         group[i] = g;
     }
     std::vector<std::shared_ptr<const QuadKernelSums>> ks(rep.size());
-    parallel_blocks((int64_t)rep.size(), 1, [&](int64_t lo, int64_t hi) {
-        for (int64_t k = lo; k < hi; ++k)
-            ks[(size_t)k] = polydecomp_kernel_sums_quad(N, &c->h_w[(size_t)rep[(size_t)k] * N], S, c->h_taus.data(), D,
-                                                        c->h_log_taus.data(), c->c_exp);
-    });
+    if (rep.size() == 1)       // one frequency list (a lone spectrum, a survey): its rows over the host threads
+        ks[0] = polydecomp_kernel_sums_quad(N, &c->h_w[(size_t)rep[0] * N], S, c->h_taus.data(), D, c->h_log_taus.data(), c->c_exp, true);
+    else
+        parallel_blocks((int64_t)rep.size(), 1, [&](int64_t lo, int64_t hi) {
+            for (int64_t k = lo; k < hi; ++k)
+                ks[(size_t)k] = polydecomp_kernel_sums_quad(N, &c->h_w[(size_t)rep[(size_t)k] * N], S, c->h_taus.data(), D,
+                                                            c->h_log_taus.data(), c->c_exp);
+        });
     parallel_blocks((int64_t)todo.size(), 1, [&](int64_t lo, int64_t hi) {
         for (int64_t i = lo; i < hi; ++i) {
             const size_t e = (size_t)todo[(size_t)i];
@@ -470,7 +473,7 @@ int bisip_polydecomp_reduced_estimates(int N, const double *w, const double *zn,
         ReducedProblem p;
         reduced_from_operands(o, loglike_const(2 * N, zn_err), p);
         if (2 * N >= n)     // a design with a triangle: the compensated tier's operands in binary128
-            reduced_make_quad(*polydecomp_kernel_sums_quad(N, w, desc->n_taus, desc->taus, D, desc->log_taus, desc->c_exp), zn, zn_err, p);
+            reduced_make_quad(*polydecomp_kernel_sums_quad(N, w, desc->n_taus, desc->taus, D, desc->log_taus, desc->c_exp, true), zn, zn_err, p);
         ReducedProbes probes;
         reduced_probes(p, lo, hi, probes);
         const double w_shell = reduced_shell_weight();
@@ -495,7 +498,7 @@ int bisip_polydecomp_reduced_reference(int N, const double *w, const double *zn,
         ReducedProblem p;
         p.n = D + 1;
         p.lconst = loglike_const(2 * N, zn_err);
-        reduced_make_quad(*polydecomp_kernel_sums_quad(N, w, desc->n_taus, desc->taus, D, desc->log_taus, desc->c_exp), zn, zn_err, p);
+        reduced_make_quad(*polydecomp_kernel_sums_quad(N, w, desc->n_taus, desc->taus, D, desc->log_taus, desc->c_exp, true), zn, zn_err, p);
         parallel_blocks(W, 256, [&](int64_t lo, int64_t hi) {
             for (int64_t i = lo; i < hi; ++i) logp[i] = reduced_logp_reference(p, theta + i * p.n);
         });

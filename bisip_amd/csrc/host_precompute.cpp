@@ -48,7 +48,7 @@ inline void x_sincos_half_pi(qd c, qd &sn, qd &cs)
 // argument is exactly pi/2.
 template <class T>
 void kernel_sums_T(int N, const double *w, int S, const double *taus, int D, const double *log_taus, double c_exp,
-                   std::vector<T> &Kr, std::vector<T> &Ki, std::vector<T> &Gr, std::vector<T> &Gi)
+                   std::vector<T> &Kr, std::vector<T> &Ki, std::vector<T> &Gr, std::vector<T> &Gi, bool threads = false)
 {
     Kr.assign((size_t)N * S, T(0));
     Ki.assign((size_t)N * S, T(0));
@@ -64,31 +64,37 @@ void kernel_sums_T(int N, const double *w, int S, const double *taus, int D, con
         for (int j = 0; j < N; ++j) wc[(size_t)j] = c_exp == 1.0 ? (T)w[j] : x_pow((T)w[j], (T)c_exp);
         for (int k = 0; k < S; ++k) tc[(size_t)k] = c_exp == 1.0 ? (T)taus[k] : x_pow((T)taus[k], (T)c_exp);
     }
-    for (int j = 0; j < N; ++j)
-        for (int k = 0; k < S; ++k) {
-            T x;
-            if constexpr (std::is_same<T, ld>::value) x = x_pow((T)w[j] * (T)taus[k], (T)c_exp);
-            else x = wc[(size_t)j] * tc[(size_t)k];
-            const T xr = x * ca, xi = x * sa;
-            const T dr = 1 + xr;
-            const T den = dr * dr + xi * xi;
-            // 1 - 1/(1+x) = x/(1+x) = x*conj(1+x)/|1+x|^2
-            Kr[(size_t)j * S + k] = (xr * dr + xi * xi) / den;
-            Ki[(size_t)j * S + k] = xi / den;
-        }
     Gr.assign((size_t)N * D, T(0));
     Gi.assign((size_t)N * D, T(0));
-    for (int j = 0; j < N; ++j)
-        for (int p = 0; p < D; ++p) {
-            T sr = 0, si = 0;
+    // every frequency's row of K and G on its own (binary128 arithmetic is software: the rows of one frequency
+    // list are spread over the host threads when the caller has nothing else running on them)
+    auto rows = [&](int64_t j_lo, int64_t j_hi) {
+        for (int64_t j = j_lo; j < j_hi; ++j) {
             for (int k = 0; k < S; ++k) {
-                const T L = (T)log_taus[(size_t)p * S + k];
-                sr += L * Kr[(size_t)j * S + k];
-                si += L * Ki[(size_t)j * S + k];
+                T x;
+                if constexpr (std::is_same<T, ld>::value) x = x_pow((T)w[j] * (T)taus[k], (T)c_exp);
+                else x = wc[(size_t)j] * tc[(size_t)k];
+                const T xr = x * ca, xi = x * sa;
+                const T dr = 1 + xr;
+                const T den = dr * dr + xi * xi;
+                // 1 - 1/(1+x) = x/(1+x) = x*conj(1+x)/|1+x|^2
+                Kr[(size_t)j * S + k] = (xr * dr + xi * xi) / den;
+                Ki[(size_t)j * S + k] = xi / den;
             }
-            Gr[(size_t)j * D + p] = sr;
-            Gi[(size_t)j * D + p] = si;
+            for (int p = 0; p < D; ++p) {
+                T sr = 0, si = 0;
+                for (int k = 0; k < S; ++k) {
+                    const T L = (T)log_taus[(size_t)p * S + k];
+                    sr += L * Kr[(size_t)j * S + k];
+                    si += L * Ki[(size_t)j * S + k];
+                }
+                Gr[(size_t)j * D + p] = sr;
+                Gi[(size_t)j * D + p] = si;
+            }
         }
+    };
+    if (threads) parallel_blocks(N, 2, rows);
+    else rows(0, N);
 }
 
 // Weighted design matrix of the linear model Z = R0 - sum_p (R0 a_p) G_p, rows = (real j..., imag j...), built
@@ -239,12 +245,12 @@ void reduced_from_operands(const PolyDecompOperands &o, double lconst, ReducedPr
 }
 
 std::shared_ptr<const QuadKernelSums> polydecomp_kernel_sums_quad(int N, const double *w, int S, const double *taus, int D,
-                                                                  const double *log_taus, double c_exp)
+                                                                  const double *log_taus, double c_exp, bool threads)
 {
     auto ks = std::make_shared<QuadKernelSums>();
     ks->N = N; ks->D = D;
     std::vector<qd> Kr, Ki;
-    kernel_sums_T<qd>(N, w, S, taus, D, log_taus, c_exp, Kr, Ki, ks->Gr, ks->Gi);
+    kernel_sums_T<qd>(N, w, S, taus, D, log_taus, c_exp, Kr, Ki, ks->Gr, ks->Gi, threads);
     return ks;
 }
 

@@ -67,8 +67,9 @@ struct ReducedProblem {
     bool has_quad() const { return (bool)quad; }
 };
 
+// threads: spread the frequencies' rows over the host threads (a caller that is not itself inside parallel_blocks)
 std::shared_ptr<const QuadKernelSums> polydecomp_kernel_sums_quad(int N, const double *w, int S, const double *taus, int D,
-                                                                  const double *log_taus, double c_exp);
+                                                                  const double *log_taus, double c_exp, bool threads = false);
 // fills p.Rc, p.Rc_lo, p.rest_c, p.quad (p.n must be set; zn, zn_err: the spectrum's (2N,) rows)
 void reduced_make_quad(const QuadKernelSums &ks, const double *zn, const double *zn_err, ReducedProblem &p);
 // a ReducedProblem's long-double part from operands computed by polydecomp_reduce
