@@ -296,7 +296,7 @@ FILES = [
     (rn('survey.jsonl'), '`python benchmarks/survey.py [--model PeltonColeCole]`', 'a 4096-spectrum survey end to end: files to posterior summaries and model bands'),
     (rn('batch_setup.jsonl'), '`python benchmarks/batch_setup.py`', 'what surrounds a survey run: batch context creation (host precompute on threads), a short fit, the summaries'),
     (rn('soak.json'), '`python benchmarks/soak.py`', 'twenty 100,000-iteration fits and twenty 10,000-iteration batch fits in one process: device memory constant, posterior means within 0.02 sigma of each other, identical summaries for identical seeds'),
-    ('r03_fuzz_*_summary.jsonl, r04_fuzz_*_summary.jsonl', '`python benchmarks/fuzz_parity.py --cases N --seed S [--widen X] [--valley]`, `fuzz_sampler.py`, `fuzz_batch.py` (r03: parity seeds 41-63, valley 301-310, sampler 2-23, batch 1-24; r04, after Dias / Shin forward / the binary128 operands changed: parity 46 (`--widen 3`, the seed with round 3\'s one violation), 64, 65 (`--widen 1.5`), valley 311, sampler 25, batch 26 (`benchmarks/collect_r04.sh`), and at the final sources parity 66, 67 (`--widen 1.5`), 68 (`--widen 3`), valley 312, sampler 27, batch 28 (`collect_r04_closing.sh`))', 'randomised campaigns (one line per seed in the tables below; earlier rounds: `r02_fuzz_*`, 41,000 problems): violations, worst errors, which kernel AUTO ran'),
+    ('r03_fuzz_*_summary.jsonl, r04_fuzz_*_summary.jsonl', '`python benchmarks/fuzz_parity.py --cases N --seed S [--widen X] [--valley]`, `fuzz_sampler.py`, `fuzz_batch.py` (r03: parity seeds 41-63, valley 301-310, sampler 2-23, batch 1-24; r04, all at the final kernel sources (`benchmarks/collect_r04_final.sh`): parity 46 (`--widen 3`, the seed with round 3\'s one violation), 64, 65 (`--widen 1.5`), 66, 67 (`--widen 1.5`), 68 (`--widen 3`), valley 311, 312, sampler 25, 27, batch 26, 28)', 'randomised campaigns (one line per seed in the tables below; earlier rounds: `r02_fuzz_*`, 41,000 problems): violations, worst errors, which kernel AUTO ran'),
     ('r03_fuzz_valley_summary.jsonl, r04_fuzz_valley_summary.jsonl', '`python benchmarks/fuzz_parity.py --cases 1500 --seed S --valley` (S = 301..303; 3000 cases each at S = 304..306, 4000 at S = 307..309, 6000 at S = 310; r04: 3000 at S = 311 with the binary128 yardstick and operands)', 'half of the checked PolynomialDecomposition rows along the valley of chi^2 / on the shell logp = 0: distances of every formulation AND of the reference from the exact value'),
     (rn('valley_rows.jsonl, valley_rows_before.jsonl'), '`python benchmarks/valley_rows.py`', 'the kernel AUTO picks, measured on 3000 valley rows per scale (1 ... 1000 sigma) of 216 designs of degree 5-10 (designs above 1e-11 are listed): with this round\'s estimate, and -- `_before` -- with round 2\'s, against plain long double'),
     (rn('micro_collapsed_r3.txt'), '`benchmarks/micro/collapsed_r3`', 'PDCollapsed: the shipped kernel against LDS-staged records, 4 rows per lane, single-wave workgroups and persistent waves, each with the engine clock it ran at and cycles per VALU instruction'),

@@ -439,17 +439,22 @@ struct ColeCole {
 #pragma unroll
             for (int k = 0; k < K; ++k) inv[k / D][k % D] = r[k];
         }
+        // Z = C + sum_i t_i (dr_i - i di_i) is accumulated first (modes in ascending order, the real part from
+        // C) and taken from the measured value last: y - Z.  With the measured value as the START of the chain
+        // the compiler moves it from its scalar registers into vector registers first (two v_mov_b32 per
+        // frequency and part for a v_fmac); as the operand of the final add it stays scalar.
+        double zr[F], zi[F];
 #pragma unroll
-        for (int f = 0; f < F; ++f) { rr[f] = rec[f][0] - s.C; ri[f] = rec[f][1]; }
-#pragma unroll
-        for (int i = 0; i < D; ++i) {          // per frequency: modes accumulate in ascending order
+        for (int i = 0; i < D; ++i) {
 #pragma unroll
             for (int f = 0; f < F; ++f) {
                 const double t = s.A[i] * inv[f][i];
-                rr[f] = fma(-t, dr[f][i], rr[f]);
-                ri[f] = fma(t, di[f][i], ri[f]);
+                zr[f] = fma(t, dr[f][i], i == 0 ? s.C : zr[f]);
+                zi[f] = i == 0 ? t * di[f][i] : fma(t, di[f][i], zi[f]);
             }
         }
+#pragma unroll
+        for (int f = 0; f < F; ++f) { rr[f] = rec[f][0] - zr[f]; ri[f] = rec[f][1] + zi[f]; }
     }
     template <bool FAST = false>
     __device__ static __forceinline__ void residual(const Setup &s, const double *__restrict__ rec,
@@ -553,8 +558,8 @@ struct Dias {
     {
         const Den d = den(s, rec[6]);
         const double t = d.n2 * (s.A * rcp_nr(d.D));
-        rr = fma(-t, d.X, rec[0] - s.C);
-        ri = fma(t, d.Y, rec[1]);
+        rr = rec[0] - fma(t, d.X, s.C);      // y - Z with Z = C + t (X - iY); the measured value last (see ColeCole)
+        ri = rec[1] + t * d.Y;
     }
     // two frequencies with their dependency chains interleaved; FAST: one reciprocal for the pair
     template <bool FAST = false>
@@ -581,8 +586,8 @@ struct Dias {
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
             const double t = d[f].n2 * Ainv[f];
-            rr[f] = fma(-t, d[f].X, rec[f][0] - s.C);
-            ri[f] = fma(t, d[f].Y, rec[f][1]);
+            rr[f] = rec[f][0] - fma(t, d[f].X, s.C);
+            ri[f] = rec[f][1] + t * d[f].Y;
         }
     }
     // Z = r0 (1-m) + r0 m n2 (X - iY)/(X^2 + Y^2)   (m = w, ln w, sqrt w); its own reciprocal: any theta may
@@ -674,15 +679,13 @@ struct Shin {
 #pragma unroll
             for (int k = 0; k < K; ++k) inv[k / 2][k % 2] = r[k];
         }
+        // real part: the measured value starts the chain (a scalar addend of the first fma); imaginary part: the
+        // model's sum first and the measured value in the final add -- as the start of ITS chain the compiler
+        // moves it into vector registers first (two v_mov_b32 per frequency; see ColeCole)
 #pragma unroll
-        for (int f = 0; f < F; ++f) { rr[f] = rec[f][0]; ri[f] = rec[f][1]; }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-            for (int f = 0; f < F; ++f) {
-                rr[f] = fma(-yr[f][i], inv[f][i], rr[f]);
-                ri[f] = fma(yi[f][i], inv[f][i], ri[f]);
-            }
+        for (int f = 0; f < F; ++f) {
+            rr[f] = fma(-yr[f][1], inv[f][1], fma(-yr[f][0], inv[f][0], rec[f][0]));
+            ri[f] = rec[f][1] + fma(yi[f][1], inv[f][1], yi[f][0] * inv[f][0]);
         }
     }
     template <bool FAST = false>
