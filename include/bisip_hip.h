@@ -388,13 +388,16 @@ void bisip_philox4x32(const uint32_t *counter, const uint32_t *key, uint32_t *ou
 int bisip_ctx_ndim(const bisip_ctx *ctx);
 int bisip_ctx_nfreq(const bisip_ctx *ctx);
 int bisip_ctx_device(const bisip_ctx *ctx);
-/* Which loop the per-frequency models (ColeCole, Shin) run for the current prior box and frequencies; bits:
- *   1  shared reciprocals, exponents unclamped: the box keeps every denominator product normal;
- *   2  (only with 1) geometric frequency grid: every spectrum's ln w_{8k+q} = ln w_{8k} + q*step to 4e-15
- *      (bisip_frequency_grid_step), so the exponentials are taken once per block of eight frequencies and
- *      stepped by multiplication.  The environment variable BISIP_NO_GRID, read when a context is created,
- *      switches bit 2 off (measurement aid).
- * 0 for the other models and for boxes widened past the limits. */
+/* Which loop the per-frequency models (ColeCole, Shin, Dias2000) run for the current prior box and frequencies; bits:
+ *   1  shared reciprocals, exponents unclamped: the box keeps every denominator product normal (ColeCole with
+ *      two or more modes and Shin: one reciprocal per group of a frequency's denominators; Dias2000: one per
+ *      pair of frequencies 2k, 2k+1);
+ *   2  (only with 1; ColeCole up to three modes, Shin) geometric frequency grid: SOME spectrum's
+ *      ln w_{8k+q} = ln w_{8k} + q*step to 4e-15 (bisip_frequency_grid_step), and every spectrum that is on
+ *      such a grid takes its exponentials once per block of eight frequencies and steps them by multiplication
+ *      (a batch decides per spectrum).  The environment variable BISIP_NO_GRID, read when a context is
+ *      created, switches bit 2 off (measurement aid).
+ * 0 for PolynomialDecomposition and for boxes widened past the limits. */
 int bisip_ctx_loop_flags(const bisip_ctx *ctx);
 /* Host-only: 1 and *step = the common step of ln w when w[0..N) is such a grid (N >= 8), else 0 and *step = 0. */
 int bisip_frequency_grid_step(int N, const double *w, double *step);
