@@ -186,6 +186,61 @@ __device__ __forceinline__ double rcp_nr(double x)
     return fma(r, fma(e, e, e), r);
 }
 
+// An FMA / product / sum whose LAST operand is wave-uniform and stays in scalar registers.  Left to itself
+// the compiler turns p = fma(p, t, CONSTANT) into two v_mov_b32 (the constant into vector registers) and a
+// v_fmac: three vector instructions per Horner step in straight-line code (inside loops it hoists the
+// constants into scalar registers by itself).  Same operation, same bits.
+__device__ __forceinline__ double fma_s(double a, double b, double c)
+{
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
+    return d;
+}
+__device__ __forceinline__ double mul_s(double a, double c)
+{
+    double d;
+    asm("v_mul_f64 %0, %1, %2" : "=v"(d) : "v"(a), "s"(c));
+    return d;
+}
+__device__ __forceinline__ double add_s(double a, double c)
+{
+    double d;
+    asm("v_add_f64 %0, %1, %2" : "=v"(d) : "v"(a), "s"(c));
+    return d;
+}
+
+// sin(c pi/2), cos(c pi/2) for c in [0, 1] -- the Cole-Cole exponent / the CPE exponent inside a prior box that
+// BOUNDS_FAST vouches for.  The general sincospi spends 85 instructions per call on range reduction, special
+// values and constants moved into vector registers; here x = c/2 lies in [0, 1/2], y = min(x, 1/2 - x) (exact)
+// in [0, 1/4], and
+//   sin(pi y) = pi y + y^3 S(y^2),   cos(pi y) = 1 + y^2 C(y^2),
+// S of degree 5 and C of degree 6 (Chebyshev fits of (sin(pi y)/y - pi)/y^2 and (cos(pi y) - 1)/y^2 on
+// y^2 in [0, 1/16], 50-digit arithmetic: truncation 4e-17 and 1e-19), 27 instructions.  Against long double
+// sin / cos on 2e7 arguments (dense near c = 0 and c = 1, where cos(c pi/2) -> 0 keeps its RELATIVE accuracy
+// because 1/2 - x is exact): 1.5 ulp at worst for both.
+__device__ __forceinline__ void sincos_unit(double c, double *sn, double *cs)
+{
+    const double x = 0.5 * c;
+    const bool upper = x > 0.25;
+    const double y = upper ? 0.5 - x : x;
+    const double t = y * y;
+    double ps = add_s(mul_s(t, 0x1.e4a9d9166f052p-12), -0x1.e3027dea82bd7p-8);
+    ps = fma_s(ps, t, 0x1.50783208843ebp-4);
+    ps = fma_s(ps, t, -0x1.32d2cce500387p-1);
+    ps = fma_s(ps, t, 0x1.466bc6775a476p+1);
+    ps = fma_s(ps, t, -0x1.4abbce625be52p+2);
+    double pc = add_s(mul_s(t, -0x1.b2f3eb054afcdp-14), 0x1.f9ce245cada0bp-10);
+    pc = fma_s(pc, t, -0x1.a6d1eef479be1p-6);
+    pc = fma_s(pc, t, 0x1.e1f5068688d5bp-3);
+    pc = fma_s(pc, t, -0x1.55d3c7e3cb241p+0);
+    pc = fma_s(pc, t, 0x1.03c1f081b5ac0p+2);
+    pc = fma_s(pc, t, -0x1.3bd3cc9be45dep+2);
+    const double s = fma(0x1.921fb54442d18p+1, y, (y * t) * ps);
+    const double k = fma(t, pc, 1.0);
+    *sn = upper ? k : s;
+    *cs = upper ? s : k;
+}
+
 // K independent values in lockstep: every Horner / Newton step is issued for all K before the
 // next step, so a wave has K independent dependency chains in flight.  One fp64 VALU op takes
 // ~8.3 cycles to its dependent successor but a SIMD can start one every ~4.5 cycles: with ONE
@@ -310,7 +365,7 @@ struct PDCollapsed {
         double a[P + 1];
         double b[P + 1];  // r0 * a_p
     };
-    __device__ static __forceinline__ Setup setup(const double (&th)[NDIM])
+    __device__ static __forceinline__ Setup setup(const double (&th)[NDIM], const bool = false)
     {
         Setup s;
         s.r0 = th[0];
@@ -370,7 +425,8 @@ struct ColeCole {
     static constexpr bool HAS_FAST = true;
     static constexpr bool HAS_GRID = true;
     static constexpr bool PAIRED = false;
-    __device__ static __forceinline__ Setup setup(const double (&th)[NDIM])
+    // unit (wave-uniform): every c of the row lies in [0, 1] (BOUNDS_FAST and the row inside the prior)
+    __device__ static __forceinline__ Setup setup(const double (&th)[NDIM], const bool unit = false)
     {
         Setup s;
         s.r0 = th[0];
@@ -380,7 +436,8 @@ struct ColeCole {
             s.m[i] = th[1 + i];
             s.lt[i] = th[1 + D + i];
             s.c[i] = th[1 + 2 * D + i];
-            sincospi(0.5 * s.c[i], &s.sn[i], &s.cs[i]);
+            if (unit) sincos_unit(s.c[i], &s.sn[i], &s.cs[i]);
+            else sincospi(0.5 * s.c[i], &s.sn[i], &s.cs[i]);
             s.A[i] = s.m[i] * th[0];
             s.c2[i] = s.c[i] * LOG2E;
             s.clt2[i] = s.c2[i] * s.lt[i];
@@ -510,7 +567,7 @@ struct Dias {
     // 1e-45 in absolute terms.  1e50 (not 1e100) so that the PRODUCT of two frequencies' X^2 + Y^2 stays
     // finite inside the reference's box (the shared reciprocal below; bound_flags in bisip_hip.hip checks it).
     static constexpr double TAUP_MAX = 1e50;
-    __device__ static __forceinline__ Setup setup(const double (&th)[NDIM])
+    __device__ static __forceinline__ Setup setup(const double (&th)[NDIM], const bool = false)
     {
         Setup s;
         s.r0 = th[0];
@@ -614,7 +671,8 @@ struct Shin {
     static constexpr bool HAS_FAST = true;
     static constexpr bool HAS_GRID = true;
     static constexpr bool PAIRED = false;
-    __device__ static __forceinline__ Setup setup(const double (&th)[NDIM])
+    // unit (wave-uniform): both n of the row lie in [0, 1] (BOUNDS_FAST and the row inside the prior)
+    __device__ static __forceinline__ Setup setup(const double (&th)[NDIM], const bool unit = false)
     {
         Setup s;
 #pragma unroll
@@ -628,7 +686,8 @@ struct Shin {
             s.invR[i] = ir;
             s.Q[i] = exp_finite(th[2 + i] > 700.0 ? 700.0 : th[2 + i]);     // finite (forward() only; NaN stays NaN)
             s.n[i] = th[4 + i];
-            sincospi(0.5 * s.n[i], &s.sn[i], &s.cs[i]);
+            if (unit) sincos_unit(s.n[i], &s.sn[i], &s.cs[i]);
+            else sincospi(0.5 * s.n[i], &s.sn[i], &s.cs[i]);
             s.n2[i] = s.n[i] * LOG2E;
             s.lq2[i] = th[2 + i] * LOG2E;
         }
@@ -1177,7 +1236,8 @@ __device__ __forceinline__ double logprob_row(const double (&th)[M::NDIM], const
 {
     static_assert(L == 1 || L == 2 || L == 4, "lanes per walker");
     if (!in_prior<M::NDIM>(th, b)) return -__builtin_inf();  // never touches the forward model
-    const typename M::Setup s = M::setup(th);
+    // (inside a box that BOUNDS_FAST vouches for, the per-walker constants take their short route as well: sincos_unit)
+    const typename M::Setup s = M::setup(th, M::HAS_FAST && (b.flags & BOUNDS_FAST) != 0);
     double acc0 = 0.0, acc1 = 0.0;
     if constexpr (M::HAS_FAST) {
         // (up to three exponentials per frequency: with four or five the steps' registers push the
@@ -1330,11 +1390,20 @@ __device__ __forceinline__ void two_diff(double a, double b, double &s, double &
 // matrix entry instead of 1, still independent of the number of frequencies.
 // RA: the operand struct -- ReducedArgs<P, COMP>, or, for COMP = false, any struct with R, bhat, e and rest
 // (a batch whose spectra run different tiers keeps one register copy of the larger layout: BatchReducedLP).
-template <int P, bool COMP = false, class RA = ReducedArgs<P, COMP>>
+// PRIOR_FIRST: decide the prior BEFORE the sums, so that its 4(P+2) scalar registers are free again when the
+// operands of the sums arrive (degree 5, compensated: 68 spilled scalars -> 0, 659 -> 521 vector instructions).
+// Only where the operands are kernel arguments: a batch fetches them per workgroup through the scalar path, and
+// a prior in front of those loads puts two memory latencies in series (measured 9.3e10 -> 5.7e10 evals/s).
+template <int P, bool COMP = false, class RA = ReducedArgs<P, COMP>, bool PRIOR_FIRST = false>
 __device__ __forceinline__ double logprob_row_reduced(const double (&th)[P + 2], const RA &r, double lconst,
                                                       const Bounds &b)
 {
     constexpr int n = P + 2;
+    int inside = 1;
+    if constexpr (PRIOR_FIRST) {
+        inside = in_prior<n>(th, b) ? 1 : 0;
+        asm volatile("" : "+v"(inside));       // keeps the comparisons here
+    }
     double chi2 = r.rest;
     if constexpr (!COMP) {
         double d[n];
@@ -1382,7 +1451,8 @@ __device__ __forceinline__ double logprob_row_reduced(const double (&th)[P + 2],
         }
     }
     const double lp = fma(-0.5, chi2, lconst);
-    return in_prior<n>(th, b) ? lp : -__builtin_inf();
+    if constexpr (PRIOR_FIRST) return inside ? lp : -__builtin_inf();
+    else return in_prior<n>(th, b) ? lp : -__builtin_inf();
 }
 
 template <int P, int BLK, bool VEC, bool COMP = false>
@@ -1399,7 +1469,7 @@ __global__ __launch_bounds__(BLK) void k_logprob_pd_reduced(const LaunchArgs a,
     double th[NDIM];
 #pragma unroll
     for (int q = 0; q < NDIM; ++q) th[q] = lds[threadIdx.x * NDIM + q];
-    a.out[row] = logprob_row_reduced<P, COMP>(th, r, a.lconst, a.b);
+    a.out[row] = logprob_row_reduced<P, COMP, ReducedArgs<P, COMP>, true>(th, r, a.lconst, a.b);
 }
 
 // ---------------------------------------------------------------------------------
