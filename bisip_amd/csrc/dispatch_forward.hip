@@ -1,10 +1,18 @@
 // dispatch_forward.hip -- batched forward() launches.
 #include "host.h"
+#include <type_traits>
 
 using namespace bisip;
 using namespace bisip::host;
 
 namespace {
+
+// PolynomialDecomposition's forward is 17 instructions per frequency: whole rows through LDS (k_forward_rows) beat
+// the 16-frequency tiles up to N = 32 (4.95 -> 5.3 TB/s of Z at N = 32).  The transcendental models keep the tiles
+// there: all of a row's arithmetic in front of all of its stores costs them more than the longer runs gain (4.9 ->
+// 4.1 TB/s, ColeCole<2>; 4.5 -> 3.8, Shin).
+template <class M> struct cheap_eval : std::false_type {};
+template <int P> struct cheap_eval<PDCollapsed<P>> : std::true_type {};
 
 // spectrum >= 0: the rows belong to `count` consecutive spectra of a batch context, starting with that one,
 // W / count rows each (bisip_forward_spectra_dev)
@@ -20,10 +28,10 @@ int launch_forward(const bisip_ctx *c, const double *theta, int64_t W, double *Z
     const unsigned grid = (unsigned)((W + 63) / 64);
     const int N = c->N;
     const bool wide = (N % 2 == 0) && ((uintptr_t)Z % 16) == 0;   // 16-byte store pieces
-    if (N % 16 != 0 && N <= 24) {
+    if ((N % 16 != 0 || cheap_eval<M>::value) && N <= 24) {
         if (wide) hipLaunchKernelGGL((k_forward_rows<M, 24, true>), dim3(grid), dim3(64), 0, st, a);
         else hipLaunchKernelGGL((k_forward_rows<M, 24, false>), dim3(grid), dim3(64), 0, st, a);
-    } else if (N % 16 != 0 && N <= 32) {
+    } else if ((N % 16 != 0 || cheap_eval<M>::value) && N <= 32) {
         if (wide) hipLaunchKernelGGL((k_forward_rows<M, 32, true>), dim3(grid), dim3(64), 0, st, a);
         else hipLaunchKernelGGL((k_forward_rows<M, 32, false>), dim3(grid), dim3(64), 0, st, a);
     } else if (N % 16 == 0 && wide) hipLaunchKernelGGL((k_forward_tiled16<M>), dim3(grid), dim3(64), 0, st, a);
