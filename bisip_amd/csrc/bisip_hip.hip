@@ -274,10 +274,13 @@ static int recenter_reduced(bisip_ctx *c)
     // as floats, an even number of them
     const size_t lo_floats = (tri + 1) & ~(size_t)1;
     const size_t red_doubles[2] = {tri + 3 * (size_t)n + 1, tri + 3 * (size_t)n + 1 + lo_floats / 2};
+    // a device image of a tier's operands: every tier of a batch; of a lone spectrum its compensated tier from
+    // degree 6 on, where the bulk kernel reads the operands from memory (dispatch_logprob.hip: launch_reduced)
+    auto has_image = [&](int tier) { return c->E > 1 || (tier == 1 && c->P >= REDUCED_COMP_MEMORY_OPERANDS_FROM); };
     for (int tier = 0; tier < 2; ++tier) {
         bisip_ctx::ReducedTier &T = c->red[tier];
         if (T.done.size() != E) { T.done.assign(E, 0); T.est.assign(E, 0.0); }
-        if (c->E > 1 && T.image.size() != red_doubles[tier] * E) T.image.assign(red_doubles[tier] * E, 0.0);
+        if (has_image(tier) && T.image.size() != red_doubles[tier] * E) T.image.assign(red_doubles[tier] * E, 0.0);
     }
     // one spectrum's entry of a tier: its image (batch) and, for spectrum 0, the kernarg copy
     auto store = [&](int tier, size_t e, const double *Rfull, const float *Rlo_full, double rest, const double *bh,
@@ -295,7 +298,7 @@ static int recenter_reduced(bisip_ctx *c)
             T.Rpacked = Rp; T.Rlo_packed = Rlo; T.rest = rest;
             T.bhat.assign(bh, bh + n); T.evec.assign(ev, ev + n); T.elo.assign(el, el + n);
         }
-        if (c->E > 1) {  // ReducedArgs<P, COMP> image: [Rlo |] R | bhat | e | elo | rest
+        if (has_image(tier)) {  // ReducedArgs<P, COMP> image: [Rlo |] R | bhat | e | elo | rest
             double *dst = &T.image[red_doubles[tier] * e];
             if (tier == 1) { std::memcpy(dst, Rlo.data(), lo_floats * sizeof(float)); dst += lo_floats / 2; }
             dst = std::copy(Rp.begin(), Rp.end(), dst);
@@ -365,11 +368,11 @@ static int recenter_reduced(bisip_ctx *c)
     }
     // a batch's compensated image needs an entry for EVERY spectrum the kernel may index: spectra on the plain
     // tier of a mixed launch read their plain operands (BatchArgs::red_plain) and leave theirs at zero
-    if (c->E > 1) {
+    {
         HIP_TRY(hipSetDevice(c->device));
         for (int tier = 0; tier < 2; ++tier) {
             bisip_ctx::ReducedTier &T = c->red[tier];
-            if (!changed[tier]) continue;
+            if (!changed[tier] || !has_image(tier) || T.image.empty()) continue;
             if (!T.d_red) HIP_TRY(hipMalloc(&T.d_red, T.image.size() * sizeof(double)));
             // set_bounds between launches: the copy is ordered after earlier work by the sync
             HIP_TRY(hipDeviceSynchronize());
@@ -655,7 +658,7 @@ static int build_context(bisip_ctx **out, int device, int model_id, int E, int N
     c->lconst = lconsts[0];
     if (rc == BISIP_OK) rc = upload(&c->d_cb, cb);
     if (rc == BISIP_OK && !cb_lp.empty()) rc = upload(&c->d_cb_lp, cb_lp);
-    if (rc == BISIP_OK && E > 1) rc = upload(&c->d_lconst, lconsts);
+    if (rc == BISIP_OK && (E > 1 || (model_id == BISIP_MODEL_POLYDECOMP && P >= REDUCED_COMP_MEMORY_OPERANDS_FROM))) rc = upload(&c->d_lconst, lconsts);
     if (rc == BISIP_OK) rc = recenter_reduced(c);
     if (rc == BISIP_OK) {
         hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);

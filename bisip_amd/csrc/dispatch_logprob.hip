@@ -55,10 +55,24 @@ int launch_collapsed(const bisip_ctx *c, const double *theta, int64_t W, double 
 template <int P, bool COMP>
 int launch_reduced(const bisip_ctx *c, const double *theta, int64_t W, double *out, hipStream_t st)
 {
+    const bool vec = ((uintptr_t)theta % 16) == 0;
+    if constexpr (COMP && P >= REDUCED_COMP_MEMORY_OPERANDS_FROM) {
+        // operands from memory (host.h: REDUCED_COMP_MEMORY_OPERANDS_FROM): the batch kernel, one spectrum
+        if (W >= SMALL_W && c->red[1].d_red && c->d_lconst) {
+            BatchArgs b = make_batch_args(c, theta, out, W);
+            b.Wp = (W + BLK_LARGE - 1) / BLK_LARGE * BLK_LARGE;    // every workgroup: spectrum 0
+            b.red = c->red[1].d_red;
+            b.tier = nullptr;
+            const unsigned grid = (unsigned)((W + BLK_LARGE - 1) / BLK_LARGE);
+            if (vec) hipLaunchKernelGGL((k_logprob_batch_reduced_stream<P, BLK_LARGE, true, true>), dim3(grid), dim3(BLK_LARGE), 0, st, b);
+            else hipLaunchKernelGGL((k_logprob_batch_reduced_stream<P, BLK_LARGE, false, true>), dim3(grid), dim3(BLK_LARGE), 0, st, b);
+            HIP_TRY(hipGetLastError());
+            return BISIP_OK;
+        }
+    }
     const LaunchArgs a = make_args(c, theta, out, W, nullptr);
     ReducedArgs<P, COMP> r;
     fill_reduced<P, COMP>(c, r);
-    const bool vec = ((uintptr_t)theta % 16) == 0;
     if (W < SMALL_W) {
         const unsigned grid = (unsigned)((W + BLK_SMALL - 1) / BLK_SMALL);
         if (vec) hipLaunchKernelGGL((k_logprob_pd_reduced<P, BLK_SMALL, true, COMP>), dim3(grid), dim3(BLK_SMALL), 0, st, a, r);

@@ -35,6 +35,12 @@ constexpr int BLK_LARGE = 256;
 constexpr int BLK_STREAM = 128;  // HBM-bound reduced kernel: 128-lane workgroups stream ~3 % faster
                                  // than 256 (interleaved A/B, benchmarks/micro/reduced_variants.hip)
 constexpr long long SMALL_W = 256LL * 256 * 2;  // below this, 64-lane workgroups
+// From this polynomial degree on, the bulk launch of a lone spectrum's COMPENSATED reduced kernel reads its operands
+// from memory through the scalar path, as a batch does, instead of taking them as kernel arguments: the triangle and
+// its low words (99 scalars at degree 6, 171 at degree 9) no longer fit the scalar registers, and where kernel
+// arguments are spilled into vector lanes (162 at degree 7), operands in memory are simply loaded again
+// (measured at 2^23 walkers: +15 % at degree 6, +13 % at 7, +22 % at 8-9, +20 % at 10; equal at degree 5).
+constexpr int REDUCED_COMP_MEMORY_OPERANDS_FROM = 6;
 constexpr double BISIP_REDUCED_ERR_MAX = 1e-12;  // AUTO keeps the QR-reduced form below this estimate
 
 #define PD_CASES(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10)
@@ -54,7 +60,7 @@ struct bisip_ctx {
     double *d_cb = nullptr;        // records for k_forward (and k_logprob of CC/Dias/Shin): (E, N, REC)
     double *d_cb_lp = nullptr;     // PolynomialDecomposition: 1/sigma-weighted log-prob records (E, N, REC)
     double *d_cb_faithful = nullptr;
-    double *d_lconst = nullptr;    // (E,)  batch only
+    double *d_lconst = nullptr;    // (E,)  batch; PolynomialDecomposition from degree 6 on
     long long cb_stride = 0;
     // QR-reduced form, two arithmetic tiers: [0] plain, [1] compensated (kernels.h:
     // logprob_row_reduced<P, COMP>); each has its own expansion point, and the compensated tier its own
@@ -66,8 +72,8 @@ struct bisip_ctx {
         double rest = 0.0;                      // spectrum 0
         double err = INFINITY;                  // worst estimated relative log-prob error over the spectra that RUN this tier; INFINITY: not estimated
         bool valid = false;                     // estimated for the current prior box (every spectrum that needs it)
-        void *d_red = nullptr;                  // (E,) ReducedArgs<P>  batch only
-        std::vector<double> image;              // batch only: host copy of d_red (entries are rewritten spectrum by spectrum)
+        void *d_red = nullptr;                  // (E,) ReducedArgs<P>: a batch's tiers; a lone spectrum's compensated tier from degree 6 on
+        std::vector<double> image;              // host copy of d_red (entries are rewritten spectrum by spectrum)
         std::vector<double> est;                // the estimate of every spectrum (tier 1: 0 where the spectrum does not run it)
         std::vector<unsigned char> done;        // per spectrum: estimated for the current box
     };

@@ -1391,18 +1391,22 @@ __device__ __forceinline__ void two_diff(double a, double b, double &s, double &
 // RA: the operand struct -- ReducedArgs<P, COMP>, or, for COMP = false, any struct with R, bhat, e and rest
 // (a batch whose spectra run different tiers keeps one register copy of the larger layout: BatchReducedLP).
 // PRIOR_FIRST: decide the prior BEFORE the sums, so that its 4(P+2) scalar registers are free again when the
-// operands of the sums arrive (degree 5, compensated: 68 spilled scalars -> 0, 659 -> 521 vector instructions).
-// Only where the operands are kernel arguments: a batch fetches them per workgroup through the scalar path, and
-// a prior in front of those loads puts two memory latencies in series (measured 9.3e10 -> 5.7e10 evals/s).
-template <int P, bool COMP = false, class RA = ReducedArgs<P, COMP>, bool PRIOR_FIRST = false>
+// operands of the sums arrive (degree 5, compensated, single spectrum: 68 spilled scalars -> 0, 659 -> 503 vector
+// instructions).  1: behind a volatile asm -- the single-spectrum kernels, whose operands are kernel arguments.
+// 2: behind a plain asm -- the batch kernels, whose operands come from memory through the scalar path: a volatile
+// asm counts as a store, everything loaded after it leaves the scalar path for the vector one (a first attempt:
+// 9.3e10 -> 5.7e10 evals/s), while the plain one, which the scheduler may move, still removes most of their spills
+// (degree 5, compensated: 144 -> 40; plain tier 30 -> 0).
+template <int P, bool COMP = false, class RA = ReducedArgs<P, COMP>, int PRIOR_FIRST = 0>
 __device__ __forceinline__ double logprob_row_reduced(const double (&th)[P + 2], const RA &r, double lconst,
                                                       const Bounds &b)
 {
     constexpr int n = P + 2;
     int inside = 1;
-    if constexpr (PRIOR_FIRST) {
+    if constexpr (PRIOR_FIRST != 0) {
         inside = in_prior<n>(th, b) ? 1 : 0;
-        asm volatile("" : "+v"(inside));       // keeps the comparisons here
+        if constexpr (PRIOR_FIRST == 1) asm volatile("" : "+v"(inside));
+        else asm("" : "+v"(inside));
     }
     double chi2 = r.rest;
     if constexpr (!COMP) {
@@ -1451,7 +1455,7 @@ __device__ __forceinline__ double logprob_row_reduced(const double (&th)[P + 2],
         }
     }
     const double lp = fma(-0.5, chi2, lconst);
-    if constexpr (PRIOR_FIRST) return inside ? lp : -__builtin_inf();
+    if constexpr (PRIOR_FIRST != 0) return inside ? lp : -__builtin_inf();
     else return in_prior<n>(th, b) ? lp : -__builtin_inf();
 }
 
@@ -1469,7 +1473,7 @@ __global__ __launch_bounds__(BLK) void k_logprob_pd_reduced(const LaunchArgs a,
     double th[NDIM];
 #pragma unroll
     for (int q = 0; q < NDIM; ++q) th[q] = lds[threadIdx.x * NDIM + q];
-    a.out[row] = logprob_row_reduced<P, COMP, ReducedArgs<P, COMP>, true>(th, r, a.lconst, a.b);
+    a.out[row] = logprob_row_reduced<P, COMP, ReducedArgs<P, COMP>, 1>(th, r, a.lconst, a.b);
 }
 
 // ---------------------------------------------------------------------------------
@@ -1682,12 +1686,12 @@ __global__ __launch_bounds__(64) void k_logprob_batch_reduced(const BatchArgs a)
     if constexpr (COMP) {
         if (a.tier && !a.tier[e]) {
             const ReducedArgs<P, false> *__restrict__ rp = reinterpret_cast<const ReducedArgs<P, false> *>(a.red_plain) + e;
-            a.out[row] = logprob_row_reduced<P, false>(th, *rp, a.lconst[e], a.b);
+            a.out[row] = logprob_row_reduced<P, false, ReducedArgs<P, false>, 2>(th, *rp, a.lconst[e], a.b);
             return;
         }
     }
     const ReducedArgs<P, COMP> *__restrict__ r = reinterpret_cast<const ReducedArgs<P, COMP> *>(a.red) + e;
-    a.out[row] = logprob_row_reduced<P, COMP>(th, *r, a.lconst[e], a.b);
+    a.out[row] = logprob_row_reduced<P, COMP, ReducedArgs<P, COMP>, 2>(th, *r, a.lconst[e], a.b);
 }
 
 // The same for big batches whose spectra hold a multiple of BLK walkers: the headline kernel's streaming
@@ -1707,15 +1711,15 @@ __global__ __launch_bounds__(BLK) void k_logprob_batch_reduced_stream(const Batc
 #pragma unroll
     for (int q = 0; q < NDIM; ++q) th[q] = lds[threadIdx.x * NDIM + q];
     const unsigned e = (unsigned)row0 / (unsigned)a.Wp;          // one spectrum per workgroup (Wp % BLK == 0)
+    const ReducedArgs<P, false> *__restrict__ rp = reinterpret_cast<const ReducedArgs<P, false> *>(a.red_plain) + e;
+    const ReducedArgs<P, COMP> *__restrict__ r = reinterpret_cast<const ReducedArgs<P, COMP> *>(a.red) + e;
     if constexpr (COMP) {
         if (a.tier && !a.tier[e]) {                              // uniform: the whole workgroup takes the plain tier
-            const ReducedArgs<P, false> *__restrict__ rp = reinterpret_cast<const ReducedArgs<P, false> *>(a.red_plain) + e;
-            a.out[row] = logprob_row_reduced<P, false>(th, *rp, a.lconst[e], a.b);
+            a.out[row] = logprob_row_reduced<P, false, ReducedArgs<P, false>, 2>(th, *rp, a.lconst[e], a.b);
             return;
         }
     }
-    const ReducedArgs<P, COMP> *__restrict__ r = reinterpret_cast<const ReducedArgs<P, COMP> *>(a.red) + e;
-    a.out[row] = logprob_row_reduced<P, COMP>(th, *r, a.lconst[e], a.b);
+    a.out[row] = logprob_row_reduced<P, COMP, ReducedArgs<P, COMP>, 2>(th, *r, a.lconst[e], a.b);
 }
 
 template <class M>

@@ -126,6 +126,48 @@ def test_valley_rows_against_the_reference_and_the_exact_value(path):
         ctx.close()
 
 
+@pytest.mark.parametrize('path', [p for p in valley_cases() if int(np.load(p)['poly_deg']) >= 6], ids=case_id)
+def test_compensated_bulk_launch_with_operands_from_memory(path):
+    """From degree 6 on, a bulk launch (>= 131072 rows) of a lone spectrum's compensated kernel reads its
+    operands from memory through the scalar path, as a batch does (host.h:
+    REDUCED_COMP_MEMORY_OPERANDS_FROM); below that size, and at lower degrees, they are kernel arguments.
+    A row's value must not depend on the route: the fixture's valley rows inside a bulk batch, the bulk
+    batch against itself in small launches, an 8-byte-aligned theta (the other staging path), and the
+    exact values of the fixture."""
+    import torch
+    g = np.load(path)
+    lo, hi = g['bounds']
+    rng = np.random.RandomState(int(g['poly_deg']))
+    W = 131072 + 257
+    theta = rng.uniform(lo, hi, (W, lo.size))
+    k = g['theta'].shape[0]
+    theta[1000:1000 + k] = g['theta']
+    ctx = make_ctx(g, 'PolynomialDecomposition', 'reduced_comp')
+    ctx.reduced_guard(False)
+    assert ctx.kernel_name == 'k_logprob_pd_reduced_comp'
+    bulk = ctx.logprob(theta)
+    pieces = np.concatenate([ctx.logprob(theta[i:i + 40000]) for i in range(0, W, 40000)])
+    assert np.array_equal(bulk, pieces)
+    exact = g['logp_exact']
+    assert np.max(np.abs(bulk[1000:1000 + k] - exact) / np.maximum(1.0, np.abs(exact))) <= 2e-11
+    dev = torch.from_numpy(np.concatenate([np.zeros((1, lo.size)), theta])).cuda()
+    view = dev.reshape(-1)[1:1 + W * lo.size]                # starts 8 bytes in: the scalar staging path
+    assert view.data_ptr() % 16 == 8
+    view.copy_(torch.from_numpy(theta.reshape(-1)))
+    out = torch.empty(W, dtype=torch.float64, device='cuda')
+    ctx.logprob_dev(view.data_ptr(), W, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), bulk)
+    # a new prior box: the device image follows the new expansion point
+    wide = np.array([lo - 0.05 * (hi - lo), hi + 0.05 * (hi - lo)])
+    ctx.set_bounds(wide)
+    bulk2 = ctx.logprob(theta)
+    pieces2 = np.concatenate([ctx.logprob(theta[i:i + 40000]) for i in range(0, W, 40000)])
+    assert np.array_equal(bulk2, pieces2)
+    assert np.max(np.abs(bulk2[1000:1000 + k] - exact) / np.maximum(1.0, np.abs(exact))) <= 2e-11
+    ctx.close()
+
+
 def _yardstick(g):
     from bisip_amd import _hip
     return _hip.polydecomp_reduced_reference(g['w'], g['zn'], g['zn_err'], g['taus'], g['log_taus'], float(g['c_exp']), g['theta'])
