@@ -1757,6 +1757,22 @@ __global__ __launch_bounds__(256) void k_forward_batch(const BatchArgs a)
 // arithmetic (measured: 2.9 -> see DESIGN.md TB/s).
 __device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
+// M::eval on a frequency record whose model part (doubles 4..REC) is read through the CONSTANT address space.
+// The records are never written while a kernel runs, but a kernel that stores Z between two tiles cannot prove
+// that its own stores leave them alone, and every record load after the first store leaves the scalar path for
+// the vector one: a tile's 16 x 12 doubles of PolynomialDecomposition operands sat in vector registers (246 of
+// them, two waves per SIMD; one from degree 6 on).  Loads from address space 4 are scalar whatever precedes them.
+template <class M>
+__device__ __forceinline__ void eval_const(const typename M::Setup &s, const double *rec, double &zr, double &zi)
+{
+    typedef const double __attribute__((address_space(4))) *const_ptr;
+    const const_ptr c = (const_ptr)(rec + 4);
+    double m[M::REC - 4];
+#pragma unroll
+    for (int q = 0; q < M::REC - 4; ++q) m[q] = c[q];
+    M::eval(s, m, zr, zi);
+}
+
 template <class M, bool VEC>
 __global__ __launch_bounds__(64) void k_forward_tiled(const LaunchArgs a)
 {
@@ -1819,7 +1835,7 @@ __global__ __launch_bounds__(64) void k_forward_tiled(const LaunchArgs a)
 #pragma unroll
             for (int jj = 0; jj < JC; ++jj) {
                 double zr = 0.0, zi = 0.0;
-                if (jj < jn) M::eval(s, rec + (long long)jj * M::REC + 4, zr, zi);
+                if (jj < jn) eval_const<M>(s, rec + (long long)jj * M::REC, zr, zi);
                 lds[lane * ROW + jj] = zr;
                 zim[jj] = zi;
             }
@@ -1874,7 +1890,7 @@ __global__ __launch_bounds__(64) void k_forward_tiled16(const LaunchArgs a)
 #pragma unroll
         for (int jj = 0; jj < JC; ++jj) {
             double zr, zi;
-            M::eval(s, rec + (long long)jj * M::REC + 4, zr, zi);
+            eval_const<M>(s, rec + (long long)jj * M::REC, zr, zi);
             lds[lane * ROW + jj] = zr;
             zim[jj] = zi;
         }
@@ -1906,8 +1922,20 @@ __global__ __launch_bounds__(64) void k_forward_columns(const LaunchArgs a)
     const typename M::Setup s = M::setup(th);
     const long long Wp = a.Wp ? a.Wp : a.W;
     const long long e = row / Wp, w = row - e * Wp;     // a block of 64 rows may straddle two spectra here: per lane
-    const double *__restrict__ cb = a.cb + e * a.cb_stride;
     double *__restrict__ col = a.out + e * 2 * N * Wp + w;
+    if (Wp % 64 == 0) {
+        // ... unless the spectra hold whole waves: one spectrum per wave, its records through the scalar path
+        const long long e0 = __builtin_amdgcn_readfirstlane((int)e);
+        const double *__restrict__ cb = a.cb + e0 * a.cb_stride;
+        for (int j = 0; j < N; ++j) {
+            double zr, zi;
+            eval_const<M>(s, cb + (long long)j * M::REC, zr, zi);
+            __builtin_nontemporal_store(zr, col + (long long)j * Wp);
+            __builtin_nontemporal_store(zi, col + (long long)(N + j) * Wp);
+        }
+        return;
+    }
+    const double *__restrict__ cb = a.cb + e * a.cb_stride;
     for (int j = 0; j < N; ++j) {
         double zr, zi;
         M::eval(s, cb + (long long)j * M::REC + 4, zr, zi);

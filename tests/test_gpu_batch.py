@@ -378,11 +378,13 @@ def test_chain_moments_entry_point(n, E, Wp, ndim, thin):
 
 @pytest.mark.parametrize('model,kw,n_freq', [('PeltonColeCole', dict(n_modes=2), 32), ('PeltonColeCole', dict(n_modes=1), 20),
                                              ('PolynomialDecomposition', dict(poly_deg=5), 20), ('Dias2000', {}, 27),
-                                             ('Shin2015', {}, 48)])
+                                             ('Shin2015', {}, 48), ('PolynomialDecomposition', dict(poly_deg=5), 48),
+                                             ('PolynomialDecomposition', dict(poly_deg=8), 64)])
 def test_batch_forward_whole_blocks_per_spectrum(model, kw, n_freq):
     """n a multiple of 64 rows per spectrum: the batch takes the tiled / whole-row forward
     kernels with a per-block record pointer; same numbers as the per-(row, frequency) kernel
-    used for ragged batches, and the oracle's."""
+    used for ragged batches, and the oracle's.  (PolynomialDecomposition at 48 / 64 frequencies: the
+    16-frequency tiles, whose records come through the constant address space -- kernels.h: eval_const.)"""
     import bisip_amd
     E, n = 5, 128
     batch = bisip_amd.SpectraBatch(model, _tables(E, n_freq), nwalkers=n, **kw)
