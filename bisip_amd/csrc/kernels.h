@@ -421,6 +421,7 @@ struct ColeCole {
         double r0;
         double m[D], lt[D], c[D], cs[D], sn[D];
         double A[D], c2[D], clt2[D], C;  // residual(): m r0, c log2e, c log2e lt, r0 - sum A
+        double cs2[D], Acs[D], Asn[D];   // the fast residual: 2 cos, A cos, A sin
     };
     static constexpr bool HAS_FAST = true;
     static constexpr bool HAS_GRID = true;
@@ -442,6 +443,9 @@ struct ColeCole {
             s.c2[i] = s.c[i] * LOG2E;
             s.clt2[i] = s.c2[i] * s.lt[i];
             s.C -= s.A[i];
+            s.cs2[i] = 2.0 * s.cs[i];
+            s.Acs[i] = s.A[i] * s.cs[i];
+            s.Asn[i] = s.A[i] * s.sn[i];
         }
         return s;
     }
@@ -475,41 +479,72 @@ struct ColeCole {
                                                              double (&ri)[F])
     {
         constexpr int K = F * D;
-        double dr[F][D], di[F][D], den[F][D], inv[F][D];
+        double zr[F], zi[F];
+        if constexpr (FAST) {
+            // Inside a box BOUNDS_FAST vouches for (0 <= c <= 1: cos >= 0, nothing cancels) the term is taken as
+            //   A conj(1+x)/|1+x|^2 = (A + A cos e - i A sin e) / (1 + e (e + 2 cos)),   e = |x|,
+            // with A cos, A sin, 2 cos per walker: six instructions per (frequency, mode) besides the reciprocal
+            // instead of seven (1 + x itself is never formed; cos^2 + sin^2 = 1 to the rounding of the pair).
+            double den[F][D], nr[F][D], ni[F][D], inv[F][D];
 #pragma unroll
-        for (int f = 0; f < F; ++f)
+            for (int f = 0; f < F; ++f)
 #pragma unroll
-            for (int i = 0; i < D; ++i) {
-                dr[f][i] = fma(e[f * D + i], s.cs[i], 1.0);   // >= 1 because cos(c pi/2) >= 0
-                di[f][i] = e[f * D + i] * s.sn[i];
+                for (int i = 0; i < D; ++i) {
+                    const double ee = e[f * D + i];
+                    den[f][i] = fma(ee, ee + s.cs2[i], 1.0);
+                    nr[f][i] = fma(ee, s.Acs[i], s.A[i]);
+                    ni[f][i] = ee * s.Asn[i];
+                }
+            if constexpr (D >= 2) rcp_groups<F, D>(den, inv);
+            else {
+                double flat[K], r[K];
+#pragma unroll
+                for (int k = 0; k < K; ++k) flat[k] = den[k][0];
+                rcp_nr_n<K>(flat, r);
+#pragma unroll
+                for (int k = 0; k < K; ++k) inv[k][0] = r[k];
             }
 #pragma unroll
-        for (int f = 0; f < F; ++f)
+            for (int i = 0; i < D; ++i) {
 #pragma unroll
-            for (int i = 0; i < D; ++i) den[f][i] = fma(dr[f][i], dr[f][i], di[f][i] * di[f][i]);
-        if constexpr (FAST && D >= 2) rcp_groups<F, D>(den, inv);
-        else {
+                for (int f = 0; f < F; ++f) {
+                    zr[f] = fma(nr[f][i], inv[f][i], i == 0 ? s.C : zr[f]);
+                    zi[f] = i == 0 ? ni[f][i] * inv[f][i] : fma(ni[f][i], inv[f][i], zi[f]);
+                }
+            }
+        } else {
+            double dr[F][D], di[F][D], den[F][D], inv[F][D];
+#pragma unroll
+            for (int f = 0; f < F; ++f)
+#pragma unroll
+                for (int i = 0; i < D; ++i) {
+                    dr[f][i] = fma(e[f * D + i], s.cs[i], 1.0);
+                    di[f][i] = e[f * D + i] * s.sn[i];
+                }
+#pragma unroll
+            for (int f = 0; f < F; ++f)
+#pragma unroll
+                for (int i = 0; i < D; ++i) den[f][i] = fma(dr[f][i], dr[f][i], di[f][i] * di[f][i]);
             double flat[K], r[K];
 #pragma unroll
             for (int k = 0; k < K; ++k) flat[k] = den[k / D][k % D];
             rcp_nr_n<K>(flat, r);
 #pragma unroll
             for (int k = 0; k < K; ++k) inv[k / D][k % D] = r[k];
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+#pragma unroll
+                for (int f = 0; f < F; ++f) {
+                    const double t = s.A[i] * inv[f][i];
+                    zr[f] = fma(t, dr[f][i], i == 0 ? s.C : zr[f]);
+                    zi[f] = i == 0 ? t * di[f][i] : fma(t, di[f][i], zi[f]);
+                }
+            }
         }
-        // Z = C + sum_i t_i (dr_i - i di_i) is accumulated first (modes in ascending order, the real part from
+        // Z = C + sum_i A_i conj(1+x_i)/|1+x_i|^2 is accumulated first (modes in ascending order, the real part from
         // C) and taken from the measured value last: y - Z.  With the measured value as the START of the chain
         // the compiler moves it from its scalar registers into vector registers first (two v_mov_b32 per
         // frequency and part for a v_fmac); as the operand of the final add it stays scalar.
-        double zr[F], zi[F];
-#pragma unroll
-        for (int i = 0; i < D; ++i) {
-#pragma unroll
-            for (int f = 0; f < F; ++f) {
-                const double t = s.A[i] * inv[f][i];
-                zr[f] = fma(t, dr[f][i], i == 0 ? s.C : zr[f]);
-                zi[f] = i == 0 ? t * di[f][i] : fma(t, di[f][i], zi[f]);
-            }
-        }
 #pragma unroll
         for (int f = 0; f < F; ++f) { rr[f] = rec[f][0] - zr[f]; ri[f] = rec[f][1] + zi[f]; }
     }
