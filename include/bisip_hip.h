@@ -101,7 +101,9 @@ int bisip_ctx_nspectra(const bisip_ctx *ctx);
 
 void bisip_ctx_destroy(bisip_ctx *ctx);
 
-/* Replace the prior box (strict inequalities, lo < theta < hi). */
+/* Replace the prior box (strict inequalities, lo < theta < hi).  PolynomialDecomposition: the reduced form's
+ * expansion points are chosen again for the new box; where their operands live in device memory (a batch; a lone
+ * spectrum's compensated tier from degree 6 on) the call waits for the device's earlier work before it rewrites them. */
 int bisip_ctx_set_bounds(bisip_ctx *ctx, const double *lo, const double *hi);
 
 /* Choose the kernel formulation (BISIP_VARIANT_*). */
