@@ -327,6 +327,44 @@ def test_reduced_kernel_tiers_estimates_on_the_host():
     assert needs_comp >= 3
 
 
+_ESTIMATES_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+from bisip_amd import _hip
+from bisip_amd.synthetic import synthetic_columns
+from bisip_amd.utils import columns_to_data
+out = []
+for n_freq, P, c, idx, width in [(32, 5, 1.0, 0, 1.0), (32, 5, 1.0, 9, 0.01), (20, 3, 1.0, 2, 1.0), (33, 6, 0.5, 3, 0.3),
+                                 (48, 8, 1.0, 4, 1.0), (32, 10, 0.5, 5, 1.0), (64, 9, 0.5, 6, 0.05), (21, 0, 1.0, 7, 1.0),
+                                 (32, 7, 0.7, 8, 2.0), (80, 6, 0.22, 1, 1.0)]:
+    d = columns_to_data(synthetic_columns(n_freq, idx), 'mrad')
+    per = np.log10(1. / d['w'])
+    lt = np.linspace(np.floor(per.min() - 1), np.floor(per.max() + 1), 2 * d['N'])
+    bounds = np.array([[0.9] + [-width] * (P + 1), [1.1] + [width] * (P + 1)])
+    est = _hip.polydecomp_reduced_estimates(d['w'], d['zn'], d['zn_err'], 10 ** lt, np.array([lt ** i for i in range(P + 1)]), c, bounds)
+    out.append(np.array(est).tobytes().hex())
+print(' '.join(out))
+"""
+
+
+def test_vector_estimate_equals_the_scalar_one_bit_for_bit():
+    """The estimate behind BISIP_VARIANT_AUTO emulates the kernel and evaluates its yardstick four probe rows
+    at a time where the CPU has AVX2 + FMA (host_precompute.cpp: chi2_kernel_plain_x4, chi2_dd_x4) -- lane-wise
+    the operations of the scalar functions in their order, so the same estimates to the last bit, on designs of
+    every degree, with odd probe counts and narrow and wide boxes.  BISIP_HOST_SCALAR_ESTIMATE=1 keeps the scalar
+    functions (read once per process: two child processes)."""
+    runs = []
+    for scalar in (False, True):
+        env = dict(os.environ)
+        env.pop('BISIP_HOST_SCALAR_ESTIMATE', None)
+        if scalar:
+            env['BISIP_HOST_SCALAR_ESTIMATE'] = '1'
+        r = subprocess.run([sys.executable, '-c', _ESTIMATES_SCRIPT, ROOT], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        runs.append(r.stdout.split())
+    assert len(runs[0]) == 10 and runs[0] == runs[1]
+
+
 def test_estimate_finds_a_shell_patch_that_random_draws_miss():
     """A prior box may cut the shell log-probability = 0 in a patch so small that none of 1,500 random
     shell rows falls inside (this design -- problem 1558 of `fuzz_parity.py --seed 308 --valley`, degree 6,
