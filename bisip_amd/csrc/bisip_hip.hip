@@ -131,6 +131,8 @@ const char *name_for(const bisip_ctx *c)
 // its clamp at 1e70 bounds the other side).  The reference's default boxes pass with y <= 26; a user who
 // widens a box past this gets the safe loop: one reciprocal per term, exponents clamped at 500 (where a
 // squared magnitude would overflow).
+static_assert(bisip::HOST_GRID_BLOCK == bisip::GRID_BLOCK, "the host's grid check and the kernels' stepped loops use one block length");
+
 static int bound_flags(const bisip_ctx *c)
 {
     constexpr double LOG2E = 1.4426950408889634, YMAX = 110.0;

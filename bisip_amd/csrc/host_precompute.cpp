@@ -845,7 +845,7 @@ bool grid_step(int N, const double *w, const double *lnw, double *dlnw)
     const double d = (double)step;
     if (!std::isfinite(d) || d == 0.0) return false;
     for (int j = 0; j < N; ++j) {
-        const ld want = logl((ld)w[j]), got = (ld)lnw[j & ~7] + (ld)(j & 7) * (ld)d;
+        const ld want = logl((ld)w[j]), got = (ld)lnw[j & ~(HOST_GRID_BLOCK - 1)] + (ld)(j & (HOST_GRID_BLOCK - 1)) * (ld)d;
         if (!(fabsl(want - got) <= 4e-15L)) return false;
     }
     *dlnw = d;

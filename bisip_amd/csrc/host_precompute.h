@@ -146,10 +146,11 @@ void read_tables(const char *const *paths, int64_t n_files, int headers, int64_t
 // -0.5 * sum_i 2*ln(zn_err_i^2), the walker-independent term of src/bisip/models.py:62
 double loglike_const(int n2, const double *zn_err);
 
-// Geometric frequency grid (kernels.h: BOUNDS_GRID): true when, in blocks of eight frequencies,
-// ln w_{8k+q} = lnw[8k] + q * dlnw to 4e-15 -- lnw[] the ROUNDED values the kernels hold, ln w_f on the left
+// Geometric frequency grid (kernels.h: BOUNDS_GRID, GRID_BLOCK): true when, in blocks of GRID_BLOCK = 16 frequencies,
+// ln w_{16k+q} = lnw[16k] + q * dlnw to 4e-15 -- lnw[] the ROUNDED values the kernels hold, ln w_f on the left
 // in long double -- for the common step dlnw = (ln w_{N-1} - ln w_0)/(N-1); N >= 8.  *dlnw is set either way
 // (0 when there is no such grid).
+constexpr int HOST_GRID_BLOCK = 16;     // == GRID_BLOCK of kernels.h (static_assert in bisip_hip.hip)
 bool grid_step(int N, const double *w, const double *lnw, double *dlnw);
 
 // ln(w_j) and 1/sigma^2 rounded from long double

@@ -828,15 +828,19 @@ struct Shin {
 
 // Geometric frequency grids (BOUNDS_GRID).  The exponentials of ColeCole / Shin at frequency f are
 // 2^(a_i ln w_f + b_i) with per-walker a_i, b_i: sixteen of their ~33 instructions per (frequency, term).
-// On a grid ln w_{8k+q} = ln w_{8k} + q dlnw they are, for the block of eight frequencies that starts at 8k,
-//   base_i = 2^(a_i ln w_{8k} + b_i)             one exponential per block and term,
-//   half_i = base_i  (q < 4)   or   base_i S4_i  (q >= 4),
-//   half_i,  half_i S1_i,  half_i S2_i,  half_i S3_i        for q mod 4 = 0..3,
-// with the per-walker steps S1 = 2^(a_i dlnw), S2 = S1 S1, S3 = S2 S1, S4 = S2 S2 -- an eighth of the
-// exponentials plus seven multiplications.  The value at frequency f is defined by THIS formula (block start
-// 8*(f/8), half (f/4)%2, step f%4, in that order) in every kernel, whichever lane evaluates it and in whatever
-// order: the same bits everywhere, as for the other paths.  Rounding: base as before; the half and the step
-// add <= 6 ulp; the grid's own deviation <= 4e-15 in the exponent's ln w, the size of the rounding of ln w.
+// On a grid ln w_{16k+q} = ln w_{16k} + q dlnw they are, for the block of GRID_BLOCK = 16 frequencies that
+// starts at 16k,
+//   quarter_0 = 2^(a_i ln w_{16k} + b_i)          one exponential per block and term,
+//   quarter_m = quarter_{m-1} S4_i                  m = 1, 2, 3: the four frequencies from 16k + 4m,
+//   quarter_m,  quarter_m S1_i,  quarter_m S2_i,  quarter_m S3_i        for q mod 4 = 0..3,
+// with the per-walker steps S1 = 2^(a_i dlnw), S2 = S1 S1, S3 = S2 S1, S4 = S2 S2 -- a sixteenth of the
+// exponentials plus fifteen multiplications (blocks of eight until round 4: one instruction more per frequency
+// and term).  The value at frequency f is defined by THIS formula (block start 16*(f/16), quarter (f/4)%4 reached
+// by multiplying quarter by quarter, step f%4, in that order) in every kernel, whichever lane evaluates it and in
+// whatever order: the same bits everywhere, as for the other paths.  Rounding: the block's exponential as before;
+// the quarters and the step add <= 22 ulp (2.5e-15 of a term whose parity tolerance is 1e-12 of max |Z|); the
+// grid's own deviation <= 4e-15 in the exponent's ln w, the size of the rounding of ln w.
+constexpr int GRID_BLOCK = 16;
 template <class M>
 struct GridSteps {
     double S[4][M::NEXP];     // 2^(a dlnw) to the powers 1, 2, 3 and 4
@@ -869,7 +873,7 @@ __device__ __forceinline__ void grid_base(const typename M::Setup &s, double lnw
     exp2_finite_n<M::NEXP>(y, base);
 }
 
-// the second half of a block of eight frequencies starts from the first half's exponential times S4
+// the next quarter of a block starts from the previous quarter's exponential times S4
 template <class M>
 __device__ __forceinline__ void grid_half(const GridSteps<M> &g, double (&base)[M::NEXP])
 {
@@ -1137,8 +1141,8 @@ __device__ __forceinline__ void logprob_sums_grid(const typename M::Setup &s, co
         for (int q = 0; q < 8; ++q) { cur[2 * q] = buf[q].x; cur[2 * q + 1] = buf[q].y; }
         const GridSteps<M> gs = grid_steps<M>(s, cur[7]);
         int j = 0;
-        // KIND 0: first pair of a block of eight (takes the block's exponential); 2: first pair of its second
-        // half (the exponential times S4); 1: the second pair of either half
+        // KIND 0: first pair of a block (takes the block's exponential); 2: first pair of a later quarter (the
+        // previous quarter's exponential times S4); 1: the second pair of a quarter
         auto pair = [&](auto kind) {
             constexpr int KIND = decltype(kind)::value;
             lds_pair_issue((j + 3 < o.N) ? rec + R2 : rec, buf, cur[5]);   // last pair: a harmless re-read
@@ -1169,21 +1173,28 @@ __device__ __forceinline__ void logprob_sums_grid(const typename M::Setup &s, co
         using K0 = std::integral_constant<int, 0>;
         using K1 = std::integral_constant<int, 1>;
         using K2 = std::integral_constant<int, 2>;
-        for (; j + 7 < o.N;) {
+        for (; j + GRID_BLOCK - 1 < o.N;) {
             pair(K0{});
             pair(K1{});
-            pair(K2{});
-            pair(K1{});
+#pragma unroll 1
+            for (int quarter = 1; quarter < GRID_BLOCK / 4; ++quarter) {
+                pair(K2{});
+                pair(K1{});
+            }
         }
-        // fewer than eight left: up to three pairs and a single frequency, in the block's order
+        // fewer than a block left: up to seven pairs and a single frequency, in the block's order
         int done = 0;                           // pairs of the last, partial block
         if (j + 1 < o.N) { pair(K0{}); done = 1; }
-        if (j + 1 < o.N) { pair(K1{}); done = 2; }
-        if (j + 1 < o.N) { pair(K2{}); done = 3; }
-        if (j < o.N) {                          // one frequency left: step 0 or 2 of the half it falls in
+#pragma unroll 1
+        while (j + 1 < o.N) {
+            if (done & 1) pair(K1{});
+            else pair(K2{});
+            ++done;
+        }
+        if (j < o.N) {                          // one frequency left: step 0 or 2 of the quarter it falls in
             double e[NE], rr[1], ri[1];
             if (done == 0) { grid_base<M>(s, rec[5], base); grid_at<M, 0>(gs, base, e); }
-            else if (done == 2) { grid_half<M>(gs, base); grid_at<M, 0>(gs, base, e); }
+            else if ((done & 1) == 0) { grid_half<M>(gs, base); grid_at<M, 0>(gs, base, e); }
             else grid_at<M, 2>(gs, base, e);
             const double *const r1[1] = {rec};
             M::template residual_from_exp<1, true>(s, r1, e, rr, ri);
@@ -1214,21 +1225,28 @@ __device__ __forceinline__ void logprob_sums_grid(const typename M::Setup &s, co
             if (left > 2) one(std::integral_constant<int, 2>{}, r + 2 * REC);
         };
         int j = 0;
-        for (; j + 7 < o.N; j += 8, rec += 8 * REC) {
+        for (; j + GRID_BLOCK - 1 < o.N; j += GRID_BLOCK, rec += GRID_BLOCK * REC) {
             grid_base<M>(s, rec[5], base);
             four(rec);
-            grid_half<M>(gs, base);
-            four(rec + 4 * REC);
+#pragma unroll
+            for (int quarter = 1; quarter < GRID_BLOCK / 4; ++quarter) {
+                grid_half<M>(gs, base);
+                four(rec + 4 * quarter * REC);
+            }
         }
-        if (j < o.N) {                           // a partial block of eight
+        if (j < o.N) {                           // a partial block: whole quarters, then up to three frequencies
             grid_base<M>(s, rec[5], base);
-            if (j + 3 < o.N) {
-                four(rec);
-                j += 4;
-                rec += 4 * REC;
-                if (j < o.N) { grid_half<M>(gs, base); upto3(rec, o.N - j); }
-            } else {
-                upto3(rec, o.N - j);
+            for (;;) {
+                if (j + 3 < o.N) {
+                    four(rec);
+                    j += 4;
+                    rec += 4 * REC;
+                    if (j >= o.N) break;
+                    grid_half<M>(gs, base);
+                } else {
+                    upto3(rec, o.N - j);
+                    break;
+                }
             }
         }
     } else {
@@ -1243,9 +1261,12 @@ __device__ __forceinline__ void logprob_sums_grid(const typename M::Setup &s, co
         for (int jb = 0; jb < o.N; jb += 4 * L) {
             const int j4 = (jb + 4 * g < o.N) ? jb + 4 * g : (last & ~3);   // clamp: its results are never adopted
             double base[NE], rr[4], ri[4], iv[4][2];
-            grid_base<M>(s, o.cb[(long long)(j4 & ~7) * REC + 5], base);
+            grid_base<M>(s, o.cb[(long long)(j4 & ~(GRID_BLOCK - 1)) * REC + 5], base);
+            const int quarter = (j4 & (GRID_BLOCK - 1)) >> 2;           // its quarter: times S4 once per quarter before it
 #pragma unroll
-            for (int i = 0; i < NE; ++i) base[i] = base[i] * ((j4 & 4) ? gs.S[3][i] : 1.0);    // second half: times S4
+            for (int m = 1; m < GRID_BLOCK / 4; ++m)
+#pragma unroll
+                for (int i = 0; i < NE; ++i) base[i] = base[i] * (m <= quarter ? gs.S[3][i] : 1.0);
             auto one = [&](auto Q) {
                 constexpr int q = decltype(Q)::value;
                 const int j = (j4 + q <= last) ? j4 + q : last;

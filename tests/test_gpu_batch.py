@@ -277,12 +277,12 @@ def test_guard_closes_a_batch_mix_before_it_closes_a_tier(monkeypatch):
     assert batch.ctx.reduced_tiers[0] >= 1
 
 
-@pytest.mark.parametrize('n_freq', [8, 9, 10, 11, 12, 13, 14, 15, 21])
+@pytest.mark.parametrize('n_freq', [8, 9, 10, 11, 12, 13, 14, 15, 16, 18, 21, 23, 29, 32, 35])
 def test_persistent_kernel_steps_a_geometric_grid_like_the_launches_do(n_freq):
     """The persistent kernel reads a spectrum's records from LDS two frequencies at a time; on a geometric
-    grid a block of eight frequencies is four such pairs, and with several lanes per walker each lane takes
-    whole half-blocks (kernels.h: logprob_sums_grid).  Every block tail -- one to three pairs, with or without a single
-    frequency after them -- and every ensemble size (1, 2, 4 lanes per walker) gives the bits of the
+    grid a block of sixteen frequencies is eight such pairs, and with several lanes per walker each lane takes
+    whole quarters of a block (kernels.h: logprob_sums_grid).  Every block tail -- one to seven pairs, with or without a
+    single frequency after them -- and every ensemble size (1, 2, 4 lanes per walker) gives the bits of the
     launch path."""
     import bisip_amd
     from bisip_amd.sampler import DeviceEnsembleSampler

@@ -1258,14 +1258,14 @@ def test_bench_two_ranks_on_one_device():
 
 
 
-@pytest.mark.parametrize('n_freq', [8, 9, 10, 11, 12, 13, 14, 15, 30, 32, 33])
+@pytest.mark.parametrize('n_freq', [8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 19, 22, 27, 30, 32, 33, 47])
 def test_grid_stepped_exponentials_agree_with_direct_ones_and_with_the_oracle(n_freq, monkeypatch):
     """On a geometric frequency grid (kernels.h: BOUNDS_GRID) ColeCole and Shin take one exponential per
-    block of eight frequencies and term and step it by multiplication.  Same answer as one exponential per
+    block of sixteen frequencies and term and step it by multiplication.  Same answer as one exponential per
     (frequency, term) -- the loop BISIP_NO_GRID=1 and every off-grid spectrum run -- to rounding, both
     within the parity tolerance of the oracle; and, as for every other loop, the same BITS whether one,
-    two or four lanes evaluate a walker (launches of 100, 6,000 and 200,000 rows), for every block tail
-    (N mod 8 = 0 ... 7)."""
+    two or four lanes evaluate a walker (launches of 100, 6,000 and 200,000 rows), for block tails of every
+    kind (whole quarters, one to three frequencies after them, one or several blocks)."""
     import oracle
     from bisip_amd import _hip
     from bisip_amd.batch import default_params
