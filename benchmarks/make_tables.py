@@ -296,7 +296,7 @@ FILES = [
     (rn('survey.jsonl'), '`python benchmarks/survey.py [--model PeltonColeCole]`', 'a 4096-spectrum survey end to end: files to posterior summaries and model bands'),
     (rn('batch_setup.jsonl'), '`python benchmarks/batch_setup.py`', 'what surrounds a survey run: batch context creation (host precompute on threads), a short fit, the summaries'),
     (rn('soak.json'), '`python benchmarks/soak.py`', 'twenty 100,000-iteration fits and twenty 10,000-iteration batch fits in one process: device memory constant, posterior means within 0.02 sigma of each other, identical summaries for identical seeds'),
-    ('r03_fuzz_*_summary.jsonl, r04_fuzz_*_summary.jsonl', '`python benchmarks/fuzz_parity.py --cases N --seed S [--widen X] [--valley]`, `fuzz_sampler.py`, `fuzz_batch.py` (r03: parity seeds 41-63, valley 301-310, sampler 2-23, batch 1-24; r04, all at the final kernel sources (`benchmarks/collect_r04_final.sh`): parity 46 (`--widen 3`, the seed with round 3\'s one violation), 64, 65 (`--widen 1.5`), 66, 67 (`--widen 1.5`), 68 (`--widen 3`), valley 311, 312, sampler 25, 27, batch 26, 28)', 'randomised campaigns (one line per seed in the tables below; earlier rounds: `r02_fuzz_*`, 41,000 problems): violations, worst errors, which kernel AUTO ran'),
+    ('r03_fuzz_*_summary.jsonl, r04_fuzz_*_summary.jsonl', '`python benchmarks/fuzz_parity.py --cases N --seed S [--widen X] [--valley]`, `fuzz_sampler.py`, `fuzz_batch.py` (r03: parity seeds 41-63, valley 301-310, sampler 2-23, batch 1-24; r04, all run again at the final kernel sources, i.e. after the paired reciprocals of ColeCole / Shin (`benchmarks/collect_r04_pairs.sh`): parity 46 (`--widen 3`, the seed with round 3\'s one violation), 64, 65 (`--widen 1.5`), 66, 67 (`--widen 1.5`), 68 (`--widen 3`), 69, 70 (`--widen 1.5`), 71 (`--widen 3`), valley 311-313, sampler 25, 27, 29, batch 26, 28, 30)', 'randomised campaigns (one line per seed in the tables below; earlier rounds: `r02_fuzz_*`, 41,000 problems): violations, worst errors, which kernel AUTO ran'),
     ('r03_fuzz_valley_summary.jsonl, r04_fuzz_valley_summary.jsonl', '`python benchmarks/fuzz_parity.py --cases 1500 --seed S --valley` (S = 301..303; 3000 cases each at S = 304..306, 4000 at S = 307..309, 6000 at S = 310; r04: 3000 at S = 311 with the binary128 yardstick and operands)', 'half of the checked PolynomialDecomposition rows along the valley of chi^2 / on the shell logp = 0: distances of every formulation AND of the reference from the exact value'),
     (rn('valley_rows.jsonl, valley_rows_before.jsonl'), '`python benchmarks/valley_rows.py`', 'the kernel AUTO picks, measured on 3000 valley rows per scale (1 ... 1000 sigma) of 216 designs of degree 5-10 (designs above 1e-11 are listed): with this round\'s estimate, and -- `_before` -- with round 2\'s, against plain long double'),
     (rn('micro_collapsed_r3.txt'), '`benchmarks/micro/collapsed_r3`', 'PDCollapsed: the shipped kernel against LDS-staged records, 4 rows per lane, single-wave workgroups and persistent waves, each with the engine clock it ran at and cycles per VALU instruction'),
@@ -320,6 +320,7 @@ FILES = [
     (rn('micro_persistent_crossover.txt'), '`python benchmarks/micro/persistent_crossover.py`', 'persistent kernel vs launch per half-step by ensemble size and model: the automatic rule'),
     (rn('micro_grid_barrier.txt'), '`benchmarks/micro/grid_barrier`', 'cost of a device-wide barrier (with and without a row exchange) for 64 / 128 / 256 workgroups'),
     (rn('micro_reduced_comp_by_degree.txt'), '`python benchmarks/micro/reduced_comp_by_degree.py`', 'round 4: bulk rate of the QR-reduced kernels by degree, lone spectrum and batch; the compensated tier with the prior decided first and, where the operands come from memory, loaded again instead of spilled (batch: +22 / +31 / +33 % at degree 5 / 7 / 9; a lone spectrum from degree 6 on takes the same route: +14 ... +29 %); before / after and the two variants not kept in the file'),
+    (rn('micro_ab_paired_reciprocals.jsonl'), '`python benchmarks/micro/ab_library.py <library>`, the build before the paired reciprocals and the present one alternately (before, after, before, after) on ONE box', 'round 4, last kernel change: ColeCole<1> / ColeCole<2> / Shin take the denominators of frequencies 2k, 2k+1 from one reciprocal: 4.28 -> 4.62e10 (+8 %), 2.77 -> 2.84e10 (+2 %), 2.73 -> 2.91e10 (+7 %) evals/s in bulk, a cfg5-shaped batch fit 5.43 -> 5.26 us per half-step; Dias (untouched) 3.87 / 3.79e10: the run-to-run spread'),
     (rn('micro_xcd_barrier.txt'), '`benchmarks/micro/xcd_barrier`', 'round 4: a barrier among the workgroups of ONE XCD (0.7-0.9 us for 8-32 workgroups, no fences: the counter and the rows go through that XCD\'s L2 with sc1 loads; 0 stale rows) and what a stretch half-step\'s row exchange costs on top, naive (every lane writes and gathers 72-B rows) and laid out for it (one lane per walker, 64-B rows, 16-B accesses): 1.4 us at 2,048 walkers, 2.1 at 8,192, **6.1 at cfg4\'s 32,768** on one XCD, 5.2-5.9 spread over the chip with write-through rows -- no better than the 6.4 us kernel boundary it would replace: the persistent multi-workgroup sampler was not built (kill criterion of VERDICT r3 #3)'),
     (rn('micro_post_run_stall.txt'), '`python benchmarks/micro/post_run_stall.py kernel`, `upload_cost.py plain`', 'the sporadic 20-30 ms delay of the first device work after a synchronisation early in a process'),
 ]

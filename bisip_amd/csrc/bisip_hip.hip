@@ -124,11 +124,12 @@ const char *name_for(const bisip_ctx *c)
 }  // namespace
 
 // May ColeCole<D> / Shin / Dias run their FAST frequency loop -- ONE reciprocal per group of denominators
-// (kernels.h: rcp_batch_n), no exponent clamp?  Only if, everywhere inside the prior box, every denominator of
+// (kernels.h: rcp_batch_n; rcp_joint for the up to four denominators of a PAIR of frequencies), no exponent
+// clamp?  Only if, everywhere inside the prior box, every denominator of
 // a frequency lies in [1, 2^225], so that a product of four is a normal number: exponents
 // y = c log2e (ln w + log_tau) (ColeCole) or log2e (n ln w + log_Q) (Shin) bounded by 110, cos(c pi/2) >= 0
 // (c or n within [0, 1]: the real part of each denominator term is then >= 1), and for Shin R <= 1 (1/R >= 1;
-// its clamp at 1e70 bounds the other side).  The reference's default boxes pass with y <= 26; a user who
+// its clamp at 2^110 bounds the other side).  The reference's default boxes pass with y <= 26; a user who
 // widens a box past this gets the safe loop: one reciprocal per term, exponents clamped at 500 (where a
 // squared magnitude would overflow).
 static_assert(bisip::HOST_GRID_BLOCK == bisip::GRID_BLOCK, "the host's grid check and the kernels' stepped loops use one block length");

@@ -281,7 +281,8 @@ __device__ __forceinline__ void rcp_nr_n(const double (&x)[K], double (&r)[K])
 // multiplications + rcp_nr instead of K rcp_nr.  v_rcp_f64 issues at a quarter of the FMA rate, so a
 // reciprocal costs 7 issue slots and a pair by this route 10 instead of 14.  F independent groups
 // (one per frequency) run in lockstep.  The caller guarantees that products of K arguments stay
-// normal (BOUNDS_FAST).  Groups are always formed WITHIN one frequency, in every kernel, so a
+// normal (BOUNDS_FAST).  These groups are formed WITHIN one frequency (three modes and more, and a last
+// unpaired frequency of the paired models; rcp_joint below takes the pairs), the same in every kernel, so a
 // walker's value does not depend on which kernel evaluated it.
 template <int F, int K>
 __device__ __forceinline__ void rcp_batch_n(const double (&x)[F][K], double (&r)[F][K])
@@ -337,6 +338,33 @@ __device__ __forceinline__ void rcp_groups(const double (&x)[F][D], double (&r)[
 #pragma unroll
             for (int k = 0; k < H; ++k) r[f][4 + k] = rb[f][k];
         }
+    }
+}
+
+// The denominators of TWO frequencies (2k, 2k+1) from ONE reciprocal (models with PAIRED, FAST loops only):
+// K = 2 (one denominator per frequency) or 4 (two per frequency, values k = (frequency k / 2, term k % 2)).
+// Four go as a tree -- (x0 x1)(x2 x3), one reciprocal, two half products back, four factors -- so that the
+// dependent chain is 2 + 4 + 2 instructions instead of the 3 + 4 + 3 of the linear form (same nine
+// multiplications): 13 instructions and 16 issue slots for what two per-frequency groups do in 14 and 20;
+// K = 2: 7 and 10 instead of 8 and 14.  BOUNDS_FAST bounds every denominator by [1, 2^225]: a product of four
+// is a normal number.  The pairs are (2k, 2k+1) in every kernel and a last unpaired frequency keeps its
+// per-frequency group: a walker's value does not depend on which kernel evaluated it.
+template <int K>
+__device__ __forceinline__ void rcp_joint(const double (&x)[K], double (&r)[K])
+{
+    static_assert(K == 2 || K == 4, "one or two denominators per frequency");
+    if constexpr (K == 2) {
+        const double t = rcp_nr(x[0] * x[1]);
+        r[0] = t * x[1];
+        r[1] = t * x[0];
+    } else {
+        const double p01 = x[0] * x[1], p23 = x[2] * x[3];
+        const double t = rcp_nr(p01 * p23);
+        const double i01 = t * p23, i23 = t * p01;
+        r[0] = i01 * x[1];
+        r[1] = i01 * x[0];
+        r[2] = i23 * x[3];
+        r[3] = i23 * x[2];
     }
 }
 
@@ -425,7 +453,9 @@ struct ColeCole {
     };
     static constexpr bool HAS_FAST = true;
     static constexpr bool HAS_GRID = true;
-    static constexpr bool PAIRED = false;
+    // FAST, one or two modes: frequencies 2k and 2k+1 take their D denominators each from ONE reciprocal
+    // (rcp_joint); three modes and more keep a group per frequency (six denominators: no normal product)
+    static constexpr bool PAIRED = D <= 2;
     // unit (wave-uniform): every c of the row lies in [0, 1] (BOUNDS_FAST and the row inside the prior)
     __device__ static __forceinline__ Setup setup(const double (&th)[NDIM], const bool unit = false)
     {
@@ -450,10 +480,12 @@ struct ColeCole {
         return s;
     }
     // Z = (r0 - sum A_i) + sum A_i (1+x_i)^-1  =>  y - Z accumulates -A_i conj(1+x_i)/|1+x_i|^2
-    // F frequencies in lockstep (F = 1: the bulk loop; F = 2: one wave per SIMD, residual2): per
-    // frequency the D exponentials, then the D reciprocals -- FAST: one per group of modes; safe: one per
-    // mode, exponents clamped -- then the modes accumulated in ascending order.  Same operations per
-    // frequency for every F, so the same bits.
+    // F frequencies in lockstep (F = 2: the pair (2k, 2k+1), residual2; F = 1: a last unpaired frequency, the
+    // safe loop, three modes and more): per frequency the D exponentials, then the D reciprocals -- FAST: one
+    // per PAIR of frequencies (PAIRED) or per frequency's group of modes; safe: one per mode, exponents
+    // clamped -- then the modes accumulated in ascending order.  Every FAST loop takes the pairs (2k, 2k+1)
+    // with F = 2 and only a last unpaired frequency with F = 1; elsewhere the operations per frequency are
+    // the same for every F: the same bits whichever kernel evaluates a walker.
     // the D exponentials of one frequency are 2^(exp_a(i) ln w + exp_b(i))   (see GridSteps below)
     static constexpr int NEXP = D;
     __device__ static __forceinline__ double exp_a(const Setup &s, int i) { return s.c2[i]; }
@@ -495,7 +527,14 @@ struct ColeCole {
                     nr[f][i] = fma(ee, s.Acs[i], s.A[i]);
                     ni[f][i] = ee * s.Asn[i];
                 }
-            if constexpr (D >= 2) rcp_groups<F, D>(den, inv);
+            if constexpr (F == 2 && PAIRED) {
+                double flat[K], r[K];
+#pragma unroll
+                for (int k = 0; k < K; ++k) flat[k] = den[k / D][k % D];
+                rcp_joint<K>(flat, r);
+#pragma unroll
+                for (int k = 0; k < K; ++k) inv[k / D][k % D] = r[k];
+            } else if constexpr (D >= 2) rcp_groups<F, D>(den, inv);
             else {
                 double flat[K], r[K];
 #pragma unroll
@@ -705,7 +744,8 @@ struct Shin {
     };
     static constexpr bool HAS_FAST = true;
     static constexpr bool HAS_GRID = true;
-    static constexpr bool PAIRED = false;
+    // FAST: frequencies 2k and 2k+1 take their four |y_i|^2 from ONE reciprocal (rcp_joint)
+    static constexpr bool PAIRED = true;
     // unit (wave-uniform): both n of the row lie in [0, 1] (BOUNDS_FAST and the row inside the prior)
     __device__ static __forceinline__ Setup setup(const double (&th)[NDIM], const bool unit = false)
     {
@@ -714,10 +754,11 @@ struct Shin {
         for (int i = 0; i < 2; ++i) {
             // R = 0 (a prior bound; forward() may be asked for it) makes the term vanish in the
             // reference: 1/0 = inf, inf^-1 = 0.  Clamping 1/R keeps |y|^2 finite here and the
-            // term at <= 1e-70 instead of inf * 0; 1e70 (not 1e150) so that the PRODUCT of the two
-            // elements' |y|^2 stays finite as well (rcp_batch_n).
+            // term at <= 2^-110 = 8e-34 instead of inf * 0; 2^110 (1e70 until round 4) so that the PRODUCT
+            // of the FOUR |y|^2 of a pair of frequencies is a normal number (rcp_joint; with the exponent
+            // bound of BOUNDS_FAST every |y|^2 <= 2^223).
             double ir = 1.0 / th[i];
-            if (fabs(ir) > 1e70) ir = copysign(1e70, ir);
+            if (fabs(ir) > 0x1p110) ir = copysign(0x1p110, ir);
             s.invR[i] = ir;
             s.Q[i] = exp_finite(th[2 + i] > 700.0 ? 700.0 : th[2 + i]);     // finite (forward() only; NaN stays NaN)
             s.n[i] = th[4 + i];
@@ -729,8 +770,9 @@ struct Shin {
         return s;
     }
     // Q (iw)^n = 2^(n log2e ln w + log_Q log2e) (cs + i sn);  Z = sum_i conj(y_i)/|y_i|^2.
-    // F frequencies in lockstep; FAST: per frequency the two elements' reciprocals come from one
-    // reciprocal of the product of the |y_i|^2; safe: one each, exponents clamped.
+    // F frequencies in lockstep; FAST: the pair (2k, 2k+1) (F = 2) takes its four reciprocals from one
+    // reciprocal of the product of the four |y_i|^2, a last unpaired frequency (F = 1) its two from the
+    // product of two; safe: one each, exponents clamped.
     static constexpr int NEXP = 2;
     __device__ static __forceinline__ double exp_a(const Setup &s, int i) { return s.n2[i]; }
     __device__ static __forceinline__ double exp_b(const Setup &s, int i) { return s.lq2[i]; }
@@ -764,7 +806,13 @@ struct Shin {
                 yi[f][i] = p[f * 2 + i] * s.sn[i];
                 den[f][i] = fma(yr[f][i], yr[f][i], yi[f][i] * yi[f][i]);
             }
-        if constexpr (FAST) rcp_batch_n<F, 2>(den, inv);
+        if constexpr (FAST && F == 2) {
+            const double flat[4] = {den[0][0], den[0][1], den[1][0], den[1][1]};
+            double r[4];
+            rcp_joint<4>(flat, r);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) inv[k / 2][k % 2] = r[k];
+        } else if constexpr (FAST) rcp_batch_n<F, 2>(den, inv);
         else {
             double flat[K], r[K];
 #pragma unroll
@@ -947,7 +995,7 @@ __device__ __forceinline__ void rotate_sums(double rr, double ri, const double *
     }
 }
 
-// One step of the travelling sums for a lane that holds TWO residuals (a pair of Dias's shared reciprocal): as
+// One step of the travelling sums for a lane that holds TWO residuals (a pair with its shared reciprocal): as
 // rotate_sums, term by term -- lane STEP's two terms are added in ascending frequency and every lane adopts the result.
 template <int L, int STEP>
 __device__ __forceinline__ void rotate_pair_sums(const double (&rr)[2], const double (&ri)[2],
@@ -1040,7 +1088,7 @@ __device__ __forceinline__ void logprob_sums(const typename M::Setup &s, const M
             acc1 = fma(ri * ri, rec[3], acc1);
         }
     } else if constexpr (L == 1 && FAST && M::PAIRED) {
-        // pairs (2k, 2k+1) share a reciprocal (Dias); the sums still take their terms one by one
+        // pairs (2k, 2k+1) share a reciprocal (Dias, ColeCole<1>, <2>, Shin); the sums still take their terms one by one
         const double *__restrict__ rec = o.cb;
         int j = 0;
         for (; j + 1 < o.N; j += 2, rec += 2 * M::REC) {
@@ -1213,15 +1261,33 @@ __device__ __forceinline__ void logprob_sums_grid(const typename M::Setup &s, co
             acc0 = fma(rr[0] * rr[0], r[2], acc0);
             acc1 = fma(ri[0] * ri[0], r[3], acc1);
         };
+        // steps Q and Q+1 of a quarter: a pair (2k, 2k+1) -- quarters start at multiples of four -- with ONE
+        // reciprocal where the model pairs its frequencies
+        auto two = [&](auto Q, const double *__restrict__ r) {
+            constexpr int q = decltype(Q)::value;
+            if constexpr (M::PAIRED) {
+                double e[2 * NE], rr[2], ri[2];
+                grid_at<M, q>(gs, base, e);
+                grid_at<M, q + 1>(gs, base, e + NE);
+                const double *const r2[2] = {r, r + REC};
+                M::template residual_from_exp<2, true>(s, r2, e, rr, ri);
+#pragma unroll
+                for (int f = 0; f < 2; ++f) {
+                    acc0 = fma(rr[f] * rr[f], r[f * REC + 2], acc0);
+                    acc1 = fma(ri[f] * ri[f], r[f * REC + 3], acc1);
+                }
+            } else {
+                one(std::integral_constant<int, q>{}, r);
+                one(std::integral_constant<int, q + 1>{}, r + REC);
+            }
+        };
         auto four = [&](const double *__restrict__ r) {
-            one(std::integral_constant<int, 0>{}, r);
-            one(std::integral_constant<int, 1>{}, r + REC);
-            one(std::integral_constant<int, 2>{}, r + 2 * REC);
-            one(std::integral_constant<int, 3>{}, r + 3 * REC);
+            two(std::integral_constant<int, 0>{}, r);
+            two(std::integral_constant<int, 2>{}, r + 2 * REC);
         };
         auto upto3 = [&](const double *__restrict__ r, int left) {
-            one(std::integral_constant<int, 0>{}, r);
-            if (left > 1) one(std::integral_constant<int, 1>{}, r + REC);
+            if (left > 1) two(std::integral_constant<int, 0>{}, r);
+            else one(std::integral_constant<int, 0>{}, r);
             if (left > 2) one(std::integral_constant<int, 2>{}, r + 2 * REC);
         };
         int j = 0;
@@ -1277,10 +1343,32 @@ __device__ __forceinline__ void logprob_sums_grid(const typename M::Setup &s, co
                 M::template residual_from_exp<1, true>(s, r1, e, r1r, r1i);
                 rr[q] = r1r[0]; ri[q] = r1i[0]; iv[q][0] = rec[2]; iv[q][1] = rec[3];
             };
-            one(std::integral_constant<int, 0>{});
-            one(std::integral_constant<int, 1>{});
-            one(std::integral_constant<int, 2>{});
-            one(std::integral_constant<int, 3>{});
+            // steps Q, Q+1 of the lane's quarter: the pair (2k, 2k+1) of the L = 1 loop with its one reciprocal
+            // when both frequencies exist; a last unpaired frequency (and the clamped re-reads past the end,
+            // whose results are never adopted) one by one
+            auto two = [&](auto Q) {
+                constexpr int q = decltype(Q)::value;
+                if constexpr (M::PAIRED) {
+                    if (j4 + q + 1 <= last) {
+                        const double *__restrict__ rec = o.cb + (long long)(j4 + q) * REC;
+                        double e[2 * NE], r2r[2], r2i[2];
+                        grid_at<M, q>(gs, base, e);
+                        grid_at<M, q + 1>(gs, base, e + NE);
+                        const double *const r2[2] = {rec, rec + REC};
+                        M::template residual_from_exp<2, true>(s, r2, e, r2r, r2i);
+#pragma unroll
+                        for (int f = 0; f < 2; ++f) {
+                            rr[q + f] = r2r[f]; ri[q + f] = r2i[f];
+                            iv[q + f][0] = rec[f * REC + 2]; iv[q + f][1] = rec[f * REC + 3];
+                        }
+                        return;
+                    }
+                }
+                one(std::integral_constant<int, q>{});
+                one(std::integral_constant<int, q + 1>{});
+            };
+            two(std::integral_constant<int, 0>{});
+            two(std::integral_constant<int, 2>{});
             rotate_block_sums<L, 0>(rr, ri, iv, jb, o.N, acc0, acc1);
         }
     }

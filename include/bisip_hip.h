@@ -392,8 +392,9 @@ int bisip_ctx_nfreq(const bisip_ctx *ctx);
 int bisip_ctx_device(const bisip_ctx *ctx);
 /* Which loop the per-frequency models (ColeCole, Shin, Dias2000) run for the current prior box and frequencies; bits:
  *   1  shared reciprocals, exponents unclamped: the box keeps every denominator product normal (ColeCole with
- *      two or more modes and Shin: one reciprocal per group of a frequency's denominators; Dias2000: one per
- *      pair of frequencies 2k, 2k+1);
+ *      one or two modes, Shin and Dias2000: one reciprocal per pair of frequencies 2k, 2k+1 -- up to four
+ *      denominators -- and a last unpaired frequency its own; ColeCole with three modes and more: one per group
+ *      of up to four of a frequency's denominators);
  *   2  (only with 1; ColeCole up to three modes, Shin) geometric frequency grid: SOME spectrum's
  *      ln w_{8k+q} = ln w_{8k} + q*step to 4e-15 (bisip_frequency_grid_step), and every spectrum that is on
  *      such a grid takes its exponentials once per block of sixteen frequencies and steps them by multiplication

@@ -942,11 +942,14 @@ def test_shared_reciprocal_is_switched_off_by_boxes_it_would_overflow_in():
         assert err.max() <= 1e-10, (n_modes, widen, err.max())
         # the same rows through set_bounds on a context created with the default box
         ctx.close()
-    # Shin: R next to 0 inside the open box (1/R clamped at 1e70: the partner element must survive)
+    # Shin: R next to 0 inside the open box (1/R clamped at 2^110: the partner element and -- one reciprocal
+    # serves the four |y|^2 of a pair of frequencies -- the neighbouring frequency must survive; both R tiny:
+    # the product of four clamped denominators is still a normal number)
     bounds = np.array(list(default_params('Shin2015').values()), float).T
     theta = rng.uniform(bounds[0], bounds[1], (2000, 6))
     theta[:300, 0] = 10.0 ** rng.uniform(-300, -60, 300)
     theta[300:600, 1] = 10.0 ** rng.uniform(-300, -60, 300)
+    theta[600:700, :2] = 10.0 ** rng.uniform(-300, -30, (100, 2))
     prob = oracle.OracleProblem('Shin2015', d['w'], d['zn'], d['zn_err'], bounds)
     with np.errstate(all='ignore'):
         want = oracle.logprob(prob, theta, n_threads=4)
@@ -995,6 +998,46 @@ def test_shared_reciprocal_is_switched_off_by_boxes_it_would_overflow_in():
         assert ctx.loop_flags == 0
         assert_logp_close(ctx.logprob(theta[:3000]), want)
         ctx.close()
+
+
+@pytest.mark.parametrize('model,n_modes', [('PeltonColeCole', 1), ('PeltonColeCole', 2), ('Shin2015', 0)])
+def test_frequency_pairs_share_a_reciprocal_in_every_loop(model, n_modes, monkeypatch):
+    """ColeCole<1>, ColeCole<2> and Shin take the denominators of frequencies 2k and 2k+1 from ONE
+    reciprocal (kernels.h: rcp_joint) in their FAST loops -- the direct loop of off-grid spectra and the
+    stepped loop of geometric grids -- and a last unpaired frequency from its own group.  Odd and even numbers
+    of frequencies, block tails of every kind, one / two / four lanes per walker: the same bits; the oracle's
+    value within the parity tolerance; exponents at the edge of what BOUNDS_FAST admits (denominators
+    ~2^200 each, a product of four ~2^800) included."""
+    import oracle
+    from bisip_amd import _hip
+    from bisip_amd.batch import default_params
+    kw = dict(n_modes=n_modes) if model == 'PeltonColeCole' else {}
+    rng = np.random.RandomState(31 + n_modes)
+    for n_freq in (1, 2, 3, 5, 18, 21, 32, 33):
+        d = _synthetic_problem(n_freq, 4)
+        bounds = np.array(list(default_params(model, **kw).values()), float).T
+        if model == 'PeltonColeCole':
+            bounds[1, 1 + n_modes:1 + 2 * n_modes] = 60.0              # tau up to e^60 s: still FAST (y <= 110)
+        theta = rng.uniform(bounds[0], bounds[1], (140000, bounds.shape[1]))
+        if model == 'PeltonColeCole':
+            theta[:400, 1 + n_modes:1 + 2 * n_modes] = rng.uniform(55, 60, (400, n_modes))
+            theta[:400, 1 + 2 * n_modes:] = rng.uniform(0.95, 1.0, (400, n_modes))
+        prob = oracle.OracleProblem(model, d['w'], d['zn'], d['zn_err'], bounds, **kw)
+        with np.errstate(all='ignore'):
+            want = oracle.logprob(prob, theta[:2000], n_threads=4)
+        for grid in (True, False):
+            if grid:
+                monkeypatch.delenv('BISIP_NO_GRID', raising=False)
+            else:
+                monkeypatch.setenv('BISIP_NO_GRID', '1')
+            ctx = _hip.HipContext(MODEL_IDS[model], d['w'], d['zn'], d['zn_err'], bounds, **kw)
+            assert ctx.loop_flags & 1, (n_freq, grid)                   # the FAST loop
+            one = ctx.logprob(theta)                                    # one lane per walker
+            assert_logp_close(one[:2000], want)
+            for rows in (40000, 20000, 5000, 3):                        # 64-lane workgroups, two lanes, four lanes
+                assert np.array_equal(ctx.logprob(theta[:rows]), one[:rows]), (model, n_modes, n_freq, grid, rows)
+            ctx.close()
+    monkeypatch.delenv('BISIP_NO_GRID', raising=False)
 
 
 def test_unsupported_shapes_fail_loudly():
