@@ -302,7 +302,7 @@ FILES = [
     (rn('micro_collapsed_r3.txt'), '`benchmarks/micro/collapsed_r3`', 'PDCollapsed: the shipped kernel against LDS-staged records, 4 rows per lane, single-wave workgroups and persistent waves, each with the engine clock it ran at and cycles per VALU instruction'),
     (rn('micro_exp2_variants.txt'), '`benchmarks/micro/exp2_variants`', 'a table-driven exp2 (16 / 32 entries in LDS) against the shipped degree-11 polynomial: cycles per exp2 per SIMD, clock, worst ulp -- not adopted'),
     (rn('micro_fit_speed_by_tier.txt'), '`python benchmarks/micro/fit_speed_by_tier.py`', 'fit() iterations/s on the plain and on the compensated reduced kernel (32 / 256 / 4096 walkers), with fit()\'s own measurement of the kernel'),
-    (rn('micro_rcp_accuracy.txt'), '`benchmarks/micro/rcp_accuracy` (hipcc from `rcp_accuracy.hip`)', '`v_rcp_f64` is good to 2^-24.4 on gfx950; one Newton step leaves 20 ulp, two 1.00 ulp, ONE cubic step `r(1 + e + e^2)` 1.00 ulp with one instruction less and a shorter chain: what `rcp_nr` does'),
+    (rn('micro_rcp_accuracy.txt'), '`benchmarks/micro/rcp_accuracy` (hipcc from `rcp_accuracy.hip`)', '`v_rcp_f64` is good to 2^-24.4 on gfx950; one Newton step leaves 20 ulp, two 1.00 ulp, ONE cubic step `r(1 + e + e^2)` 1.00 ulp with one instruction less and a shorter chain: what `rcp_nr` does; the reciprocals that the two / four denominators of a pair of frequencies take from one `rcp_nr` of their product (`rcp_joint`): 2.4 / 3.7 ulp at worst over [1, 2^221)'),
     (rn('micro_grid_vs_direct.txt'), '`python benchmarks/micro/grid_vs_direct.py`', 'ColeCole (1-3 modes) and Shin bulk launches on geometric frequency grids (exponentials stepped by multiplication in blocks of eight: 1.38-1.65x) against one exponential per frequency (`BISIP_NO_GRID=1`), with the largest difference between the two; rounded grid and bundled field spectrum as controls (no grid: the same loop twice)'),
     (rn('micro_grid_small_ensembles.txt'), '`python benchmarks/micro/grid_small_ensembles.py`', '`fit()` of one spectrum with 32-1024 walkers and emcee-sized calls, stepped against direct: 1.08-1.31x on an exact grid (lanes that share a walker take whole half-blocks), 1.0 on the bundled spectrum (no grid)'),
     (rn('micro_grid_small_ensembles_before.txt'), 'the same script on two designs that were taken out', 'one frequency per lane and round on a grid: 0.92-1.0x; a series-corrected tier for grids rounded in data files: 0.71-0.94x on the bundled spectrum (1.09-1.16x in bulk launches) -- why field data keeps the direct loop'),
