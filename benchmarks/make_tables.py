@@ -321,6 +321,7 @@ FILES = [
     (rn('micro_grid_barrier.txt'), '`benchmarks/micro/grid_barrier`', 'cost of a device-wide barrier (with and without a row exchange) for 64 / 128 / 256 workgroups'),
     (rn('micro_reduced_comp_by_degree.txt'), '`python benchmarks/micro/reduced_comp_by_degree.py`', 'round 4: bulk rate of the QR-reduced kernels by degree, lone spectrum and batch; the compensated tier with the prior decided first and, where the operands come from memory, loaded again instead of spilled (batch: +22 / +31 / +33 % at degree 5 / 7 / 9; a lone spectrum from degree 6 on takes the same route: +14 ... +29 %); before / after and the two variants not kept in the file'),
     (rn('micro_ab_paired_reciprocals.jsonl'), '`python benchmarks/micro/ab_library.py <library>`, the build before the paired reciprocals and the present one alternately (before, after, before, after) on ONE box', 'round 4, last kernel change: ColeCole<1> / ColeCole<2> / Shin take the denominators of frequencies 2k, 2k+1 from one reciprocal: 4.28 -> 4.62e10 (+8 %), 2.77 -> 2.84e10 (+2 %), 2.73 -> 2.91e10 (+7 %) evals/s in bulk, a cfg5-shaped batch fit 5.43 -> 5.26 us per half-step; Dias (untouched) 3.87 / 3.79e10: the run-to-run spread'),
+    (rn('micro_ab_big_ensemble.txt'), '`rocprofv3 --kernel-trace --stats -- python3 benchmarks/micro/ab_big_ensemble.py <library>` (builds before / after the paired reciprocals), and `run_mcmc`\'s own `timing` before / after the shortcut of `walkers_independent`', 'ensembles of 131,072 - 1,048,576 double Cole-Cole walkers: the one-lane-per-walker half-step kernel keeps two waves per SIMD for four after the pairing and is no slower (34.5 -> 33.7 us on average); the initial-state test (singular values of the (W, ndim) positions) cost more than 200 iterations of sampling: 3.0 -> 0.9 ms at 32,768 walkers, 152 -> 36 ms at a million'),
     (rn('micro_xcd_barrier.txt'), '`benchmarks/micro/xcd_barrier`', 'round 4: a barrier among the workgroups of ONE XCD (0.7-0.9 us for 8-32 workgroups, no fences: the counter and the rows go through that XCD\'s L2 with sc1 loads; 0 stale rows) and what a stretch half-step\'s row exchange costs on top, naive (every lane writes and gathers 72-B rows) and laid out for it (one lane per walker, 64-B rows, 16-B accesses): 1.4 us at 2,048 walkers, 2.1 at 8,192, **6.1 at cfg4\'s 32,768** on one XCD, 5.2-5.9 spread over the chip with write-through rows -- no better than the 6.4 us kernel boundary it would replace: the persistent multi-workgroup sampler was not built (kill criterion of VERDICT r3 #3)'),
     (rn('micro_post_run_stall.txt'), '`python benchmarks/micro/post_run_stall.py kernel`, `upload_cost.py plain`', 'the sporadic 20-30 ms delay of the first device work after a synchronisation early in a process'),
 ]

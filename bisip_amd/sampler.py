@@ -43,10 +43,61 @@ import numpy as np
 from .dist import all_gather_rows, shard_range
 
 
+class _one_blas_thread(object):
+    """The Gram product of a block on ONE thread.  A threaded BLAS wakes its whole pool for a product of a
+    few hundred microseconds and the pool then spins for milliseconds: inside a container's CPU quota that
+    stalls the process (measured: 10 ms in the first device allocation after the product -- the kind of
+    stall utils.respect_cpu_quota describes).  Without threadpoolctl: einsum's own loops, no BLAS."""
+
+    _controller = None      # NumPy's BLAS is mapped long before the first ensemble: looked up once (0.4 ms)
+
+    def __enter__(self):
+        self._ctx = None
+        try:
+            import threadpoolctl
+            if _one_blas_thread._controller is None:
+                _one_blas_thread._controller = threadpoolctl.ThreadpoolController()
+            self._ctx = _one_blas_thread._controller.limit(limits=1, user_api='blas')
+            return lambda b: b.T @ b
+        except (ImportError, AttributeError):      # no threadpoolctl, or one older than its controller class
+            return lambda b: np.einsum('ij,ik->jk', b, b)
+
+    def __exit__(self, *exc):
+        if self._ctx is not None:
+            self._ctx.restore_original_limits()
+        return False
+
+
 def walkers_independent(coords):
     """True when the initial ensemble spans the parameter space (no degenerate
-    directions): condition number of the centred, column-scaled positions <= 1e8."""
+    directions): condition number of the centred, column-scaled positions <= 1e8 (emcee's test).
+
+    The singular values of a (W, ndim) matrix cost more than hundreds of half-steps once W is
+    in the tens of thousands (3 ms at 32,768 walkers, 150 ms at a million: run_mcmc's
+    ``timing['check_s']``).  The columns scaled to unit length have the correlation matrix
+    R = D c^T c D as their Gram matrix and cond = sqrt(lambda_max / lambda_min) of it -- one
+    matrix product.  A Gram matrix squares the condition number, so it DECIDES only where
+    that costs nothing: lambda_min / lambda_max above 1e4 W eps (a condition number below
+    ~1e3 at a million walkers, ~5e3 at 32,768; ensembles drawn in a ball or a box have
+    1-100) is far inside the limit whatever the rounding of the product.  Everything else --
+    near-degenerate, degenerate, non-finite or under/overflowing products -- takes the
+    singular values as before, so the answer is emcee's in every case."""
     coords = np.asarray(coords, dtype=np.float64)
+    if coords.ndim == 2 and coords.shape[0] >= 64 * max(coords.shape[1], 1):
+        with np.errstate(all='ignore'):
+            # block by block (a block stays in cache between its centring and its product); a NaN or an inf
+            # anywhere makes the mean, and with it g, non-finite: no separate pass for them here
+            mean = coords.mean(axis=0)
+            g = np.zeros((coords.shape[1], coords.shape[1]))
+            with _one_blas_thread() as gram:
+                for lo in range(0, coords.shape[0], 16384):
+                    blk = coords[lo:lo + 16384] - mean
+                    g += gram(blk)
+            d = np.sqrt(np.diag(g))
+            if np.all(np.isfinite(g)) and np.all(d > 1e-150):
+                lam = np.linalg.eigvalsh(g / np.outer(d, d))
+                if lam[-1] > 0 and lam[0] / lam[-1] >= max(1e-8, 1e4 * coords.shape[0] * np.finfo(np.float64).eps):
+                    return True
     if not np.all(np.isfinite(coords)):
         return False
     c = coords - coords.mean(axis=0)[None, :]

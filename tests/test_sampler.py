@@ -97,6 +97,62 @@ def test_input_validation():
     assert not walkers_independent(np.zeros((10, 3)))
 
 
+def _walkers_independent_by_singular_values(coords):
+    """emcee's test as it reads (the published algorithm): the yardstick of the shortcut."""
+    coords = np.asarray(coords, dtype=np.float64)
+    if not np.all(np.isfinite(coords)):
+        return False
+    c = coords - coords.mean(axis=0)[None, :]
+    colmax = np.abs(c).max(axis=0)
+    if np.any(colmax == 0):
+        return False
+    c = c / colmax
+    c = c / np.sqrt((c ** 2).sum(axis=0))
+    return bool(np.linalg.cond(c) <= 1e8)
+
+
+def test_walkers_independent_decides_as_the_singular_values_do():
+    """Big ensembles take the condition number from the correlation matrix where that is safe (far inside the
+    limit) and from the singular values elsewhere: the answer is the singular values' in every case -- balls
+    and boxes, columns of very different scale and offset, condition numbers from 1 to 1e12 (both sides of the
+    1e8 limit, and the band the shortcut must hand over), duplicated and constant columns, NaN / inf, columns
+    whose squares under- or overflow."""
+    rng = np.random.RandomState(5)
+    cases = []
+    for W, nd in ((512, 3), (2048, 7), (40000, 7), (70000, 13)):
+        ball = np.array(rng.uniform(-12, 12, nd)) + 1e-4 * rng.randn(W, nd)
+        cases.append(('ball', ball))
+        cases.append(('box', rng.uniform(-1, 1, (W, nd)) * 10.0 ** rng.uniform(-6, 6, nd) + 1e3))
+        for k in (1e1, 1e3, 1e5, 1e7, 3e7, 3e8, 1e10, 1e12):
+            q, _ = np.linalg.qr(rng.randn(nd, nd))
+            x = rng.randn(W, nd) * np.logspace(0, -np.log10(k), nd)
+            cases.append((f'cond {k:g}', x @ q.T + rng.uniform(-5, 5, nd)))
+        dup = rng.randn(W, nd)
+        dup[:, -1] = dup[:, 0]
+        cases.append(('duplicated column', dup))
+        const = rng.randn(W, nd)
+        const[:, 1] = 3.0
+        cases.append(('constant column', const))
+        bad = rng.randn(W, nd)
+        bad[7, 0] = np.nan
+        cases.append(('nan', bad))
+        bad = rng.randn(W, nd)
+        bad[9, 1] = np.inf
+        cases.append(('inf', bad))
+        tiny = rng.randn(W, nd)
+        tiny[:, 0] *= 1e-170
+        cases.append(('squares underflow', tiny))
+        huge = rng.randn(W, nd)
+        huge[:, 0] *= 1e160
+        cases.append(('squares overflow', huge))
+    seen = set()
+    for name, x in cases:
+        want = _walkers_independent_by_singular_values(x)
+        assert walkers_independent(x) == want, (name, x.shape)
+        seen.add(want)
+    assert seen == {True, False}
+
+
 def test_minus_inf_proposals_are_always_rejected():
     """Walkers start inside the box; -inf (out-of-prior) proposals never get accepted."""
     g = np.load([p for p in golden_cases() if 'PeltonColeCole_SIP-K389175' in p][0])
