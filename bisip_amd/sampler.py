@@ -899,7 +899,8 @@ class DeviceEnsembleSampler(_SamplerBase):
                 for e in np.unique(np.linspace(0, self.n_ensembles - 1, 32).astype(int)):
                     if not walkers_independent(p0[e * Wp:(e + 1) * Wp]):
                         raise ValueError(f'Initial state of ensemble {e} has a large condition number.')
-        self._check_coords(p0)
+        if self.live_dangerously or self.n_ensembles > 1:
+            self._check_coords(p0)        # (a single ensemble that passed walkers_independent is finite throughout)
         t1 = time.perf_counter()
         self._upload_state(p0)
         return dict(check_s=t1 - t0, upload_s=time.perf_counter() - t1)
