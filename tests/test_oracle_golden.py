@@ -56,11 +56,11 @@ def test_valley_rows_reference_oracle_and_exact_value(path):
     on the shell logp = 0 the fixtures hold the REAL reference's log-probability and the exact value of its
     formula (50 digits).  (1) The oracle is still the reference, bit for bit.  (2) The host yardstick
     (bisip_polydecomp_reduced_reference: what the reduced kernels are estimated, checked and guarded
-    against) is the exact value to 2e-11 -- except on the worst-conditioned design here (degree 9, 64
-    frequencies, c = 0.5: terms 6e7 times the row sums), where x87 long double itself runs out and it is
-    2e-10 away.  (3) The reference is up to 8e-9 from the exact value on the degree 7-10 designs -- eighty
-    times the parity tolerance, and fifty times further than the yardstick on that worst design -- and
-    within 4e-12 on degree <= 6."""
+    against; operands and evaluation in binary128) is the exact value to 1e-12 on EVERY design here --
+    the tolerance tests/test_gpu_parity.py holds it to -- including the worst-conditioned one (degree 9,
+    64 frequencies, c = 0.5: terms 6e7 times the row sums).  (3) The reference is up to 8e-9 from the
+    exact value on the degree 7-10 designs -- eighty times the parity tolerance -- and within 4e-12 on
+    degree <= 6."""
     from bisip_amd import _hip
     g = np.load(path)
     prob = oracle.OracleProblem.from_golden(g, 'PolynomialDecomposition')
@@ -70,7 +70,7 @@ def test_valley_rows_reference_oracle_and_exact_value(path):
     mine = _hip.polydecomp_reduced_reference(g['w'], g['zn'], g['zn_err'], g['taus'], g['log_taus'], float(g['c_exp']), g['theta'])
     P = int(g['poly_deg'])
     mine_off = float(np.max(np.abs(mine - exact) / scale))
-    assert mine_off <= (3e-10 if P >= 9 and g['w'].size >= 48 else 2e-11)
+    assert mine_off <= 1e-12
     ref_off = float(np.max(np.abs(g['logp'] - exact) / scale))
     assert ref_off <= 4e-12 or mine_off <= ref_off / 20
     print(f'{case_id(path)}: degree {P}: reference {ref_off:.1e}, yardstick {mine_off:.1e} from the exact value')
