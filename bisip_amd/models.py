@@ -178,13 +178,12 @@ class Inversion(_utils.utils):
             raise AssertionError('Model is not fitted! Fit the model to a '
                                  'dataset before attempting to plot results.')
 
-    # ensembles from this size on draw the stretch move's random stream on the device by default
-    # (rng='auto'): the host's sequential MT19937 stream costs ~30 ns per walker-step, which is what a
-    # run waits for beyond a couple of thousand walkers (4096 walkers 16 k vs 44 k
-    # iterations/s, 32768 walkers 1.9 k vs 7.7 k; below ~1000 walkers the two are within 10 %)
+    # from this size on the host's sequential MT19937 stream (~30 ns per walker-step) is what a run waits for
+    # (4096 walkers 16 k vs 44 k iterations/s, 32768 walkers 1.9 k vs 7.7 k; below ~1000 walkers the two
+    # streams are within 10 %): fit() then RECOMMENDS rng='philox' and rng='auto' picks it
     _PHILOX_FROM_WALKERS = 2048
 
-    def fit(self, p0=None, pool=None, moves=None, sampler='device', rng='auto', thin_by=1,
+    def fit(self, p0=None, pool=None, moves=None, sampler='device', rng=None, thin_by=1,
             persistent=None, chain='host'):
         """Sample the posterior with the stretch-move ensemble sampler.
 
@@ -200,15 +199,15 @@ class Inversion(_utils.utils):
             sampler (str): 'device' (default) keeps the ensemble and the chain on the GPU
                 and runs one fused kernel per half-step; 'host' runs the stretch move in
                 NumPy around the vectorised GPU log-probability.  Same chain either way.
-            rng (str): 'numpy' draws the stretch-move random stream on the host in emcee's
-                consumption order from NumPy's global state (``np.random.seed`` pins the run, and the
-                chain is the host sampler's bit for bit); 'philox' generates it on the device: its own
-                reproducible stream (keyed from the seeded global state), and the one for ensembles of
-                thousands of walkers, where drawing NumPy's sequential MT19937 stream on the host
-                (~30 ns per walker-step) is what a run waits for (32768 walkers: 1.9 k vs 7.7 k
-                iterations/s).  'auto' (default): 'numpy' below 2048 walkers, 'philox' from there on,
-                with a UserWarning that names ``rng='numpy'`` for those who need emcee's stream.
-                Device sampler only.
+            rng (str): 'numpy' (default) draws the stretch-move random stream on the host in emcee's
+                consumption order from NumPy's global state: ``np.random.seed`` pins the run as it does in
+                the reference's notebooks, and the chain is the host sampler's bit
+                for bit.  'philox' generates the stream on the device: its own reproducible stream (keyed
+                from the seeded global state), and the faster one for ensembles of thousands of walkers,
+                where drawing MT19937 on the host (~30 ns per walker-step) is what a run waits for (32768
+                walkers: 1.9 k vs 7.7 k iterations/s).  'auto': 'numpy' below 2048 walkers, 'philox' from
+                there on.  Left at its default with 2048 walkers or more, fit() keeps NumPy's stream and
+                says in a UserWarning that rng='philox' is 3-4x faster at that size.  Device sampler only.
             thin_by (int): store one sample every ``thin_by`` iterations.
             chain (str): device sampler: 'host' (default) copies the stored samples to host memory
                 as the run proceeds; 'device' keeps them in HBM -- get_param_mean / get_param_std /
@@ -238,13 +237,15 @@ class Inversion(_utils.utils):
         elif sampler == 'device':
             if chain not in ('host', 'device'):
                 raise ValueError("chain must be 'host' or 'device'")
-            if rng == 'auto':
+            if rng is None:
                 rng = 'numpy'
                 if self.nwalkers >= self._PHILOX_FROM_WALKERS:
-                    rng = 'philox'
-                    warnings.warn(f'{self.nwalkers} walkers: the stretch move draws its random numbers on the '
-                                  "device (rng='philox', 3-4x faster at this size); pass rng='numpy' for the "
-                                  "host stream in emcee's order", UserWarning, stacklevel=2)
+                    warnings.warn(f"{self.nwalkers} walkers: the stretch move's random numbers are drawn on the "
+                                  "host in emcee's order (rng='numpy', the reference's seeding behaviour); "
+                                  "rng='philox' draws them on the device, 3-4x faster at this size",
+                                  UserWarning, stacklevel=2)
+            elif rng == 'auto':
+                rng = 'philox' if self.nwalkers >= self._PHILOX_FROM_WALKERS else 'numpy'
             self._sampler = DeviceEnsembleSampler(self.nwalkers, self.ndim, ctx, rng=rng,
                                                   persistent=persistent, chain_on_device=(chain == 'device'))
         elif sampler == 'host':
