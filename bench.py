@@ -85,7 +85,11 @@ def load_json(name):
 # The PMC counters this file replays (profiles/pmc_traffic.json, valu_counts.json) were collected from a
 # particular build of the log-probability kernels: the files carry the SHA-256 of these sources as they were
 # on the GPU box, and a line printed from other sources reports the counters as stale instead of quoting them.
-KERNEL_SOURCES = ('bisip_amd/csrc/kernels.h', 'bisip_amd/csrc/sampler_kernels.h', 'bisip_amd/csrc/dispatch_logprob.hip')
+# (everything that decides WHICH kernel runs or what it compiles to: the kernels, their dispatch, the host's
+# loop / tier choices and constants, the compiler flags)
+KERNEL_SOURCES = ('bisip_amd/csrc/kernels.h', 'bisip_amd/csrc/sampler_kernels.h', 'bisip_amd/csrc/dispatch_logprob.hip',
+                  'bisip_amd/csrc/bisip_hip.hip', 'bisip_amd/csrc/host.h', 'bisip_amd/csrc/philox.h',
+                  'bisip_amd/csrc/stretch_launch.h', 'bisip_amd/csrc/Makefile')
 
 
 def kernel_sources_sha256():

@@ -7,6 +7,7 @@
 #include <sched.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstddef>
 #include <cstdio>
@@ -529,11 +530,21 @@ int candidates(int n, const std::vector<ld> &bhat_ls, const double *lo, const do
 
 }  // namespace
 
+// BISIP_SHELL_WEIGHT (a test hook: tests force an estimate to pass with 0) changes which reduced tier AUTO
+// selects, so an override is never silent: it is validated ([0, 1], else ignored) and announced on stderr once
+// per process.  Read on every (re)estimate; BISIP_HOST_SCALAR_ESTIMATE (have_avx2) is latched on first use.
 double reduced_shell_weight()
 {
     const char *s = std::getenv("BISIP_SHELL_WEIGHT");
-    const double w = s ? std::atof(s) : 0.05;
-    return w >= 0.0 && w <= 1.0 ? w : 0.05;
+    if (!s) return 0.05;
+    char *end = nullptr;
+    const double w = std::strtod(s, &end);
+    const bool ok = end != s && w >= 0.0 && w <= 1.0;
+    static std::atomic<bool> said{false};
+    if (!said.exchange(true))
+        std::fprintf(stderr, "bisip: BISIP_SHELL_WEIGHT=%s %s (default 0.05): the error estimate behind BISIP_VARIANT_AUTO "
+                             "weighs shell probes differently -- a test / measurement hook\n", s, ok ? "overrides the shell-probe weight" : "ignored");
+    return ok ? w : 0.05;
 }
 
 void reduced_probes(const ReducedProblem &p, const double *lo, const double *hi, ReducedProbes &out)

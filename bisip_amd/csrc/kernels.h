@@ -39,9 +39,9 @@ struct Bounds {
 };
 constexpr int BOUNDS_FAST = 1;
 // BOUNDS_GRID (only together with BOUNDS_FAST): the frequencies of at least one spectrum of the context lie on a
-// geometric grid, ln w_{8k+q} = ln w_{8k} + q * dlnw to 4e-15 (grid_step in host_precompute.cpp; rec[7] of
+// geometric grid, ln w_{16k+q} = ln w_{16k} + q * dlnw (q < 16) to 4e-15 (grid_step in host_precompute.cpp; rec[7] of
 // every record of a spectrum holds ITS dlnw, 0 for a spectrum on no grid: logprob_row looks there).  The exponentials of the per-frequency models are then taken once per block of
-// eight frequencies and stepped by multiplication (GridSteps below).
+// GRID_BLOCK = 16 frequencies and stepped by multiplication (GridSteps below).
 constexpr int BOUNDS_GRID = 2;
 constexpr int GRID_MAX_TERMS = 3;     // ColeCole with up to three modes, Shin (two elements)
 // The safe loop clamps the exponent y of 2^y = |(i w tau)^c| (ColeCole) or Q w^n (Shin) at 500: beyond,
@@ -666,7 +666,7 @@ struct Dias {
     // term is positive: nothing cancels.
     static constexpr bool HAS_FAST = true;
     static constexpr bool HAS_GRID = false;
-    // FAST (bound_flags: everywhere in the box D lies in [1e-145, 1e145]): the reciprocals of frequencies 2k and
+    // FAST (bound_flags: everywhere in the box D lies in [1e-140, 1e140]): the reciprocals of frequencies 2k and
     // 2k+1 come from ONE reciprocal of D_2k D_2k+1 (v_rcp_f64 issues at a quarter of the FMA rate).  The pairs
     // are (2k, 2k+1) in every kernel, a last unpaired frequency takes its own reciprocal: a walker's value does
     // not depend on which kernel evaluated it.

@@ -47,24 +47,39 @@ class _one_blas_thread(object):
     """The Gram product of a block on ONE thread.  A threaded BLAS wakes its whole pool for a product of a
     few hundred microseconds and the pool then spins for milliseconds: inside a container's CPU quota that
     stalls the process (measured: 10 ms in the first device allocation after the product -- the kind of
-    stall utils.respect_cpu_quota describes).  Without threadpoolctl: einsum's own loops, no BLAS."""
+    stall utils.respect_cpu_quota describes).  Without threadpoolctl (or when it fails in any way): einsum's
+    own loops, no BLAS.  The limit is process-wide while it holds, so entries are serialised by a lock (the
+    restore of one thread must not undo the limit of another), and the controller is rebuilt when libraries
+    were loaded since it was made (a BLAS / OpenMP runtime that arrived later -- torch's -- is then limited too)."""
 
+    _lock = None
     _controller = None      # NumPy's BLAS is mapped long before the first ensemble: looked up once (0.4 ms)
+    _n_libs = -1
 
     def __enter__(self):
+        import threading
+        cls = _one_blas_thread
+        if cls._lock is None:
+            cls._lock = threading.Lock()
         self._ctx = None
+        cls._lock.acquire()
         try:
+            import sys
             import threadpoolctl
-            if _one_blas_thread._controller is None:
-                _one_blas_thread._controller = threadpoolctl.ThreadpoolController()
-            self._ctx = _one_blas_thread._controller.limit(limits=1, user_api='blas')
+            n_libs = len(sys.modules)          # a cheap proxy for "something new may have been mapped"
+            if cls._controller is None or n_libs != cls._n_libs:
+                cls._controller, cls._n_libs = threadpoolctl.ThreadpoolController(), n_libs
+            self._ctx = cls._controller.limit(limits=1, user_api='blas')
             return lambda b: b.T @ b
-        except (ImportError, AttributeError):      # no threadpoolctl, or one older than its controller class
+        except Exception:                      # no threadpoolctl, one older than its controller class, a library it cannot read
             return lambda b: np.einsum('ij,ik->jk', b, b)
 
     def __exit__(self, *exc):
-        if self._ctx is not None:
-            self._ctx.restore_original_limits()
+        try:
+            if self._ctx is not None:
+                self._ctx.restore_original_limits()
+        finally:
+            _one_blas_thread._lock.release()
         return False
 
 
@@ -81,7 +96,12 @@ def walkers_independent(coords):
     ~1e3 at a million walkers, ~5e3 at 32,768; ensembles drawn in a ball or a box have
     1-100) is far inside the limit whatever the rounding of the product.  Everything else --
     near-degenerate, degenerate, non-finite or under/overflowing products -- takes the
-    singular values as before, so the answer is emcee's in every case."""
+    singular values as before, so the answer is emcee's in every case.
+
+    INVARIANT callers rely on (DeviceEnsembleSampler._start_from uploads without a second finiteness pass):
+    True implies every coordinate is finite -- a NaN or an inf makes the mean, hence the Gram matrix,
+    non-finite, which sends the decision to the slow branch and its isfinite test
+    (tests/test_gpu_sampler.py::test_non_finite_start_of_a_big_ensemble_is_refused)."""
     coords = np.asarray(coords, dtype=np.float64)
     if coords.ndim == 2 and coords.shape[0] >= 64 * max(coords.shape[1], 1):
         with np.errstate(all='ignore'):

@@ -396,7 +396,7 @@ int bisip_ctx_device(const bisip_ctx *ctx);
  *      denominators -- and a last unpaired frequency its own; ColeCole with three modes and more: one per group
  *      of up to four of a frequency's denominators);
  *   2  (only with 1; ColeCole up to three modes, Shin) geometric frequency grid: SOME spectrum's
- *      ln w_{8k+q} = ln w_{8k} + q*step to 4e-15 (bisip_frequency_grid_step), and every spectrum that is on
+ *      ln w_{16k+q} = ln w_{16k} + q*step (q < 16) to 4e-15 (bisip_frequency_grid_step), and every spectrum that is on
  *      such a grid takes its exponentials once per block of sixteen frequencies and steps them by multiplication
  *      (a batch decides per spectrum).  The environment variable BISIP_NO_GRID, read when a context is
  *      created, switches bit 2 off (measurement aid).

@@ -163,6 +163,30 @@ def test_out_of_prior_start_and_nan_detection():
     ctx.close()
 
 
+def test_non_finite_start_of_a_big_ensemble_is_refused():
+    """A big single ensemble is uploaded without a second finiteness pass: _start_from relies on
+    walkers_independent() returning False for any NaN / inf (its fast Gram-matrix branch cannot say True for
+    them).  Through run_mcmc, 32,768 walkers: one NaN and one inf each raise before anything reaches the device."""
+    from bisip_amd.sampler import DeviceEnsembleSampler, walkers_independent
+    g = np.load(_case('case15_'))
+    ctx = make_ctx(g, 'PeltonColeCole')
+    W = 32768
+    p0 = _start(g, W, 3)
+    assert walkers_independent(p0)
+    np.random.seed(4)
+    s = DeviceEnsembleSampler(W, 4, ctx, rng='philox', seed=1)
+    for poison in (np.nan, np.inf, -np.inf):
+        bad = p0.copy()
+        bad[W // 2 + 5, 2] = poison
+        assert not walkers_independent(bad)
+        with pytest.raises(ValueError):
+            s.run_mcmc(bad, 2)
+        assert s._dev is None or np.isfinite(s._dev['coords'].cpu().numpy()).all()
+    s.run_mcmc(p0, 2)                                        # and a finite start still runs
+    assert np.isfinite(s.get_chain()).all()
+    ctx.close()
+
+
 def test_nan_in_the_initial_log_probability_raises_before_the_run():
     """emcee raises 'Probability function returned NaN' for the initial state before it samples.  The
     device sampler computes and checks the initial log-probabilities on the device without a host
