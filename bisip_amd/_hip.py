@@ -135,6 +135,11 @@ SYMBOLS = {
     'bisip_ctx_reduced_guard': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int64),
                                                _dp, ctypes.POINTER(ctypes.c_int)]),
     'bisip_clock_probe_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p]),
+    'bisip_ctx_reduced_guard_rows': (ctypes.c_int, [ctypes.c_void_p, _dp, ctypes.c_int64, _dp, _dp, ctypes.POINTER(ctypes.c_int)]),
+    'bisip_chain_shell_rows_workspace': (ctypes.c_int64, [ctypes.c_int64]),
+    'bisip_chain_shell_rows_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                                  ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                                  ctypes.c_void_p, ctypes.c_void_p]),
     'bisip_polydecomp_reduced_reference': (ctypes.c_int, [ctypes.c_int, _dp, _dp, _dp, ctypes.POINTER(ModelDesc),
                                                           _dp, ctypes.c_int64, _dp]),
     'bisip_abi_version': (ctypes.c_int, []),
@@ -322,6 +327,7 @@ class HipContext:
         # bisip_logprob's guard of the QR-reduced kernels (see logprob)
         self._guarded = self.model_id == MODEL_POLYDECOMP
         self._calls, self._escalations_seen, self._guard_warned, self._forced = 0, 0, False, False
+        self._guard_enabled = True
         if variant != 'auto':
             self.set_variant(variant)
 
@@ -424,6 +430,29 @@ class HipContext:
         _check(self._lib.bisip_ctx_reduced_check(self._h, _p(theta), theta.shape[0], _p(logp), _p(out)))
         return float(out[0])
 
+    def reduced_guard_rows(self, theta, logp):
+        """The guard for rows that came from the DEVICE (bisip_ctx_reduced_guard_rows): measure the
+        log-probabilities the context's QR-reduced kernel gave ``theta`` as ``reduced_check`` does and, past
+        2e-11 on a context that chose its formulation itself ('auto'), move the context to the next
+        formulation.  Returns ``(worst relative error, escalated)``; after an escalation every
+        log-probability the caller holds is stale (the device sampler re-runs its chunk).  Rows with a NaN
+        (unfilled slots of chain_shell_rows_dev) and rows outside the prior are skipped."""
+        theta = self._theta2d(theta)
+        logp = _c(logp).ravel()
+        if logp.size != theta.shape[0]:
+            raise ValueError('one log-probability per row of theta')
+        worst, esc = np.empty(1), ctypes.c_int(0)
+        _check(self._lib.bisip_ctx_reduced_guard_rows(self._h, _p(theta), theta.shape[0], _p(logp), _p(worst),
+                                                      ctypes.byref(esc)))
+        return float(worst[0]), bool(esc.value)
+
+    @property
+    def guards_itself(self):
+        """True for a PolynomialDecomposition context that CHOSE a QR-reduced kernel from its estimate
+        ('auto'): the formulation the device sampler measures on its own rows and may move."""
+        return (self.model_id == MODEL_POLYDECOMP and not self._forced and self.variant in ('reduced', 'reduced_comp')
+                and self._guard_enabled)
+
     @property
     def loglike_const(self):
         return float(self._lib.bisip_ctx_loglike_const(self._h))
@@ -455,6 +484,8 @@ class HipContext:
         """(checks made, worst relative error seen, formulation changes) of the guard bisip_logprob runs
         on the QR-reduced kernels; ``enable`` True / False switches it on / off."""
         n, w, e = ctypes.c_int64(0), ctypes.c_double(0.0), ctypes.c_int(0)
+        if enable is not None:
+            self._guard_enabled = bool(enable)
         _check(self._lib.bisip_ctx_reduced_guard(self._h, -1 if enable is None else int(bool(enable)),
                                                  ctypes.byref(n), ctypes.cast(ctypes.byref(w), _dp), ctypes.byref(e)))
         return int(n.value), float(w.value), int(e.value)
@@ -609,6 +640,21 @@ def chain_moments_dev(d_chain_ptr, n_samples, sample_stride, n_ensembles, walker
     _check(load_library().bisip_chain_moments_dev(d_chain_ptr, n_samples, sample_stride, n_ensembles,
                                                   walkers_per_ensemble, ndim, d_mean_ptr, d_std_ptr,
                                                   d_work_ptr, stream))
+
+
+def chain_shell_rows_workspace(n_ensembles):
+    """Bytes of device scratch chain_shell_rows_dev needs."""
+    return int(load_library().bisip_chain_shell_rows_workspace(int(n_ensembles)))
+
+
+def chain_shell_rows_dev(d_chain_ptr, d_logp_ptr, n_samples, n_ensembles, walkers_per_ensemble, ndim, k, n_stride,
+                         d_out_ptr, d_work_ptr, stream=0, ties=True):
+    """Per ensemble the k stored samples of smallest |logp| (+ n_stride walkers of the first sample) into
+    d_out (n_ensembles, k + n_stride, ndim + 1); device pointers (ints), asynchronous on ``stream``.
+    ``ties=False`` leaves out the samples that tie with the k-th (a reproducible set)."""
+    _check(load_library().bisip_chain_shell_rows_dev(d_chain_ptr, d_logp_ptr, int(n_samples), int(n_ensembles),
+                                                     int(walkers_per_ensemble), int(ndim), int(k), int(n_stride),
+                                                     int(bool(ties)), d_out_ptr, d_work_ptr, stream))
 
 
 def chain_percentiles_workspace(n_samples, n_ensembles, walkers_per_ensemble, ndim, n_percentiles):

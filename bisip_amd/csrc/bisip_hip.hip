@@ -39,8 +39,8 @@ int effective_variant(const bisip_ctx *c)
     // else the compensated kernel under the same test (ill-conditioned designs: high degree,
     // small exponent), else the per-frequency form, which mirrors the reference's sums
     if (2 * c->N < c->P + 2) return BISIP_VARIANT_COLLAPSED;
-    if (c->red[0].err <= BISIP_REDUCED_ERR_MAX && !c->demoted[0]) return BISIP_VARIANT_REDUCED;
-    if (c->red[1].err <= BISIP_REDUCED_ERR_MAX && !c->demoted[1]) return BISIP_VARIANT_REDUCED_COMP;
+    if (c->red[0].err <= c->auto_err_max && !c->demoted[0]) return BISIP_VARIANT_REDUCED;
+    if (c->red[1].err <= c->auto_err_max && !c->demoted[1]) return BISIP_VARIANT_REDUCED_COMP;
     return BISIP_VARIANT_COLLAPSED;
 }
 
@@ -134,6 +134,21 @@ const char *name_for(const bisip_ctx *c)
 // squared magnitude would overflow).
 static_assert(bisip::HOST_GRID_BLOCK == bisip::GRID_BLOCK, "the host's grid check and the kernels' stepped loops use one block length");
 
+// The estimate below which BISIP_VARIANT_AUTO keeps a QR-reduced tier.  BISIP_AUTO_ERR_MAX (a test hook, read
+// when a context is created: tests let a tier's estimate "pass" on a design where it would not, to see the
+// guards catch it) overrides the 1e-12; validated ((0, 1]) and announced on stderr, never silent.
+static double auto_err_max_from_env()
+{
+    const char *s = std::getenv("BISIP_AUTO_ERR_MAX");
+    if (!s) return BISIP_REDUCED_ERR_MAX;
+    char *end = nullptr;
+    const double v = std::strtod(s, &end);
+    const bool ok = end != s && v > 0.0 && v <= 1.0;
+    std::fprintf(stderr, "bisip: BISIP_AUTO_ERR_MAX=%s %s (default %.0e): BISIP_VARIANT_AUTO keeps a QR-reduced tier below "
+                         "this ESTIMATE -- a test hook\n", s, ok ? "overrides the threshold" : "ignored", BISIP_REDUCED_ERR_MAX);
+    return ok ? v : BISIP_REDUCED_ERR_MAX;
+}
+
 static int bound_flags(const bisip_ctx *c)
 {
     constexpr double LOG2E = 1.4426950408889634, YMAX = 110.0;
@@ -209,7 +224,7 @@ static int update_tiers(bisip_ctx *c)
     c->tier_of.assign(E, 1);
     size_t plain = 0;
     for (size_t e = 0; e < E; ++e)
-        if (c->red[0].est[e] <= BISIP_REDUCED_ERR_MAX) { c->tier_of[e] = 0; ++plain; }
+        if (c->red[0].est[e] <= c->auto_err_max) { c->tier_of[e] = 0; ++plain; }
     if (plain == 0) return BISIP_OK;
     HIP_TRY(hipSetDevice(c->device));
     if (!c->d_tier) HIP_TRY(hipMalloc((void **)&c->d_tier, E));
@@ -226,7 +241,7 @@ static bool needs_comp(const bisip_ctx *c, size_t e)
     if (c->variant == BISIP_VARIANT_REDUCED_COMP) return true;
     if (c->variant != BISIP_VARIANT_AUTO) return false;
     if (c->demoted[0] || c->mix_off) return true;
-    return c->red[0].done.size() > e && c->red[0].done[e] && !(c->red[0].est[e] <= BISIP_REDUCED_ERR_MAX);
+    return c->red[0].done.size() > e && c->red[0].done[e] && !(c->red[0].est[e] <= c->auto_err_max);
 }
 
 // binary128 operands of the spectra in `need` that lack them: the kernel sums once per distinct frequency list
@@ -560,6 +575,7 @@ static int build_context(bisip_ctx **out, int device, int model_id, int E, int N
     if (!c) return fail(BISIP_ENOMEM, "out of host memory");
     c->device = device; c->model_id = model_id; c->N = N; c->ndim = ndim; c->E = E;
     c->P = P; c->D = D; c->S = S;
+    if (model_id == BISIP_MODEL_POLYDECOMP) c->auto_err_max = auto_err_max_from_env();
     for (int q = 0; q < MAXD; ++q) { c->bounds.lo[q] = 0.0; c->bounds.hi[q] = 0.0; }
     for (int q = 0; q < ndim; ++q) { c->bounds.lo[q] = lo[q]; c->bounds.hi[q] = hi[q]; }
     c->lnw_min = INFINITY; c->lnw_max = -INFINITY;
@@ -1112,16 +1128,30 @@ void bisip_philox4x32(const uint32_t *counter, const uint32_t *key, uint32_t *ou
 
 static int logprob_host_once(bisip_ctx *c, const double *theta, int64_t W, double *logp);
 
+// a measured tier past this (a fifth of the parity tolerance) is closed to BISIP_VARIANT_AUTO
+constexpr double GUARD_TOL = 2e-11;
+
+// Close the tier a context on BISIP_VARIANT_AUTO runs (it was just MEASURED past GUARD_TOL) and move to the next
+// formulation: a mixed batch first to "every spectrum compensated", else plain -> compensated -> per-frequency.
+// The choice holds until the prior box changes (bisip_ctx_set_bounds).
+static int guard_escalate(bisip_ctx *c, int v)
+{
+    if (v == BISIP_VARIANT_REDUCED_COMP && c->mixed) c->mix_off = true;   // first every spectrum compensated
+    else c->demoted[v == BISIP_VARIANT_REDUCED ? 0 : 1] = true;
+    ++c->guard_escalations;
+    const int rc = guarded([&] { return recenter_reduced(c); });    // the next tier may not have been estimated yet
+    c->kernel_name = name_for(c);
+    return rc;
+}
+
 // The QR-reduced kernels were chosen from an error ESTIMATE on probe rows (recenter_reduced); here the
 // kernel that just ran is MEASURED on up to 256 rows of the caller's own batch against the reduced form
 // in long double -- on the first call of a context and on every 2^n-th after it, so a long emcee run pays
-// a few dozen checks of ~50 us.  Past GUARD_TOL (a fifth of the parity tolerance) a context on
-// BISIP_VARIANT_AUTO closes that tier, moves to the next formulation (compensated, then per-frequency),
-// and the batch is evaluated again with it; a caller-forced variant is only recorded
-// (bisip_ctx_reduced_guard reports both).
+// a few dozen checks of ~50 us.  Past GUARD_TOL a context on BISIP_VARIANT_AUTO closes that tier, moves to the
+// next formulation (compensated, then per-frequency), and the batch is evaluated again with it; a
+// caller-forced variant is only recorded (bisip_ctx_reduced_guard reports both).
 static int guard_after_logprob(bisip_ctx *c, const double *theta, int64_t W, double *logp)
 {
-    constexpr double GUARD_TOL = 2e-11;
     if (!c->guard_on || c->model_id != BISIP_MODEL_POLYDECOMP || c->reduced.empty()) return BISIP_OK;
     if (c->E > 1 && W % c->E) return BISIP_OK;
     const int64_t call = ++c->guard_calls;
@@ -1134,15 +1164,38 @@ static int guard_after_logprob(bisip_ctx *c, const double *theta, int64_t W, dou
         ++c->guard_checks;
         if (!(worst <= c->guard_worst)) c->guard_worst = worst;
         if (worst <= GUARD_TOL || c->variant != BISIP_VARIANT_AUTO) return BISIP_OK;
-        if (v == BISIP_VARIANT_REDUCED_COMP && c->mixed) c->mix_off = true;   // first every spectrum compensated
-        else c->demoted[v == BISIP_VARIANT_REDUCED ? 0 : 1] = true;
-        ++c->guard_escalations;
-        int rc = guarded([&] { return recenter_reduced(c); });    // the next tier may not have been estimated yet
+        int rc = guard_escalate(c, v);
         if (rc != BISIP_OK) return rc;
-        c->kernel_name = name_for(c);
         rc = logprob_host_once(c, theta, W, logp);
         if (rc != BISIP_OK) return rc;
     }
+    return BISIP_OK;
+}
+
+// The same measurement for callers that hold their rows on the device and bring a few of them to the host: the
+// device sampler's own guard (rows of the initial ensemble and, chunk by chunk, the stored samples nearest to
+// the shell logp = 0; bisip_chain_shell_rows_dev picks them).  Does not evaluate anything: the caller re-runs.
+int bisip_ctx_reduced_guard_rows(bisip_ctx *c, const double *theta, int64_t W, const double *logp, double *worst_rel,
+                                 int *escalated)
+{
+    if (!c || !worst_rel || !escalated || (W > 0 && (!theta || !logp))) return fail(BISIP_EINVAL, "null argument");
+    *worst_rel = 0.0;
+    *escalated = 0;
+    if (c->model_id != BISIP_MODEL_POLYDECOMP || c->reduced.empty())
+        return fail(BISIP_EUNSUPPORTED, "only PolynomialDecomposition contexts have a QR-reduced form");
+    if (W < 0 || (c->E > 1 && W % c->E)) return fail(BISIP_EINVAL, "W=%lld is not a multiple of the %d spectra", (long long)W, c->E);
+    const int v = effective_variant(c);
+    if (v != BISIP_VARIANT_REDUCED && v != BISIP_VARIANT_REDUCED_COMP) return BISIP_OK;      // nothing estimated runs
+    double worst = 0.0;
+    int rc = bisip_ctx_reduced_check(c, theta, W, logp, &worst);
+    if (rc != BISIP_OK) return rc;
+    ++c->guard_checks;
+    if (!(worst <= c->guard_worst)) c->guard_worst = worst;
+    *worst_rel = worst;
+    if (worst <= GUARD_TOL || c->variant != BISIP_VARIANT_AUTO || !c->guard_on) return BISIP_OK;
+    rc = guard_escalate(c, v);
+    if (rc != BISIP_OK) return rc;
+    *escalated = 1;
     return BISIP_OK;
 }
 

@@ -53,6 +53,7 @@ struct bisip_ctx {
     int device = 0, model_id = 0, N = 0, ndim = 0, variant = BISIP_VARIANT_AUTO;
     int P = 0, D = 0, S = 0;
     double c_exp = 1.0, lconst = 0.0;
+    double auto_err_max = bisip::host::BISIP_REDUCED_ERR_MAX;   // AUTO keeps a QR-reduced tier whose estimate is below this
     bisip::Bounds bounds{};
     double lnw_min = 0.0, lnw_max = 0.0;   // over every frequency of every spectrum (bound_flags)
     bool grid_ok = false;                  // some spectrum's frequencies lie on a geometric grid (grid_step; BOUNDS_GRID; the loop is chosen per spectrum)

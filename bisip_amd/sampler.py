@@ -513,27 +513,42 @@ class HipStretchBackend:
         torch = self.torch
         status_t.bitwise_or_(torch.isnan(logp_t).any().to(torch.int32) * 2)
 
-    def snapshot(self, dev_t):
+    def snapshot(self, dev_t, slot='snapshot', frozen=True):
         """Start a device->host copy of a small tensor AS IT IS NOW (ordered after the work queued so
         far, on a side stream, so work queued later does not delay it).  Returns (pinned host tensor,
-        event of the copy's completion)."""
+        event of the copy's completion).  ``slot`` names the pinned block (two snapshots that are alive
+        together use different slots); ``frozen=False``: nothing queued later writes dev_t, no copy of it."""
         torch = self.torch
         if not hasattr(self, '_copy_stream'):
             self._copy_stream = torch.cuda.Stream(self.device)
-        frozen = dev_t.clone()                   # on the compute stream, before anything later touches dev_t
+        src = dev_t.clone() if frozen else dev_t  # on the compute stream, before anything later touches dev_t
         ev2 = torch.cuda.Event()
         ev2.record(torch.cuda.current_stream(self.device))
         # pinned memory that outlives the sampler (pinning costs more than a short run); a previous
         # snapshot's copy has long been waited for by the run that asked for it
         nbytes = dev_t.numel() * dev_t.element_size()
-        host = _pinned_scratch(self._key + 'snapshot', nbytes)[:nbytes].view(dev_t.dtype).view(dev_t.shape)
+        host = _pinned_scratch(self._key + slot, nbytes)[:nbytes].view(dev_t.dtype).view(dev_t.shape)
         self._copy_stream.wait_event(ev2)
         with torch.cuda.stream(self._copy_stream):
-            host.copy_(frozen, non_blocking=True)
+            host.copy_(src, non_blocking=True)
             done = torch.cuda.Event()
             done.record(self._copy_stream)
-        frozen.record_stream(self._copy_stream)
+        src.record_stream(self._copy_stream)
         return host, done
+
+    def shell_rows(self, chain_t, logp_t, n_samples, n_ensembles, walkers_per_ensemble, k, n_stride=0, ties=True,
+                   slot='guard'):
+        """Per ensemble the k stored samples of smallest |logp| of a chain slab (``bisip_chain_shell_rows_dev``,
+        + n_stride walkers of the first sample), selected on the device behind the work queued so far; their
+        copy to the host starts at once.  Returns (pinned host tensor (E, k + n_stride, ndim + 1), event)."""
+        from . import _hip
+        torch = self.torch
+        ndim = int(chain_t.shape[-1])
+        out = torch.empty((n_ensembles, k + n_stride, ndim + 1), dtype=torch.float64, device=self.device)
+        work = torch.empty((_hip.chain_shell_rows_workspace(n_ensembles),), dtype=torch.uint8, device=self.device)
+        _hip.chain_shell_rows_dev(chain_t.data_ptr(), logp_t.data_ptr(), n_samples, n_ensembles, walkers_per_ensemble,
+                                  ndim, k, n_stride, out.data_ptr(), work.data_ptr(), self.stream(), ties=ties)
+        return self.snapshot(out, slot=slot, frozen=False)
 
     def empty(self, shape, dtype):
         return self.torch.empty(shape, dtype=dtype, device=self.device)
@@ -746,6 +761,19 @@ class DeviceEnsembleSampler(_SamplerBase):
     ``bisip_amd._hip.HipContext``; ``backend`` is injectable so the multi-rank driver
     logic can be exercised on CPU (tests/test_dist.py).
     ``chunk`` bounds the number of steps whose RNG stream / chain slab are resident at once.
+
+    **No chunk is kept that a failing tier produced.**  PolynomialDecomposition samples with a QR-reduced
+    kernel that BISIP_VARIANT_AUTO chose from an error estimate on probe rows.  The launches here hand over
+    device pointers and never synchronise, so the library cannot measure them itself; the sampler does: rows
+    of the initial ensemble (the samples nearest to the shell logp = 0 and a stride across it) and, chunk by
+    chunk, the stored samples nearest to the shell (``bisip_chain_shell_rows_dev``: selected where the chain
+    lies, 256 rows per check) are measured against the host's binary128 / long-double yardstick while the NEXT
+    chunk runs (``bisip_ctx_reduced_guard_rows``).  Past 2e-11 the context moves to the next formulation
+    (compensated, then per-frequency), the chunk's initial state -- saved on the device -- comes back, its
+    log-probabilities are evaluated again and the chunk re-runs on the same random stream (counter-based, or
+    re-drawn from the saved generator state); what was queued behind it is discarded.  ``guard_`` reports
+    checks, rows, worst accepted error, escalations and re-runs.  A caller-forced variant is not moved
+    (``Inversion.fit`` measures it after the run and warns).
     """
 
     def __init__(self, nwalkers, ndim, ctx=None, a=2.0, live_dangerously=False, group=None,
@@ -877,9 +905,55 @@ class DeviceEnsembleSampler(_SamplerBase):
             # as in emcee, at the price of one wait that the chunk's kernels overlap
             if hasattr(be, 'snapshot'):
                 dev['status0'] = be.snapshot(dev['status'])
+            # the guard's first rows: the initial ensemble's samples nearest to the shell and a stride across it
+            guard = self._guard_plan()
+            if guard is not None:
+                Wp = self.walkers_per_ensemble
+                near = min(Wp, max(1, 3 * guard['k'] // 4))
+                dev['guard0'] = be.shell_rows(dev['coords'], dev['logp'], 1, self.n_ensembles, Wp, near,
+                                              n_stride=min(Wp, guard['k'] - near), ties=guard['ties'], slot='guard_init')
         else:
             dev['logp'] = be.tensor(lp, torch.float64, slot='b')
         self._dev = dev
+
+    def _guard_plan(self):
+        """How this run measures the kernel it samples with, or None when there is nothing to measure: only a
+        PolynomialDecomposition context that chose a QR-reduced kernel from its estimate ('auto') is guarded
+        (HipContext.guards_itself).  ``k`` rows per ensemble and check: 256 for one ensemble, fewer per spectrum
+        of a batch (4096 rows in all, at least 4 each).  Several ranks: ties are left out of the selection, so
+        that every rank measures the same rows and takes the same decision without a collective."""
+        be = self.backend
+        ctx = getattr(be, 'ctx', None)
+        if ctx is None or not hasattr(be, 'shell_rows') or not getattr(ctx, 'guards_itself', False):
+            return None
+        return dict(k=int(max(4, min(256, 4096 // self.n_ensembles))), ties=self._world == 1)
+
+    def _guard_passes(self, rec):
+        """Measure the rows selected from chunk rec['k'] (and, with chunk 0, from the initial ensemble) against
+        the host's yardstick (bisip_ctx_reduced_guard_rows).  False: the context has just left the tier that
+        produced them -- the chunk is to be run again."""
+        import time
+        t0 = time.perf_counter()
+        ctx = self.backend.ctx
+        E, ndim = self.n_ensembles, self.ndim
+        parts = []
+        for host, ev in rec['rows']:
+            ev.synchronize()
+            parts.append(host.numpy().reshape(E, -1, ndim + 1))
+        rows = (np.concatenate(parts, axis=1) if len(parts) > 1 else parts[0]).reshape(-1, ndim + 1)
+        theta, lp = np.ascontiguousarray(rows[:, :ndim]), np.ascontiguousarray(rows[:, ndim])
+        worst, escalated = ctx.reduced_guard_rows(theta, lp)
+        g = self.guard_
+        g['checks'] += 1
+        g['rows'] += int(np.isfinite(lp).sum())
+        if escalated:
+            g['escalations'] += 1
+            g['rejected'] = max(g.get('rejected', 0.0), worst) if worst == worst else float('nan')
+            g['kernel'] = ctx.kernel_name
+        elif not worst <= g['worst']:
+            g['worst'] = worst
+        self.timing['guard_s'] = self.timing.get('guard_s', 0.0) + time.perf_counter() - t0
+        return not escalated
 
     def _chunk_steps(self, nsteps):
         if self.chunk:
@@ -932,6 +1006,7 @@ class DeviceEnsembleSampler(_SamplerBase):
         worker thread for every chunk but the first (the C generator and NumPy's log release the
         GIL), so chunk k+1 is drawn while the main thread enqueues chunk k's kernels."""
         from ._hip import numpy_stretch_stream
+        state0 = self._random.get_state()         # a chunk the guard sends back is drawn again from here
         stage = self.backend.stream_staging(n, nh, slot)
         _, _, zz, u = numpy_stretch_stream(
             self._random, self.nwalkers, self.a, n,
@@ -941,7 +1016,7 @@ class DeviceEnsembleSampler(_SamplerBase):
             np.log(zz, out=factor)
             factor *= self.ndim - 1.0
             np.log(u, out=u)             # 'logu' staging held u
-        return stage
+        return stage, state0
 
     def _advance(self, st, n, nh, it0):
         """Enqueue the n iterations of a chunk: persistent kernel, fused launches, or (several
@@ -1012,101 +1087,160 @@ class DeviceEnsembleSampler(_SamplerBase):
         # where a run spends its time
         self.timing = dict(setup_s=time.perf_counter() - t_start, stream_s=0.0, enqueue_s=0.0, alloc_s=0.0,
                            drain_s=0.0, finish_s=0.0, **setup_detail)
-        done = 0                                 # stored samples so far
-        it0 = self._iterations_run
+        it_start = self._iterations_run
         # stored samples per chunk, known up front so that the next chunk's stream can be drawn ahead
         sizes, left = [], nsteps
         while left > 0:
             sizes.append(min(max(1, self._chunk_steps(nsteps * thin_by) // thin_by), left))
             left -= sizes[-1]
+        first_sample = [0]                       # stored samples before chunk k
+        for ns in sizes:
+            first_sample.append(first_sample[-1] + ns)
         ahead = None                             # (worker thread, its result holder) for the next chunk
         rng_state0 = self._random.get_state() if self.rng == 'numpy' else None
         nan_initial = False
-        try:
-            for k, ns in enumerate(sizes):
-                t_a = time.perf_counter()
-                n = ns * thin_by                     # iterations in this chunk
-                st = dict(self._dev)
-                st['nh'] = nh
-                st['thin'] = thin_by
-                if self.n_ensembles > 1:
-                    st['wp'] = self.walkers_per_ensemble
-                if self.rng == 'numpy':
-                    if ahead is None:
-                        stage = self._numpy_stream_host(n, nh, k % 2)
-                    else:
-                        ahead[0].join()
-                        if 'error' in ahead[1]:
-                            raise ahead[1]['error']
-                        stage = ahead[1]['stage']
-                    st.update(be.upload_staged(stage, k % 2))
-                    ahead = None
-                    if k + 1 < len(sizes):           # draw the next chunk while this one is enqueued
-                        import threading
-                        box = {}
+        # The guard of the QR-reduced kernels (class docstring): the tier a context on 'auto' runs was chosen from
+        # an estimate; rows of this run -- the initial ensemble, then chunk by chunk the stored samples nearest to
+        # the shell logp = 0 -- are measured against the host's yardstick while the next chunk runs, and a chunk
+        # whose tier fails is run again, from its saved initial state, by the next formulation.
+        guard = self._guard_plan()
+        self.guard_ = dict(checks=0, rows=0, worst=0.0, escalations=0, reruns=0, kernel=None)
+        saved = {}                               # chunk -> (coords, naccept, status) as the chunk found them
+        E, Wp = self.n_ensembles, self.walkers_per_ensemble
 
-                        def draw(n_next=sizes[k + 1] * thin_by, slot=(k + 1) % 2, box=box):
-                            try:
-                                box['stage'] = self._numpy_stream_host(n_next, nh, slot)
-                            except BaseException as exc:     # re-raised on the main thread
-                                box['error'] = exc
-                        worker = threading.Thread(target=draw, daemon=True)
-                        worker.start()
-                        ahead = (worker, box)
+        def enqueue(k):
+            """Everything chunk k needs, queued behind chunk k-1: stream, chain slab, kernels, copies out."""
+            nonlocal ahead, dev_chain, dev_logp, chain_host, logp_host, perm_ev, nan_initial
+            t_a = time.perf_counter()
+            ns = sizes[k]
+            n = ns * thin_by                     # iterations in this chunk
+            done, it0 = first_sample[k], it_start + first_sample[k] * thin_by
+            rec = dict(k=k, ns=ns)
+            st = dict(self._dev)
+            st['nh'] = nh
+            st['thin'] = thin_by
+            if self.n_ensembles > 1:
+                st['wp'] = self.walkers_per_ensemble
+            if self.rng == 'numpy':
+                if ahead is None:
+                    stage, rec['rng_state'] = self._numpy_stream_host(n, nh, k % 2)
                 else:
-                    # only the per-step split is drawn on the host; the stream is generated on
-                    # the device from (seed, step, half, slot) counters
-                    off = it0 - self._iterations_run
-                    st['perm'] = perm_all[off:off + n]
-                if self.chain_on_device:
-                    if dev_chain is None:
-                        dev_chain = be.empty((nsteps, W, ndim), torch.float64)
-                        dev_logp = be.empty((nsteps, W), torch.float64)
-                    st['chain'], st['logp_chain'] = dev_chain[done:done + ns], dev_logp[done:done + ns]
+                    ahead[0].join()
+                    if 'error' in ahead[1]:
+                        raise ahead[1]['error']
+                    stage, rec['rng_state'] = ahead[1]['stage']
+                st.update(be.upload_staged(stage, k % 2))
+                ahead = None
+                if k + 1 < len(sizes):           # draw the next chunk while this one is enqueued
+                    import threading
+                    box = {}
+
+                    def draw(n_next=sizes[k + 1] * thin_by, slot=(k + 1) % 2, box=box):
+                        try:
+                            box['stage'] = self._numpy_stream_host(n_next, nh, slot)
+                        except BaseException as exc:     # re-raised on the main thread
+                            box['error'] = exc
+                    worker = threading.Thread(target=draw, daemon=True)
+                    worker.start()
+                    ahead = (worker, box)
+            else:
+                # only the per-step split is drawn on the host; the stream is generated on
+                # the device from (seed, step, half, slot) counters
+                off = it0 - self._iterations_run
+                st['perm'] = perm_all[off:off + n]
+            if self.chain_on_device:
+                if dev_chain is None:
+                    dev_chain = be.empty((nsteps, W, ndim), torch.float64)
+                    dev_logp = be.empty((nsteps, W), torch.float64)
+                st['chain'], st['logp_chain'] = dev_chain[done:done + ns], dev_logp[done:done + ns]
+            else:
+                st['chain'] = be.empty((ns, W, ndim), torch.float64)
+                st['logp_chain'] = be.empty((ns, W), torch.float64)
+            t_b = time.perf_counter()
+            if self.rng == 'philox':
+                b = k % 2
+                if stream_bufs[0] is None:       # chunks never grow: later ones reuse these two sets
+                    for i, rows in enumerate([sizes[0] * thin_by] + ([sizes[1] * thin_by] if len(sizes) > 1 else [])):
+                        stream_bufs[i] = {name: be.empty((rows, 2, nh), dt) for name, dt in (
+                            ('active', torch.int32), ('partner', torch.int32), ('zz', torch.float64),
+                            ('factor', torch.float64), ('logu', torch.float64))}
+                    if perm_ev is not None:      # the side stream starts after the split upload AND these
+                        perm_ev = be.mark()      # allocations (the allocator may hand out memory still in use upstream)
+                for name, buf in stream_bufs[b].items():
+                    st[name] = buf[:n]
+                if len(sizes) > 1 and perm_ev is not None:
+                    # beside the previous chunk's kernels; this set was last read two chunks ago
+                    be.draw(st, self.walkers_per_ensemble, self.a, self.seed, it0, n, after=(perm_ev, free_ev[b]))
                 else:
-                    st['chain'] = be.empty((ns, W, ndim), torch.float64)
-                    st['logp_chain'] = be.empty((ns, W), torch.float64)
-                t_b = time.perf_counter()
-                if self.rng == 'philox':
-                    b = k % 2
-                    if k == 0:                       # chunks never grow: later ones reuse these two sets
-                        for i, rows in enumerate([n] + ([sizes[1] * thin_by] if len(sizes) > 1 else [])):
-                            stream_bufs[i] = {name: be.empty((rows, 2, nh), dt) for name, dt in (
-                                ('active', torch.int32), ('partner', torch.int32), ('zz', torch.float64),
-                                ('factor', torch.float64), ('logu', torch.float64))}
-                        if perm_ev is not None:      # the side stream starts after the split upload AND these
-                            perm_ev = be.mark()      # allocations (the allocator may hand out memory still in use upstream)
-                    for name, buf in stream_bufs[b].items():
-                        st[name] = buf[:n]
-                    if len(sizes) > 1 and perm_ev is not None:
-                        # beside the previous chunk's kernels; this set was last read two chunks ago
-                        be.draw(st, self.walkers_per_ensemble, self.a, self.seed, it0, n, after=(perm_ev, free_ev[b]))
-                    else:
-                        be.draw(st, self.walkers_per_ensemble, self.a, self.seed, it0, n)
-                self._advance(st, n, nh, it0)
-                if self.rng == 'philox' and len(sizes) > 1 and perm_ev is not None:
-                    free_ev[k % 2] = be.mark()
-                early = self._dev.pop('status0', None) if k == 0 else None
-                if early is not None:
-                    early[1].synchronize()               # the initial log-probabilities only: not this chunk
-                    if int(early[0][0]) & 2:
-                        nan_initial = True
-                        raise ValueError('Probability function returned NaN')
-                t_alloc = 0.0
-                if not self.chain_on_device:
-                    if chain_host is None:
-                        # pinning a big host chain takes tens of ms: do it while the first chunk runs
-                        t_h = time.perf_counter()
-                        chain_host = be.host_buffer((nsteps, W, ndim))
-                        logp_host = be.host_buffer((nsteps, W))
-                        t_alloc = time.perf_counter() - t_h
-                        self.timing['alloc_s'] = t_alloc
-                    be.copy_out(chain_host[done:done + ns], st['chain'])
-                    be.copy_out(logp_host[done:done + ns], st['logp_chain'])
-                done += ns
-                it0 += n
-                self.timing['stream_s'] += t_b - t_a
-                self.timing['enqueue_s'] += time.perf_counter() - t_b - t_alloc
+                    be.draw(st, self.walkers_per_ensemble, self.a, self.seed, it0, n)
+            if guard is not None:
+                saved[k] = tuple(self._dev[name].clone() for name in ('coords', 'naccept', 'status'))
+            self._advance(st, n, nh, it0)
+            if self.rng == 'philox' and len(sizes) > 1 and perm_ev is not None:
+                free_ev[k % 2] = be.mark()
+            if guard is not None:
+                rec['rows'] = [be.shell_rows(st['chain'], st['logp_chain'], ns, E, Wp, guard['k'], ties=guard['ties'],
+                                             slot=f'guard{k % 2}')]
+                init = self._dev.pop('guard0', None) if k == 0 else None
+                if init is not None:
+                    rec['rows'].append(init)
+            early = self._dev.pop('status0', None) if k == 0 else None
+            if early is not None:
+                early[1].synchronize()               # the initial log-probabilities only: not this chunk
+                if int(early[0][0]) & 2:
+                    nan_initial = True
+                    raise ValueError('Probability function returned NaN')
+            t_alloc = 0.0
+            if not self.chain_on_device:
+                if chain_host is None:
+                    # pinning a big host chain takes tens of ms: do it while the first chunk runs
+                    t_h = time.perf_counter()
+                    chain_host = be.host_buffer((nsteps, W, ndim))
+                    logp_host = be.host_buffer((nsteps, W))
+                    t_alloc = time.perf_counter() - t_h
+                    self.timing['alloc_s'] = t_alloc
+                be.copy_out(chain_host[done:done + ns], st['chain'])
+                be.copy_out(logp_host[done:done + ns], st['logp_chain'])
+            self.timing['stream_s'] += t_b - t_a
+            self.timing['enqueue_s'] += time.perf_counter() - t_b - t_alloc
+            return rec
+
+        def send_back(rec):
+            """Chunk rec['k'] ran on a tier that its own rows have just failed: the context has moved on; put the
+            ensemble back where the chunk found it, evaluate it with the new kernel, and draw the chunk again."""
+            nonlocal ahead, guard
+            be.synchronize()                     # whatever was queued behind the chunk is discarded work
+            if ahead is not None:                # the next chunk's stream was drawn past the point we return to
+                ahead[0].join()
+                ahead = None
+            if 'rng_state' in rec:
+                self._random.set_state(rec['rng_state'])
+            coords0, naccept0, status0 = saved[rec['k']]
+            self._dev['coords'].copy_(coords0)
+            self._dev['naccept'].copy_(naccept0)
+            self._dev['status'].copy_(status0)
+            be.logprob(self._dev['coords'], self._dev['logp'])
+            be.flag_nan(self._dev['logp'], self._dev['status'])
+            saved.clear()
+            free_ev[0] = free_ev[1] = None
+            self.guard_['reruns'] += 1
+            guard = self._guard_plan()           # the per-frequency form needs no guard
+            return rec['k']
+
+        try:
+            k, pending = 0, None                 # pending: the chunk whose selected rows have not been measured yet
+            while True:
+                rec = enqueue(k) if k < len(sizes) else None
+                if pending is not None:
+                    if not self._guard_passes(pending):
+                        k, pending = send_back(pending), None
+                        continue
+                    saved.pop(pending['k'], None)
+                pending = rec if (rec is not None and 'rows' in rec) else None
+                if rec is None:
+                    break
+                k += 1
+            done, it0 = nsteps, it_start + nsteps * thin_by
         except BaseException:
             self._dev = None             # the device ensemble is part-way through a chunk: nothing to continue from
             try:                         # nothing of this run may still be writing when its buffers go back to the allocator

@@ -39,8 +39,9 @@ extern "C" {
 /* 2: entry points added since 1 (all additions, nothing changed or removed): loglike_z, forward_percentiles,
  * column / grouped / columns percentiles, forward_spectrum(s) / forward_columns, stretch_run_sharded + rccl_*, ctx_set_spectrum_offset,
  * ctx_reduced_check, polydecomp_reduced_estimates, read_tables; BISIP_VARIANT_REDUCED_COMP, BISIP_ERCCL.
- * 3: clock_probe_dev, ctx_reduced_guard, polydecomp_reduced_reference, stretch_run_sharded_sim_dev (additions only). */
-#define BISIP_ABI_VERSION 3
+ * 3: clock_probe_dev, ctx_reduced_guard, polydecomp_reduced_reference, stretch_run_sharded_sim_dev (additions only).
+ * 4: chain_shell_rows_dev (+ _workspace), ctx_reduced_guard_rows (additions only). */
+#define BISIP_ABI_VERSION 4
 
 /* model_id -- the four reference model classes (src/bisip/models.py:182,232,274,308) */
 #define BISIP_MODEL_POLYDECOMP 0 /* PolynomialDecomposition -> Decomp_cyth  */
@@ -361,8 +362,9 @@ int bisip_ctx_reduced_check(bisip_ctx *ctx, const double *theta, int64_t W, cons
  * until bisip_ctx_set_bounds.  A caller-forced variant is measured and left alone.  enable: 1 / 0 turn
  * the guard on (default) / off, anything else leaves it; outputs (each may be NULL): checks made so far,
  * the worst relative error any of them saw, how many times the context changed formulation.
- * The device-pointer entry bisip_logprob_dev never synchronises and is not guarded: its callers hold
- * the rows and can call bisip_ctx_reduced_check (the device sampler's fit() does).
+ * The device-pointer entry bisip_logprob_dev never synchronises and cannot guard itself: its callers hold
+ * the rows and bring some of them to bisip_ctx_reduced_guard_rows (the device sampler does, chunk by chunk,
+ * before it keeps a chunk).
  * The guard's findings are CONTEXT STATE: an escalation is remembered by the context, and every later launch on
  * it -- bisip_logprob_dev and the stretch-move entries included -- runs the formulation the guard moved to.  A
  * context that only ever sees device-pointer calls keeps the formulation its estimate chose; so a host-loop
@@ -371,6 +373,38 @@ int bisip_ctx_reduced_check(bisip_ctx *ctx, const double *theta, int64_t W, cons
  * bisip_logprob updates that state and the context's workspace: like every entry that takes a context it is
  * not re-entrant for ONE context (contexts are not shared across threads without locking). */
 int bisip_ctx_reduced_guard(bisip_ctx *ctx, int enable, int64_t *n_checks, double *worst_rel, int *escalations);
+
+/* The guard for callers whose rows live on the DEVICE (bisip_logprob_dev and the stretch-move entries never
+ * synchronise, so they cannot measure themselves): the caller brings a few rows and the log-probabilities the
+ * context's kernel gave them to the host -- the device sampler brings rows of its initial ensemble and, chunk by
+ * chunk, the stored samples nearest to the shell logp = 0 (bisip_chain_shell_rows_dev), and does so BEFORE it
+ * keeps a chunk -- and this call measures them as bisip_ctx_reduced_check does (rows outside the prior and NaN
+ * rows are skipped; batch context: the (E*m, ndim) layout, m rows per spectrum).  *worst_rel: the measurement.
+ * *escalated = 1: it was past 2e-11, the context runs on BISIP_VARIANT_AUTO and has just moved to the next
+ * formulation, exactly as bisip_logprob's guard moves it -- the caller's log-probabilities of this and every
+ * later row are stale: re-evaluate its state and re-run what it ran (the device sampler restores the chunk's
+ * initial state and runs the chunk again: its random stream is counter-based or saved).  A caller-forced
+ * variant, a context whose guard is off, or one that already runs the per-frequency form: measured (or not
+ * at all), never moved.  PolynomialDecomposition contexts only (BISIP_EUNSUPPORTED otherwise). */
+int bisip_ctx_reduced_guard_rows(bisip_ctx *ctx, const double *theta, int64_t W, const double *logp,
+                                 double *worst_rel, int *escalated);
+
+/* Per ensemble the k stored samples whose |log-probability| is smallest -- where the relative parity tolerance
+ * max(1, |logp|) has denominator 1 and a kernel's absolute error shows -- of a chain resident in device memory:
+ * d_chain (n_samples, n_ensembles*walkers_per_ensemble, ndim), d_logp (n_samples, n_ensembles*walkers_per_ensemble),
+ * both contiguous.  d_out (n_ensembles, k + n_stride, ndim + 1): each row = a sample's theta followed by its
+ * log-probability; slots no sample fills (fewer than k finite log-probabilities) are NaN rows.  Selection on
+ * the bits of |logp| to 24 bits (exponent + 13 bits of mantissa): every sample nearer than the k-th is
+ * there; of the samples that tie with the k-th to that resolution (1e-4 relative) the first to arrive fill the
+ * remaining slots (ties != 0) or none does (ties == 0: the selected SET is then the same in every run and on
+ * every rank of a sharded run, which therefore take the same decision from it with no collective).
+ * n_stride > 0 (<= 256, <= walkers_per_ensemble) appends n_stride evenly spaced walkers of the FIRST sample.  d_work:
+ * bisip_chain_shell_rows_workspace(n_ensembles) bytes.  Asynchronous on stream.  (No reference counterpart:
+ * it serves the guard above; the run it guards is src/bisip/models.py:111-118.) */
+int64_t bisip_chain_shell_rows_workspace(int64_t n_ensembles);
+int bisip_chain_shell_rows_dev(const double *d_chain, const double *d_logp, int64_t n_samples, int64_t n_ensembles,
+                               int64_t walkers_per_ensemble, int ndim, int k, int n_stride, int ties, double *d_out,
+                               void *d_work, void *stream);
 
 /* Host: read n_files 5-column spectrum files (freq, amp, pha, amp_err, pha_err; comma separated,
  * `headers` lines skipped, '#' comments and blank lines ignored -- what the reference reads one

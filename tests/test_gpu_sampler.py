@@ -525,3 +525,136 @@ def test_samplers_on_two_threads_do_not_share_staging():
             assert not isinstance(both[seed], BaseException), both[seed]
             assert np.array_equal(both[seed][0], alone[seed][0])
             assert np.array_equal(both[seed][1], alone[seed][1])
+
+
+# ----------------------------------------------------------------------------------
+# the device sampler's own guard of the QR-reduced kernels: no chunk of a failing tier is kept
+# ----------------------------------------------------------------------------------
+
+def _valley(prefix):
+    import glob
+    import os
+    return np.load(glob.glob(os.path.join(os.path.dirname(__file__), 'golden', prefix + '*.npz'))[0])
+
+
+def _yardstick_rel(g, theta, lp):
+    """|lp - exact| / max(1, |exact|) of stored log-probabilities against the library's binary128 yardstick
+    (bisip_polydecomp_reduced_reference: 1e-13 from the 50-digit value on the valley fixtures)."""
+    from bisip_amd import _hip
+    exact = _hip.polydecomp_reduced_reference(g['w'], g['zn'], g['zn_err'], g['taus'], g['log_taus'], float(g['c_exp']),
+                                              np.ascontiguousarray(theta))
+    return np.abs(lp - exact) / np.maximum(1.0, np.abs(exact))
+
+
+def test_device_fit_never_keeps_a_chunk_of_a_failing_tier(monkeypatch, tmp_path):
+    """The default fit() samples PolynomialDecomposition with a QR-reduced kernel that AUTO chose from an
+    ESTIMATE.  Here the estimate is made to pass (BISIP_AUTO_ERR_MAX, a test hook) on the worst-conditioned
+    valley fixture's design -- degree 9, 64 frequencies, c = 0.5, where the plain triangle is 7e-9 off on the
+    shell logp = 0 -- and the walkers start ON the fixture's valley / shell rows.  The device sampler measures
+    rows of its own run against the binary128 yardstick before it keeps a chunk: the context ends on the
+    compensated kernel, the chunk was run again from its saved initial state, EVERY stored log-probability is
+    within 1e-10 of the exact value of the reference's formula, the chain is bit for bit the chain of a run
+    that sampled with the compensated kernel from the start, and nothing warns."""
+    import warnings
+    import bisip_amd
+    from bisip_amd.synthetic import write_spectrum_file
+    g = _valley('valley06_')
+    path = write_spectrum_file(str(tmp_path / 's.csv'), 64, 0)
+    rows = g['theta'][np.all((g['bounds'][0] < g['theta']) & (g['theta'] < g['bounds'][1]), axis=1)]
+    W = len(rows) - len(rows) % 2
+    assert W >= 2 * rows.shape[1]
+    p0 = np.ascontiguousarray(rows[:W])
+
+    def model(variant):
+        m = bisip_amd.PolynomialDecomposition(path, nwalkers=W, nsteps=240, poly_deg=9, c_exp=0.5, variant=variant)
+        assert np.array_equal(m.data['w'], g['w']) and np.array_equal(m.data['zn'], g['zn'])     # the fixture's design
+        return m
+    m = model('auto')
+    monkeypatch.setenv('BISIP_AUTO_ERR_MAX', '1e-6')
+    ctx = m._context()
+    monkeypatch.delenv('BISIP_AUTO_ERR_MAX')
+    assert ctx.variant == 'reduced' and ctx.kernel_name == 'k_logprob_pd_reduced' and ctx.reduced_error > 1e-10
+    # what the plain kernel would have stored: far outside the tolerance on the starting rows themselves
+    ctx.reduced_guard(False)
+    assert _yardstick_rel(g, p0, ctx.logprob(p0)).max() > 1e-10
+    ctx.reduced_guard(True)
+    for chunk in (None, 60):                      # one chunk; several (the guard's rows of chunk k are measured beside chunk k+1)
+        ctx.set_bounds(m.param_bounds + 1e-9)     # a new box forgets what the guard found ...
+        ctx.set_bounds(m.param_bounds)            # ... so each round starts on the plain tier again
+        assert ctx.kernel_name == 'k_logprob_pd_reduced'
+        np.random.seed(5)
+        with warnings.catch_warnings():
+            warnings.simplefilter('error', RuntimeWarning)
+            if chunk is None:
+                m.fit(p0=p0)
+                s = m.sampler
+            else:
+                from bisip_amd.sampler import DeviceEnsembleSampler
+                s = DeviceEnsembleSampler(W, p0.shape[1], ctx, chunk=chunk)
+                s.run_mcmc(p0, 240)
+        assert ctx.kernel_name == 'k_logprob_pd_reduced_comp' and ctx.variant == 'reduced_comp'
+        assert s.guard_['escalations'] == 1 and s.guard_['reruns'] == 1 and s.guard_['rejected'] > 2e-11
+        assert s.guard_['checks'] >= 2 and s.guard_['worst'] <= 2e-11
+        chain, lp = s.get_chain(), s.get_log_prob()
+        assert chain.shape == (240, W, p0.shape[1])
+        rel = _yardstick_rel(g, chain.reshape(-1, chain.shape[-1]), lp.ravel())
+        assert rel.max() <= 1e-10, rel.max()       # EVERY stored log-probability
+        assert rel.max() <= 2e-11                  # (the compensated kernel's own bar on this design)
+        ref = model('reduced_comp')
+        np.random.seed(5)
+        ref.fit(p0=p0)
+        assert np.array_equal(chain, ref.get_chain()) and np.array_equal(lp, ref.sampler.get_log_prob())
+        assert np.array_equal(s.acceptance_fraction, ref.sampler.acceptance_fraction)
+    if chunk is None:
+        assert m.reduced_check_ <= 2e-11
+
+
+def test_guard_sends_back_the_chunk_in_which_the_walkers_reach_the_shell(monkeypatch):
+    """A run that starts uniform in the prior box (|logp| ~ 1e5: every tier is accurate RELATIVELY) and crosses
+    the shell logp = 0 some chunks later, on a degree-7 design whose plain triangle is ~1e-9 off there while
+    its estimate is let through (BISIP_AUTO_ERR_MAX, a test hook).  The chunks before the crossing
+    are the plain kernel's and stay; the chunk of the crossing is run again by the compensated kernel, from the
+    state and the random stream it had started with; both random streams."""
+    from bisip_amd.sampler import DeviceEnsembleSampler
+    from test_gpu_parity import _pd_context
+    n_freq, poly_deg, c_exp, idx = 48, 7, 0.5, 0
+    monkeypatch.setenv('BISIP_AUTO_ERR_MAX', '1e-9')
+    ctx, bounds, d, taus, log_taus = _pd_context(n_freq, poly_deg, c_exp, idx)
+    monkeypatch.delenv('BISIP_AUTO_ERR_MAX')
+    g = dict(w=d['w'], zn=d['zn'], zn_err=d['zn_err'], taus=taus, log_taus=log_taus, c_exp=c_exp)
+    W, ndim, nsteps, chunk = 64, poly_deg + 2, 600, 50
+    p0 = np.random.RandomState(3).uniform(bounds[0], bounds[1], (W, ndim))
+    comp = _pd_context(n_freq, poly_deg, c_exp, idx, variant='reduced_comp')[0]
+    plain = _pd_context(n_freq, poly_deg, c_exp, idx, variant='reduced')[0]
+    for rng in ('numpy', 'philox'):
+        ctx.set_bounds(bounds + 1e-9)
+        ctx.set_bounds(bounds)
+        assert ctx.variant == 'reduced'
+        np.random.seed(11)
+        s = DeviceEnsembleSampler(W, ndim, ctx, rng=rng, seed=7, chunk=chunk, persistent=False)
+        s.run_mcmc(p0, nsteps)
+        assert ctx.variant == 'reduced_comp' and s.guard_['escalations'] == 1 and s.guard_['reruns'] == 1
+        chain, lp = s.get_chain(), s.get_log_prob()
+        assert np.abs(lp).min() < 1.0                      # the walkers did cross the shell
+        rel = _yardstick_rel(g, chain.reshape(-1, ndim), lp.ravel())
+        assert rel.max() <= 2e-11, rel.max()
+        # which chunk came back: its stored log-probabilities are the compensated kernel's, the chunks before it
+        # are still the plain kernel's
+        is_comp = np.array([np.array_equal(comp.logprob(chain[i]), lp[i]) for i in range(nsteps)])
+        is_plain = np.array([np.array_equal(plain.logprob(chain[i]), lp[i]) for i in range(nsteps)])
+        first = int(np.argmax(is_comp & ~is_plain))
+        assert first % chunk == 0 and first > 0, first
+        assert is_plain[:first].all() and is_comp[first:].all()
+        # the same run with the guard switched off keeps the plain kernel and its error on the shell
+        ctx.set_bounds(bounds + 1e-9)
+        ctx.set_bounds(bounds)
+        ctx.reduced_guard(False)
+        np.random.seed(11)
+        off = DeviceEnsembleSampler(W, ndim, ctx, rng=rng, seed=7, chunk=chunk, persistent=False)
+        off.run_mcmc(p0, nsteps)
+        ctx.reduced_guard(True)
+        assert ctx.variant == 'reduced' and off.guard_['checks'] == 0
+        assert np.array_equal(off.get_chain()[:first], chain[:first])          # identical until the chunk that came back
+        assert _yardstick_rel(g, off.get_chain().reshape(-1, ndim), off.get_log_prob().ravel()).max() > 2e-11
+    for c in (ctx, comp, plain):
+        c.close()
