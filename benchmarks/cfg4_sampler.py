@@ -34,6 +34,9 @@ def main():
                          "communicator / one of its own) or the Python loop over torch.distributed")
     ap.add_argument('--chain', default='host', choices=['host', 'device'],
                     help="'device': the chain stays in HBM (no pinned host buffer, no copy)")
+    ap.add_argument('--no-guard', action='store_true',
+                    help="switch the sampler's guard of the QR-reduced tier off (A/B of its cost: the selection of "
+                         "the stored samples nearest to the shell, their copy, the yardstick on the host)")
     args = ap.parse_args()
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # before the GPU is first touched
     import torch
@@ -52,6 +55,8 @@ def main():
                                           nsteps=args.steps, device=local_rank)
     assert m.taus.size == 40 and m.data['N'] == 20
     ctx = m._context()
+    if args.no_guard:
+        ctx.reduced_guard(False)
     lo, hi = m.param_bounds
     np.random.seed(2024)
     centre = np.array([1.0, 0.005, -0.003, -0.001, 0.0005, 0.0002, 0.00001])
@@ -95,6 +100,7 @@ def main():
                           # drain also covers the device->host copy of the chain
                           'us_per_half_step': round((s.timing['enqueue_s'] + s.timing['drain_s']) / args.steps / 2 * 1e6, 1),
                           'timing_s': {k: round(v, 4) for k, v in s.timing.items()},
+                          'guard': getattr(s, 'guard_', None),
                           'acceptance': round(float(s.acceptance_fraction.mean()), 3)}))
     dist.barrier()
     dist.destroy_process_group()

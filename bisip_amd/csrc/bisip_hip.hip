@@ -955,21 +955,37 @@ int bisip_stretch_run_dev(bisip_ctx *c, const bisip_stretch_args *first, int64_t
     return BISIP_OK;
 }
 
-// rows lo, lo + stride, ... < hi of a (W, ndim) batch against the reduced form in long double
+// rows lo, lo + stride, ... < hi of a (W, ndim) batch against the yardstick of the spectrum each belongs to
+// (reduced_logp_reference_rows), in blocks of up to 64 rows of one spectrum
 static double reduced_check_rows(const bisip_ctx *c, const double *theta, int64_t W, const double *logp,
                                  int64_t lo, int64_t hi, int64_t stride)
 {
+    constexpr int BLOCK = 64;
     const int64_t per = c->E > 1 ? W / c->E : W;
+    const int n = c->ndim;
+    double rows[BLOCK * MAXD], want[BLOCK], got[BLOCK];
+    int held = 0;
+    int64_t spectrum = -1;
     double w = 0.0;
+    auto flush = [&] {
+        if (!held) return;
+        reduced_logp_reference_rows(c->reduced[(size_t)spectrum], rows, held, want);
+        for (int r = 0; r < held; ++r) {
+            const double scale = std::fabs(want[r]) > 1.0 ? std::fabs(want[r]) : 1.0;
+            const double rel = std::fabs(got[r] - want[r]) / scale;
+            if (!(rel <= w)) w = rel;                          // NaN counts as worst
+        }
+        held = 0;
+    };
     for (int64_t i = lo; i < hi; i += stride) {
-        const double *th = theta + i * c->ndim;
+        const double *th = theta + i * n;
         if (!in_prior_host(th, c)) continue;                  // the prior decides those rows, exactly
-        // from the spectrum's binary128 operands where it has them (the spectra on the compensated tier do)
-        const double want = reduced_logp_reference(c->reduced[(size_t)(per ? i / per : 0)], th);
-        const double scale = std::fabs(want) > 1.0 ? std::fabs(want) : 1.0;
-        const double rel = std::fabs(logp[i] - want) / scale;
-        if (!(rel <= w)) w = rel;                              // NaN counts as worst
+        const int64_t e = per ? i / per : 0;
+        if (e != spectrum || held == BLOCK) { flush(); spectrum = e; }
+        std::memcpy(rows + held * n, th, sizeof(double) * (size_t)n);
+        got[held++] = logp[i];
     }
+    flush();
     return w;
 }
 
@@ -982,7 +998,7 @@ int bisip_ctx_reduced_check(bisip_ctx *c, const double *theta, int64_t W, const 
     std::vector<double> worst((size_t)host_threads() + 1, 0.0);
     return guarded([&] {
         std::atomic<int> slot{0};
-        parallel_blocks(W, 4096, [&](int64_t lo, int64_t hi) {
+        parallel_blocks(W, 2048, [&](int64_t lo, int64_t hi) {
             worst[(size_t)slot.fetch_add(1)] = reduced_check_rows(c, theta, W, logp, lo, hi, 1);
         });
         double all = 0.0;

@@ -840,6 +840,32 @@ double reduced_logp_reference(const ReducedProblem &p, const double *theta)
     return (double)(-0.5L * reduced_chi2_exact(p.n, p.Rl, p.qty, p.rest, theta) + (ld)p.lconst);
 }
 
+// The yardstick for `count` contiguous rows.  A spectrum with binary128 operands (the compensated tier's): row by
+// row in binary128.  Otherwise the plain tier's own yardstick -- the one its estimate is made against
+// (reduced_center_plain): rows as double-doubles from exact hi / lo splits of the long-double QR, four rows per
+// AVX2 instruction where the host has it (0.08 us per row against 0.45 for the long-double pairs).  What the
+// guards measure a few hundred rows against while a sampler waits (bisip_ctx_reduced_guard_rows).
+void reduced_logp_reference_rows(const ReducedProblem &p, const double *theta, int64_t count, double *out)
+{
+    const int n = p.n;
+    if (p.has_quad() || p.Rl.empty()) {
+        for (int64_t i = 0; i < count; ++i) out[i] = reduced_logp_reference(p, theta + i * n);
+        return;
+    }
+    double Rhi[BISIP_HOST_MAXN * BISIP_HOST_MAXN], Rlo[BISIP_HOST_MAXN * BISIP_HOST_MAXN], qhi[BISIP_HOST_MAXN], qlo[BISIP_HOST_MAXN];
+    for (int i = 0; i < n * n; ++i) { Rhi[i] = (double)p.Rl[(size_t)i]; Rlo[i] = (double)(p.Rl[(size_t)i] - (ld)Rhi[i]); }
+    for (int i = 0; i < n; ++i) { qhi[i] = (double)p.qty[(size_t)i]; qlo[i] = (double)(p.qty[(size_t)i] - (ld)qhi[i]); }
+    int64_t done = 0;
+    if (have_avx2())
+        for (; done + 4 <= count; done += 4) {
+            ld c4[4];
+            chi2_dd_x4(n, Rhi, Rlo, qhi, qlo, p.rest, theta + done * n, c4);
+            for (int k = 0; k < 4; ++k) out[done + k] = (double)(-0.5L * c4[k] + (ld)p.lconst);
+        }
+    for (; done < count; ++done)
+        out[done] = (double)(-0.5L * chi2_dd(n, Rhi, Rlo, qhi, qlo, p.rest, theta + done * n) + (ld)p.lconst);
+}
+
 double reduced_logp_reference(int n, const std::vector<long double> &Rl, const std::vector<long double> &qty,
                               double rest, double lconst, const double *theta)
 {

@@ -129,6 +129,10 @@ double reduced_center(int n, const std::vector<double> &R, const std::vector<lon
 // compute, without their rounding.  From the binary128 operands when the spectrum has them, else from the
 // long-double ones with rows accumulated as pairs of long doubles.
 double reduced_logp_reference(const ReducedProblem &p, const double *theta);
+// ... of `count` contiguous rows, through the yardstick the guards and checks of a context use: binary128 where the
+// spectrum has such operands, else rows as double-doubles from exact splits of the long-double QR (the yardstick
+// the plain tier's estimate is made against; four rows per AVX2 instruction, the same bits as one by one)
+void reduced_logp_reference_rows(const ReducedProblem &p, const double *theta, int64_t count, double *out);
 double reduced_logp_reference(int n, const std::vector<long double> &Rl, const std::vector<long double> &qty,
                               double rest, double lconst, const double *theta);
 

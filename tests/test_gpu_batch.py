@@ -765,3 +765,123 @@ def test_forward_columns_and_their_percentiles():
     with pytest.raises(ValueError):
         b.ctx.forward_columns_dev(0, 2, th.data_ptr(), 3 * 77, cols.data_ptr(), st)             # 231 rows over 2 spectra
     b.close()
+
+
+# ----------------------------------------------------------------------------------
+# the stored samples nearest to the shell logp = 0 (bisip_chain_shell_rows_dev) and the guard they serve
+# ----------------------------------------------------------------------------------
+
+@pytest.mark.parametrize('n,E,Wp,ndim,k,n_stride,kind', [
+    (1, 1, 5000, 7, 192, 64, 'wide'),        # an initial ensemble: one sample, stride rows; split over workgroups
+    (40, 1, 4096, 4, 256, 0, 'posterior'),   # one ensemble's chunk: clustered log-probabilities, split path
+    (64, 1, 32768, 7, 256, 0, 'crossing'),   # 2M samples, a few hundred near the shell
+    (37, 600, 64, 5, 6, 0, 'crossing'),      # a survey: one workgroup per ensemble
+    (9, 3, 100, 7, 256, 0, 'wide'),          # few ensembles, k below the sample count
+    (2, 2, 50, 3, 256, 8, 'wide'),           # fewer samples than k: every finite one is taken, the rest NaN
+    (5, 1, 1000, 2, 16, 0, 'ties'),          # many equal log-probabilities at the k-th place
+])
+def test_shell_rows_selection_against_numpy(n, E, Wp, ndim, k, n_stride, kind):
+    """Per ensemble the k stored samples of smallest |logp|: every sample nearer than the k-th (to the 24 bits
+    the selection resolves) is there, k of them in all (ties != 0) or exactly the strictly nearer ones
+    (ties == 0); every output row is a (theta, logp) pair of that ensemble; -inf / NaN never selected;
+    unfilled slots are NaN rows; the stride rows are the first sample's evenly spaced walkers."""
+    import torch
+    from bisip_amd import _hip
+    rng = np.random.RandomState(n * 31 + E + k)
+    lp = {'wide': lambda: rng.standard_normal((n, E * Wp)) * 10.0 ** rng.uniform(-3, 6, (n, E * Wp)),
+          'posterior': lambda: 384.5 - rng.chisquare(4, (n, E * Wp)) / 2,
+          'crossing': lambda: 400.0 - np.abs(rng.standard_normal((n, E * Wp))) * np.linspace(3e5, 1, n)[:, None] ** 1.0,
+          'ties': lambda: np.round(rng.standard_normal((n, E * Wp)) * 3.0) * 0.5 + 0.25}[kind]()
+    lp.ravel()[rng.choice(lp.size, max(1, lp.size // 50), replace=False)] = -np.inf       # out-of-prior samples
+    lp.ravel()[rng.choice(lp.size, 3, replace=False)] = np.nan
+    chain = rng.standard_normal((n, E * Wp, ndim))
+    d_chain, d_lp = torch.from_numpy(chain).cuda(), torch.from_numpy(lp).cuda()
+    work = torch.empty(_hip.chain_shell_rows_workspace(E), dtype=torch.uint8, device='cuda')
+
+    def key24(x):
+        return (np.abs(x).view(np.uint64) & np.uint64(0x7fffffffffffffff)) >> np.uint64(39)
+    for ties in (True, False):
+        out = torch.full((E, k + n_stride, ndim + 1), 7.0, dtype=torch.float64, device='cuda')
+        _hip.chain_shell_rows_dev(d_chain.data_ptr(), d_lp.data_ptr(), n, E, Wp, ndim, k, n_stride, out.data_ptr(),
+                                  work.data_ptr(), torch.cuda.current_stream().cuda_stream, ties=ties)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        for e in range(E):
+            mine_lp = lp[:, e * Wp:(e + 1) * Wp].ravel()
+            mine_th = chain[:, e * Wp:(e + 1) * Wp].reshape(-1, ndim)
+            fin = np.isfinite(mine_lp)
+            order = np.argsort(np.abs(mine_lp[fin]), kind='stable')
+            want_abs = np.abs(mine_lp[fin])[order]
+            rows = got[e, :k]
+            filled = ~np.isnan(rows[:, ndim])
+            assert np.isnan(rows[~filled]).all()
+            sel_lp = rows[filled, ndim]
+            assert np.isfinite(sel_lp).all()
+            n_fin = int(fin.sum())
+            if n_fin <= k:
+                assert filled.sum() == n_fin and np.array_equal(np.sort(np.abs(sel_lp)), want_abs)
+            else:
+                thr = key24(want_abs[k - 1:k])[0]                  # the k-th nearest's 24-bit key
+                strictly = want_abs[key24(want_abs) < thr]
+                got_keys = key24(np.sort(np.abs(sel_lp)))
+                assert np.array_equal(np.sort(np.abs(sel_lp))[:len(strictly)], strictly)       # all the nearer ones
+                if ties:
+                    assert filled.sum() == k and (got_keys[len(strictly):] == thr).all()
+                else:
+                    assert filled.sum() == len(strictly)
+            # every selected row is a real sample of THIS ensemble: its theta goes with its log-probability
+            lookup = {}
+            for i in np.flatnonzero(fin):
+                lookup.setdefault(mine_lp[i], []).append(i)
+            for r in rows[filled]:
+                assert any(np.array_equal(mine_th[i], r[:ndim]) for i in lookup[r[ndim]])
+            for j in range(n_stride):
+                w = Wp * j // n_stride
+                assert np.array_equal(got[e, k + j, :ndim], chain[0, e * Wp + w])
+                a, b = got[e, k + j, ndim], lp[0, e * Wp + w]
+                assert a == b or (np.isnan(a) and np.isnan(b))
+    with pytest.raises(ValueError):
+        _hip.chain_shell_rows_dev(d_chain.data_ptr(), d_lp.data_ptr(), n, E, Wp, ndim, 0, 0, 1, work.data_ptr(), 0)
+
+
+def test_batch_fit_is_guarded_per_spectrum(monkeypatch):
+    """SpectraBatch.fit: every spectrum's stored samples nearest to the shell are measured before a chunk is
+    kept.  Sixteen degree-6 designs whose plain estimates are let through (BISIP_AUTO_ERR_MAX, a test hook), the
+    walkers of each started on its own shell logp = 0, where the plain triangle reads 4-8e-11: the batch ends on
+    the compensated kernels, every stored log-probability of every spectrum is within 2e-11 of the yardstick,
+    and the chains are those of a batch that ran the compensated kernels from the start."""
+    import warnings
+    import bisip_amd
+    from bisip_amd import _hip
+    from test_gpu_parity import _shell_rows
+    E, Wp, nsteps = 16, 64, 30
+    tables = _tables(E, 64)
+    monkeypatch.setenv('BISIP_AUTO_ERR_MAX', '1e-9')
+    batch = bisip_amd.SpectraBatch('PolynomialDecomposition', tables, nwalkers=Wp, nsteps=nsteps, poly_deg=6)
+    monkeypatch.delenv('BISIP_AUTO_ERR_MAX')
+    assert batch.ctx.reduced_tiers == (E, 0) and batch.ctx.variant == 'reduced'
+    bounds = np.array(batch.param_bounds)
+    p0 = np.empty((E, Wp, 8))
+    for e in range(E):
+        ops = _hip.polydecomp_operands(batch.w[e], batch.zn[e], batch.zn_err[e], batch.taus, batch.log_taus, batch.c_exp)
+        rows = _shell_rows(ops, bounds, 4000, e)
+        assert len(rows) >= Wp
+        p0[e] = rows[:Wp]
+    with warnings.catch_warnings():
+        warnings.simplefilter('error', RuntimeWarning)
+        batch.fit(p0, seed=3)
+    g = batch._sampler.guard_
+    assert batch.ctx.variant == 'reduced_comp' and batch.ctx.reduced_tiers == (0, E)
+    assert g['escalations'] == 1 and g['reruns'] == 1 and g['rejected'] > 2e-11 and g['worst'] <= 2e-11
+    chain, lp = batch.get_chain(), batch.get_log_prob()           # (nsteps, E, Wp, ndim), (nsteps, E, Wp)
+    for e in range(E):
+        exact = _hip.polydecomp_reduced_reference(batch.w[e], batch.zn[e], batch.zn_err[e], batch.taus, batch.log_taus,
+                                                  batch.c_exp, np.ascontiguousarray(chain[:, e].reshape(-1, 8)))
+        rel = np.abs(lp[:, e].ravel() - exact) / np.maximum(1.0, np.abs(exact))
+        assert rel.max() <= 2e-11, (e, rel.max())
+    forced = bisip_amd.SpectraBatch('PolynomialDecomposition', tables, nwalkers=Wp, nsteps=nsteps, poly_deg=6)
+    forced.ctx.set_variant('reduced_comp')
+    forced.fit(p0, seed=3)
+    assert np.array_equal(forced.get_chain(), chain) and np.array_equal(forced.get_log_prob(), lp)
+    batch.close()
+    forced.close()
