@@ -137,6 +137,9 @@ SYMBOLS = {
     'bisip_clock_probe_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p]),
     'bisip_ctx_reduced_guard_rows': (ctypes.c_int, [ctypes.c_void_p, _dp, ctypes.c_int64, _dp, _dp, ctypes.POINTER(ctypes.c_int)]),
     'bisip_chain_shell_rows_workspace': (ctypes.c_int64, [ctypes.c_int64]),
+    'bisip_ensemble_gram_workspace': (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int]),
+    'bisip_ensemble_gram_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                               ctypes.c_void_p]),
     'bisip_chain_shell_rows_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
                                                   ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                                   ctypes.c_void_p, ctypes.c_void_p]),
@@ -640,6 +643,17 @@ def chain_moments_dev(d_chain_ptr, n_samples, sample_stride, n_ensembles, walker
     _check(load_library().bisip_chain_moments_dev(d_chain_ptr, n_samples, sample_stride, n_ensembles,
                                                   walkers_per_ensemble, ndim, d_mean_ptr, d_std_ptr,
                                                   d_work_ptr, stream))
+
+
+def ensemble_gram_workspace(W, ndim):
+    """Doubles of device scratch ensemble_gram_dev needs (0: ndim beyond 8)."""
+    return int(load_library().bisip_ensemble_gram_workspace(int(W), int(ndim)))
+
+
+def ensemble_gram_dev(d_coords_ptr, W, ndim, d_out_ptr, d_work_ptr, stream=0):
+    """Shifted sums and second moments of a device-resident (W, ndim) ensemble into d_out
+    (ndim + ndim (ndim + 1) / 2 doubles); device pointers (ints), asynchronous on ``stream``."""
+    _check(load_library().bisip_ensemble_gram_dev(d_coords_ptr, int(W), int(ndim), d_out_ptr, d_work_ptr, stream))
 
 
 def chain_shell_rows_workspace(n_ensembles):

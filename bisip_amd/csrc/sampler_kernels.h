@@ -365,6 +365,14 @@ __global__ __launch_bounds__(BLK) void k_stretch_half(const StretchArgs a, const
     if (live && g == 0) commit_row<LP::NDIM>(a, i, row, lp_row, acc);
 }
 
+// (Measured and not kept, round 5: the rows of a chip-filling launch fetched and stored by FOUR lanes each through
+// LDS, 16 bytes per lane, instead of one lane per row -- same chain; 524,288 proposals of a 1,048,576-walker
+// ensemble: PolynomialDecomposition 65.2 -> 63.4 us per half-step, double Cole-Cole 66.3 -> 73.1.  Both models take the
+// same 65 us: the half-step is bound by the memory system's rate of SCATTERED lines, not by requests per
+// instruction and not by arithmetic -- FETCH_SIZE 127 MB + WRITE_SIZE 51 MB per launch for 113 MB of algorithmic
+// bytes: a 56-byte row at a random address costs one or two 64-byte lines each way, an 8-byte log-probability a
+// line of its own.  profiles/r05_micro_ab_big_ensemble_rows.jsonl.)
+
 // sharded half-step, part 1: this rank's slots -> block rows (row, logp, accepted)
 template <class LP>
 __global__ __launch_bounds__(64) void k_stretch_eval(const StretchArgs a, const LP lp)

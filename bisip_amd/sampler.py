@@ -83,6 +83,29 @@ class _one_blas_thread(object):
         return False
 
 
+def gram_decides(g, nwalkers):
+    """True when the centred Gram matrix ``g`` of ``nwalkers`` positions settles emcee's test in favour of the
+    ensemble: the correlation matrix's eigenvalue ratio is far inside the limit (see walkers_independent).
+    False says nothing -- non-finite, degenerate or merely not clear-cut: the singular values then decide."""
+    with np.errstate(all='ignore'):
+        d = np.sqrt(np.diag(g))
+        if np.all(np.isfinite(g)) and np.all(d > 1e-150):
+            lam = np.linalg.eigvalsh(g / np.outer(d, d))
+            return bool(lam[-1] > 0 and lam[0] / lam[-1] >= max(1e-8, 1e4 * nwalkers * np.finfo(np.float64).eps))
+    return False
+
+
+def gram_from_shifted_sums(sums, nwalkers, ndim):
+    """The centred Gram matrix from what bisip_ensemble_gram_dev returns: S (ndim,) and the upper triangle of P,
+    both of the positions shifted by walker 0:  G = P - S S^T / W."""
+    S = np.asarray(sums[:ndim], dtype=np.float64)
+    P = np.zeros((ndim, ndim))
+    P[np.triu_indices(ndim)] = sums[ndim:]
+    P = P + np.triu(P, 1).T
+    with np.errstate(all='ignore'):           # (non-finite sums: the caller's decision sends them to the exact test)
+        return P - np.outer(S, S) / float(nwalkers)
+
+
 def walkers_independent(coords):
     """True when the initial ensemble spans the parameter space (no degenerate
     directions): condition number of the centred, column-scaled positions <= 1e8 (emcee's test).
@@ -113,11 +136,8 @@ def walkers_independent(coords):
                 for lo in range(0, coords.shape[0], 16384):
                     blk = coords[lo:lo + 16384] - mean
                     g += gram(blk)
-            d = np.sqrt(np.diag(g))
-            if np.all(np.isfinite(g)) and np.all(d > 1e-150):
-                lam = np.linalg.eigvalsh(g / np.outer(d, d))
-                if lam[-1] > 0 and lam[0] / lam[-1] >= max(1e-8, 1e4 * coords.shape[0] * np.finfo(np.float64).eps):
-                    return True
+            if gram_decides(g, coords.shape[0]):
+                return True
     if not np.all(np.isfinite(coords)):
         return False
     c = coords - coords.mean(axis=0)[None, :]
@@ -295,16 +315,21 @@ class _SamplerBase:
     def _log_prob(self):
         return self._joined(self._log_prob_parts, (0, self.nwalkers))
 
-    def _check_initial(self, initial_state):
-        p0 = np.array(initial_state, dtype=np.float64, copy=True)
+    _DEPENDENT = ('Initial state has a large condition number. Make sure that '
+                  'your walkers are linearly independent for the best performance')
+
+    def _check_initial(self, initial_state, copy=True, independence=True):
+        """emcee's checks of a new initial state.  ``copy=False``: the caller only reads it (the device sampler
+        uploads it); ``independence=False``: the caller runs that test itself (on the device, where a big
+        ensemble is going anyway)."""
+        p0 = np.array(initial_state, dtype=np.float64, copy=True) if copy else np.ascontiguousarray(initial_state, dtype=np.float64)
         if p0.shape != (self.nwalkers, self.ndim):
             raise ValueError(f'incompatible input dimensions {p0.shape}')
         if not self.live_dangerously and self.nwalkers < 2 * self.ndim:
             raise RuntimeError('It is unadvisable to use a red-blue move with fewer walkers '
                                'than twice the number of dimensions.')
-        if not self.live_dangerously and not walkers_independent(p0):
-            raise ValueError('Initial state has a large condition number. Make sure that '
-                             'your walkers are linearly independent for the best performance')
+        if independence and not self.live_dangerously and not walkers_independent(p0):
+            raise ValueError(self._DEPENDENT)
         return p0
 
     @staticmethod
@@ -535,6 +560,17 @@ class HipStretchBackend:
             done.record(self._copy_stream)
         src.record_stream(self._copy_stream)
         return host, done
+
+    def gram(self, coords_t):
+        """Shifted sums and second moments of the ensemble (``bisip_ensemble_gram_dev``) behind the work queued
+        so far; their copy to the host starts at once.  Returns (pinned host tensor, event)."""
+        from . import _hip
+        torch = self.torch
+        W, ndim = (int(x) for x in coords_t.shape)
+        out = torch.empty((ndim + ndim * (ndim + 1) // 2,), dtype=torch.float64, device=self.device)
+        work = torch.empty((_hip.ensemble_gram_workspace(W, ndim),), dtype=torch.float64, device=self.device)
+        _hip.ensemble_gram_dev(coords_t.data_ptr(), W, ndim, out.data_ptr(), work.data_ptr(), self.stream())
+        return self.snapshot(out, slot='gram', frozen=False)
 
     def side_stream(self, name):
         """Context: torch's current stream is a side stream of this backend (one per ``name``) that starts behind
@@ -926,6 +962,16 @@ class DeviceEnsembleSampler(_SamplerBase):
             dev['logp'] = be.tensor(lp, torch.float64, slot='b')
         self._dev = dev
 
+    _GRAM_ON_DEVICE_FROM = 16384      # walkers from which the independence test of a new ensemble runs on the device
+
+    def _independent_on_device(self, pending):
+        """Decide emcee's independence test from the moments the device formed of the uploaded ensemble; what they
+        do not settle (near-degenerate, degenerate, non-finite) goes through the host's singular values."""
+        (host, ev), p0 = pending
+        ev.synchronize()
+        g = gram_from_shifted_sums(np.array(host.numpy(), copy=True), self.nwalkers, self.ndim)
+        return gram_decides(g, self.nwalkers) or walkers_independent(p0)
+
     def _guard_plan(self):
         """How this run measures the kernel it samples with, or None when there is nothing to measure: only a
         PolynomialDecomposition context that chose a QR-reduced kernel from its estimate ('auto') is guarded
@@ -991,8 +1037,15 @@ class DeviceEnsembleSampler(_SamplerBase):
             if self._dev is None:
                 raise ValueError('Cannot have `initial_state=None` if run_mcmc has never been called.')
             return {}
+        on_device = False
         if self.n_ensembles == 1:
-            p0 = self._check_initial(initial_state)
+            # emcee's independence test of a big ensemble runs where the ensemble is going anyway: the device forms
+            # the second moments (bisip_ensemble_gram_dev), the ndim x ndim decision is looked at once the first
+            # chunk is queued (run_mcmc) -- on the host it costs more than hundreds of half-steps (26 ms at a
+            # million walkers).  ndim <= 8; anything the moments do not settle clearly still takes the singular values.
+            on_device = (not self.live_dangerously and W >= self._GRAM_ON_DEVICE_FROM and ndim <= 8
+                         and hasattr(self.backend, 'gram'))
+            p0 = self._check_initial(initial_state, copy=False, independence=not on_device)
         else:
             p0 = np.asarray(initial_state, dtype=np.float64).reshape(W, ndim)   # only read
             Wp = self.walkers_per_ensemble
@@ -1007,6 +1060,8 @@ class DeviceEnsembleSampler(_SamplerBase):
             self._check_coords(p0)        # (a single ensemble that passed walkers_independent is finite throughout)
         t1 = time.perf_counter()
         self._upload_state(p0)
+        if on_device:
+            self._dev['gram0'] = (self.backend.gram(self._dev['coords']), p0)
         return dict(check_s=t1 - t0, upload_s=time.perf_counter() - t1)
 
     def _numpy_stream_host(self, n, nh, slot):
@@ -1231,6 +1286,9 @@ class DeviceEnsembleSampler(_SamplerBase):
                 final.clear()
                 final.update({name: be.snapshot(self._dev[name], slot='final_' + name, frozen=False)
                               for name in ('status', 'naccept', 'coords', 'logp')})
+            gram0 = self._dev.pop('gram0', None) if k == 0 else None
+            if gram0 is not None and not self._independent_on_device(gram0):
+                raise ValueError(self._DEPENDENT)
             early = self._dev.pop('status0', None) if k == 0 else None
             if early is not None:
                 early[1].synchronize()               # the initial log-probabilities only: not this chunk
@@ -1329,6 +1387,8 @@ class DeviceEnsembleSampler(_SamplerBase):
         self._coords = ends['coords']
         self._lp = ends['logp']
         self.timing['finish_s'] = time.perf_counter() - t_e
+        if self._coords.nbytes >= (8 << 20):      # a big ensemble: the arrays returned are the sampler's own host copy
+            return self._coords, self._lp         # of its last state (another 56 MB copy at a million walkers: 5 ms)
         return self._coords.copy(), self._lp.copy()
 
     # -- summaries of a device-resident chain -------------------------------------------

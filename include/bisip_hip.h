@@ -40,7 +40,7 @@ extern "C" {
  * column / grouped / columns percentiles, forward_spectrum(s) / forward_columns, stretch_run_sharded + rccl_*, ctx_set_spectrum_offset,
  * ctx_reduced_check, polydecomp_reduced_estimates, read_tables; BISIP_VARIANT_REDUCED_COMP, BISIP_ERCCL.
  * 3: clock_probe_dev, ctx_reduced_guard, polydecomp_reduced_reference, stretch_run_sharded_sim_dev (additions only).
- * 4: chain_shell_rows_dev (+ _workspace), ctx_reduced_guard_rows (additions only). */
+ * 4: chain_shell_rows_dev (+ _workspace), ctx_reduced_guard_rows, ensemble_gram_dev (+ _workspace) (additions only). */
 #define BISIP_ABI_VERSION 4
 
 /* model_id -- the four reference model classes (src/bisip/models.py:182,232,274,308) */
@@ -405,6 +405,17 @@ int64_t bisip_chain_shell_rows_workspace(int64_t n_ensembles);
 int bisip_chain_shell_rows_dev(const double *d_chain, const double *d_logp, int64_t n_samples, int64_t n_ensembles,
                                int64_t walkers_per_ensemble, int ndim, int k, int n_stride, int ties, double *d_out,
                                void *d_work, void *stream);
+
+/* Sums and second moments of an ensemble's positions, shifted by walker 0: d_coords (W, ndim) device ->
+ * d_out (ndim + ndim (ndim + 1) / 2) device = S_j = sum_i (x_ij - x_0j), then P_jk = sum_i (x_ij - x_0j)(x_ik - x_0k)
+ * for k >= j, row by row.  What emcee's initial-state test -- the condition number of the centred, column-scaled
+ * positions, raised inside emcee.EnsembleSampler.run_mcmc (src/bisip/models.py:111-118) -- needs of a big
+ * ensemble that is on the device anyway: the host forms the centred Gram matrix P - S S^T / W and decides
+ * (bisip_amd/sampler.py:walkers_independent); a NaN or an inf anywhere makes the sums non-finite.  ndim <= 8
+ * (BISIP_EUNSUPPORTED beyond: the sums live in registers).  d_work: bisip_ensemble_gram_workspace() doubles.
+ * Fixed summation order; asynchronous on stream. */
+int64_t bisip_ensemble_gram_workspace(int64_t W, int ndim);
+int bisip_ensemble_gram_dev(const double *d_coords, int64_t W, int ndim, double *d_out, double *d_work, void *stream);
 
 /* Host: read n_files 5-column spectrum files (freq, amp, pha, amp_err, pha_err; comma separated,
  * `headers` lines skipped, '#' comments and blank lines ignored -- what the reference reads one

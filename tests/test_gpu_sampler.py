@@ -187,6 +187,51 @@ def test_non_finite_start_of_a_big_ensemble_is_refused():
     ctx.close()
 
 
+def test_independence_test_of_a_big_ensemble_runs_on_the_device():
+    """emcee's initial-state test (condition number of the centred, column-scaled positions) for ensembles of
+    16,384 walkers and more: the device forms the shifted sums and second moments of the uploaded ensemble
+    (bisip_ensemble_gram_dev), the host decides from ndim (ndim + 3) / 2 numbers -- the same answers as the host
+    test: a spanning ensemble runs, linearly dependent columns and a constant column raise emcee's error, and the
+    moments are NumPy's to rounding."""
+    import torch
+    from bisip_amd import _hip
+    from bisip_amd.sampler import DeviceEnsembleSampler, gram_from_shifted_sums, walkers_independent
+    g = np.load(_case('case04_'))
+    ctx = make_ctx(g, 'PolynomialDecomposition')
+    ndim = g['bounds'].shape[1]
+    W = 40001
+    p0 = _start(g, W, 8)
+    # the moments themselves
+    t = torch.from_numpy(p0).cuda()
+    out = torch.empty(ndim + ndim * (ndim + 1) // 2, dtype=torch.float64, device='cuda')
+    work = torch.empty(_hip.ensemble_gram_workspace(W, ndim), dtype=torch.float64, device='cuda')
+    _hip.ensemble_gram_dev(t.data_ptr(), W, ndim, out.data_ptr(), work.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    G = gram_from_shifted_sums(out.cpu().numpy(), W, ndim)
+    c = p0 - p0.mean(axis=0)
+    want = c.T @ c
+    assert np.abs(G - want).max() <= 1e-9 * np.abs(want).max()
+    with pytest.raises(RuntimeError):
+        _hip.ensemble_gram_dev(t.data_ptr(), W, 9, out.data_ptr(), work.data_ptr(), 0)
+    # through run_mcmc
+    s = DeviceEnsembleSampler(W, ndim, ctx, rng='philox', seed=3)
+    s.run_mcmc(p0, 2)
+    assert s.timing['check_s'] < 0.5 * 1e-3 * W / 16384 and np.isfinite(s.get_log_prob()).all()      # no pass over the ensemble on the host
+    for spoil in ('dependent', 'constant', 'nearly'):
+        bad = p0.copy()
+        if spoil == 'dependent':
+            bad[:, 3] = 2.0 * bad[:, 1] - bad[:, 2]
+        elif spoil == 'constant':
+            bad[:, 4] = 0.25                 # (a value whose mean over W walkers is exact: the centred column is exactly zero)
+        else:
+            bad[:, 3] = bad[:, 1] * (1.0 + 1e-11 * np.random.RandomState(1).randn(W))      # cond ~ 1e11: the moments cannot say, the singular values do
+        assert not walkers_independent(bad)
+        with pytest.raises(ValueError, match='condition number'):
+            s.run_mcmc(bad, 2)
+    s.run_mcmc(p0, 2)
+    ctx.close()
+
+
 def test_nan_in_the_initial_log_probability_raises_before_the_run():
     """emcee raises 'Probability function returned NaN' for the initial state before it samples.  The
     device sampler computes and checks the initial log-probabilities on the device without a host
