@@ -717,6 +717,7 @@ void bisip_ctx_destroy(bisip_ctx *c)
     if (c->d_tier) (void)hipFree(c->d_tier);
     if (c->d_ws) (void)hipFree(c->d_ws);
     if (c->d_gather) (void)hipFree(c->d_gather);
+    if (c->d_group) (void)hipFree(c->d_group);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1124,16 +1125,38 @@ int bisip_stretch_persistent_dev(bisip_ctx *c, const bisip_persist_args *u, void
     if (E != c->E) return fail(BISIP_EINVAL, "n_walkers/walkers_per_ensemble=%lld but the context holds %d spectra", (long long)E, c->E);
     if (c->E > 1 && (Wp & 1)) return fail(BISIP_EINVAL, "batch context: walkers per spectrum must be even");
     if (u->thin_by < 1 || u->n_steps < 0 || u->n_steps % u->thin_by) return fail(BISIP_EINVAL, "n_steps must be a multiple of thin_by");
-    if ((size_t)Wp * (c->ndim + 1) * sizeof(double) > 65536 || (Wp + 1) / 2 > 512)
-        return fail(BISIP_EUNSUPPORTED, "ensemble of %lld walkers does not fit one workgroup", (long long)Wp);
+    const bool one_workgroup = !((size_t)Wp * (c->ndim + 1) * sizeof(double) > 65536 || (Wp + 1) / 2 > 512);
+    // a single ensemble beyond one workgroup: several workgroups and a barrier of their own per half-step
+    // (k_stretch_group), up to 8,192 walkers of at most 7 parameters
+    const bool group = !one_workgroup && c->E == 1 && Wp <= 8192 && c->ndim <= 7;
+    if (!one_workgroup && !group)
+        return fail(BISIP_EUNSUPPORTED, "ensemble of %lld walkers does not fit one workgroup%s", (long long)Wp,
+                    c->E == 1 && Wp <= 8192 ? " and its rows do not fit 64 bytes (ndim > 7)" : "");
     if (u->n_steps == 0) return BISIP_OK;
+    if (u->n_steps * 2 * 64 > 0x7fffffffLL) return fail(BISIP_EINVAL, "n_steps=%lld: chunk the run", (long long)u->n_steps);
     HIP_TRY(hipSetDevice(c->device));
     PersistArgs p;
+    p.gstate = nullptr; p.gsync = nullptr; p.G = 0; p.spin_limit = 0;
+    if (group) {
+        const size_t need = 256 + (size_t)Wp * 64;
+        if (c->group_bytes < need) {
+            if (c->d_group) { HIP_TRY(hipDeviceSynchronize()); (void)hipFree(c->d_group); c->d_group = nullptr; c->group_bytes = 0; }
+            hipError_t e = hipMalloc((void **)&c->d_group, need);
+            if (e != hipSuccess) return fail(BISIP_ENOMEM, "hipMalloc(%zu) failed: %s", need, hipGetErrorString(e));
+            c->group_bytes = need;
+        }
+        // counters 0, the smallest XCC id seen so far "none" (0xffffffff); ordered before the kernel on its stream
+        HIP_TRY(hipMemsetAsync(c->d_group, 0, 256, (hipStream_t)stream));
+        HIP_TRY(hipMemsetAsync(c->d_group + 32 * sizeof(unsigned), 0xff, sizeof(unsigned), (hipStream_t)stream));
+        p.gsync = (unsigned *)c->d_group;
+        p.gstate = (double *)(c->d_group + 256);
+        p.spin_limit = 1u << 22;        // ~0.3 s of polling: only workgroups that never become resident together get there
+    }
     p.coords = u->coords; p.logp = u->logp; p.W = Wp; p.E = E; p.n_steps = u->n_steps;
     p.thin_by = u->thin_by;
     p.active = u->active; p.partner = u->partner; p.zz = u->zz; p.factor = u->factor; p.logu = u->logu;
     p.chain = u->chain; p.logp_chain = u->logp_chain; p.naccept = u->naccept; p.status = u->status;
-    return dispatch_stretch(c, StretchWork{STRETCH_PERSIST, nullptr, &p}, Wp, (hipStream_t)stream);
+    return dispatch_stretch(c, StretchWork{group ? STRETCH_GROUP : STRETCH_PERSIST, nullptr, &p}, Wp, (hipStream_t)stream);
 }
 
 void bisip_philox4x32(const uint32_t *counter, const uint32_t *key, uint32_t *out)

@@ -103,6 +103,8 @@ struct bisip_ctx {
     size_t ws_bytes = 0;
     double *d_gather = nullptr;    // sharded sampler: world slabs of ceil(slots/world) x (ndim+2)
     size_t gather_bytes = 0;
+    char *d_group = nullptr;       // multi-workgroup persistent sampler: 256 B of synchronisation words, then W rows of 64 B
+    size_t group_bytes = 0;
     int64_t spectrum_offset = 0;   // batch: survey index of spectrum 0 (keys the Philox stream)
     char *h_pin = nullptr;         // pinned, device-mapped staging for small host-buffer calls
     char *d_pin = nullptr;         // its device-side address
@@ -150,7 +152,7 @@ int dispatch_forward_columns(const bisip_ctx *c, const double *theta, int64_t W,
                              long long count);
 
 // dispatch_stretch.hip
-enum StretchKind { STRETCH_HALF, STRETCH_EVAL, STRETCH_PERSIST };
+enum StretchKind { STRETCH_HALF, STRETCH_EVAL, STRETCH_PERSIST, STRETCH_GROUP };
 
 // what one stretch dispatch launches: a half-step / eval kernel over StretchArgs, or the
 // persistent kernel over PersistArgs

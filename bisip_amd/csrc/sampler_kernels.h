@@ -44,8 +44,15 @@ struct StretchArgs {
 // L = lanes per walker (see logprob_row); g = this lane's index inside its group.
 // Functors over per-frequency records (CAN_STAGE) also say where a walker's records live and
 // evaluate against a copy of them -- the persistent kernel keeps that copy in LDS.
+// does the functor evaluate a single-spectrum context (the multi-workgroup sampler exists for those only)?
+template <class LP, class = void>
+struct SingleSpectrum : std::false_type {};
+template <class LP>
+struct SingleSpectrum<LP, std::void_t<decltype(LP::SINGLE_SPECTRUM)>> : std::bool_constant<LP::SINGLE_SPECTRUM> {};
+
 template <class M, int L_ = 1>
 struct GenericLP {
+    static constexpr bool SINGLE_SPECTRUM = true;
     static constexpr int NDIM = M::NDIM;
     static constexpr int L = L_;
     static constexpr bool CAN_STAGE = true;
@@ -115,6 +122,7 @@ struct StagesFromArgs<LP, std::void_t<decltype(LP::STAGE_FROM_ARGS)>> : std::boo
 
 template <int P, bool COMP = false>
 struct ReducedLP {
+    static constexpr bool SINGLE_SPECTRUM = true;
     static constexpr int NDIM = P + 2;
     static constexpr int L = 1;
     // compensated tier: the low words live in LDS (see BatchReducedLP); the operands are kernel arguments here,
@@ -545,6 +553,12 @@ struct PersistArgs {
     // lanes each (a multiple of 64, so no wave straddles two ensembles)
     int lanes_per_ens, epw;
     long long rec_stride;   // STAGED: doubles between two ensembles' record copies in LDS (even)
+    // k_stretch_group (one ensemble over several workgroups): its state in memory, 8 doubles per walker, its
+    // synchronisation words (see there), workgroups in the group, polls before a barrier gives up
+    double *gstate;
+    unsigned *gsync;
+    int G;
+    unsigned spin_limit;
 };
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every
@@ -653,6 +667,194 @@ __global__ __launch_bounds__(512) void k_stretch_persistent(const PersistArgs a,
     if (ens_live) {
         for (long long i = lane; i < a.W * NDIM; i += a.lanes_per_ens) a.coords[base * NDIM + i] = xs[i];
         for (long long i = lane; i < a.W; i += a.lanes_per_ens) a.logp[base + i] = ls[i];
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Persistent sampler for ONE ensemble too big for a workgroup (1,024 < W <= 8,192 walkers; BASELINE config 2's
+// 4,096 sit here): G workgroups run every iteration of a chunk inside one launch and meet at a barrier of their
+// own after every half-step.  A half-step of such an ensemble is 0.1-0.5 us of arithmetic; as a launch of its own
+// it costs 5-10 us (launch gap, ramp, two dependent trips to memory).
+//
+// State: one 64-byte row per walker in memory -- theta[0..NDIM), padding, the log-probability in [7] -- so that a
+// slot fetches its walker and its partner with two independent line reads and commits with one line write.
+// Slot t of a half-step belongs to L adjacent lanes of workgroup t / (256 / L), as in k_stretch_half; the random
+// stream is the pre-drawn one of every other driver; the chain is bit-identical to theirs.
+//
+// The barrier and the hand-off (benchmarks/micro/xcd_barrier.hip measured both; MI355X_MICROARCH.md, "inter-workgroup
+// visibility"): the group is the workgroups with blockIdx.x % 8 == 0 of a grid of 8 G -- the dispatcher deals
+// blocks round-robin over the 8 XCDs, so the group USUALLY shares one XCD and one L2.  That is observed, not
+// promised, so it is checked, per launch: every workgroup reports its HW_REG_XCC_ID before the first barrier.
+//   * placement-independent protocol (always correct; the first barrier, and every barrier unless all ids agree):
+//     rows stored write-through (sc1) and drained, workgroup barrier, ONE lane adds to an agent-scope counter and
+//     polls it with sc1 loads, workgroup barrier, rows loaded with sc1 (past the L1).
+//   * one-XCD protocol (all ids equal): plain row stores -- the lines stay in the XCD's L2 -- drained, the counter
+//     added to at workgroup scope (executes in that L2), the same sc1 poll and sc1 row loads: 1.35 us against 2.4
+//     per half-step at 2,048 slots.
+// Every poll loop is bounded (spin_limit): if the workgroups cannot all be resident (a GPU shared with another
+// process) each gives up, sets status bit 2 and ends; the host then refuses the chunk.
+// ---------------------------------------------------------------------------------
+constexpr int GROUP_ROW = 8;            // doubles per state row: one 64-byte line
+constexpr int GROUP_BLK = 256;
+
+__device__ __forceinline__ void group_store_row(double *p, const dbl2 (&v)[4], bool through)
+{
+    if (through) {
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1\n\t"
+                     "global_store_dwordx4 %0, %3, off offset:32 sc1\n\tglobal_store_dwordx4 %0, %4, off offset:48 sc1"
+                     :: "v"(p), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "memory");
+    } else {
+        asm volatile("global_store_dwordx4 %0, %1, off\n\tglobal_store_dwordx4 %0, %2, off offset:16\n\t"
+                     "global_store_dwordx4 %0, %3, off offset:32\n\tglobal_store_dwordx4 %0, %4, off offset:48"
+                     :: "v"(p), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "memory");
+    }
+}
+
+// two rows (a slot's walker and its partner), all eight loads in flight, past the L1
+__device__ __forceinline__ void group_load_rows(const double *ps, const double *pc, dbl2 (&s)[4], dbl2 (&c)[4])
+{
+    asm volatile("global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %8, off offset:16 sc1\n\t"
+                 "global_load_dwordx4 %2, %8, off offset:32 sc1\n\tglobal_load_dwordx4 %3, %8, off offset:48 sc1\n\t"
+                 "global_load_dwordx4 %4, %9, off sc1\n\tglobal_load_dwordx4 %5, %9, off offset:16 sc1\n\t"
+                 "global_load_dwordx4 %6, %9, off offset:32 sc1\n\tglobal_load_dwordx4 %7, %9, off offset:48 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(s[0]), "=&v"(s[1]), "=&v"(s[2]), "=&v"(s[3]), "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3])
+                 : "v"(ps), "v"(pc) : "memory");
+}
+
+// all workgroups of the group have arrived `target` times in all; false: gave up waiting
+__device__ __forceinline__ bool group_barrier(unsigned *counter, unsigned target, bool one_xcd, unsigned limit, int *flag)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's state rows have left
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (one_xcd) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        int ok = 1;
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > limit) { ok = 0; break; }
+        }
+        *flag = ok;
+    }
+    __syncthreads();
+    return *flag != 0;
+}
+
+__device__ __forceinline__ int group_xcc_id()
+{
+    int v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return v & 15;
+}
+
+template <class LP, bool STAGED>
+__global__ __launch_bounds__(GROUP_BLK) void k_stretch_group(const PersistArgs a, const LP lp)
+{
+    constexpr int NDIM = LP::NDIM;
+    constexpr int L = LP::L;
+    static_assert(NDIM < GROUP_ROW, "a state row holds theta and the log-probability in 8 doubles");
+    if (blockIdx.x % 8 != 0) return;                      // the group: workgroups 0, 8, 16, ... of the grid
+    extern __shared__ __attribute__((aligned(16))) double lds_records[];
+    __shared__ int flag;
+    const int member = blockIdx.x / 8;
+    const int tid = threadIdx.x;
+    // sync words (one 64-byte line each): [0] first barrier, [16] the half-steps' barriers, [32] min XCC id, [33] max
+    unsigned *first = a.gsync, *rounds = a.gsync + 16, *xmin = a.gsync + 32, *xmax = a.gsync + 33;
+    const double *recs = nullptr;
+    if constexpr (STAGED) {
+        if constexpr (StagesFromArgs<LP>::value) lp.stage_from_args(lds_records, tid);
+        else {
+            const double *__restrict__ src = lp.records(0);
+            const int n = lp.n_freq() * LP::REC_DOUBLES;
+            for (int i = tid; i < n; i += GROUP_BLK) lds_records[i] = src[i];
+        }
+        recs = lds_records;
+    }
+    // the state into its rows (write-through: any placement may read them), then the first barrier
+    for (long long w = (long long)member * GROUP_BLK + tid; w < a.W; w += (long long)a.G * GROUP_BLK) {
+        dbl2 v[4];
+        double r[GROUP_ROW];
+#pragma unroll
+        for (int q = 0; q < GROUP_ROW; ++q) r[q] = q < NDIM ? a.coords[w * NDIM + q] : 0.0;
+        r[GROUP_ROW - 1] = a.logp[w];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { v[q].x = r[2 * q]; v[q].y = r[2 * q + 1]; }
+        group_store_row(a.gstate + w * GROUP_ROW, v, true);
+    }
+    if (tid == 0) {
+        const unsigned id = (unsigned)group_xcc_id();
+        __hip_atomic_fetch_min(xmin, id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_max(xmax, id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    bool ok = group_barrier(first, (unsigned)a.G, false, a.spin_limit, &flag);
+    const bool one_xcd = __hip_atomic_load(xmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+                         __hip_atomic_load(xmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const long long nh = (a.W + 1) / 2;
+    constexpr int SPW = GROUP_BLK / L;                    // slots per workgroup
+    const long long slot = (long long)member * SPW + tid / L;
+    const int g = tid % L;
+    const long long t0 = slot < nh ? slot : nh - 1;
+    const long long t1 = slot < a.W / 2 ? slot : a.W / 2 - 1;
+    const typename LP::Local loc = lp.local(0);
+    SlotStream cur = load_slot(a, t0);
+    unsigned round = 0;
+    long long srow = 0, until_store = a.thin_by;
+    for (long long k = 0; ok && k < a.n_steps; ++k) {
+        const bool store = --until_store == 0;
+        for (int h = 0; h < 2; ++h) {
+            const bool live = slot < (h ? a.W / 2 : nh);
+            const int i = cur.active, p = cur.partner;
+            dbl2 sv[4], cv[4];
+            group_load_rows(a.gstate + (long long)i * GROUP_ROW, a.gstate + (long long)p * GROUP_ROW, sv, cv);
+            // the next half-step's entries travel while this one is evaluated
+            const long long kn = h ? (k + 1 < a.n_steps ? k + 1 : k) : k;
+            const SlotStream nxt = load_slot(a, (kn * 2 + (1 - h)) * nh + (h ? t0 : t1));
+            double s_row[GROUP_ROW], c_row[GROUP_ROW];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { s_row[2 * q] = sv[q].x; s_row[2 * q + 1] = sv[q].y; c_row[2 * q] = cv[q].x; c_row[2 * q + 1] = cv[q].y; }
+            double row[NDIM], lp_row;
+            const bool acc = stretch_move<STAGED ? 2 : 1>(s_row, c_row, s_row[GROUP_ROW - 1], cur.z, cur.factor, cur.logu, lp, i, g,
+                                                          a.status, row, lp_row, &loc, recs);
+            if (live && g == 0) {
+                if (acc) {
+                    dbl2 v[4];
+                    double r[GROUP_ROW];
+#pragma unroll
+                    for (int q = 0; q < GROUP_ROW; ++q) r[q] = q < NDIM ? row[q] : 0.0;
+                    r[GROUP_ROW - 1] = lp_row;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { v[q].x = r[2 * q]; v[q].y = r[2 * q + 1]; }
+                    group_store_row(a.gstate + (long long)i * GROUP_ROW, v, !one_xcd);
+                    if (a.naccept) atomicAdd(a.naccept + i, 1);
+                }
+                if (store && a.chain) {
+                    double *cr = a.chain + (srow * a.W + i) * NDIM;
+#pragma unroll
+                    for (int q = 0; q < NDIM; ++q) __builtin_nontemporal_store(row[q], cr + q);
+                }
+                if (store && a.logp_chain) __builtin_nontemporal_store(lp_row, a.logp_chain + srow * a.W + i);
+            }
+            cur = nxt;
+            ok = group_barrier(rounds, ++round * (unsigned)a.G, one_xcd, a.spin_limit, &flag);
+            if (!ok) break;
+        }
+        if (store) { ++srow; until_store = a.thin_by; }
+    }
+    if (!ok) {
+        if (tid == 0) atomicOr(a.status, 4);
+        return;
+    }
+    for (long long w = (long long)member * GROUP_BLK + tid; w < a.W; w += (long long)a.G * GROUP_BLK) {
+        dbl2 v[4], dummy[4];
+        group_load_rows(a.gstate + w * GROUP_ROW, a.gstate + w * GROUP_ROW, v, dummy);
+        double r[GROUP_ROW];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { r[2 * q] = v[q].x; r[2 * q + 1] = v[q].y; }
+#pragma unroll
+        for (int q = 0; q < NDIM; ++q) a.coords[w * NDIM + q] = r[q];
+        a.logp[w] = r[GROUP_ROW - 1];
     }
 }
 

@@ -47,11 +47,44 @@ int launch_persistent(const PersistArgs &p0, const LP &lp, hipStream_t st)
     return BISIP_OK;
 }
 
+// One ensemble over several workgroups (k_stretch_group): G workgroups of 256 lanes hold the larger half's slots,
+// LP::L lanes each; the grid is 8 G (the group is its every eighth workgroup: see the kernel).
+constexpr int GROUP_MAX_WORKGROUPS = 64;
+template <class LP>
+int launch_group(const PersistArgs &p0, const LP &lp, hipStream_t st)
+{
+    if constexpr (LP::NDIM >= GROUP_ROW || !SingleSpectrum<LP>::value) {
+        return fail(BISIP_EUNSUPPORTED, "the multi-workgroup sampler takes one spectrum and keeps a walker in one 64-byte row (ndim=%d)", LP::NDIM);
+    } else {
+        PersistArgs p = p0;
+        const long long nh = (p.W + 1) / 2;
+        p.G = (int)((nh * LP::L + GROUP_BLK - 1) / GROUP_BLK);
+        if (p.G > GROUP_MAX_WORKGROUPS) return fail(BISIP_EUNSUPPORTED, "ensemble of %lld walkers: more than %d workgroups", p.W, GROUP_MAX_WORKGROUPS);
+        size_t rec_bytes = 0;
+        if constexpr (LP::CAN_STAGE) {
+            rec_bytes = (((size_t)lp.n_freq() * LP::REC_DOUBLES + 1) & ~(size_t)1) * sizeof(double);
+            if (rec_bytes > 60000 || std::getenv("BISIP_NO_LDS_STAGING") != nullptr) rec_bytes = 0;
+        }
+        const dim3 grid((unsigned)(8 * p.G)), block(GROUP_BLK);
+        if constexpr (LP::CAN_STAGE) {
+            if (rec_bytes) {
+                hipLaunchKernelGGL((k_stretch_group<LP, true>), grid, block, rec_bytes, st, p, lp);
+                HIP_TRY(hipGetLastError());
+                return BISIP_OK;
+            }
+        }
+        hipLaunchKernelGGL((k_stretch_group<LP, false>), grid, block, 0, st, p, lp);
+        HIP_TRY(hipGetLastError());
+        return BISIP_OK;
+    }
+}
+
 template <class LP>
 int launch_stretch(const StretchWork &work, const LP &lp, hipStream_t st)
 {
     const StretchKind kind = work.kind;
     if (kind == STRETCH_PERSIST) return launch_persistent(*work.persist, lp, st);
+    if (kind == STRETCH_GROUP) return launch_group(*work.persist, lp, st);
     const StretchArgs &a = *work.half;
     if (kind == STRETCH_HALF) {
         // a launch that fills the chip (>= one wave per SIMD) goes out as four-wave workgroups, one
@@ -81,10 +114,16 @@ inline int stretch_lanes(const StretchWork &w)
     if (const char *env = std::getenv("BISIP_STRETCH_LANES")) {
         const int v = std::atoi(env);
         if (v == 1 || v == 2 || v == 4) {
+            if (w.kind == STRETCH_GROUP) return v;
             if (w.kind != STRETCH_PERSIST) return v;
             const long long nh = (w.persist->W + 1) / 2;
             return nh * v <= 512 ? v : (nh * 2 <= 512 ? 2 : 1);
         }
+    }
+    if (w.kind == STRETCH_GROUP) {
+        // as many lanes per slot as keep the group within one XCD's 32 compute units (one workgroup each)
+        const long long nh = (w.persist->W + 1) / 2;
+        return nh * 4 <= 32 * GROUP_BLK ? 4 : (nh * 2 <= 32 * GROUP_BLK ? 2 : 1);
     }
     if (w.kind == STRETCH_PERSIST) {
         const long long nh = (w.persist->W + 1) / 2;

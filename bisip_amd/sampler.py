@@ -1091,7 +1091,9 @@ class DeviceEnsembleSampler(_SamplerBase):
         W, ndim = self.nwalkers, self.ndim
         single = self._world == 1 and not self.force_sharded_path
         if single and self.persistent and be.run_persistent(st, self.walkers_per_ensemble, n):
-            self.last_path = 'persistent'
+            # one workgroup per ensemble, or -- a single ensemble beyond that -- several with a barrier of their own
+            self.last_path = 'persistent' if self.walkers_per_ensemble * (ndim + 1) * 8 <= 65536 and (self.walkers_per_ensemble + 1) // 2 <= 512 \
+                else 'persistent-multi-workgroup'
         elif single:
             be.run(st, n)
             self.last_path = 'launch-per-half-step'
@@ -1375,6 +1377,10 @@ class DeviceEnsembleSampler(_SamplerBase):
                 ends[name] = np.array(final[name][0].numpy(), copy=True)     # (the pinned block is scratch)
             else:
                 ends[name] = self._dev[name].cpu().numpy()
+        if int(ends['status'][0]) & 4:                 # bit 2: the multi-workgroup kernel's workgroups never met
+            self._dev = None
+            raise RuntimeError('the multi-workgroup persistent sampler gave up at a barrier: its workgroups were not all '
+                               'resident (a GPU shared with other work?); nothing of this run is kept -- run with persistent=False')
         if int(ends['status'][0]) & 3:                 # bit 0: a proposal, bit 1: the initial state
             self._dev = None                           # nothing of this run is kept
             raise ValueError('Probability function returned NaN')

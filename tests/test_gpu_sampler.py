@@ -523,15 +523,64 @@ def test_compensated_persistent_kernel_with_and_without_staged_low_words(poly_de
 
 
 def test_persistent_falls_back_when_ensemble_too_large():
+    """Beyond one workgroup a single ensemble of up to 8,192 walkers and 7 parameters has the multi-workgroup
+    persistent kernel; past either limit persistent=True quietly runs a launch per half-step."""
     from bisip_amd.sampler import DeviceEnsembleSampler
     g = np.load(_case('case15_'))
     ctx = make_ctx(g, 'PeltonColeCole')
-    W = 4096                                    # nh = 2048 > 1024 lanes
-    p0 = _start(g, W, 9)
-    np.random.seed(2)
-    s = DeviceEnsembleSampler(W, 4, ctx, rng='philox', seed=5)
-    s.run_mcmc(p0, 3)
+    for W, want in ((4096, 'persistent-multi-workgroup'), (8194, 'launch-per-half-step')):
+        p0 = _start(g, W, 9)
+        np.random.seed(2)
+        s = DeviceEnsembleSampler(W, 4, ctx, rng='philox', seed=5, persistent=True)
+        s.run_mcmc(p0, 3)
+        assert s.last_path == want
+    ctx.close()
+    g = np.load(_case('case17_'))                # three modes: ndim 10, a row does not fit 64 bytes
+    ctx = make_ctx(g, 'PeltonColeCole')
+    s = DeviceEnsembleSampler(2048, 10, ctx, rng='philox', seed=5, persistent=True)
+    s.run_mcmc(_start(g, 2048, 9), 3)
     assert s.last_path == 'launch-per-half-step'
+    ctx.close()
+
+
+@pytest.mark.parametrize('prefix,model,variant', [c for c in CASES if c[0] != 'case17_'] + [('case13_', 'PolynomialDecomposition', 'reduced_comp')])
+def test_multi_workgroup_persistent_kernel_equals_launch_per_half_step(prefix, model, variant, monkeypatch):
+    """One ensemble of 1,025 ... 8,192 walkers (BASELINE config 2: 4,096): k_stretch_group runs every iteration
+    of a chunk in ONE launch -- several workgroups, the state in 64-byte rows in memory, a barrier of their own
+    after every half-step -- and reproduces the launch-per-half-step path bit for bit: both random streams, odd
+    ensembles (halves of different sizes, a last workgroup with dead slots), thinning, chunked runs,
+    continuation, 1 / 2 / 4 lanes per slot, records staged in LDS or read through the scalar cache."""
+    from bisip_amd.sampler import DeviceEnsembleSampler
+    g = np.load(_case(prefix))
+    ndim = g['bounds'].shape[1]
+    if ndim > 7:
+        pytest.skip('rows of more than 7 parameters do not fit the 64-byte state row')
+    ctx = make_ctx(g, model, variant)
+    for W, nsteps, chunk, thin, rng, lanes in [(2048, 12, None, 1, 'philox', None), (4096, 9, 4, 1, 'numpy', None),
+                                               (4097, 6, None, 2, 'philox', '1'), (8192, 5, None, 1, 'philox', None),
+                                               (1026, 8, 3, 1, 'philox', '2'), (3001, 6, None, 3, 'numpy', '4')]:
+        p0 = _start(g, W, 500 + W)
+        out = []
+        for persistent in (True, False):
+            if lanes is None:
+                monkeypatch.delenv('BISIP_STRETCH_LANES', raising=False)
+            else:
+                monkeypatch.setenv('BISIP_STRETCH_LANES', lanes)
+            if W == 1026 and persistent:
+                monkeypatch.setenv('BISIP_NO_LDS_STAGING', '1')
+            else:
+                monkeypatch.delenv('BISIP_NO_LDS_STAGING', raising=False)
+            np.random.seed(17)
+            s = DeviceEnsembleSampler(W, ndim, ctx, rng=rng, seed=99, chunk=chunk, persistent=persistent)
+            s.run_mcmc(p0, nsteps, thin_by=thin)
+            s.run_mcmc(None, 3, thin_by=thin)       # continuation
+            out.append(s)
+        a, b = out
+        assert a.last_path == 'persistent-multi-workgroup' and b.last_path == 'launch-per-half-step', (a.last_path, b.last_path)
+        assert np.array_equal(a.get_chain(), b.get_chain()), W
+        assert np.array_equal(a.get_log_prob(), b.get_log_prob()), W
+        assert np.array_equal(a.acceptance_fraction, b.acceptance_fraction), W
+        assert np.array_equal(a._coords, b._coords) and np.array_equal(a._lp, b._lp)
     ctx.close()
 
 
