@@ -408,6 +408,22 @@ class HipContext:
         return 512          # Shin, per-frequency PolynomialDecomposition
 
     @property
+    def group_walkers(self):
+        """Largest single ensemble, beyond one workgroup, for which the multi-workgroup persistent kernel
+        (k_stretch_group: a barrier among the ensemble's workgroups per half-step instead of a launch) beats one
+        launch per half-step -- benchmarks/micro/group_sampler.py: 4.0-5.7 us against 4.6-6.5 per half-step at
+        2,048 and 4,096 walkers for the reduced PolynomialDecomposition kernels, Cole-Cole, Dias and Shin (1.15-1.4x);
+        at 8,192 the two tie or the launches win (fewer lanes per walker), and the per-frequency
+        PolynomialDecomposition form, one lane per walker, loses everywhere.  0: never.  A walker's row must fit 64
+        bytes (ndim <= 7)."""
+        if self.ndim > 7 or self.n_spectra != 1:
+            return 0
+        name = self.kernel_name
+        if 'PDCollapsed' in name or 'faithful' in name or 'wave' in name:
+            return 0
+        return 4096
+
+    @property
     def persistent_in_big_batches(self):
         """A batch that fills the chip (>= 65,536 walkers in all) runs its launches in the bulk regime; the
         persistent kernel -- one workgroup per ensemble, waiting on dependency chains -- still wins with every

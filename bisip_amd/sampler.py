@@ -888,7 +888,9 @@ class DeviceEnsembleSampler(_SamplerBase):
             if int(nwalkers) * self.n_ensembles >= 65536 and self.n_ensembles > 1:      # a batch that fills the chip
                 persistent = limit > 0 and int(nwalkers) <= 1024 and getattr(ctx, 'persistent_in_big_batches', True)
             else:
-                persistent = int(nwalkers) <= limit
+                # one workgroup up to `limit`; beyond 1,024 walkers (where one workgroup ends) a single ensemble has
+                # the multi-workgroup kernel up to HipContext.group_walkers
+                persistent = int(nwalkers) <= limit or (self.n_ensembles == 1 and 1024 < int(nwalkers) <= getattr(ctx, 'group_walkers', 0))
         self.persistent = bool(persistent)
         # keep the stored samples in HBM: nothing is copied to the host until get_chain() /
         # get_log_prob() ask for it, and param_moments() summarises the chain where it lies
