@@ -430,6 +430,69 @@ __global__ __launch_bounds__(64) void k_clock_probe(long long *out, long long ti
 }
 }  // namespace
 
+// A very big host-buffer call as a pipeline over chunks of rows: the caller's (pageable) rows are copied into a
+// pinned buffer by the host threads, go up on one stream, are evaluated there, and the results come back on a
+// second stream into a pinned buffer from which the host threads copy them out -- chunk k+1 is being staged while
+// chunk k travels and chunk k-1 returns; the device holds two chunks, not the whole batch (bisip_forward of 4M
+// rows: 2.3 GB otherwise).  What it buys in time is modest and only beyond the host's last-level cache: measured
+// (profiles/r05_micro_host_pipeline.txt) a call is bound by the host's copy out of pageable memory -- 54 GB/s over the
+// link while the source sits in cache (64 MB), 37-41 GB/s from DRAM (256 MB) whichever way it is staged, overlapped
+// or not -- so the pipeline starts at 192 MB (+4-6 % there) and everything smaller keeps the one-launch path.
+// launch(d_in, rows, d_out, stream) enqueues the kernel for one chunk.  Same bits as one launch over everything: a
+// row's value does not depend on where it sits in a batch.
+constexpr size_t PIPE_CHUNK_BYTES = 64u << 20;      // rows in + results out of one chunk
+constexpr size_t PIPE_FROM_BYTES = 192u << 20;      // smaller calls: the direct path (one synchronisation)
+
+template <class Launch>
+static int host_pipeline(bisip_ctx *c, const char *in, size_t in_row, char *out, size_t out_row, int64_t W, Launch &&launch)
+{
+    int64_t rows = (int64_t)(PIPE_CHUNK_BYTES / (in_row + out_row));
+    rows = rows < 256 ? 256 : (rows / 256) * 256;
+    const size_t in_al = ((size_t)rows * in_row + 255) & ~(size_t)255, out_al = ((size_t)rows * out_row + 255) & ~(size_t)255;
+    const size_t need = 2 * (in_al + out_al);
+    if (c->pipe_bytes < need) {
+        if (c->h_pipe) { HIP_TRY(hipStreamSynchronize(c->stream)); (void)hipHostFree(c->h_pipe); c->h_pipe = nullptr; c->pipe_bytes = 0; }
+        HIP_TRY(hipHostMalloc((void **)&c->h_pipe, need, hipHostMallocDefault));
+        c->pipe_bytes = need;
+    }
+    if (!c->stream_back) HIP_TRY(hipStreamCreateWithFlags(&c->stream_back, hipStreamNonBlocking));
+    for (hipEvent_t &ev : c->pipe_ev)
+        if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    int rc = ensure_ws(c, need);
+    if (rc != BISIP_OK) return rc;
+    char *h_in[2] = {c->h_pipe, c->h_pipe + in_al}, *h_out[2] = {c->h_pipe + 2 * in_al, c->h_pipe + 2 * in_al + out_al};
+    char *d_in[2] = {(char *)c->d_ws, (char *)c->d_ws + in_al}, *d_out[2] = {(char *)c->d_ws + 2 * in_al, (char *)c->d_ws + 2 * in_al + out_al};
+    hipEvent_t *up = c->pipe_ev, *done = c->pipe_ev + 2, *back = c->pipe_ev + 4;     // per buffer: rows are up / evaluated / results are back
+    const int64_t chunks = (W + rows - 1) / rows;
+    auto copy = [](char *dst, const char *src, size_t bytes) {
+        parallel_blocks((int64_t)bytes, 1 << 20, [&](int64_t lo, int64_t hi) { std::memcpy(dst + lo, src + lo, (size_t)(hi - lo)); });
+    };
+    auto collect = [&](int64_t k) -> int {         // chunk k's results, once they are back
+        const int b = (int)(k & 1);
+        const int64_t r0 = k * rows, n = (W - r0 < rows) ? W - r0 : rows;
+        HIP_TRY(hipEventSynchronize(back[b]));
+        copy(out + (size_t)r0 * out_row, h_out[b], (size_t)n * out_row);
+        return BISIP_OK;
+    };
+    for (int64_t k = 0; k < chunks; ++k) {
+        const int b = (int)(k & 1);
+        const int64_t r0 = k * rows, n = (W - r0 < rows) ? W - r0 : rows;
+        if (k >= 2) HIP_TRY(hipEventSynchronize(up[b]));                 // chunk k-2 has left this staging buffer
+        copy(h_in[b], in + (size_t)r0 * in_row, (size_t)n * in_row);
+        HIP_TRY(hipMemcpyAsync(d_in[b], h_in[b], (size_t)n * in_row, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipEventRecord(up[b], c->stream));
+        if (k >= 2) HIP_TRY(hipStreamWaitEvent(c->stream, back[b], 0));  // chunk k-2's results have left d_out[b]
+        rc = launch(d_in[b], n, d_out[b], c->stream);
+        if (rc != BISIP_OK) { (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->stream_back); return rc; }
+        HIP_TRY(hipEventRecord(done[b], c->stream));
+        if (k >= 1) { rc = collect(k - 1); if (rc != BISIP_OK) return rc; }   // (h_out[b] was emptied by collect(k - 2) one round ago)
+        HIP_TRY(hipStreamWaitEvent(c->stream_back, done[b], 0));
+        HIP_TRY(hipMemcpyAsync(h_out[b], d_out[b], (size_t)n * out_row, hipMemcpyDeviceToHost, c->stream_back));
+        HIP_TRY(hipEventRecord(back[b], c->stream_back));
+    }
+    return collect(chunks - 1);
+}
+
 extern "C" {
 
 int bisip_abi_version(void) { return BISIP_ABI_VERSION; }
@@ -719,6 +782,9 @@ void bisip_ctx_destroy(bisip_ctx *c)
     if (c->d_gather) (void)hipFree(c->d_gather);
     if (c->d_group) (void)hipFree(c->d_group);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
+    if (c->h_pipe) (void)hipHostFree(c->h_pipe);
+    for (hipEvent_t ev : c->pipe_ev) if (ev) (void)hipEventDestroy(ev);
+    if (c->stream_back) (void)hipStreamDestroy(c->stream_back);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1253,6 +1319,13 @@ static int logprob_host_once(bisip_ctx *c, const double *theta, int64_t W, doubl
     HIP_TRY(hipSetDevice(c->device));
     const size_t tb = (size_t)W * c->ndim * sizeof(double), ob = (size_t)W * sizeof(double);
     const size_t tb_al = (tb + 255) & ~(size_t)255;
+    if (c->E == 1 && tb + ob >= PIPE_FROM_BYTES && std::getenv("BISIP_NO_HOST_PIPELINE") == nullptr)
+        return guarded([&] {
+            return host_pipeline(c, (const char *)theta, (size_t)c->ndim * sizeof(double), (char *)logp, sizeof(double), W,
+                                 [&](char *d_in, int64_t n, char *d_res, hipStream_t st) {
+                                     return dispatch_logprob(c, (const double *)d_in, n, (double *)d_res, st);
+                                 });
+        });
     int rc = ensure_ws(c, tb_al + ob);
     if (rc != BISIP_OK) return rc;
     double *d_theta = c->d_ws;
@@ -1299,6 +1372,13 @@ int bisip_forward(bisip_ctx *c, const double *theta, int64_t W, double *Z)
     HIP_TRY(hipSetDevice(c->device));
     const size_t tb = (size_t)W * c->ndim * sizeof(double), zb = (size_t)W * 2 * c->N * sizeof(double);
     const size_t tb_al = (tb + 255) & ~(size_t)255;
+    if (c->E == 1 && tb + zb >= PIPE_FROM_BYTES && std::getenv("BISIP_NO_HOST_PIPELINE") == nullptr)
+        return guarded([&] {
+            return host_pipeline(c, (const char *)theta, (size_t)c->ndim * sizeof(double), (char *)Z, (size_t)2 * c->N * sizeof(double), W,
+                                 [&](char *d_in, int64_t n, char *d_res, hipStream_t st) {
+                                     return dispatch_forward(c, (const double *)d_in, n, (double *)d_res, st);
+                                 });
+        });
     int rc = ensure_ws(c, tb_al + zb);
     if (rc != BISIP_OK) return rc;
     double *d_theta = c->d_ws;

@@ -106,6 +106,12 @@ struct bisip_ctx {
     char *d_group = nullptr;       // multi-workgroup persistent sampler: 256 B of synchronisation words, then W rows of 64 B
     size_t group_bytes = 0;
     int64_t spectrum_offset = 0;   // batch: survey index of spectrum 0 (keys the Philox stream)
+    // big host-buffer calls (bisip_logprob / bisip_forward): pinned double buffers, a second stream for the way
+    // back, events per buffer (host_pipeline in bisip_hip.hip)
+    char *h_pipe = nullptr;
+    size_t pipe_bytes = 0;
+    hipStream_t stream_back = nullptr;
+    hipEvent_t pipe_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     char *h_pin = nullptr;         // pinned, device-mapped staging for small host-buffer calls
     char *d_pin = nullptr;         // its device-side address
     static constexpr size_t PIN_BYTES = 1 << 20;

@@ -217,6 +217,48 @@ def test_ragged_batch_sizes(W):
         ctx.close()
 
 
+@pytest.mark.parametrize('case,model', [('PolynomialDecomposition_synthetic-N32-i0', 'PolynomialDecomposition'),
+                                        ('case16_', 'PeltonColeCole'), ('case18_', 'Dias2000')])
+def test_big_host_buffer_calls_are_pipelined_and_keep_their_bits(case, model, monkeypatch):
+    """bisip_logprob / bisip_forward on host buffers of 192 MB and more run as a pipeline over 64 MB chunks of rows
+    (pinned double buffers, the rows up on one stream, the results back on another, the copies on the host
+    threads; the device holds two chunks).  A row's value does not depend on the chunk it travels in: the results
+    equal the single-launch path's (BISIP_NO_HOST_PIPELINE=1) bit for bit -- a size that ends inside a chunk, one
+    just past the threshold; -inf rows; rows against the oracle."""
+    import oracle
+    path = [p for p in golden_cases() if case in p][0]
+    g = np.load(path)
+    lo, hi = g['bounds']
+    ndim = lo.size
+    prob = _oracle_problem(g, model)
+    ctx = make_ctx(g, model)
+    if model == 'PolynomialDecomposition':
+        ctx.reduced_guard(False)
+    row_bytes = 8 * (ndim + 1)
+    for W in ((192 << 20) // row_bytes + 5, (64 << 20) // row_bytes // 256 * 256 * 4 + 777):
+        theta = np.random.RandomState(W % 1000).uniform(lo, hi, (W, ndim))
+        theta[::9973, 0] = hi[0] + 1.0                        # some rows outside the prior
+        got = ctx.logprob(theta)
+        monkeypatch.setenv('BISIP_NO_HOST_PIPELINE', '1')
+        want = ctx.logprob(theta)
+        monkeypatch.delenv('BISIP_NO_HOST_PIPELINE')
+        assert np.array_equal(got, want) and np.isneginf(got[::9973]).all()
+        pick = np.random.RandomState(1).choice(W, 300, replace=False)
+        assert_logp_close(got[pick], oracle.logprob(prob, theta[pick]))
+        del theta, got, want
+    # forward: 16 N bytes come back per row
+    N = g['w'].size
+    Wf = (192 << 20) // (8 * ndim + 16 * N) + 33
+    theta = np.random.RandomState(5).uniform(lo, hi, (Wf, ndim))
+    Z = ctx.forward(theta)
+    monkeypatch.setenv('BISIP_NO_HOST_PIPELINE', '1')
+    Z1 = ctx.forward(theta)
+    monkeypatch.delenv('BISIP_NO_HOST_PIPELINE')
+    assert Z.shape == (Wf, 2, N) and np.array_equal(Z, Z1)
+    assert_Z_close(Z[-50:], oracle.forward(prob, theta[-50:]))
+    ctx.close()
+
+
 def test_unaligned_device_pointer_path():
     """bisip_logprob_dev on a theta view that starts 8 B (not 16 B) aligned takes the
     scalar-load staging path; results must be identical."""
