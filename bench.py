@@ -399,6 +399,11 @@ def main():
     ap.add_argument('--extras-only', action='store_true',
                     help='N > 1: ONLY the cfg4 / cfg5 sampler measurements (what the second group runs); '
                          'lines on stderr, no result line')
+    ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak',
+                    help="N > 1: which measurement is the line's `value`.  weak (default, the contract's per-GPU work "
+                         "fixed): every rank its own --walkers rows.  strong: --walkers rows IN ALL, split into contiguous "
+                         "blocks by shard_range (SURVEY 8e) -- the north star's '>= 6x at 8 GPUs' reading.  Both are "
+                         "measured in every N > 1 run; the other one is in the line's `weak` / `strong` object.")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-variants', action='store_true')
     ap.add_argument('--pmc-pass', action='store_true',
@@ -514,6 +519,19 @@ def main():
                 break
             stalled_blocks.append(wall / max(args.steps, 1) * 1e3)
             wall, kern_ms = time_launches(step, args.steps, 0, torch, stream, dist)
+        # Strong scaling beside it (N > 1): the SAME W rows in all, rank r its contiguous block shard_range(W, N, r)
+        # (SURVEY 8e), timed exactly as above -- K launches between barriers, the slowest rank's clock.
+        strong = None
+        if dist is not None and world > 1:
+            from bisip_amd.dist import shard_range
+            lo_s, hi_s = shard_range(W, world, rank)
+            n_s = hi_s - lo_s
+
+            def step_strong():
+                ctx.logprob_dev(theta_t.data_ptr(), n_s, out_t.data_ptr(), stream.cuda_stream)
+            prime(step_strong, min(args.prime_seconds, 0.1), torch)
+            wall_s, kern_s = time_launches(step_strong, args.steps, args.warmup, torch, stream, dist)
+            strong = (wall_s, kern_s, n_s)
 
     ranks_seen, per_rank_kernel_ms = 1, [kern_ms]
     parity = None
@@ -539,6 +557,15 @@ def main():
         wall, kern_ms = float(t[0]), float(t[1])       # slowest rank
         ranks_seen = int(round(float(one[0])))
         per_rank_kernel_ms = [float(x) for x in every.cpu()]
+        if not rehearse and world > 1:
+            ts = torch.tensor([strong[0]], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+            mine_s = torch.tensor([strong[1], float(strong[2])], dtype=torch.float64, device=coll_dev)
+            every_s = torch.empty(2 * world, dtype=torch.float64, device=coll_dev)
+            dist.all_gather_into_tensor(every_s, mine_s)
+            every_s = every_s.cpu().view(world, 2)
+            strong = {'wall': float(ts[0]), 'per_rank_kernel_ms': [float(x) for x in every_s[:, 0]],
+                      'walkers_per_gpu': [int(x) for x in every_s[:, 1]]}
 
     if rank == 0:
         result = {
@@ -577,6 +604,23 @@ def main():
                                                if traffic is not None else None},
             })
             result['kernel_sources_sha256'] = kernel_sources_sha256()
+            if world > 1 and isinstance(strong, dict):
+                # both readings of "N GPUs" in one line: `value` is the one --scaling names
+                weak_obj = {'value': result['value'], 'ms_per_step': result['ms_per_step'], 'global_walkers': W * world,
+                            'walkers_per_gpu': W, 'per_rank_kernel_ms': per_rank_kernel_ms}
+                strong_obj = {'value': float(W) * args.steps / strong['wall'], 'ms_per_step': strong['wall'] / args.steps * 1e3,
+                              'global_walkers': W, 'walkers_per_gpu': strong['walkers_per_gpu'],
+                              'per_rank_kernel_ms': strong['per_rank_kernel_ms'],
+                              'partition': 'contiguous blocks shard_range(W, N, rank), no data-path collective'}
+                result['weak'], result['strong'] = weak_obj, strong_obj
+                if args.scaling == 'strong':
+                    slow = max(range(world), key=lambda r: strong['per_rank_kernel_ms'][r])
+                    k_ms, n_slow = strong['per_rank_kernel_ms'][slow], strong['walkers_per_gpu'][slow]
+                    ach = bytes_per_eval * n_slow / (k_ms * 1e-3) / 1e9
+                    result.update({'scaling': 'strong', 'value': strong_obj['value'], 'ms_per_step': strong_obj['ms_per_step']})
+                    result['config'].update({'walkers_per_gpu': strong['walkers_per_gpu'], 'global_walkers': W})
+                    result['roofline'].update({'achieved': ach, 'frac': ach / HBM_PEAK_GBS, 'kernel_ms': k_ms, 'traffic': None,
+                                               'traffic_source': None, 'per_rank_kernel_ms': strong['per_rank_kernel_ms']})
             if traffic_stale:
                 result['roofline']['counters_stale'] = True     # collected from other kernel sources: not quoted
             if parity is not None:

@@ -107,6 +107,11 @@ def test_bench_four_ranks_on_one_device():
     rec = json.loads(lines[0])
     assert rec['n_gpus'] == 4 and rec['ranks_seen'] == 4 and rec['scaling'] == 'weak'
     assert rec['config']['global_walkers'] == 4 << 20 and len(rec['roofline']['per_rank_kernel_ms']) == 4
+    # both readings of "4 GPUs" are in the line: weak (every rank its own 2^20 rows: the value) and strong (2^20 rows
+    # in all, contiguous blocks of shard_range)
+    assert rec['weak']['value'] == rec['value'] and rec['weak']['global_walkers'] == 4 << 20
+    assert rec['strong']['global_walkers'] == 1 << 20 and rec['strong']['walkers_per_gpu'] == [1 << 18] * 4
+    assert len(rec['strong']['per_rank_kernel_ms']) == 4 and rec['strong']['value'] > 0
     assert rec['parity']['ranks_checked'] == 4 and rec['parity']['neg_inf_rows_match'] is True
     assert rec['parity']['max_rel_err_vs_oracle'] <= 1e-10
     cfg4 = [json.loads(ln)['sampler_cfg4'] for ln in r.stderr.splitlines() if ln.startswith('{"sampler_cfg4"')]
