@@ -121,10 +121,20 @@ def valu_roofline(label, W, kernel_ms, counts):
         return None
     per_eval = float(rec['valu_wave_instr_per_eval'])
     achieved = per_eval * W / (kernel_ms * 1e-3)
-    return {'bound': 'fp64-valu-issue', 'achieved': achieved, 'peak': VALU_PEAK_WAVE_INSTR_S,
-            'unit': 'VALU wave-instr/s', 'frac': achieved / VALU_PEAK_WAVE_INSTR_S,
-            'valu_wave_instr_per_eval': per_eval, 'kernel': rec.get('kernel'),
-            'source': 'profiles/valu_counts.json (SQ_INSTS_VALU per launch / walkers); peak = 1024 SIMDs x 2.4 GHz / 4 cycles'}
+    out = {'bound': 'fp64-valu-issue', 'achieved': achieved, 'peak': VALU_PEAK_WAVE_INSTR_S,
+           'unit': 'VALU wave-instr/s', 'frac': achieved / VALU_PEAK_WAVE_INSTR_S,
+           'valu_wave_instr_per_eval': per_eval, 'kernel': rec.get('kernel'),
+           'source': 'profiles/valu_counts.json (SQ_INSTS_VALU per launch / walkers); peak = 1024 SIMDs x 2.4 GHz / 4 cycles'}
+    if 'issue_slots_per_eval' in rec:
+        # the same ceiling with every instruction at its own price: a quarter-rate fp64 transcendental (v_rcp_f64, ...;
+        # SQ_INSTS_VALU_TRANS_F64) occupies the issue port for four slots
+        slots = float(rec['issue_slots_per_eval'])
+        out.update({'trans_f64_wave_instr_per_eval': float(rec['trans_f64_wave_instr_per_eval']),
+                    'issue_slots_per_eval': slots,
+                    'frac_issue_slots': slots * W / (kernel_ms * 1e-3) / VALU_PEAK_WAVE_INSTR_S})
+        if 'wave_cycle_fractions' in rec:
+            out['wave_cycle_fractions'] = rec['wave_cycle_fractions']
+    return out
 
 
 def prime(fn, seconds, torch):
@@ -189,6 +199,8 @@ def with_clock(rv, clock_ghz):
     if rv and clock_ghz:
         rv['clock_ghz'] = clock_ghz
         rv['frac_at_clock'] = rv['achieved'] / (N_SIMD * clock_ghz * 1e9 / 4.0)
+        if 'frac_issue_slots' in rv:
+            rv['frac_issue_slots_at_clock'] = rv['frac_issue_slots'] * 2.4 / clock_ghz
         rv['cycles_per_valu_instr_per_simd'] = N_SIMD * clock_ghz * 1e9 / rv['achieved']
     return rv
 

@@ -37,8 +37,10 @@ if [ "$what" = bench ] || [ "$what" = all ]; then
         python3 "$repo/bench.py" --no-cpu-baseline --no-variants --steps 20 --prime-seconds 0.1 > "$out/pmc_$c.json" 2> "$out/pmc_$c.err") || echo "!! a rocprofv3 step failed" | tee -a "$out/progress.log"
     keep "$scratch/pmc_$c" pmc_$c
   done
-  echo "== bench.py --pmc-pass --pmc SQ_INSTS_VALU" | tee -a "$out/progress.log"
-  (cd /tmp && rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU --output-format csv -d "$scratch/pmc_valu" -- \
+  # one pass, eight SQ counters: the instruction counts behind roofline_valu (all VALU, and the quarter-rate fp64
+  # transcendentals among them) and where the waves' cycles go (parked at a wait, stalled at issue, issuing)
+  echo "== bench.py --pmc-pass --pmc SQ_INSTS_VALU SQ_INSTS_VALU_TRANS_F64 + wait / active cycles" | tee -a "$out/progress.log"
+  (cd /tmp && rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_VALU_TRANS_F64 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_INSTS_SMEM --output-format csv -d "$scratch/pmc_valu" -- \
       python3 "$repo/bench.py" --pmc-pass > "$out/pmc_valu.json" 2> "$out/pmc_valu.err") || echo "!! a rocprofv3 step failed" | tee -a "$out/progress.log"
   keep "$scratch/pmc_valu" pmc_valu
 fi

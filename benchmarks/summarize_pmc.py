@@ -93,17 +93,24 @@ def valu_counts():
     if order is None:
         sys.exit(f'no pmc_pass line in {order_file}')
     disp = []
+    other = {}          # dispatch id -> the other SQ counters of the pass (summed over the rows of a dispatch)
     for f in files:
         for r in csv.DictReader(open(f)):
-            if r['Counter_Name'] == 'SQ_INSTS_VALU' and 'k_logprob' in r['Kernel_Name']:
+            if 'k_logprob' not in r['Kernel_Name']:
+                continue
+            if r['Counter_Name'] == 'SQ_INSTS_VALU':
                 disp.append((int(r['Dispatch_Id']), r['Kernel_Name'], float(r['Counter_Value']), int(r['Grid_Size'])))
+            else:
+                o = other.setdefault(int(r['Dispatch_Id']), {})
+                o[r['Counter_Name']] = o.get(r['Counter_Name'], 0.0) + float(r['Counter_Value'])
     disp.sort()
     # a dispatch may appear once per XCD/agent row: sum rows of one dispatch id
     merged = {}
     for d, name, val, grid in disp:
         m = merged.setdefault(d, [name, 0.0, grid])
         m[1] += val
-    rows = [merged[k] for k in sorted(merged)]
+    ids = sorted(merged)
+    rows = [merged[k] for k in ids]
     if len(rows) != len(order):
         sys.exit(f'{len(rows)} log-prob dispatches in the counter file, {len(order)} in the pass order')
     out = {}
@@ -115,9 +122,25 @@ def valu_counts():
             sys.exit(f'dispatch order mismatch: expected {o["kernel"]}, saw {name}')
         out[o['label']] = {'kernel': name, 'walkers': o['walkers'], 'SQ_INSTS_VALU_per_launch': val,
                            'valu_wave_instr_per_eval': val / o['walkers']}
+        extra = other.get(ids[len(out) - 1], {})
+        if 'SQ_INSTS_VALU_TRANS_F64' in extra:
+            # v_rcp_f64 / v_sqrt_f64 / v_rsq_f64 issue at a quarter of the FMA rate (benchmarks/micro/valu_rates.hip):
+            # one of them takes four issue slots
+            t = extra['SQ_INSTS_VALU_TRANS_F64'] / o['walkers']
+            out[o['label']].update({'trans_f64_wave_instr_per_eval': t,
+                                    'issue_slots_per_eval': val / o['walkers'] + 3.0 * t})
+        wc = extra.get('SQ_WAVE_CYCLES')
+        if wc:
+            out[o['label']]['wave_cycle_fractions'] = {
+                'parked_at_a_wait (SQ_WAIT_ANY)': round(extra.get('SQ_WAIT_ANY', 0.0) / wc, 3),
+                'stalled_at_issue (SQ_WAIT_INST_ANY)': round(extra.get('SQ_WAIT_INST_ANY', 0.0) / wc, 3),
+                'issuing (SQ_ACTIVE_INST_ANY)': round(extra.get('SQ_ACTIVE_INST_ANY', 0.0) / wc, 3),
+                'issuing_valu (SQ_ACTIVE_INST_VALU)': round(extra.get('SQ_ACTIVE_INST_VALU', 0.0) / wc, 3)}
+            out[o['label']]['smem_instr_per_wave'] = round(extra.get('SQ_INSTS_SMEM', 0.0) / (o['walkers'] / 64.0), 1)
     out['kernel_sources_sha256'] = sources_hash(order_file, 'pmc_pass')
-    out['_note'] = (f'rocprofv3 --pmc SQ_INSTS_VALU on `python3 bench.py --pmc-pass` ({tag}); one launch per kernel; '
-                    'wave-instructions summed over all waves of the launch')
+    out['_note'] = (f'rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_TRANS_F64 SQ_WAIT_* SQ_ACTIVE_* SQ_WAVE_CYCLES SQ_INSTS_SMEM on '
+                    f'`python3 bench.py --pmc-pass` ({tag}); one launch per kernel; wave-instructions summed over all waves of the '
+                    'launch; issue_slots_per_eval = all VALU + 3 x the quarter-rate fp64 transcendentals')
     json.dump(out, open(os.path.join(dst, 'valu_counts.json'), 'w'), indent=1)
     print(json.dumps(out))
 

@@ -21,10 +21,12 @@ int stretch_generic_batch(const bisip_ctx *c, const StretchWork &a, long long Wp
 {
     // a wave of 64/L slots must stay inside one spectrum for the uniform (scalar) operand path
     // (the persistent kernel's workgroup is one ensemble: always inside one spectrum)
-    const int want = CoopLimit<M>::value > 0 ? stretch_lanes(a) : 1;
-    const bool whole = !U || a.kind == STRETCH_PERSIST;
-    if (want == 4 && (whole || (Wp / 2) % 16 == 0)) return stretch_generic_batch_l<M, U, 4>(c, a, Wp, st);
-    if (want >= 2 && (whole || (Wp / 2) % 32 == 0)) return stretch_generic_batch_l<M, U, 2>(c, a, Wp, st);
+    if constexpr (CoopLimit<M>::value > 0) {      // (models whose frequency loop is too cheap to split have one lane per slot: no other kernels exist)
+        const int want = stretch_lanes(a);
+        const bool whole = !U || a.kind == STRETCH_PERSIST;
+        if (want == 4 && (whole || (Wp / 2) % 16 == 0)) return stretch_generic_batch_l<M, U, 4>(c, a, Wp, st);
+        if (want >= 2 && (whole || (Wp / 2) % 32 == 0)) return stretch_generic_batch_l<M, U, 2>(c, a, Wp, st);
+    }
     return stretch_generic_batch_l<M, U, 1>(c, a, Wp, st);
 }
 

@@ -44,6 +44,12 @@ struct StretchArgs {
 // L = lanes per walker (see logprob_row); g = this lane's index inside its group.
 // Functors over per-frequency records (CAN_STAGE) also say where a walker's records live and
 // evaluate against a copy of them -- the persistent kernel keeps that copy in LDS.
+// a batch functor whose waves may straddle two spectra never runs a persistent kernel (a workgroup there IS an ensemble)
+template <class LP, class = void>
+struct MayPersist : std::true_type {};
+template <class LP>
+struct MayPersist<LP, std::void_t<decltype(LP::WAVE_IN_ONE_SPECTRUM)>> : std::bool_constant<LP::WAVE_IN_ONE_SPECTRUM> {};
+
 // does the functor evaluate a single-spectrum context (the multi-workgroup sampler exists for those only)?
 template <class LP, class = void>
 struct SingleSpectrum : std::false_type {};
@@ -181,6 +187,7 @@ struct ReducedLP {
 // batch of spectra: operands of the spectrum that owns walker i (i / Wp)
 template <class M, bool UNIFORM, int L_ = 1>
 struct BatchGenericLP {
+    static constexpr bool WAVE_IN_ONE_SPECTRUM = UNIFORM;     // (the persistent kernels are launched for these only)
     static constexpr int NDIM = M::NDIM;
     static constexpr int L = L_;
     static constexpr bool CAN_STAGE = true;
@@ -215,6 +222,7 @@ struct BatchGenericLP {
 
 template <int P, bool UNIFORM, bool COMP = false>
 struct BatchReducedLP {
+    static constexpr bool WAVE_IN_ONE_SPECTRUM = UNIFORM;
     static constexpr int NDIM = P + 2;
     static constexpr int L = 1;
     // The compensated tier's register copy of a spectrum's operands (Local) is 130 dwords: with the rest of

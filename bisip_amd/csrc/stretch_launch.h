@@ -83,7 +83,10 @@ template <class LP>
 int launch_stretch(const StretchWork &work, const LP &lp, hipStream_t st)
 {
     const StretchKind kind = work.kind;
-    if (kind == STRETCH_PERSIST) return launch_persistent(*work.persist, lp, st);
+    if (kind == STRETCH_PERSIST) {
+        if constexpr (MayPersist<LP>::value) return launch_persistent(*work.persist, lp, st);
+        else return fail(BISIP_EUNSUPPORTED, "internal: a persistent launch for a functor whose waves straddle spectra");
+    }
     if (kind == STRETCH_GROUP) return launch_group(*work.persist, lp, st);
     const StretchArgs &a = *work.half;
     if (kind == STRETCH_HALF) {
@@ -97,8 +100,13 @@ int launch_stretch(const StretchWork &work, const LP &lp, hipStream_t st)
             hipLaunchKernelGGL((k_stretch_half<LP, 64>), dim3(grid), dim3(64), 0, st, a, lp);
         }
     } else {
-        const unsigned grid = (unsigned)(((a.slot_hi - a.slot_lo) * LP::L + 63) / 64);
-        hipLaunchKernelGGL((k_stretch_eval<LP>), dim3(grid), dim3(64), 0, st, a, lp);
+        // (the sharded half-step: a batch of spectra shards as whole replicas and never comes here)
+        if constexpr (SingleSpectrum<LP>::value) {
+            const unsigned grid = (unsigned)(((a.slot_hi - a.slot_lo) * LP::L + 63) / 64);
+            hipLaunchKernelGGL((k_stretch_eval<LP>), dim3(grid), dim3(64), 0, st, a, lp);
+        } else {
+            return fail(BISIP_EUNSUPPORTED, "the sharded half-step takes a single-spectrum context");
+        }
     }
     HIP_TRY(hipGetLastError());
     return BISIP_OK;

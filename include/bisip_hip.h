@@ -183,7 +183,8 @@ typedef struct bisip_stretch_args {
 
 /* Single-rank half-step: evaluate all n_slots slots and update the state (one launch). */
 int bisip_stretch_half_dev(bisip_ctx *ctx, const bisip_stretch_args *args, void *stream);
-/* Sharded half-step: evaluate slots [slot_lo, slot_hi) into args->block ... */
+/* Sharded half-step: evaluate slots [slot_lo, slot_hi) into args->block ... (single-spectrum contexts: a batch of
+ * spectra shards as whole replicas; BISIP_EUNSUPPORTED for a batch context) */
 int bisip_stretch_eval_dev(bisip_ctx *ctx, const bisip_stretch_args *args, void *stream);
 /* ... and, after the caller's all-gather of the blocks, apply all n_slots slots. */
 int bisip_stretch_apply_dev(bisip_ctx *ctx, const bisip_stretch_args *args, void *stream);
