@@ -33,5 +33,5 @@ for W in (131072, 524288, 1048576):
                    'us_per_half_step_device': round((best_t['enqueue_s'] + best_t['drain_s'] + best_t.get('guard_s', 0.0)) / 400 * 1e6, 1),
                    'timing_ms': {k: round(v * 1e3, 2) for k, v in best_t.items()}}
 out['model'] = which
-out['rows_kernel'] = os.environ.get('BISIP_STRETCH_ROWS', '1') != '0'
+out['packed_state'] = os.environ.get('BISIP_NO_PACKED_STATE') is None
 print(json.dumps(out))

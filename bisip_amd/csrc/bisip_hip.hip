@@ -781,6 +781,7 @@ void bisip_ctx_destroy(bisip_ctx *c)
     if (c->d_ws) (void)hipFree(c->d_ws);
     if (c->d_gather) (void)hipFree(c->d_gather);
     if (c->d_group) (void)hipFree(c->d_group);
+    if (c->d_packed) (void)hipFree(c->d_packed);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->h_pipe) (void)hipHostFree(c->h_pipe);
     for (hipEvent_t ev : c->pipe_ev) if (ev) (void)hipEventDestroy(ev);
@@ -1004,6 +1005,23 @@ int bisip_stretch_run_dev(bisip_ctx *c, const bisip_stretch_args *first, int64_t
     HIP_TRY(hipSetDevice(c->device));
     const int64_t nh = (W + 1) / 2;
     bisip_stretch_args u = *first;
+    // A single ensemble that fills the chip with one lane per slot samples this chunk on a packed state: one aligned
+    // 64-byte row per walker (k_stretch_half_packed), packed here, unpacked after the last half-step.
+    // BISIP_NO_PACKED_STATE (read per call) keeps the plain layout: A/B runs and the test of their equality.
+    const bool packed = c->E == 1 && c->ndim < PACKED_ROW && W / 2 >= 65536 && lanes_per_walker(W / 2) == 1 && n_steps > 0 &&
+                        std::getenv("BISIP_NO_PACKED_STATE") == nullptr;
+    if (packed) {
+        const size_t need = (size_t)W * PACKED_ROW * sizeof(double);
+        if (c->packed_bytes < need) {
+            if (c->d_packed) { HIP_TRY(hipDeviceSynchronize()); (void)hipFree(c->d_packed); c->d_packed = nullptr; c->packed_bytes = 0; }
+            hipError_t e = hipMalloc((void **)&c->d_packed, need);
+            if (e != hipSuccess) return fail(BISIP_ENOMEM, "hipMalloc(%zu) failed: %s", need, hipGetErrorString(e));
+            c->packed_bytes = need;
+        }
+        hipLaunchKernelGGL(k_state_repack<true>, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           first->coords, first->logp, c->d_packed, (long long)W, c->ndim);
+        HIP_TRY(hipGetLastError());
+    }
     for (int64_t k = 0; k < n_steps; ++k) {
         for (int h = 0; h < 2; ++h) {
             const int64_t off = (k * 2 + h) * nh;
@@ -1014,10 +1032,16 @@ int bisip_stretch_run_dev(bisip_ctx *c, const bisip_stretch_args *first, int64_t
             const int64_t srow = k / thin_by;
             u.chain_row = (store && first->chain_row) ? first->chain_row + srow * W * c->ndim : nullptr;
             u.logp_row = (store && first->logp_row) ? first->logp_row + srow * W : nullptr;
-            const StretchArgs a = to_device_args(&u);
+            StretchArgs a = to_device_args(&u);
+            if (packed) a.packed = c->d_packed;
             int rc = dispatch_stretch(c, StretchWork{STRETCH_HALF, &a, nullptr}, u.walkers_per_spectrum, (hipStream_t)stream);
             if (rc != BISIP_OK) return rc;
         }
+    }
+    if (packed) {
+        hipLaunchKernelGGL(k_state_repack<false>, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           first->coords, first->logp, c->d_packed, (long long)W, c->ndim);
+        HIP_TRY(hipGetLastError());
     }
     return BISIP_OK;
 }

@@ -47,6 +47,7 @@ StretchArgs to_device_args(const bisip_stretch_args *u)
     a.block = u->block; a.chain_row = u->chain_row; a.logp_row = u->logp_row;
     a.naccept = u->naccept; a.status = u->status;
     a.pad = u->pad;
+    a.packed = nullptr;
     const long long world = u->world > 0 ? u->world : 1;
     a.base = u->n_slots / world;
     a.extra = u->n_slots % world;

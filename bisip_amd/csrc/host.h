@@ -103,6 +103,8 @@ struct bisip_ctx {
     size_t ws_bytes = 0;
     double *d_gather = nullptr;    // sharded sampler: world slabs of ceil(slots/world) x (ndim+2)
     size_t gather_bytes = 0;
+    double *d_packed = nullptr;    // big single ensembles: the chunk's state as one 64-byte row per walker (bisip_stretch_run_dev)
+    size_t packed_bytes = 0;
     char *d_group = nullptr;       // multi-workgroup persistent sampler: 256 B of synchronisation words, then W rows of 64 B
     size_t group_bytes = 0;
     int64_t spectrum_offset = 0;   // batch: survey index of spectrum 0 (keys the Philox stream)

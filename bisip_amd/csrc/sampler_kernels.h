@@ -39,6 +39,9 @@ struct StretchArgs {
     // apply kernel: layout of the gathered block = world slabs of `pad` rows; the first
     // `extra` ranks own base+1 slots, the others base
     long long pad, base, extra;
+    // k_stretch_half_packed: the state as ONE 64-byte row per walker (theta, padding, the log-probability in [7]);
+    // null: coords / logp as above
+    double *packed;
 };
 
 // L = lanes per walker (see logprob_row); g = this lane's index inside its group.
@@ -379,6 +382,72 @@ __global__ __launch_bounds__(BLK) void k_stretch_half(const StretchArgs a, const
     double row[LP::NDIM], lp_row;
     const bool acc = stretch_slot(a, lp, t, g, i, row, lp_row);
     if (live && g == 0) commit_row<LP::NDIM>(a, i, row, lp_row, acc);
+}
+
+// The half-step of an ensemble that fills the chip with one lane per slot (131,072 walkers and more) on a PACKED
+// state.  With rows of 8 NDIM bytes at random addresses and the log-probabilities in an array of their own, a
+// proposal pulls a line or two for its walker's row, as many for its partner's, one more for 8 bytes of
+// log-probability, and writes the same way: FETCH_SIZE 242 B + WRITE_SIZE 98 B per proposal for 216 algorithmic
+// bytes, and the launch is bound by exactly that -- scattered lines (PolynomialDecomposition and double Cole-Cole
+// take the same 65 us per 524,288 proposals).  bisip_stretch_run_dev therefore keeps the state of such a chunk as one
+// aligned 64-byte row per walker -- theta[0..NDIM), padding, the log-probability in [7] (NDIM <= 7) -- packed once
+// before the chunk's first half-step and unpacked after its last: a walker and its log-probability are ONE line
+// to read and ONE full line to write, its partner one line.  Same operations on the same operands as
+// k_stretch_half: the chain does not change by a bit.
+constexpr int PACKED_ROW = 8;
+
+template <class LP, int BLK = 256>
+__global__ __launch_bounds__(BLK) void k_stretch_half_packed(const StretchArgs a, const LP lp)
+{
+    static_assert(LP::L == 1 && LP::NDIM < PACKED_ROW, "one lane per slot, a walker in one 64-byte row");
+    constexpr int NDIM = LP::NDIM;
+    const long long slot = (long long)blockIdx.x * BLK + threadIdx.x;
+    const bool live = slot < a.n_slots;
+    const long long t = live ? slot : a.n_slots - 1;
+    const int i = __builtin_nontemporal_load(a.active + t), p = __builtin_nontemporal_load(a.partner + t);
+    const dbl2 *srow = reinterpret_cast<const dbl2 *>(a.packed + (long long)i * PACKED_ROW);
+    const dbl2 *crow = reinterpret_cast<const dbl2 *>(a.packed + (long long)p * PACKED_ROW);
+    dbl2 sv[4], cv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { sv[q] = srow[q]; cv[q] = crow[q]; }
+    const double z = __builtin_nontemporal_load(a.zz + t), factor = __builtin_nontemporal_load(a.factor + t);
+    const double logu = __builtin_nontemporal_load(a.logu + t);
+    double s_row[PACKED_ROW], c_row[PACKED_ROW];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { s_row[2 * q] = sv[q].x; s_row[2 * q + 1] = sv[q].y; c_row[2 * q] = cv[q].x; c_row[2 * q + 1] = cv[q].y; }
+    double row[NDIM], lp_row;
+    const bool acc = stretch_move(s_row, c_row, s_row[PACKED_ROW - 1], z, factor, logu, lp, i, 0, a.status, row, lp_row);
+    if (!live) return;
+    if (acc) {
+        double r[PACKED_ROW];
+#pragma unroll
+        for (int q = 0; q < PACKED_ROW; ++q) r[q] = q < NDIM ? row[q] : 0.0;
+        r[PACKED_ROW - 1] = lp_row;
+        dbl2 *dst = reinterpret_cast<dbl2 *>(a.packed + (long long)i * PACKED_ROW);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { dbl2 v; v.x = r[2 * q]; v.y = r[2 * q + 1]; dst[q] = v; }
+        if (a.naccept) atomicAdd(a.naccept + i, 1);
+    }
+    if (a.chain_row) {
+#pragma unroll
+        for (int k = 0; k < NDIM; ++k) __builtin_nontemporal_store(row[k], a.chain_row + (long long)i * NDIM + k);
+    }
+    if (a.logp_row) __builtin_nontemporal_store(lp_row, a.logp_row + i);
+}
+
+// (W, NDIM) + (W,) -> (W, 8) and back; one lane per walker (a chunk's first and last launch)
+template <bool PACK>
+__global__ __launch_bounds__(256) void k_state_repack(double *coords, double *logp, double *packed, long long W, int ndim)
+{
+    const long long w = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (w >= W) return;
+    if (PACK) {
+        for (int q = 0; q < PACKED_ROW - 1; ++q) packed[w * PACKED_ROW + q] = q < ndim ? coords[w * ndim + q] : 0.0;
+        packed[w * PACKED_ROW + PACKED_ROW - 1] = logp[w];
+    } else {
+        for (int q = 0; q < ndim; ++q) coords[w * ndim + q] = packed[w * PACKED_ROW + q];
+        logp[w] = packed[w * PACKED_ROW + PACKED_ROW - 1];
+    }
 }
 
 // (Measured and not kept, round 5: the rows of a chip-filling launch fetched and stored by FOUR lanes each through

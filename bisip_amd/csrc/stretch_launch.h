@@ -92,7 +92,15 @@ int launch_stretch(const StretchWork &work, const LP &lp, hipStream_t st)
     if (kind == STRETCH_HALF) {
         // a launch that fills the chip (>= one wave per SIMD) goes out as four-wave workgroups, one
         // per CU; smaller ones as single waves so that they spread over as many CUs as possible
-        if (a.n_slots * LP::L >= 65536) {
+        if (a.packed) {
+            // the chunk's state is packed (bisip_stretch_run_dev: a single spectrum, one lane per slot, ndim <= 7)
+            if constexpr (LP::L == 1 && LP::NDIM < PACKED_ROW && SingleSpectrum<LP>::value) {
+                const unsigned grid = (unsigned)((a.n_slots + 255) / 256);
+                hipLaunchKernelGGL((k_stretch_half_packed<LP, 256>), dim3(grid), dim3(256), 0, st, a, lp);
+            } else {
+                return fail(BISIP_EUNSUPPORTED, "internal: a packed state for a kernel that has no packed form");
+            }
+        } else if (a.n_slots * LP::L >= 65536) {
             const unsigned grid = (unsigned)((a.n_slots * LP::L + 255) / 256);
             hipLaunchKernelGGL((k_stretch_half<LP, 256>), dim3(grid), dim3(256), 0, st, a, lp);
         } else {
@@ -139,6 +147,7 @@ inline int stretch_lanes(const StretchWork &w)
         const int want = lanes_per_walker(nh * w.persist->E);
         return want < fit ? want : fit;
     }
+    if (w.kind == STRETCH_HALF && w.half->packed) return 1;
     return lanes_per_walker(w.kind == STRETCH_HALF ? w.half->n_slots : w.half->slot_hi - w.half->slot_lo);
 }
 
