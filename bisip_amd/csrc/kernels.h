@@ -995,21 +995,27 @@ __device__ __forceinline__ void rotate_sums(double rr, double ri, const double *
     }
 }
 
-// One step of the travelling sums for a lane that holds TWO residuals (a pair with its shared reciprocal): as
-// rotate_sums, term by term -- lane STEP's two terms are added in ascending frequency and every lane adopts the result.
+// The travelling sums for lanes that hold TWO residuals each (a pair with its shared reciprocal).  The sums visit
+// the lanes in order; lane STEP adds its two terms, in ascending frequency, to what arrives and hands the result
+// on -- ONE exchange per lane and sum, not one per term: every lane forms "the arriving sums plus my terms" (its
+// own, speculatively; a term past the last frequency is skipped) and all adopt lane STEP's.  The additions are
+// those of the one-lane loop, in its order, on its operands: the same bits.  (Until round 5 every TERM was handed
+// round: four times the DPP traffic on the chain that bounds a small launch.)
 template <int L, int STEP>
 __device__ __forceinline__ void rotate_pair_sums(const double (&rr)[2], const double (&ri)[2],
-                                                 const double (&iv)[2][2], int jb, int N, double &acc0,
+                                                 const double (&iv)[2][2], int jb, int N, int g, double &acc0,
                                                  double &acc1)
 {
     if constexpr (STEP < L) {
+        double c0 = acc0, c1 = acc1;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const double c0 = fma(rr[q] * rr[q], iv[q][0], acc0), c1 = fma(ri[q] * ri[q], iv[q][1], acc1);
-            const double n0 = group_broadcast<STEP, L>(c0), n1 = group_broadcast<STEP, L>(c1);
-            if (jb + 2 * STEP + q < N) { acc0 = n0; acc1 = n1; }   // uniform inside the group
+            const double t0 = fma(rr[q] * rr[q], iv[q][0], c0), t1 = fma(ri[q] * ri[q], iv[q][1], c1);
+            if (jb + 2 * g + q < N) { c0 = t0; c1 = t1; }
         }
-        rotate_pair_sums<L, STEP + 1>(rr, ri, iv, jb, N, acc0, acc1);
+        acc0 = group_broadcast<STEP, L>(c0);
+        acc1 = group_broadcast<STEP, L>(c1);
+        rotate_pair_sums<L, STEP + 1>(rr, ri, iv, jb, N, g, acc0, acc1);
     }
 }
 
@@ -1137,7 +1143,7 @@ __device__ __forceinline__ void logprob_sums(const typename M::Setup &s, const M
                 rr[1] = 0.0; ri[1] = 0.0; iv[1][0] = 0.0; iv[1][1] = 0.0;
             }
             iv[0][0] = ra[2]; iv[0][1] = ra[3];
-            rotate_pair_sums<L, 0>(rr, ri, iv, j0, o.N, acc0, acc1);
+            rotate_pair_sums<L, 0>(rr, ri, iv, j0, o.N, g, acc0, acc1);
         }
     } else {
         for (int j0 = 0; j0 < o.N; j0 += L) {
@@ -1150,21 +1156,23 @@ __device__ __forceinline__ void logprob_sums(const typename M::Setup &s, const M
     }
 }
 
-// One step of the travelling sums for a lane that holds FOUR residuals (a block): as rotate_sums, term by
-// term -- lane STEP's four terms are added in ascending frequency and every lane adopts the result.
+// The travelling sums for lanes that hold FOUR residuals each (a block): as rotate_pair_sums -- lane STEP adds its
+// four terms in ascending frequency to the arriving sums, one exchange per lane and sum.
 template <int L, int STEP>
 __device__ __forceinline__ void rotate_block_sums(const double (&rr)[4], const double (&ri)[4],
-                                                  const double (&iv)[4][2], int jb, int N, double &acc0,
+                                                  const double (&iv)[4][2], int jb, int N, int g, double &acc0,
                                                   double &acc1)
 {
     if constexpr (STEP < L) {
+        double c0 = acc0, c1 = acc1;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const double c0 = fma(rr[q] * rr[q], iv[q][0], acc0), c1 = fma(ri[q] * ri[q], iv[q][1], acc1);
-            const double n0 = group_broadcast<STEP, L>(c0), n1 = group_broadcast<STEP, L>(c1);
-            if (jb + 4 * STEP + q < N) { acc0 = n0; acc1 = n1; }   // uniform inside the group
+            const double t0 = fma(rr[q] * rr[q], iv[q][0], c0), t1 = fma(ri[q] * ri[q], iv[q][1], c1);
+            if (jb + 4 * g + q < N) { c0 = t0; c1 = t1; }
         }
-        rotate_block_sums<L, STEP + 1>(rr, ri, iv, jb, N, acc0, acc1);
+        acc0 = group_broadcast<STEP, L>(c0);
+        acc1 = group_broadcast<STEP, L>(c1);
+        rotate_block_sums<L, STEP + 1>(rr, ri, iv, jb, N, g, acc0, acc1);
     }
 }
 
@@ -1369,7 +1377,7 @@ __device__ __forceinline__ void logprob_sums_grid(const typename M::Setup &s, co
             };
             two(std::integral_constant<int, 0>{});
             two(std::integral_constant<int, 2>{});
-            rotate_block_sums<L, 0>(rr, ri, iv, jb, o.N, acc0, acc1);
+            rotate_block_sums<L, 0>(rr, ri, iv, jb, o.N, g, acc0, acc1);
         }
     }
 }
