@@ -1,0 +1,53 @@
+#!/bin/bash
+# The one evidence run of a round, at the FINAL kernel sources, in stages that each fit one gpurun call (<= 20 min):
+#   bash benchmarks/collect_final.sh <tag> tests|bench|sweep|sampler|micro|campaign-a|campaign-b
+# Everything lands under gpurun_out/ (scratch); `bash benchmarks/import_profiles.sh <tag>` then copies what is judged
+# into profiles/ and regenerates the tables.  (Replaces the per-round collect_rNN_*.sh scripts.)
+set -o pipefail
+tag=${1:?round tag, e.g. r05}
+what=${2:?stage}
+out=gpurun_out
+mkdir -p $out
+fz() {   # fz <kind> <script> <args...>: one campaign, its summary line appended to the kind's file
+  local kind=$1 script=$2; shift 2
+  python3 benchmarks/$script "$@" 2>> $out/fuzz.err | tail -1 >> $out/fuzz_${kind}_summary.jsonl
+  echo "$script $* done"
+}
+case $what in
+tests)
+  python3 -m pytest tests -m gpu -q > $out/${tag}_gpu_tests_final.txt 2>&1; echo "pytest rc=$?" >> $out/${tag}_gpu_tests_final.txt
+  tail -3 $out/${tag}_gpu_tests_final.txt ;;
+bench)
+  # counters summarised ON THE BOX so that the bench line taken afterwards quotes them
+  bash benchmarks/collect_profiles.sh bench > $out/collect_bench.log 2>&1
+  python3 benchmarks/summarize_pmc.py $out profiles $tag > /dev/null && python3 bench.py > $out/bench_final.json 2> $out/bench_final.err
+  echo "bench rc=$?"; cut -c1-300 $out/bench_final.json ;;
+sweep|sampler|micro)
+  bash benchmarks/collect_profiles.sh $what > $out/collect_$what.log 2>&1; echo "rc=$?"; tail -3 $out/progress.log
+  if [ $what = micro ]; then
+    python3 benchmarks/micro/group_sampler.py 2> /dev/null > $out/micro_group_sampler.jsonl
+    for m in cc2 pd; do for plain in 1 0; do
+      if [ $plain = 1 ]; then BIG_MODEL=$m BISIP_NO_PACKED_STATE=1 python3 benchmarks/micro/ab_big_ensemble.py 2> /dev/null | grep '^{'
+      else BIG_MODEL=$m python3 benchmarks/micro/ab_big_ensemble.py 2> /dev/null | grep '^{'; fi
+    done; done > $out/micro_ab_big_ensemble_packed.jsonl
+    for i in 1 2 3; do
+      python3 benchmarks/cfg4_sampler.py --steps 200 --fused --chain device --repeat 7 | grep '^{'
+      python3 benchmarks/cfg4_sampler.py --steps 200 --fused --chain device --repeat 7 --no-guard | grep '^{'
+    done > $out/guard_overhead_cfg4.jsonl 2> /dev/null
+  fi ;;
+campaign-a)
+  fz parity fuzz_parity.py --cases 1500 --seed 46 --widen 3
+  fz parity fuzz_parity.py --cases 4000 --seed 64
+  fz parity fuzz_parity.py --cases 2000 --seed 65 --widen 1.5
+  fz valley fuzz_parity.py --cases 3000 --seed 311 --valley
+  fz sampler fuzz_sampler.py --cases 1500 --seed 25
+  fz batch fuzz_batch.py --cases 600 --seed 26
+  fz parity fuzz_parity.py --cases 10000 --seed 66 ;;
+campaign-b)
+  fz parity fuzz_parity.py --cases 10000 --seed 67 --widen 1.5
+  fz parity fuzz_parity.py --cases 4000 --seed 68 --widen 3
+  fz valley fuzz_parity.py --cases 6000 --seed 312 --valley
+  fz sampler fuzz_sampler.py --cases 6000 --seed 27
+  fz batch fuzz_batch.py --cases 2000 --seed 28 ;;
+*) echo "unknown stage $what" >&2; exit 2 ;;
+esac
