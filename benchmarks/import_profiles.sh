@@ -36,6 +36,13 @@ for m in issue_latency row_latency half_step_phases forward_rows_variants grid_b
   cpy $src/micro_$m.txt $dst/${tag}_micro_$m.txt
 done
 cpy $src/micro_small_call_latency.jsonl $dst/${tag}_micro_small_call_latency.jsonl
+cpy $src/micro_group_sampler.jsonl $dst/${tag}_micro_group_sampler.jsonl
+cpy $src/micro_ab_big_ensemble_packed.jsonl $dst/${tag}_micro_ab_big_ensemble_packed.jsonl
+cpy $src/guard_overhead_cfg4.jsonl $dst/${tag}_guard_overhead_cfg4.jsonl
+cpy $src/${tag}_gpu_tests_final.txt $dst/${tag}_gpu_tests_final.txt
+for k in parity valley sampler batch; do cpy $src/fuzz_${k}_summary.jsonl $dst/${tag}_fuzz_${k}_summary.jsonl; done
+# the headline line of the round is the one taken AFTER the counters were summarised on the box (collect_final.sh bench)
+[ -s $src/bench_final.json ] && cp $src/bench_final.json $dst/${tag}_bench.json
 cpy $src/valley_rows.jsonl $dst/${tag}_valley_rows.jsonl
 python3 benchmarks/summarize_pmc.py $src $dst $tag
 python3 benchmarks/make_tables.py

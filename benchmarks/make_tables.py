@@ -21,7 +21,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROF = os.path.join(ROOT, 'profiles')
-ROUNDS = ['r04', 'r03']     # a measurement is quoted from the newest round that repeated it
+ROUNDS = ['r05', 'r04', 'r03']     # a measurement is quoted from the newest round that repeated it
 
 
 def rn(suffix):
@@ -119,11 +119,16 @@ def table_variants():
                          f"{rv['frac']:.2f}" if rv else '-',
                          f"{v['clock_ghz']:.2f}" if v.get('clock_ghz') else '-',
                          f"{rv['cycles_per_valu_instr_per_simd']:.2f}" if rv and rv.get('cycles_per_valu_instr_per_simd') else '-',
-                         f"**{rv['frac_at_clock']:.2f}**" if rv and rv.get('frac_at_clock') else '-'])
+                         f"{rv['frac_at_clock']:.2f}" if rv and rv.get('frac_at_clock') else '-',
+                         f"{rv['trans_f64_wave_instr_per_eval']:.2f}" if rv and 'trans_f64_wave_instr_per_eval' in rv else '-',
+                         f"**{rv['frac_issue_slots_at_clock']:.2f}**" if rv and rv.get('frac_issue_slots_at_clock') else '-',
+                         ' / '.join(f"{x:.2f}" for x in list(rv['wave_cycle_fractions'].values())[:3]) if rv and rv.get('wave_cycle_fractions') else '-'])
     return md(rows, ['kernel', 'workload', 'evals/s', 'us per launch', 'fraction of HBM peak',
                      'VALU wave-instr per eval (PMC)', 'fraction of fp64 issue peak at 2.4 GHz',
                      'engine clock held, GHz (in-run probe)', 'cycles per VALU instr per SIMD',
-                     'fraction of fp64 issue peak at that clock'])
+                     'fraction of fp64 issue peak at that clock', 'of them quarter-rate fp64 (v_rcp_f64 ...: SQ_INSTS_VALU_TRANS_F64)',
+                     'fraction of the ISSUE SLOTS at that clock (a quarter-rate instruction = 4 slots)',
+                     "a wave's cycles: parked at a wait / stalled at issue / issuing"])
 
 
 def table_sweep():
@@ -270,7 +275,45 @@ def table_auto_by_degree():
     return md(rows, ['poly_deg', 'problems', 'plain reduced', 'compensated reduced', 'collapsed', 'fraction on a reduced kernel'])
 
 
+def table_group_sampler():
+    rows = []
+    for d in jlines(rn('micro_group_sampler.jsonl')):
+        g, l = d.get('persistent-multi-workgroup'), d.get('launch-per-half-step')
+        if not g or not l:
+            continue
+        rows.append([d['case'], d['walkers'], f"{g['device_us_per_half_step']:.2f}", f"{l['device_us_per_half_step']:.2f}",
+                     f"{l['device_us_per_half_step'] / g['device_us_per_half_step']:.2f}", f"{g['it_per_s'] / 1e3:.1f}", f"{l['it_per_s'] / 1e3:.1f}"])
+    return md(rows, ['one ensemble beyond a workgroup (philox stream, chain on the device, 1000 iterations)', 'walkers',
+                     'us per half-step: ONE launch per chunk, a barrier among the workgroups per half-step (`k_stretch_group`)',
+                     'us per half-step: a launch each', 'ratio', 'k iterations/s end to end: multi-workgroup', 'launches'])
+
+
+def table_big_ensemble():
+    rows = []
+    for d in jlines(rn('micro_ab_big_ensemble_packed.jsonl')):
+        for W in ('131072', '524288', '1048576'):
+            r = d[W]
+            rows.append([{'cc2': 'double Cole-Cole', 'pd': 'PolynomialDecomposition (reduced)'}[d['model']], int(W),
+                         'one 64-byte row per walker' if d['packed_state'] else 'coords (W, ndim) + logp (W,)',
+                         r['us_per_half_step_device'], r['wall_ms'],
+                         f"{r['wall_ms'] / ((r['timing_ms']['enqueue_s'] + r['timing_ms']['drain_s'] + r['timing_ms'].get('guard_s', 0.0)) or 1):.2f}"])
+    return md(rows, ['big single ensembles, 200 iterations, philox stream, chain thinned by 50 on the device', 'walkers', 'state of a chunk',
+                     'us per half-step (device)', 'run_mcmc end to end, ms', 'end to end / device work'])
+
+
+def table_guard():
+    rows = []
+    for d in jlines(rn('guard_overhead_cfg4.jsonl')):
+        g = d.get('guard') or {}
+        runs = sorted(d['seconds_all_runs'])
+        rows.append(['on' if g.get('checks') else 'off', f"{runs[0] * 1e3:.2f}", f"{runs[len(runs) // 2] * 1e3:.2f}", g.get('checks', 0), g.get('rows', 0),
+                     f"{g.get('worst', 0.0):.1e}" if g.get('checks') else '-'])
+    return md(rows, ["cfg4's ensemble (32,768 walkers, 200 iterations, one GPU, fused half-steps): the sampler's guard of the reduced tier", 'fastest of 7 runs, ms', 'median, ms',
+                     'checks', 'rows measured', 'worst relative error seen (tolerance 2e-11)'])
+
+
 TABLES = {
+    'group_sampler': table_group_sampler, 'big_ensemble': table_big_ensemble, 'guard': table_guard,
     'bench': table_bench, 'variants': table_variants, 'sweep': table_sweep, 'forward': table_forward,
     'host_path': table_host_path, 'samplers': table_samplers, 'cfg4': table_cfg4, 'cfg5': table_cfg5,
     'fuzz': table_fuzz, 'auto_by_degree': table_auto_by_degree, 'ingest': table_ingest,
@@ -323,6 +366,13 @@ FILES = [
     (rn('micro_ab_paired_reciprocals.jsonl'), '`python benchmarks/micro/ab_library.py <library>`, the build before the paired reciprocals and the present one alternately (before, after, before, after) on ONE box', 'round 4, last kernel change: ColeCole<1> / ColeCole<2> / Shin take the denominators of frequencies 2k, 2k+1 from one reciprocal: 4.28 -> 4.62e10 (+8 %), 2.77 -> 2.84e10 (+2 %), 2.73 -> 2.91e10 (+7 %) evals/s in bulk, a cfg5-shaped batch fit 5.43 -> 5.26 us per half-step; Dias (untouched) 3.87 / 3.79e10: the run-to-run spread'),
     (rn('micro_ab_big_ensemble.txt'), '`rocprofv3 --kernel-trace --stats -- python3 benchmarks/micro/ab_big_ensemble.py <library>` (builds before / after the paired reciprocals), and `run_mcmc`\'s own `timing` before / after the shortcut of `walkers_independent`', 'ensembles of 131,072 - 1,048,576 double Cole-Cole walkers: the one-lane-per-walker half-step kernel keeps two waves per SIMD for four after the pairing and is no slower (34.5 -> 33.7 us on average); the initial-state test (singular values of the (W, ndim) positions) cost more than 200 iterations of sampling: 3.0 -> 0.9 ms at 32,768 walkers, 152 -> 36 ms at a million'),
     (rn('micro_xcd_barrier.txt'), '`benchmarks/micro/xcd_barrier`', 'round 4: a barrier among the workgroups of ONE XCD (0.7-0.9 us for 8-32 workgroups, no fences: the counter and the rows go through that XCD\'s L2 with sc1 loads; 0 stale rows) and what a stretch half-step\'s row exchange costs on top, naive (every lane writes and gathers 72-B rows) and laid out for it (one lane per walker, 64-B rows, 16-B accesses): 1.4 us at 2,048 walkers, 2.1 at 8,192, **6.1 at cfg4\'s 32,768** on one XCD, 5.2-5.9 spread over the chip with write-through rows -- no better than the 6.4 us kernel boundary it would replace: the persistent multi-workgroup sampler was not built (kill criterion of VERDICT r3 #3)'),
+    (rn('guard_overhead_cfg4.jsonl'), '`python benchmarks/cfg4_sampler.py --steps 200 --fused --chain device --repeat 7 [--no-guard]`, alternately, three times', "round 5: what the sampler's guard of the QR-reduced tier costs at cfg4's size (selection of the rows nearest to the shell, their copy, the yardstick): 2-3 %"),
+    (rn('micro_group_sampler.jsonl'), '`python benchmarks/micro/group_sampler.py`', 'round 5: `k_stretch_group` (one ensemble of 1,025 ... 8,192 walkers over several workgroups, a barrier of their own per half-step) against one launch per half-step, every model; cfg2 is the first case'),
+    (rn('micro_group_phases.txt'), 'a temporary build of `k_stretch_group` with `s_memrealtime` timers around its phases', "round 5: where cfg2's half-step goes inside the kernel: gather 0.58, evaluation 2.15, commit + drain 0.5, barrier 1.07 us"),
+    (rn('micro_ab_big_ensemble_packed.jsonl'), '`BIG_MODEL=cc2|pd [BISIP_NO_PACKED_STATE=1] python benchmarks/micro/ab_big_ensemble.py`, alternately', 'round 5: ensembles of 131,072 ... 1,048,576 walkers on the packed state (one 64-byte row per walker) and on the plain layout; device time per half-step and end to end'),
+    (rn('micro_ab_big_ensemble_rows.jsonl'), 'the same script on a build with `k_stretch_half_rows` (rows moved by four lanes each through LDS; not kept)', 'round 5: PolynomialDecomposition 65 -> 63 us, double Cole-Cole 66 -> 73 us per half-step of 524,288 proposals: requests per instruction were not the bound'),
+    (rn('big_ensemble_host_setup.json'), '`BIG_MODEL=pd python benchmarks/micro/ab_big_ensemble.py` after the set-up moved to the device', "round 5: run_mcmc's own timing at 131,072 / 524,288 / 1,048,576 walkers: check_s 0 (the independence test runs on the device), 70.7 -> 33.3 ms end to end at a million walkers"),
+    (rn('micro_host_pipeline.txt'), 'a scratch experiment with chunk size, staging and thread count as knobs', 'round 5: the host-buffer entry is bound by the host copy out of pageable memory (54 GB/s from a cache-resident 64 MB source, 37-41 GB/s from DRAM at 256 MB however it is staged or overlapped)'),
     (rn('micro_post_run_stall.txt'), '`python benchmarks/micro/post_run_stall.py kernel`, `upload_cost.py plain`', 'the sporadic 20-30 ms delay of the first device work after a synchronisation early in a process'),
 ]
 
@@ -335,7 +385,7 @@ def readme():
            md([[f'`{f}`', c, w] for f, c, w in FILES], ['file', 'command', 'what to read']), '']
     for name, title in (('bench', 'Headline'), ('variants', 'Formulations and the other kernels, with both rooflines'),
                         ('sweep', 'Every log-probability kernel at the BASELINE shapes'), ('forward', 'Batched forward'),
-                        ('host_path', 'Host-buffer entry'), ('samplers', '`fit()` workloads'), ('cfg4', 'BASELINE config 4'),
+                        ('host_path', 'Host-buffer entry'), ('samplers', '`fit()` workloads'), ('guard', "The device sampler's guard, cost"), ('group_sampler', 'One ensemble over several workgroups (BASELINE config 2 and its neighbours)'), ('big_ensemble', 'Big single ensembles'), ('cfg4', 'BASELINE config 4'),
                         ('cfg5', 'BASELINE config 5'), ('batch_models', 'Batch of spectra, every model'), ('survey', 'A survey end to end'), ('ingest', 'Survey ingest'), ('batch_setup', 'Survey set-up'), ('fuzz', 'Randomised campaigns'), ('valley', 'Valley / shell rows: every formulation and the reference against the exact value'), ('auto_by_degree', 'Which kernel AUTO ran, by polynomial degree'), ('latency', 'One call with host buffers')):
         out += [f'## {title}', '', TABLES[name](), '']
     return '\n'.join(out)

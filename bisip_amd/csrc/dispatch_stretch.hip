@@ -13,6 +13,7 @@ int stretch_generic(const bisip_ctx *c, const StretchWork &a, hipStream_t st)
     const ModelOperands o{c->d_cb_lp ? c->d_cb_lp : c->d_cb, c->N, c->lconst};
     if constexpr (CoopLimit<M>::value > 0) {      // (else one lane per slot: the other kernels are never instantiated)
         switch (stretch_lanes(a)) {
+        case 8: { GenericLP<M, 8> lp; lp.o = o; lp.b = c->bounds; return launch_stretch(a, lp, st); }     // (the multi-workgroup sampler only)
         case 4: { GenericLP<M, 4> lp; lp.o = o; lp.b = c->bounds; return launch_stretch(a, lp, st); }
         case 2: { GenericLP<M, 2> lp; lp.o = o; lp.b = c->bounds; return launch_stretch(a, lp, st); }
         default: break;

@@ -955,7 +955,7 @@ struct ModelOperands {
 // and imaginary squared residuals -- accumulated in ascending frequency order.
 //
 // L = 1: a plain loop in one lane.
-// L in {2, 4}: L adjacent lanes (an aligned pair / quad) cooperate on one walker for launches
+// L in {2, 4, 8}: L adjacent lanes (an aligned pair / quad / half-row; 8 in the multi-workgroup sampler) cooperate on one walker for launches
 // with too few walkers to fill the chip.  In each round lane g evaluates the residual of
 // frequency j0+g -- the expensive part, in parallel -- and then the running sums travel
 // through the group: for step = 0..L-1 every lane forms "its term added to the sums" and all
@@ -966,13 +966,26 @@ struct ModelOperands {
 template <int STEP, int L>
 __device__ __forceinline__ double group_broadcast(double x)
 {
-    // quad_perm selecting lane STEP of each aligned group of L inside a quad
-    constexpr int P0 = STEP, P1 = (L == 4) ? STEP : STEP, P2 = (L == 4) ? STEP : 2 + STEP,
-                  P3 = (L == 4) ? STEP : 2 + STEP;
+    static_assert(L == 2 || L == 4 || L == 8, "an aligned pair, quad or half-row of lanes");
+    // quad_perm selecting lane STEP % 4 of each aligned group of min(L, 4) inside a quad
+    constexpr int S4 = STEP % 4;
+    constexpr int P0 = S4, P1 = S4, P2 = (L >= 4) ? S4 : 2 + S4, P3 = (L >= 4) ? S4 : 2 + S4;
     constexpr int CTRL = P0 | (P1 << 2) | (P2 << 4) | (P3 << 6);
     const long long bits = __double_as_longlong(x);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)bits, CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(bits >> 32), CTRL, 0xf, 0xf, false);
+    int lo = __builtin_amdgcn_update_dpp(0, (int)bits, CTRL, 0xf, 0xf, false);
+    int hi = __builtin_amdgcn_update_dpp(0, (int)(bits >> 32), CTRL, 0xf, 0xf, false);
+    if constexpr (L == 8) {
+        // Eight lanes = half a DPP row (two quads).  Each quad now holds ITS lane STEP % 4; the quad that does not
+        // contain lane STEP takes the other one's: a row shift by four lanes, written only into that quad of every
+        // half-row (bank mask: quads 1, 3 from quads 0, 2 -- or the reverse).
+        if constexpr (STEP < 4) {
+            lo = __builtin_amdgcn_update_dpp(lo, lo, 0x114 /* row_shr:4 */, 0xf, 0xa, false);
+            hi = __builtin_amdgcn_update_dpp(hi, hi, 0x114, 0xf, 0xa, false);
+        } else {
+            lo = __builtin_amdgcn_update_dpp(lo, lo, 0x104 /* row_shl:4 */, 0xf, 0x5, false);
+            hi = __builtin_amdgcn_update_dpp(hi, hi, 0x104, 0xf, 0x5, false);
+        }
+    }
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
@@ -1386,7 +1399,7 @@ template <class M, int L = 1, bool LDSREC = false>
 __device__ __forceinline__ double logprob_row(const double (&th)[M::NDIM], const ModelOperands &o,
                                               const Bounds &b, const int g = 0)
 {
-    static_assert(L == 1 || L == 2 || L == 4, "lanes per walker");
+    static_assert(L == 1 || L == 2 || L == 4 || L == 8, "lanes per walker");
     if (!in_prior<M::NDIM>(th, b)) return -__builtin_inf();  // never touches the forward model
     // (inside a box that BOUNDS_FAST vouches for, the per-walker constants take their short route as well: sincos_unit)
     const typename M::Setup s = M::setup(th, M::HAS_FAST && (b.flags & BOUNDS_FAST) != 0);

@@ -83,6 +83,10 @@ template <class LP>
 int launch_stretch(const StretchWork &work, const LP &lp, hipStream_t st)
 {
     const StretchKind kind = work.kind;
+    if constexpr (LP::L == 8) {       // eight lanes per slot exist for the multi-workgroup sampler alone
+        if (kind != STRETCH_GROUP) return fail(BISIP_EUNSUPPORTED, "internal: eight lanes per slot outside the multi-workgroup sampler");
+        return launch_group(*work.persist, lp, st);
+    } else {
     if (kind == STRETCH_PERSIST) {
         if constexpr (MayPersist<LP>::value) return launch_persistent(*work.persist, lp, st);
         else return fail(BISIP_EUNSUPPORTED, "internal: a persistent launch for a functor whose waves straddle spectra");
@@ -118,6 +122,7 @@ int launch_stretch(const StretchWork &work, const LP &lp, hipStream_t st)
     }
     HIP_TRY(hipGetLastError());
     return BISIP_OK;
+    }
 }
 
 // lanes per slot of a stretch dispatch: as many as lanes_per_walker() grants for the number of
@@ -129,17 +134,22 @@ inline int stretch_lanes(const StretchWork &w)
     // never changes a result -- logprob_row is bit-identical for every L -- only the wave count)
     if (const char *env = std::getenv("BISIP_STRETCH_LANES")) {
         const int v = std::atoi(env);
+        if (w.kind == STRETCH_GROUP && (v == 1 || v == 2 || v == 4 || v == 8)) return v;
         if (v == 1 || v == 2 || v == 4) {
-            if (w.kind == STRETCH_GROUP) return v;
             if (w.kind != STRETCH_PERSIST) return v;
             const long long nh = (w.persist->W + 1) / 2;
             return nh * v <= 512 ? v : (nh * 2 <= 512 ? 2 : 1);
         }
     }
     if (w.kind == STRETCH_GROUP) {
-        // as many lanes per slot as keep the group within one XCD's 32 compute units (one workgroup each)
+        // One evaluation at one wave per SIMD is what a half-step of this kernel waits for (2.15 of 4.4 us at cfg2 with
+        // four lanes per slot): as many lanes per slot -- up to eight, half a DPP row -- as keep the group within the
+        // 32 compute units of one XCD, one workgroup each.  (Measured with 64 workgroups, two per compute unit: cfg2
+        // with eight lanes 6.1 us against 4.4 with four; 2,048 walkers: eight lanes 3.7 us, four 3.85.)
         const long long nh = (w.persist->W + 1) / 2;
-        return nh * 4 <= 32 * GROUP_BLK ? 4 : (nh * 2 <= 32 * GROUP_BLK ? 2 : 1);
+        for (int lanes = 8; lanes > 1; lanes /= 2)
+            if (nh * lanes <= 32LL * GROUP_BLK) return lanes;
+        return 1;
     }
     if (w.kind == STRETCH_PERSIST) {
         const long long nh = (w.persist->W + 1) / 2;

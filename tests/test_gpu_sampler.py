@@ -594,7 +594,8 @@ def test_multi_workgroup_persistent_kernel_equals_launch_per_half_step(prefix, m
     of a chunk in ONE launch -- several workgroups, the state in 64-byte rows in memory, a barrier of their own
     after every half-step -- and reproduces the launch-per-half-step path bit for bit: both random streams, odd
     ensembles (halves of different sizes, a last workgroup with dead slots), thinning, chunked runs,
-    continuation, 1 / 2 / 4 lanes per slot, records staged in LDS or read through the scalar cache."""
+    continuation, 1 / 2 / 4 / 8 lanes per slot (8: half a DPP row, this kernel's default up to 4,096 walkers), records
+    staged in LDS or read through the scalar cache."""
     from bisip_amd.sampler import DeviceEnsembleSampler
     g = np.load(_case(prefix))
     ndim = g['bounds'].shape[1]
@@ -603,7 +604,8 @@ def test_multi_workgroup_persistent_kernel_equals_launch_per_half_step(prefix, m
     ctx = make_ctx(g, model, variant)
     for W, nsteps, chunk, thin, rng, lanes in [(2048, 12, None, 1, 'philox', None), (4096, 9, 4, 1, 'numpy', None),
                                                (4097, 6, None, 2, 'philox', '1'), (8192, 5, None, 1, 'philox', None),
-                                               (1026, 8, 3, 1, 'philox', '2'), (3001, 6, None, 3, 'numpy', '4')]:
+                                               (1026, 8, 3, 1, 'philox', '2'), (3001, 6, None, 3, 'numpy', '4'),
+                                               (1500, 7, None, 1, 'numpy', '8'), (4096, 5, 2, 2, 'philox', '8')]:
         p0 = _start(g, W, 500 + W)
         out = []
         for persistent in (True, False):

@@ -145,12 +145,23 @@ def test_walkers_independent_decides_as_the_singular_values_do():
         huge = rng.randn(W, nd)
         huge[:, 0] *= 1e160
         cases.append(('squares overflow', huge))
-    seen = set()
+    from bisip_amd.sampler import gram_decides, gram_from_shifted_sums
+    seen, settled = set(), 0
     for name, x in cases:
         want = _walkers_independent_by_singular_values(x)
         assert walkers_independent(x) == want, (name, x.shape)
         seen.add(want)
-    assert seen == {True, False}
+        # the device route of big ensembles (bisip_ensemble_gram_dev): shifted sums and second moments, here formed
+        # by NumPy as the kernel forms them; what they settle is settled as the singular values would, the rest
+        # goes to the host's test
+        W, nd = x.shape
+        with np.errstate(all='ignore'):
+            d = x - x[0]
+            sums = np.concatenate([d.sum(axis=0), (d.T @ d)[np.triu_indices(nd)]])
+            decided = gram_decides(gram_from_shifted_sums(sums, W, nd), W)
+        assert not decided or want, name                 # "independent" from the moments is never wrong
+        settled += decided
+    assert seen == {True, False} and settled >= 12      # and the moments do settle the ordinary ensembles
 
 
 def test_minus_inf_proposals_are_always_rejected():
