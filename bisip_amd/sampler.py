@@ -572,17 +572,18 @@ class HipStretchBackend:
         _hip.ensemble_gram_dev(coords_t.data_ptr(), W, ndim, out.data_ptr(), work.data_ptr(), self.stream())
         return self.snapshot(out, slot='gram', frozen=False)
 
-    def side_stream(self, name):
+    def side_stream(self, name, after=None):
         """Context: torch's current stream is a side stream of this backend (one per ``name``) that starts behind
-        everything queued on the compute stream so far -- work queued inside runs beside what the compute stream
-        gets next."""
+        ``after`` (an event of the compute stream; default: everything queued on it so far) -- work queued inside
+        runs beside what the compute stream has after that point."""
         torch = self.torch
         streams = self.__dict__.setdefault('_side_streams', {})
         if name not in streams:
             streams[name] = torch.cuda.Stream(self.device)
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(self.device))
-        streams[name].wait_event(ev)
+        if after is None:
+            after = torch.cuda.Event()
+            after.record(torch.cuda.current_stream(self.device))
+        streams[name].wait_event(after)
         return torch.cuda.stream(streams[name])
 
     def shell_rows(self, chain_t, logp_t, n_samples, n_ensembles, walkers_per_ensemble, k, n_stride=0, ties=True,
@@ -1244,8 +1245,10 @@ class DeviceEnsembleSampler(_SamplerBase):
                 else:
                     be.draw(st, self.walkers_per_ensemble, self.a, self.seed, it0, n)
             fresh = bool(self._dev.pop('fresh', False)) and k == 0
+            saved_ev = None
             if guard is not None:
                 saved[k] = tuple(self._dev[name].clone() for name in ('coords', 'naccept', 'status', 'logp'))
+                saved_ev = be.mark()             # the copies exist from here on: what reads them need not wait for the chunk
             # A big chunk's rows are selected in two parts: the first 7/8 of its samples on a side stream WHILE the
             # last eighth still runs, so that what follows the chunk's last kernel -- and, for the last chunk, ends
             # the run -- is the selection over an eighth of the samples (~25 us instead of ~100 at 6.5M samples).
@@ -1278,10 +1281,11 @@ class DeviceEnsembleSampler(_SamplerBase):
                                                  slot=f'guard{k % 2}')]
                 if fresh:
                     # the guard's first rows: the initial ensemble's samples nearest to the shell and a stride across
-                    # it, selected from the copy saved above on a side stream -- queued BEHIND the chunk's launches
-                    # (the device had been idle until the host had queued them), measured beside them
+                    # it, selected from the copy saved above on a side stream: QUEUED behind the chunk's launches (the
+                    # device had been idle until the host had queued them) but ORDERED only behind the copy, so that it
+                    # runs, and is measured, beside the chunk
                     near = min(Wp, max(1, 3 * guard['k'] // 4))
-                    with be.side_stream('guard'):
+                    with be.side_stream('guard_init', after=saved_ev):
                         rec['init'] = be.shell_rows(saved[0][0], saved[0][3], 1, E, Wp, near,
                                                     n_stride=min(Wp, guard['k'] - near), ties=guard['ties'], slot='guard_init')
             if k == len(sizes) - 1 and hasattr(be, 'snapshot'):

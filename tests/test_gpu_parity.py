@@ -892,6 +892,43 @@ def _shell_rows(ops, bounds, n_rows, seed):
     return np.ascontiguousarray(t[np.all((bounds[0] < t) & (t < bounds[1]), axis=1)])
 
 
+def test_guard_rows_entry_measures_and_moves_only_what_auto_chose(monkeypatch):
+    """bisip_ctx_reduced_guard_rows -- the guard for rows a caller brings from the device: measures them as
+    bisip_ctx_reduced_check does; moves a context that chose its tier itself ('auto') past 2e-11 and says so; only
+    measures a forced variant or a context whose guard is switched off; has nothing to measure once the
+    per-frequency form runs; refuses models without a reduced form."""
+    from bisip_amd import _hip
+    n_freq, poly_deg, c_exp, idx = 64, 6, 1.0, 2
+    monkeypatch.setenv('BISIP_SHELL_WEIGHT', '0')
+    ctx, bounds, d, taus, log_taus = _pd_context(n_freq, poly_deg, c_exp, idx)
+    forced, *_ = _pd_context(n_freq, poly_deg, c_exp, idx, variant='reduced')
+    monkeypatch.delenv('BISIP_SHELL_WEIGHT')
+    ops = _hip.polydecomp_operands(d['w'], d['zn'], d['zn_err'], taus, log_taus, c_exp)
+    theta = _shell_rows(ops, bounds, 3000, 5)[:512]
+    ctx.reduced_guard(False)
+    plain = ctx.logprob(theta)                      # what the plain kernel says on the shell (no guard: nothing moves)
+    far = ctx.reduced_check(theta, plain)
+    assert far > 2e-11 and ctx.variant == 'reduced'
+    assert ctx.reduced_guard_rows(theta, plain) == (far, False) and ctx.variant == 'reduced'      # guard off: measured only
+    ctx.reduced_guard(True)
+    rows = np.vstack([theta, np.full((3, theta.shape[1]), np.nan)])                                   # unfilled slots are skipped
+    worst, moved = ctx.reduced_guard_rows(rows, np.r_[plain, np.nan, np.nan, np.nan])
+    assert worst == far and moved and ctx.variant == 'reduced_comp' and ctx.reduced_guard()[2] == 1
+    comp = ctx.logprob(theta)
+    worst, moved = ctx.reduced_guard_rows(theta, comp)
+    assert worst <= 2e-12 and not moved and ctx.variant == 'reduced_comp'
+    assert forced.reduced_guard_rows(theta, forced.logprob(theta)) == (far, False) and forced.variant == 'reduced'
+    forced.set_variant('collapsed')
+    assert forced.reduced_guard_rows(theta, forced.logprob(theta)) == (0.0, False)
+    with pytest.raises(ValueError):
+        ctx.reduced_guard_rows(theta, comp[:-1])
+    cc = make_ctx(np.load([p for p in golden_cases() if 'case15_' in p][0]), 'PeltonColeCole')
+    with pytest.raises(RuntimeError):
+        cc.reduced_guard_rows(np.zeros((2, 4)), np.zeros(2))
+    for c in (ctx, forced, cc):
+        c.close()
+
+
 def test_logprob_guard_moves_a_context_off_a_reduced_kernel_that_fails_on_its_batch(monkeypatch):
     """bisip_logprob -- what log_prob() and emcee's vectorised callback call -- measures the QR-reduced
     kernel on rows of the caller's own batch (first call, then every 2^n-th) and a context on 'auto' that
