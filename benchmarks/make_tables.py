@@ -372,6 +372,7 @@ FILES = [
     (rn('micro_ab_big_ensemble_packed.jsonl'), '`BIG_MODEL=cc2|pd [BISIP_NO_PACKED_STATE=1] python benchmarks/micro/ab_big_ensemble.py`, alternately', 'round 5: ensembles of 131,072 ... 1,048,576 walkers on the packed state (one 64-byte row per walker) and on the plain layout; device time per half-step and end to end'),
     (rn('micro_ab_big_ensemble_rows.jsonl'), 'the same script on a build with `k_stretch_half_rows` (rows moved by four lanes each through LDS; not kept)', 'round 5: PolynomialDecomposition 65 -> 63 us, double Cole-Cole 66 -> 73 us per half-step of 524,288 proposals: requests per instruction were not the bound'),
     (rn('big_ensemble_host_setup.json'), '`BIG_MODEL=pd python benchmarks/micro/ab_big_ensemble.py` after the set-up moved to the device', "round 5: run_mcmc's own timing at 131,072 / 524,288 / 1,048,576 walkers: check_s 0 (the independence test runs on the device), 70.7 -> 33.3 ms end to end at a million walkers"),
+    (rn('micro_fma_operands.txt'), '`benchmarks/micro/fma_operands` (hipcc from `fma_operands.hip`)', 'round 5: a fp64 FMA with three vector sources costs 2-4 % more issue time than one with a scalar source, whatever the banks: not what holds Dias2000 back'),
     (rn('micro_host_pipeline.txt'), 'a scratch experiment with chunk size, staging and thread count as knobs', 'round 5: the host-buffer entry is bound by the host copy out of pageable memory (54 GB/s from a cache-resident 64 MB source, 37-41 GB/s from DRAM at 256 MB however it is staged or overlapped)'),
     (rn('micro_post_run_stall.txt'), '`python benchmarks/micro/post_run_stall.py kernel`, `upload_cost.py plain`', 'the sporadic 20-30 ms delay of the first device work after a synchronisation early in a process'),
 ]
