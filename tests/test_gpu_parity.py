@@ -914,7 +914,8 @@ def test_guard_rows_entry_measures_and_moves_only_what_auto_chose(monkeypatch):
     rows = np.vstack([theta, np.full((3, theta.shape[1]), np.nan)])                                   # unfilled slots are skipped
     worst, moved = ctx.reduced_guard_rows(rows, np.r_[plain, np.nan, np.nan, np.nan])
     assert worst == far and moved and ctx.variant == 'reduced_comp' and ctx.reduced_guard()[2] == 1
-    comp = ctx.logprob(theta)
+    with pytest.warns(RuntimeWarning, match='k_logprob_pd_reduced_comp'):      # the next host-buffer call reports the move
+        comp = ctx.logprob(theta)
     worst, moved = ctx.reduced_guard_rows(theta, comp)
     assert worst <= 2e-12 and not moved and ctx.variant == 'reduced_comp'
     assert forced.reduced_guard_rows(theta, forced.logprob(theta)) == (far, False) and forced.variant == 'reduced'
