@@ -194,6 +194,34 @@ def engine_clock_ghz(fn, kernel_ms, torch, launches=40):
     return (t1 - t0) / (r1 - r0) * 0.1
 
 
+def fp64_stream_ceiling(torch, stream, seconds=0.3, rounds=400):
+    """What a stream of independent fp64 FMAs reaches on this chip, measured the way the kernels are (primed, ten
+    back-to-back launches of ~0.2 ms, HIP events on the launch stream; bisip_fp64_stream_probe_dev: 8 waves per
+    SIMD on every compute unit, operands with full mantissas): the ceiling the compute-bound kernels are held to.
+    The nominal issue peak (1024 SIMDs x 2.4 GHz / 4 cycles) is not reachable: under fp64-dense load the chip
+    holds 2.2-2.3 GHz and a wave-instruction takes 4.25-4.45 cycles (benchmarks/micro/fp64_stream_ceiling.hip)."""
+    from bisip_amd import _hip
+    buf = torch.empty(_hip.fp64_stream_probe_lanes(), dtype=torch.float64, device='cuda')
+    n = [0]
+
+    def fn():
+        n[0] = _hip.fp64_stream_probe_dev(buf.data_ptr(), rounds, stream.cuda_stream)
+    prime(fn, seconds, torch)
+    _, ms = time_launches(fn, 10, 2, torch, stream)
+    rate = n[0] / (ms * 1e-3)
+    return {'wave_instr_per_s': rate, 'frac_of_nominal_peak': rate / VALU_PEAK_WAVE_INSTR_S, 'kernel_ms': ms,
+            'clock_ghz': engine_clock_ghz(fn, ms, torch),
+            'what': 'independent v_fma_f64 (d = d * s + v), 8 waves per SIMD on 256 CUs, full-mantissa operands, '
+                    f'{32 * rounds} per wave and launch'}
+
+
+def against_stream(rv, stream_rec):
+    """The kernel's issue-slot rate as a fraction of the measured FMA stream's."""
+    if rv and stream_rec and 'frac_issue_slots' in rv:
+        rv['frac_of_fma_stream'] = rv['frac_issue_slots'] * VALU_PEAK_WAVE_INSTR_S / stream_rec['wave_instr_per_s']
+    return rv
+
+
 def with_clock(rv, clock_ghz):
     """fp64-issue fraction at the clock the chip actually held (DVFS) beside the one at 2.4 GHz."""
     if rv and clock_ghz:
@@ -644,8 +672,9 @@ def main():
                     result['valu_counters_stale'] = True        # no roofline_valu below
                 gpu_logp = out_t.cpu().numpy()
                 if not args.no_variants:
-                    result['variants'] = time_variants(ctx, args, step, W, torch, stream, counts)
-                    result['kernels'] = time_zoo(data, args, torch, stream, counts, local_rank)
+                    fma = result['fp64_fma_stream'] = fp64_stream_ceiling(torch, stream, min(args.prime_seconds, 0.3))
+                    result['variants'] = time_variants(ctx, args, step, W, torch, stream, counts, fma)
+                    result['kernels'] = time_zoo(data, args, torch, stream, counts, local_rank, fma)
                 if not args.no_cpu_baseline:
                     cb, err, same_inf = cpu_baseline(data, taus, log_taus, bounds, theta, gpu_logp)
                     result['cpu_baseline'] = cb
@@ -790,7 +819,7 @@ def batch_extra(dist, torch, rank, world, local_rank, spectra_per_gpu=512, walke
     b.close()
 
 
-def time_variants(ctx, args, step, W, torch, stream, counts):
+def time_variants(ctx, args, step, W, torch, stream, counts, fma=None):
     """The other formulations of the same log-probability (same theta, same W), each primed
     like the headline before it is timed."""
     variants = {}
@@ -805,7 +834,7 @@ def time_variants(ctx, args, step, W, torch, stream, counts):
             rec['note'] = ('not a product path: the north star\'s one-wave-per-walker mapping, kept as a measured '
                            'comparison; AUTO never selects it')
         rec['clock_ghz'] = engine_clock_ghz(step, ms, torch)
-        rv = with_clock(valu_roofline(v, W, ms, counts), rec['clock_ghz'])
+        rv = against_stream(with_clock(valu_roofline(v, W, ms, counts), rec['clock_ghz']), fma)
         if rv:
             rec['roofline_valu'] = rv
         variants[v] = rec
@@ -828,7 +857,7 @@ def zoo_contexts(data, local_rank, W):
 ZOO_WALKERS = 1 << 22
 
 
-def time_zoo(data, args, torch, stream, counts, local_rank):
+def time_zoo(data, args, torch, stream, counts, local_rank, fma=None):
     """The transcendental-bound models at N = 32 (cfg2 / cfg5's kernels), 4M walkers each."""
     out = {}
     for label, ctx, th, o, ndim in zoo_contexts(data, local_rank, ZOO_WALKERS):
@@ -840,7 +869,7 @@ def time_zoo(data, args, torch, stream, counts, local_rank):
                'walkers': ZOO_WALKERS, 'n_freq': N_FREQ,
                'hbm_frac': 8 * (ndim + 1) * ZOO_WALKERS / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
         rec['clock_ghz'] = engine_clock_ghz(fn, ms, torch)
-        rv = with_clock(valu_roofline(label, ZOO_WALKERS, ms, counts), rec['clock_ghz'])
+        rv = against_stream(with_clock(valu_roofline(label, ZOO_WALKERS, ms, counts), rec['clock_ghz']), fma)
         if rv:
             rec['roofline_valu'] = rv
         out[label] = rec

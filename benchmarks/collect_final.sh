@@ -21,7 +21,9 @@ bench)
   # counters summarised ON THE BOX so that the bench line taken afterwards quotes them
   bash benchmarks/collect_profiles.sh bench > $out/collect_bench.log 2>&1
   python3 benchmarks/summarize_pmc.py $out profiles $tag > /dev/null && python3 bench.py > $out/bench_final.json 2> $out/bench_final.err
-  echo "bench rc=$?"; cut -c1-300 $out/bench_final.json ;;
+  echo "bench rc=$?"; cut -c1-300 $out/bench_final.json
+  # the ceiling bench.py holds the compute-bound kernels to, in the open: cold / sustained, the clock the waves saw
+  [ -x benchmarks/micro/fp64_stream_ceiling ] && timeout -k 5 120 benchmarks/micro/fp64_stream_ceiling 0.5 > $out/micro_fp64_stream_ceiling.txt 2>&1 ;;
 sweep|sampler|micro)
   bash benchmarks/collect_profiles.sh $what > $out/collect_$what.log 2>&1; echo "rc=$?"; tail -3 $out/progress.log
   if [ $what = micro ]; then

@@ -111,6 +111,11 @@ def table_bench():
 def table_variants():
     b = jload(rn('bench.json'))
     rows = []
+    fma = b.get('fp64_fma_stream')
+    if fma:
+        rows.append(['independent `v_fma_f64` (the ceiling; `bisip_fp64_stream_probe_dev`)', '8 waves per SIMD, full-mantissa operands',
+                     f"({sci(fma['wave_instr_per_s'])} wave-instr/s)", f"{fma['kernel_ms'] * 1e3:.1f}", '-', '-',
+                     f"{fma['frac_of_nominal_peak']:.2f}", f"{fma['clock_ghz']:.2f}" if fma.get('clock_ghz') else '-', '-', '-', '**1.00**', '-'])
     for group, title in (('variants', 'PolynomialDecomposition P=5, N=32, W=2^24'), ('kernels', 'N=32, W=2^22')):
         for label, v in b[group].items():
             rv = v.get('roofline_valu')
@@ -118,16 +123,15 @@ def table_variants():
                          f"{v['hbm_frac']:.3f}", f"{rv['valu_wave_instr_per_eval']:.2f}" if rv else '-',
                          f"{rv['frac']:.2f}" if rv else '-',
                          f"{v['clock_ghz']:.2f}" if v.get('clock_ghz') else '-',
-                         f"{rv['cycles_per_valu_instr_per_simd']:.2f}" if rv and rv.get('cycles_per_valu_instr_per_simd') else '-',
-                         f"{rv['frac_at_clock']:.2f}" if rv and rv.get('frac_at_clock') else '-',
                          f"{rv['trans_f64_wave_instr_per_eval']:.2f}" if rv and 'trans_f64_wave_instr_per_eval' in rv else '-',
-                         f"**{rv['frac_issue_slots_at_clock']:.2f}**" if rv and rv.get('frac_issue_slots_at_clock') else '-',
+                         f"{rv['frac_issue_slots']:.2f}" if rv and rv.get('frac_issue_slots') else '-',
+                         f"**{rv['frac_of_fma_stream']:.2f}**" if rv and rv.get('frac_of_fma_stream') else '-',
                          ' / '.join(f"{x:.2f}" for x in list(rv['wave_cycle_fractions'].values())[:3]) if rv and rv.get('wave_cycle_fractions') else '-'])
     return md(rows, ['kernel', 'workload', 'evals/s', 'us per launch', 'fraction of HBM peak',
-                     'VALU wave-instr per eval (PMC)', 'fraction of fp64 issue peak at 2.4 GHz',
-                     'engine clock held, GHz (in-run probe)', 'cycles per VALU instr per SIMD',
-                     'fraction of fp64 issue peak at that clock', 'of them quarter-rate fp64 (v_rcp_f64 ...: SQ_INSTS_VALU_TRANS_F64)',
-                     'fraction of the ISSUE SLOTS at that clock (a quarter-rate instruction = 4 slots)',
+                     'VALU wave-instr per eval (PMC)', 'fraction of the nominal fp64 issue peak (1024 SIMDs x 2.4 GHz / 4)',
+                     'engine clock, GHz (in-run probe)', 'of them quarter-rate fp64 (v_rcp_f64 ...: SQ_INSTS_VALU_TRANS_F64)',
+                     'ISSUE SLOTS (a quarter-rate instruction = 4) / nominal peak',
+                     'issue slots / the MEASURED FMA stream of the same run',
                      "a wave's cycles: parked at a wait / stalled at issue / issuing"])
 
 
@@ -372,6 +376,7 @@ FILES = [
     (rn('micro_ab_big_ensemble_packed.jsonl'), '`BIG_MODEL=cc2|pd [BISIP_NO_PACKED_STATE=1] python benchmarks/micro/ab_big_ensemble.py`, alternately', 'round 5: ensembles of 131,072 ... 1,048,576 walkers on the packed state (one 64-byte row per walker) and on the plain layout; device time per half-step and end to end'),
     (rn('micro_ab_big_ensemble_rows.jsonl'), 'the same script on a build with `k_stretch_half_rows` (rows moved by four lanes each through LDS; not kept)', 'round 5: PolynomialDecomposition 65 -> 63 us, double Cole-Cole 66 -> 73 us per half-step of 524,288 proposals: requests per instruction were not the bound'),
     (rn('big_ensemble_host_setup.json'), '`BIG_MODEL=pd python benchmarks/micro/ab_big_ensemble.py` after the set-up moved to the device', "round 5: run_mcmc's own timing at 131,072 / 524,288 / 1,048,576 walkers: check_s 0 (the independence test runs on the device), 70.7 -> 33.3 ms end to end at a million walkers"),
+    (rn('micro_fp64_stream_ceiling.txt'), '`benchmarks/micro/fp64_stream_ceiling 0.5` (hipcc from `fp64_stream_ceiling.hip`)', 'round 5: what a stream of independent fp64 FMAs reaches (0.82-0.89 of the nominal issue peak with full-mantissa operands, the waves at 2.2-2.3 GHz; 0.87-0.94 on small integers): the ceiling `bench.py` measures in every run (`fp64_fma_stream`)'),
     (rn('micro_fma_operands.txt'), '`benchmarks/micro/fma_operands` (hipcc from `fma_operands.hip`)', 'round 5: a fp64 FMA with three vector sources costs 2-4 % more issue time than one with a scalar source, whatever the banks: not what holds Dias2000 back'),
     (rn('micro_host_pipeline.txt'), 'a scratch experiment with chunk size, staging and thread count as knobs', 'round 5: the host-buffer entry is bound by the host copy out of pageable memory (54 GB/s from a cache-resident 64 MB source, 37-41 GB/s from DRAM at 256 MB however it is staged or overlapped)'),
     (rn('micro_post_run_stall.txt'), '`python benchmarks/micro/post_run_stall.py kernel`, `upload_cost.py plain`', 'the sporadic 20-30 ms delay of the first device work after a synchronisation early in a process'),

@@ -135,6 +135,8 @@ SYMBOLS = {
     'bisip_ctx_reduced_guard': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int64),
                                                _dp, ctypes.POINTER(ctypes.c_int)]),
     'bisip_clock_probe_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p]),
+    'bisip_fp64_stream_probe_lanes': (ctypes.c_int64, []),
+    'bisip_fp64_stream_probe_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int64), ctypes.c_void_p]),
     'bisip_ctx_reduced_guard_rows': (ctypes.c_int, [ctypes.c_void_p, _dp, ctypes.c_int64, _dp, _dp, ctypes.POINTER(ctypes.c_int)]),
     'bisip_chain_shell_rows_workspace': (ctypes.c_int64, [ctypes.c_int64]),
     'bisip_ensemble_gram_workspace': (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int]),
@@ -626,6 +628,20 @@ def clock_probe_dev(d_out_ptr, window_us, stream=0):
     four int64 at ``d_out_ptr``: enqueue it on a side stream next to a kernel under measurement;
     engine clock in GHz = (out[1] - out[0]) / (out[3] - out[2]) * 0.1."""
     _check(load_library().bisip_clock_probe_dev(ctypes.c_void_p(d_out_ptr), float(window_us), ctypes.c_void_p(stream)))
+
+
+def fp64_stream_probe_lanes():
+    """Doubles the output buffer of :func:`fp64_stream_probe_dev` must hold."""
+    return int(load_library().bisip_fp64_stream_probe_lanes())
+
+
+def fp64_stream_probe_dev(d_out_ptr, rounds, stream=0):
+    """One launch of a stream of independent fp64 FMAs (8 waves per SIMD on every compute unit, 32 * ``rounds``
+    per wave, operands with full mantissas): the ceiling a compute-bound kernel is held to.  Returns the launch's
+    number of wave-instructions; the caller times it."""
+    n = ctypes.c_int64(0)
+    _check(load_library().bisip_fp64_stream_probe_dev(ctypes.c_void_p(d_out_ptr), int(rounds), ctypes.byref(n), ctypes.c_void_p(stream)))
+    return int(n.value)
 
 
 def rccl_unique_id():

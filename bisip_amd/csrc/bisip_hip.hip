@@ -414,6 +414,7 @@ static int guarded(F &&body)
 }
 
 namespace {
+constexpr int FP64_PROBE_GROUPS = 256 * 8;     // 8 waves per SIMD on each of the 256 compute units
 // one wave; sleeps (s_sleep: no issue slots taken from the kernel under measurement) until the
 // 100 MHz counter has advanced by `ticks`, at most `max_polls` polls so that the wave always ends
 __global__ __launch_bounds__(64) void k_clock_probe(long long *out, long long ticks, int max_polls)
@@ -427,6 +428,32 @@ __global__ __launch_bounds__(64) void k_clock_probe(long long *out, long long ti
     const long long t1 = clock64();
     r1 = wall_clock64();
     if (threadIdx.x == 0) { out[0] = t0; out[1] = t1; out[2] = r0; out[3] = r1; }
+}
+
+// A stream of independent fp64 FMAs, nothing to wait for, no memory: the ceiling the compute-bound kernels are held
+// to (bisip_fp64_stream_probe_dev).  8 accumulators in fixed registers, d = d * s + v with one scalar source (the
+// commonest form in kernels.h), operands with full mantissas -- a stream of small integers draws less power and
+// holds a higher clock than any real kernel (benchmarks/micro/fp64_stream_ceiling.hip).
+#define BISIP_FMA8(d0, d1, d2, d3, d4, d5, d6, d7)                                                            \
+    "v_fma_f64 " d0 ", " d0 ", s[20:21], v[42:43]\n v_fma_f64 " d1 ", " d1 ", s[20:21], v[42:43]\n"            \
+    "v_fma_f64 " d2 ", " d2 ", s[20:21], v[42:43]\n v_fma_f64 " d3 ", " d3 ", s[20:21], v[42:43]\n"            \
+    "v_fma_f64 " d4 ", " d4 ", s[20:21], v[42:43]\n v_fma_f64 " d5 ", " d5 ", s[20:21], v[42:43]\n"            \
+    "v_fma_f64 " d6 ", " d6 ", s[20:21], v[42:43]\n v_fma_f64 " d7 ", " d7 ", s[20:21], v[42:43]\n"
+#define BISIP_FMA8_ROUND BISIP_FMA8("v[20:21]", "v[22:23]", "v[24:25]", "v[26:27]", "v[28:29]", "v[30:31]", "v[32:33]", "v[34:35]")
+#define BISIP_FMA_CLOBBER "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35"
+__global__ __launch_bounds__(256) void k_fp64_stream_probe(double *out, int rounds, double seed)
+{
+    asm volatile("v_mov_b64 v[40:41], %0\n v_mov_b64 v[42:43], %1\n s_mov_b64 s[20:21], %2\n"
+                 "v_mov_b64 v[20:21], v[40:41]\n v_mov_b64 v[22:23], v[42:43]\n v_mov_b64 v[24:25], v[40:41]\n"
+                 "v_mov_b64 v[26:27], v[42:43]\n v_mov_b64 v[28:29], v[40:41]\n v_mov_b64 v[30:31], v[42:43]\n"
+                 "v_mov_b64 v[32:33], v[40:41]\n v_mov_b64 v[34:35], v[42:43]\n"
+                 :: "v"(seed * (1.0 + 1e-9 * threadIdx.x)), "v"(0.7853981633974483 + 1e-7 * threadIdx.x), "s"(1.0000003141592653)
+                 : BISIP_FMA_CLOBBER, "v40", "v41", "v42", "v43", "s20", "s21");
+    for (int it = 0; it < rounds; ++it)
+        asm volatile(BISIP_FMA8_ROUND BISIP_FMA8_ROUND BISIP_FMA8_ROUND BISIP_FMA8_ROUND ::: BISIP_FMA_CLOBBER);
+    double r;
+    asm volatile("v_add_f64 %0, v[20:21], v[34:35]" : "=v"(r));
+    out[(long long)blockIdx.x * blockDim.x + threadIdx.x] = r;
 }
 }  // namespace
 
@@ -506,6 +533,18 @@ int bisip_clock_probe_dev(int64_t *d_out, double window_us, void *stream)
     const int max_polls = (int)(window_us * 2.0) + 64;
     hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long *)d_out, ticks, max_polls);
     HIP_TRY(hipGetLastError());
+    return BISIP_OK;
+}
+
+int64_t bisip_fp64_stream_probe_lanes(void) { return (int64_t)FP64_PROBE_GROUPS * 256; }
+
+int bisip_fp64_stream_probe_dev(double *d_out, int rounds, int64_t *wave_instructions, void *stream)
+{
+    if (!d_out) return fail(BISIP_EINVAL, "bisip_fp64_stream_probe_dev: null output");
+    if (rounds < 1 || rounds > (1 << 20)) return fail(BISIP_EINVAL, "bisip_fp64_stream_probe_dev: rounds=%d not in [1, 2^20]", rounds);
+    hipLaunchKernelGGL(k_fp64_stream_probe, dim3(FP64_PROBE_GROUPS), dim3(256), 0, (hipStream_t)stream, d_out, rounds, 1.2345678901234567);
+    HIP_TRY(hipGetLastError());
+    if (wave_instructions) *wave_instructions = (int64_t)FP64_PROBE_GROUPS * 4 * 32 * rounds;
     return BISIP_OK;
 }
 

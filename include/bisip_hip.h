@@ -40,7 +40,8 @@ extern "C" {
  * column / grouped / columns percentiles, forward_spectrum(s) / forward_columns, stretch_run_sharded + rccl_*, ctx_set_spectrum_offset,
  * ctx_reduced_check, polydecomp_reduced_estimates, read_tables; BISIP_VARIANT_REDUCED_COMP, BISIP_ERCCL.
  * 3: clock_probe_dev, ctx_reduced_guard, polydecomp_reduced_reference, stretch_run_sharded_sim_dev (additions only).
- * 4: chain_shell_rows_dev (+ _workspace), ctx_reduced_guard_rows, ensemble_gram_dev (+ _workspace) (additions only). */
+ * 4: chain_shell_rows_dev (+ _workspace), ctx_reduced_guard_rows, ensemble_gram_dev (+ _workspace),
+ *    fp64_stream_probe_dev (+ _lanes) (additions only). */
 #define BISIP_ABI_VERSION 4
 
 /* model_id -- the four reference model classes (src/bisip/models.py:182,232,274,308) */
@@ -495,6 +496,16 @@ int bisip_polydecomp_reduced_estimates(int N, const double *w, const double *zn,
  * that kernel's load -- fp64-dense kernels run at 1.9-2.1 GHz, not at the 2.4 GHz the issue peak is
  * quoted at (benchmarks/micro/collapsed_r3.hip) -- without touching the kernel itself. */
 int bisip_clock_probe_dev(int64_t *d_out, double window_us, void *stream);
+
+/* Measurement aid (no reference counterpart): the rate a stream of INDEPENDENT fp64 FMAs reaches on this chip --
+ * no dependency to wait for, no memory, 8 waves per SIMD on every compute unit, operands with full mantissas --
+ * i.e. the ceiling a compute-bound log-probability kernel can be held to: 0.82-0.89 of the nominal
+ * 1024 SIMDs x 2.4 GHz / 4 cycles with real data (the chip holds 2.2-2.3 GHz under it and a wave-instruction
+ * takes 4.25-4.45 cycles; benchmarks/micro/fp64_stream_ceiling.hip).  One launch: every wave issues 32 * rounds
+ * v_fma_f64; *wave_instructions (host, optional) = the launch's total.  d_out: bisip_fp64_stream_probe_lanes()
+ * doubles on the device (written so that nothing is optimised away).  The caller times the launch. */
+int64_t bisip_fp64_stream_probe_lanes(void);
+int bisip_fp64_stream_probe_dev(double *d_out, int rounds, int64_t *wave_instructions, void *stream);
 
 /* Host-only yardstick (no GPU, no prior): the PolynomialDecomposition log-likelihood
  * -0.5 (chi^2 + sum 2 ln sigma^2) of src/bisip/models.py:59-62 + cython_funcs.pyx:75-94 for W rows of theta,

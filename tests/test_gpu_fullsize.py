@@ -191,3 +191,30 @@ def test_bench_cfg5_extra_on_one_rank(one_rank_rccl_group, capsys):
     rec = json.loads([ln for ln in err.splitlines() if ln.startswith('{"sampler_cfg5"')][-1])['sampler_cfg5']
     assert rec['n_gpus'] == 1 and rec['spectra'] == 64 and rec['iterations'] == 400 and rec['path'] == 'persistent'
     assert rec['finite_means'] and rec['walker_steps_per_s'] > 1e7 and rec['collectives_on_the_data_path'] == 0
+
+
+def test_fp64_stream_probe_is_the_ceiling_bench_holds_the_kernels_to():
+    """bench.py's `fp64_fma_stream`: a stream of independent v_fma_f64 (bisip_fp64_stream_probe_dev) reaches most of the
+    nominal issue peak and never more, its result depends on nothing but its arguments, and bad arguments are
+    refused before anything is launched."""
+    import sys
+    import torch
+    from conftest import ROOT
+    from bisip_amd import _hip
+    sys.path.insert(0, ROOT)
+    import bench
+    rec = bench.fp64_stream_ceiling(torch, torch.cuda.current_stream(), seconds=0.1)
+    assert 0.6 < rec['frac_of_nominal_peak'] < 1.02, rec
+    assert rec['wave_instr_per_s'] == pytest.approx(rec['frac_of_nominal_peak'] * bench.VALU_PEAK_WAVE_INSTR_S)
+    lanes = _hip.fp64_stream_probe_lanes()
+    a, b = (torch.zeros(lanes, dtype=torch.float64, device='cuda') for _ in range(2))
+    n = _hip.fp64_stream_probe_dev(a.data_ptr(), 3)
+    assert n == lanes // 64 * 32 * 3
+    _hip.fp64_stream_probe_dev(b.data_ptr(), 3)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and bool(torch.isfinite(a).all()) and float(a.abs().min()) > 0.0
+    for bad in (0, -1, (1 << 20) + 1):
+        with pytest.raises(ValueError):
+            _hip.fp64_stream_probe_dev(a.data_ptr(), bad)
+    with pytest.raises(ValueError):
+        _hip.fp64_stream_probe_dev(0, 3)
