@@ -28,10 +28,12 @@ sweep|sampler|micro)
   bash benchmarks/collect_profiles.sh $what > $out/collect_$what.log 2>&1; echo "rc=$?"; tail -3 $out/progress.log
   if [ $what = micro ]; then
     python3 benchmarks/micro/group_sampler.py 2> /dev/null > $out/micro_group_sampler.jsonl
-    for m in cc2 pd; do for plain in 1 0; do
-      if [ $plain = 1 ]; then BIG_MODEL=$m BISIP_NO_PACKED_STATE=1 python3 benchmarks/micro/ab_big_ensemble.py 2> /dev/null | grep '^{'
-      else BIG_MODEL=$m python3 benchmarks/micro/ab_big_ensemble.py 2> /dev/null | grep '^{'; fi
-    done; done > $out/micro_ab_big_ensemble_packed.jsonl
+    for m in cc2 pd; do      # plain layout / packed state, stream arrays / packed state, stream drawn in place
+      BIG_MODEL=$m BISIP_NO_PACKED_STATE=1 python3 benchmarks/micro/ab_big_ensemble.py 2> /dev/null | grep '^{'
+      BIG_MODEL=$m BISIP_NO_INLINE_DRAW=1 python3 benchmarks/micro/ab_big_ensemble.py 2> /dev/null | grep '^{'
+      BIG_MODEL=$m python3 benchmarks/micro/ab_big_ensemble.py 2> /dev/null | grep '^{'
+    done > $out/micro_ab_big_ensemble_packed.jsonl
+    [ -x benchmarks/micro/random_lines ] && (timeout -k 5 120 benchmarks/micro/random_lines 1048576 && timeout -k 5 120 benchmarks/micro/random_lines 8388608) > $out/micro_random_lines.txt 2>&1
     for i in 1 2 3; do
       python3 benchmarks/cfg4_sampler.py --steps 200 --fused --chain device --repeat 7 | grep '^{'
       python3 benchmarks/cfg4_sampler.py --steps 200 --fused --chain device --repeat 7 --no-guard | grep '^{'

@@ -32,7 +32,7 @@ for f in cfg4_fused_device_chain cfg4_sharded_python cfg4_sharded_rccl-own cfg4_
 done
 cpy "$(newest $src/prof_cfg5/runc kernel_stats.csv)"    $dst/${tag}_cfg5_kernel_stats.csv
 cpy "$(newest $src/prof_batch_models/runc kernel_stats.csv)" $dst/${tag}_batch_models_kernel_stats.csv
-for m in issue_latency row_latency half_step_phases forward_rows_variants grid_barrier xcd_barrier post_run_stall cfg5_pmc batch_pd_pmc batch_logprob_rate select_vs_sort model_percentile_single persistent_crossover collapsed_r3 exp2_variants rcp_accuracy fp64_stream_ceiling; do
+for m in issue_latency row_latency half_step_phases forward_rows_variants grid_barrier xcd_barrier post_run_stall cfg5_pmc batch_pd_pmc batch_logprob_rate select_vs_sort model_percentile_single persistent_crossover collapsed_r3 exp2_variants rcp_accuracy fp64_stream_ceiling random_lines; do
   cpy $src/micro_$m.txt $dst/${tag}_micro_$m.txt
 done
 cpy $src/micro_small_call_latency.jsonl $dst/${tag}_micro_small_call_latency.jsonl

@@ -295,14 +295,15 @@ def table_group_sampler():
 def table_big_ensemble():
     rows = []
     for d in jlines(rn('micro_ab_big_ensemble_packed.jsonl')):
-        for W in ('131072', '524288', '1048576'):
+        for W in ('524288', '1048576'):       # (131,072 walkers are in the file as well)
             r = d[W]
             rows.append([{'cc2': 'double Cole-Cole', 'pd': 'PolynomialDecomposition (reduced)'}[d['model']], int(W),
                          'one 64-byte row per walker' if d['packed_state'] else 'coords (W, ndim) + logp (W,)',
-                         r['us_per_half_step_device'], r['wall_ms'],
-                         f"{r['wall_ms'] / ((r['timing_ms']['enqueue_s'] + r['timing_ms']['drain_s'] + r['timing_ms'].get('guard_s', 0.0)) or 1):.2f}"])
+                         {'in place': 'drawn in place', 'arrays': 'arrays (a draw kernel per chunk)'}.get(r.get('stream'), '-'),
+                         r.get('us_per_half_step_launches', '-'), r['wall_ms']])
     return md(rows, ['big single ensembles, 200 iterations, philox stream, chain thinned by 50 on the device', 'walkers', 'state of a chunk',
-                     'us per half-step (device)', 'run_mcmc end to end, ms', 'end to end / device work'])
+                     'philox stream', "us per half-step: a chunk's launches (HIP events; the draw kernel of the array form not included)",
+                     'run_mcmc end to end, ms'])
 
 
 def table_guard():
@@ -373,9 +374,10 @@ FILES = [
     (rn('guard_overhead_cfg4.jsonl'), '`python benchmarks/cfg4_sampler.py --steps 200 --fused --chain device --repeat 7 [--no-guard]`, alternately, three times', "round 5: what the sampler's guard of the QR-reduced tier costs at cfg4's size (selection of the rows nearest to the shell, their copy, the yardstick): 2-3 %"),
     (rn('micro_group_sampler.jsonl'), '`python benchmarks/micro/group_sampler.py`', 'round 5: `k_stretch_group` (one ensemble of 1,025 ... 8,192 walkers over several workgroups, a barrier of their own per half-step) against one launch per half-step, every model; cfg2 is the first case'),
     (rn('micro_group_phases.txt'), 'a temporary build of `k_stretch_group` with `s_memrealtime` timers around its phases', "round 5: where cfg2's half-step goes inside the kernel: gather 0.58, evaluation 2.15, commit + drain 0.5, barrier 1.07 us"),
-    (rn('micro_ab_big_ensemble_packed.jsonl'), '`BIG_MODEL=cc2|pd [BISIP_NO_PACKED_STATE=1] python benchmarks/micro/ab_big_ensemble.py`, alternately', 'round 5: ensembles of 131,072 ... 1,048,576 walkers on the packed state (one 64-byte row per walker) and on the plain layout; device time per half-step and end to end'),
+    (rn('micro_ab_big_ensemble_packed.jsonl'), '`BIG_MODEL=cc2|pd [BISIP_NO_PACKED_STATE=1 | BISIP_NO_INLINE_DRAW=1] python benchmarks/micro/ab_big_ensemble.py`', 'round 5: ensembles of 131,072 ... 1,048,576 walkers on the plain layout, on the packed state (one 64-byte row per walker) with stream arrays, and on the packed state with the philox stream drawn in place; a chunk\'s launches timed by HIP events, and end to end'),
     (rn('micro_ab_big_ensemble_rows.jsonl'), 'the same script on a build with `k_stretch_half_rows` (rows moved by four lanes each through LDS; not kept)', 'round 5: PolynomialDecomposition 65 -> 63 us, double Cole-Cole 66 -> 73 us per half-step of 524,288 proposals: requests per instruction were not the bound'),
     (rn('big_ensemble_host_setup.json'), '`BIG_MODEL=pd python benchmarks/micro/ab_big_ensemble.py` after the set-up moved to the device', "round 5: run_mcmc's own timing at 131,072 / 524,288 / 1,048,576 walkers: check_s 0 (the independence test runs on the device), 70.7 -> 33.3 ms end to end at a million walkers"),
+    (rn('micro_random_lines.txt'), '`benchmarks/micro/random_lines 1048576`, `... 8388608` (hipcc from `random_lines.hip`)', 'round 5: what the chip delivers for the access pattern of a big ensemble\'s half-step -- whole 64-byte rows at random places: two read per proposal 20.4 us per 524,288, and one written 25.8 (3.3-4.1 TB/s; sequential rows 6-7.4): the half-step (29-31 us with its evaluation and its draw) is at 0.85-0.9 of it'),
     (rn('micro_fp64_stream_ceiling.txt'), '`benchmarks/micro/fp64_stream_ceiling 0.5` (hipcc from `fp64_stream_ceiling.hip`)', 'round 5: what a stream of independent fp64 FMAs reaches (0.82-0.89 of the nominal issue peak with full-mantissa operands, the waves at 2.2-2.3 GHz; 0.87-0.94 on small integers): the ceiling `bench.py` measures in every run (`fp64_fma_stream`)'),
     (rn('micro_fma_operands.txt'), '`benchmarks/micro/fma_operands` (hipcc from `fma_operands.hip`)', 'round 5: a fp64 FMA with three vector sources costs 2-4 % more issue time than one with a scalar source, whatever the banks: not what holds Dias2000 back'),
     (rn('micro_host_pipeline.txt'), 'a scratch experiment with chunk size, staging and thread count as knobs', 'round 5: the host-buffer entry is bound by the host copy out of pageable memory (54 GB/s from a cache-resident 64 MB source, 37-41 GB/s from DRAM at 256 MB however it is staged or overlapped)'),

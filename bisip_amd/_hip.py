@@ -89,6 +89,10 @@ SYMBOLS = {
     'bisip_stretch_draw_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_double,
                                               ctypes.c_uint64, ctypes.c_int64, ctypes.c_int64] +
                                [ctypes.c_void_p] * 7),
+    'bisip_stretch_philox_inline': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64]),
+    'bisip_stretch_run_philox_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(StretchArgs), ctypes.c_int64, ctypes.c_int64,
+                                                    ctypes.c_int64, ctypes.c_double, ctypes.c_uint64, ctypes.c_int64,
+                                                    ctypes.c_void_p, ctypes.c_void_p]),
     'bisip_stretch_persistent_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(PersistArgs), ctypes.c_void_p]),
     'bisip_chain_moments_workspace': (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int64, ctypes.c_int]),
     'bisip_chain_moments_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
@@ -611,6 +615,19 @@ class HipContext:
             return False
         _check(rc)
         return True
+
+    def stretch_philox_inline(self, W):
+        """True where :meth:`stretch_run_philox_dev` serves this context's ensemble of ``W`` walkers (a single
+        ensemble big enough for the packed-state half-step)."""
+        return bool(self._lib.bisip_stretch_philox_inline(self._h, int(W)))
+
+    def stretch_run_philox_dev(self, first_args, W, n_steps, thin_by, a, seed, step0, perm, stream=0):
+        """:meth:`stretch_run_dev` with the Philox stream drawn in place by every half-step launch: no stream arrays
+        (``first_args``' five stream pointers are ignored); ``perm``: device pointer of this chunk's (n_steps, 3)
+        affine splits.  Same chain as :meth:`stretch_draw_dev` + :meth:`stretch_run_dev`."""
+        _check(self._lib.bisip_stretch_run_philox_dev(self._h, ctypes.byref(first_args), int(W), int(n_steps), int(thin_by),
+                                                      float(a), int(seed), int(step0), ctypes.c_void_p(perm),
+                                                      ctypes.c_void_p(stream)))
 
     def stretch_draw_dev(self, W, a, seed, step0, n_steps, perm, active, partner, zz, factor, logu,
                          stream=0):

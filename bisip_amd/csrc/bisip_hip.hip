@@ -1032,23 +1032,31 @@ int bisip_stretch_apply_dev(bisip_ctx *c, const bisip_stretch_args *u, void *str
     return dispatch_apply(c, to_device_args(u), (hipStream_t)stream);
 }
 
-int bisip_stretch_run_dev(bisip_ctx *c, const bisip_stretch_args *first, int64_t W, int64_t n_steps,
-                          int64_t thin_by, void *stream)
+// does a chunk of this context's ensemble sample on a packed state (k_stretch_half_packed)?
+static bool packed_state(const bisip_ctx *c, int64_t W, int64_t n_steps)
 {
-    if (!c || !first) return fail(BISIP_EINVAL, "null argument");
-    if (thin_by < 1 || n_steps % thin_by) return fail(BISIP_EINVAL, "n_steps=%lld must be a multiple of thin_by=%lld", (long long)n_steps, (long long)thin_by);
-    if (W < 2 || n_steps < 0) return fail(BISIP_EINVAL, "bad W=%lld or n_steps=%lld", (long long)W, (long long)n_steps);
-    if (!first->coords || !first->logp || !first->active || !first->partner || !first->zz ||
-        !first->factor || !first->logu || !first->status)
-        return fail(BISIP_EINVAL, "null buffer");
-    HIP_TRY(hipSetDevice(c->device));
+    // BISIP_NO_PACKED_STATE (read per call) keeps the plain layout: A/B runs and the test of their equality.
+    return c->E == 1 && c->ndim < PACKED_ROW && W / 2 >= 65536 && lanes_per_walker(W / 2) == 1 && n_steps > 0 &&
+           std::getenv("BISIP_NO_PACKED_STATE") == nullptr;
+}
+
+// what bisip_stretch_run_philox_dev adds to a chunk: the philox contract's parameters instead of its arrays
+struct PhiloxStream {
+    double a;
+    uint64_t seed;
+    int64_t step0;
+    const int32_t *d_perm;   // (n_steps, 3): A, Ainv, B per iteration
+};
+
+static int stretch_run(bisip_ctx *c, const bisip_stretch_args *first, int64_t W, int64_t n_steps, int64_t thin_by,
+                       const PhiloxStream *draw, void *stream)
+{
     const int64_t nh = (W + 1) / 2;
     bisip_stretch_args u = *first;
     // A single ensemble that fills the chip with one lane per slot samples this chunk on a packed state: one aligned
     // 64-byte row per walker (k_stretch_half_packed), packed here, unpacked after the last half-step.
-    // BISIP_NO_PACKED_STATE (read per call) keeps the plain layout: A/B runs and the test of their equality.
-    const bool packed = c->E == 1 && c->ndim < PACKED_ROW && W / 2 >= 65536 && lanes_per_walker(W / 2) == 1 && n_steps > 0 &&
-                        std::getenv("BISIP_NO_PACKED_STATE") == nullptr;
+    const bool packed = packed_state(c, W, n_steps);
+    if (draw && !packed) return fail(BISIP_EUNSUPPORTED, "the stream is drawn in place only by the packed-state half-step (bisip_stretch_philox_inline)");
     if (packed) {
         const size_t need = (size_t)W * PACKED_ROW * sizeof(double);
         if (c->packed_bytes < need) {
@@ -1064,8 +1072,10 @@ int bisip_stretch_run_dev(bisip_ctx *c, const bisip_stretch_args *first, int64_t
     for (int64_t k = 0; k < n_steps; ++k) {
         for (int h = 0; h < 2; ++h) {
             const int64_t off = (k * 2 + h) * nh;
-            u.active = first->active + off; u.partner = first->partner + off;
-            u.zz = first->zz + off; u.factor = first->factor + off; u.logu = first->logu + off;
+            if (!draw) {
+                u.active = first->active + off; u.partner = first->partner + off;
+                u.zz = first->zz + off; u.factor = first->factor + off; u.logu = first->logu + off;
+            }
             u.n_slots = h ? W / 2 : nh;
             const bool store = ((k + 1) % thin_by) == 0;   // the walkers of BOTH halves of a stored step
             const int64_t srow = k / thin_by;
@@ -1073,6 +1083,12 @@ int bisip_stretch_run_dev(bisip_ctx *c, const bisip_stretch_args *first, int64_t
             u.logp_row = (store && first->logp_row) ? first->logp_row + srow * W : nullptr;
             StretchArgs a = to_device_args(&u);
             if (packed) a.packed = c->d_packed;
+            if (draw) {
+                a.perm = draw->d_perm + 3 * k;
+                a.draw_W = W; a.draw_a = draw->a; a.draw_ndim_m1 = (double)(c->ndim - 1);
+                a.seed_lo = (unsigned int)(draw->seed & 0xffffffffu); a.seed_hi = (unsigned int)(draw->seed >> 32);
+                a.draw_step = (unsigned int)(draw->step0 + k); a.draw_e = (unsigned int)c->spectrum_offset; a.draw_h = h;
+            }
             int rc = dispatch_stretch(c, StretchWork{STRETCH_HALF, &a, nullptr}, u.walkers_per_spectrum, (hipStream_t)stream);
             if (rc != BISIP_OK) return rc;
         }
@@ -1083,6 +1099,40 @@ int bisip_stretch_run_dev(bisip_ctx *c, const bisip_stretch_args *first, int64_t
         HIP_TRY(hipGetLastError());
     }
     return BISIP_OK;
+}
+
+int bisip_stretch_run_dev(bisip_ctx *c, const bisip_stretch_args *first, int64_t W, int64_t n_steps,
+                          int64_t thin_by, void *stream)
+{
+    if (!c || !first) return fail(BISIP_EINVAL, "null argument");
+    if (thin_by < 1 || n_steps % thin_by) return fail(BISIP_EINVAL, "n_steps=%lld must be a multiple of thin_by=%lld", (long long)n_steps, (long long)thin_by);
+    if (W < 2 || n_steps < 0) return fail(BISIP_EINVAL, "bad W=%lld or n_steps=%lld", (long long)W, (long long)n_steps);
+    if (!first->coords || !first->logp || !first->active || !first->partner || !first->zz ||
+        !first->factor || !first->logu || !first->status)
+        return fail(BISIP_EINVAL, "null buffer");
+    HIP_TRY(hipSetDevice(c->device));
+    return stretch_run(c, first, W, n_steps, thin_by, nullptr, stream);
+}
+
+int bisip_stretch_philox_inline(const bisip_ctx *c, int64_t W)
+{
+    return c && W >= 2 && W <= 0x7fffffffLL && packed_state(c, W, 1) ? 1 : 0;
+}
+
+int bisip_stretch_run_philox_dev(bisip_ctx *c, const bisip_stretch_args *first, int64_t W, int64_t n_steps,
+                                 int64_t thin_by, double a, uint64_t seed, int64_t step0, const int32_t *d_perm,
+                                 void *stream)
+{
+    if (!c || !first || !d_perm) return fail(BISIP_EINVAL, "null argument");
+    if (thin_by < 1 || n_steps % thin_by) return fail(BISIP_EINVAL, "n_steps=%lld must be a multiple of thin_by=%lld", (long long)n_steps, (long long)thin_by);
+    if (W < 2 || W > 0x7fffffffLL || n_steps < 0 || step0 < 0 || step0 + n_steps > 0xffffffffLL)
+        return fail(BISIP_EINVAL, "bad W=%lld or step range [%lld, +%lld)", (long long)W, (long long)step0, (long long)n_steps);
+    if (!(a > 0.0)) return fail(BISIP_EINVAL, "stretch scale a=%g must be positive", a);
+    if (!first->coords || !first->logp || !first->status) return fail(BISIP_EINVAL, "null buffer");
+    if (n_steps == 0) return BISIP_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    const PhiloxStream draw{a, seed, step0, d_perm};
+    return stretch_run(c, first, W, n_steps, thin_by, &draw, stream);
 }
 
 // rows lo, lo + stride, ... < hi of a (W, ndim) batch against the yardstick of the spectrum each belongs to

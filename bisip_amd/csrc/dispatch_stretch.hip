@@ -49,6 +49,8 @@ StretchArgs to_device_args(const bisip_stretch_args *u)
     a.naccept = u->naccept; a.status = u->status;
     a.pad = u->pad;
     a.packed = nullptr;
+    a.perm = nullptr; a.draw_W = 0; a.draw_a = 0.0; a.draw_ndim_m1 = 0.0;
+    a.seed_lo = a.seed_hi = a.draw_step = a.draw_e = 0u; a.draw_h = 0;
     const long long world = u->world > 0 ? u->world : 1;
     a.base = u->n_slots / world;
     a.extra = u->n_slots % world;

@@ -42,6 +42,13 @@ struct StretchArgs {
     // k_stretch_half_packed: the state as ONE 64-byte row per walker (theta, padding, the log-probability in [7]);
     // null: coords / logp as above
     double *packed;
+    // k_stretch_half_packed with the slot's stream entries DRAWN IN PLACE (bisip_stretch_run_philox_dev): perm = the
+    // iteration's (A, Ainv, B) of the philox contract (see draw_slot); null: the five arrays above are read
+    const int *perm;
+    long long draw_W;
+    double draw_a, draw_ndim_m1;
+    unsigned int seed_lo, seed_hi, draw_step, draw_e;
+    int draw_h;
 };
 
 // L = lanes per walker (see logprob_row); g = this lane's index inside its group.
@@ -364,6 +371,51 @@ __device__ __forceinline__ void commit_row(const StretchArgs &a, int i, const do
     if (a.naccept && acc) atomicAdd(a.naccept + i, 1);
 }
 
+// pi^-1(y) = Ainv * (y - B) mod W for y, B in [0, W), Ainv in [1, W) (the philox contract: the comment at DrawArgs).
+// y - B needs no division at all, and for W <= 65536 (every ensemble that is not one huge one) the product fits
+// 32 bits.  Same integers either way.
+__device__ __forceinline__ int perm_inverse(long long y, long long W, long long Ainv, long long B)
+{
+    long long v = y - B;
+    if (v < 0) v += W;
+    if (W <= 65536) return (int)(((unsigned)Ainv * (unsigned)v) % (unsigned)W);
+    // Ainv v < 2^62: the quotient estimated in double (relative error 3 x 2^-53 of a number < 2^31: off by one at
+    // most, and only next to an integer), the remainder set right -- the same integer as (Ainv v) % W without the
+    // ~100 instructions of a 64-bit division (two per slot were half of the draw kernel's time on a big ensemble)
+    const unsigned long long prod = (unsigned long long)Ainv * (unsigned long long)v;
+    const unsigned q = (unsigned)((double)prod * (1.0 / (double)W));
+    long long r = (long long)(prod - (unsigned long long)q * (unsigned long long)W);
+    if (r < 0) r += W;
+    if (r >= W) r -= W;
+    return (int)r;
+}
+
+// the per-slot draw of the philox contract
+struct SlotDraw {
+    int active, partner;  // walker indices inside the ensemble
+    double z, factor, logu;
+};
+
+__device__ __forceinline__ SlotDraw draw_slot(long long W, double a, double ndim_m1, unsigned seed_lo,
+                                              unsigned seed_hi, unsigned step, int h, unsigned e,
+                                              long long t, long long A_inv, long long B)
+{
+    const long long Nc = h ? (W + 1) / 2 : W / 2;
+    const unsigned c2 = (unsigned)h | (e << 1);
+    const Philox4 r0 = philox4x32_10((unsigned)t, step, c2, 0u, seed_lo, seed_hi);
+    const Philox4 r1 = philox4x32_10((unsigned)t, step, c2, 1u, seed_lo, seed_hi);
+    const double uz = u53(r0.v[0], r0.v[1]);
+    const long long r = (long long)(((unsigned long long)r0.v[2] * (unsigned long long)Nc) >> 32);
+    const double v = (a - 1.0) * uz + 1.0;
+    SlotDraw d;
+    d.z = (v * v) / a;
+    d.active = perm_inverse(2 * t + h, W, A_inv, B);
+    d.partner = perm_inverse(2 * r + (1 - h), W, A_inv, B);
+    d.factor = ndim_m1 * log(d.z);
+    d.logu = log(u53(r1.v[0], r1.v[1]));
+    return d;
+}
+
 // single-rank half-step: evaluate every slot and update the state in place.
 // LP::L lanes per slot; a wave holds 64/L slots.  When a wave's last slots do not exist the
 // lanes still run (clamped to the last slot) so the wavefront exchanges stay uniform; only
@@ -404,14 +456,24 @@ __global__ __launch_bounds__(BLK) void k_stretch_half_packed(const StretchArgs a
     const long long slot = (long long)blockIdx.x * BLK + threadIdx.x;
     const bool live = slot < a.n_slots;
     const long long t = live ? slot : a.n_slots - 1;
-    const int i = __builtin_nontemporal_load(a.active + t), p = __builtin_nontemporal_load(a.partner + t);
+    int i, p;
+    double z, factor, logu;
+    if (a.perm) {      // the slot's entries from their Philox counters: nothing of the stream touches memory
+        const SlotDraw d = draw_slot(a.draw_W, a.draw_a, a.draw_ndim_m1, a.seed_lo, a.seed_hi, a.draw_step, a.draw_h,
+                                     a.draw_e, t, a.perm[1], a.perm[2]);
+        i = d.active; p = d.partner; z = d.z; factor = d.factor; logu = d.logu;
+    } else {
+        i = __builtin_nontemporal_load(a.active + t); p = __builtin_nontemporal_load(a.partner + t);
+    }
     const dbl2 *srow = reinterpret_cast<const dbl2 *>(a.packed + (long long)i * PACKED_ROW);
     const dbl2 *crow = reinterpret_cast<const dbl2 *>(a.packed + (long long)p * PACKED_ROW);
     dbl2 sv[4], cv[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) { sv[q] = srow[q]; cv[q] = crow[q]; }
-    const double z = __builtin_nontemporal_load(a.zz + t), factor = __builtin_nontemporal_load(a.factor + t);
-    const double logu = __builtin_nontemporal_load(a.logu + t);
+    if (!a.perm) {
+        z = __builtin_nontemporal_load(a.zz + t); factor = __builtin_nontemporal_load(a.factor + t);
+        logu = __builtin_nontemporal_load(a.logu + t);
+    }
     double s_row[PACKED_ROW], c_row[PACKED_ROW];
 #pragma unroll
     for (int q = 0; q < 4; ++q) { s_row[2 * q] = sv[q].x; s_row[2 * q + 1] = sv[q].y; c_row[2 * q] = cv[q].x; c_row[2 * q + 1] = cv[q].y; }
@@ -435,21 +497,48 @@ __global__ __launch_bounds__(BLK) void k_stretch_half_packed(const StretchArgs a
     if (a.logp_row) __builtin_nontemporal_store(lp_row, a.logp_row + i);
 }
 
-// (W, NDIM) + (W,) -> (W, 8) and back; one lane per walker (a chunk's first and last launch)
+// (W, NDIM) + (W,) -> (W, 8) and back (a chunk's first and last launch): a tile of 256 walkers goes through LDS so that
+// both sides are read and written as whole lines by consecutive lanes -- a lane per walker walking its own row
+// (stride 8 NDIM bytes between lanes) moved 128 MB in 103 / 91 us at a million walkers.
 template <bool PACK>
 __global__ __launch_bounds__(256) void k_state_repack(double *coords, double *logp, double *packed, long long W, int ndim)
 {
-    const long long w = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (w >= W) return;
+    __shared__ __attribute__((aligned(16))) double tile[256 * PACKED_ROW];
+    const long long row0 = (long long)blockIdx.x * 256;
+    const int rows = (int)(W - row0 < 256 ? W - row0 : 256);
+    const int tid = threadIdx.x;
+    dbl2 *tile2 = reinterpret_cast<dbl2 *>(tile);
+    dbl2 *packed2 = reinterpret_cast<dbl2 *>(packed + row0 * PACKED_ROW);
     if (PACK) {
-        for (int q = 0; q < PACKED_ROW - 1; ++q) packed[w * PACKED_ROW + q] = q < ndim ? coords[w * ndim + q] : 0.0;
-        packed[w * PACKED_ROW + PACKED_ROW - 1] = logp[w];
+        for (int idx = tid; idx < rows * ndim; idx += 256) {
+            const int w = idx / ndim, q = idx - w * ndim;
+            tile[w * PACKED_ROW + q] = coords[row0 * ndim + idx];
+        }
+        if (tid < rows) {
+            for (int q = ndim; q < PACKED_ROW - 1; ++q) tile[tid * PACKED_ROW + q] = 0.0;
+            tile[tid * PACKED_ROW + PACKED_ROW - 1] = logp[row0 + tid];
+        }
+        __syncthreads();
+        for (int j = tid; j < rows * (PACKED_ROW / 2); j += 256) packed2[j] = tile2[j];
     } else {
-        for (int q = 0; q < ndim; ++q) coords[w * ndim + q] = packed[w * PACKED_ROW + q];
-        logp[w] = packed[w * PACKED_ROW + PACKED_ROW - 1];
+        for (int j = tid; j < rows * (PACKED_ROW / 2); j += 256) tile2[j] = packed2[j];
+        __syncthreads();
+        for (int idx = tid; idx < rows * ndim; idx += 256) {
+            const int w = idx / ndim, q = idx - w * ndim;
+            coords[row0 * ndim + idx] = tile[w * PACKED_ROW + q];
+        }
+        if (tid < rows) logp[row0 + tid] = tile[tid * PACKED_ROW + PACKED_ROW - 1];
     }
 }
 
+// (What bounds it, round 5: the memory system's rate of RANDOM 64-byte lines.  Parts of a half-step of 524,288 proposals
+// taken out one at a time (1,048,576 walkers, PolynomialDecomposition, stream drawn in place: 31 us): rows at
+// sequential instead of random places -13 us, no row written -4, no counter bumped -3, no draw -1; the times ADD UP
+// and do not depend on the occupancy (2 ... 6 waves per SIMD, limited through LDS), i.e. every part is a share of one
+// resource's time.  benchmarks/micro/random_lines.hip asks the chip for the bare pattern: two random rows read per
+// proposal 20.6 us, and one written 25.8 -- the half-step is at 0.85-0.9 of that.  Two slots per lane, software-
+// pipelined (the second slot's rows travelling while the first is evaluated): 31.7 us, double Cole-Cole 40.7 -> 47.7;
+// eight waves per SIMD forced (spills): 33.9 / 126.  Not kept.)
 // (Measured and not kept, round 5: the rows of a chip-filling launch fetched and stored by FOUR lanes each through
 // LDS, 16 bytes per lane, instead of one lane per row -- same chain; 524,288 proposals of a 1,048,576-walker
 // ensemble: PolynomialDecomposition 65.2 -> 63.4 us per half-step, double Cole-Cole 66.3 -> 73.1.  Both models take the
@@ -524,44 +613,6 @@ struct DrawArgs {
     int *active, *partner;
     double *zz, *factor, *logu;
 };
-
-// pi^-1(y) = Ainv * (y - B) mod W for y, B in [0, W), Ainv in [1, W).  A 64-bit division is ~100
-// instructions and the draw kernel had four per slot -- more than its two Philox blocks: y - B needs
-// no division at all, and for W <= 65536 (every ensemble that is not one huge one) the product fits
-// 32 bits.  Same integers either way.
-__device__ __forceinline__ int perm_inverse(long long y, long long W, long long Ainv, long long B)
-{
-    long long v = y - B;
-    if (v < 0) v += W;
-    if (W <= 65536) return (int)(((unsigned)Ainv * (unsigned)v) % (unsigned)W);
-    return (int)((Ainv * v) % W);
-}
-
-// the per-slot draw of the philox contract
-struct SlotDraw {
-    int active, partner;  // walker indices inside the ensemble
-    double z, factor, logu;
-};
-
-__device__ __forceinline__ SlotDraw draw_slot(long long W, double a, double ndim_m1, unsigned seed_lo,
-                                              unsigned seed_hi, unsigned step, int h, unsigned e,
-                                              long long t, long long A_inv, long long B)
-{
-    const long long Nc = h ? (W + 1) / 2 : W / 2;
-    const unsigned c2 = (unsigned)h | (e << 1);
-    const Philox4 r0 = philox4x32_10((unsigned)t, step, c2, 0u, seed_lo, seed_hi);
-    const Philox4 r1 = philox4x32_10((unsigned)t, step, c2, 1u, seed_lo, seed_hi);
-    const double uz = u53(r0.v[0], r0.v[1]);
-    const long long r = (long long)(((unsigned long long)r0.v[2] * (unsigned long long)Nc) >> 32);
-    const double v = (a - 1.0) * uz + 1.0;
-    SlotDraw d;
-    d.z = (v * v) / a;
-    d.active = perm_inverse(2 * t + h, W, A_inv, B);
-    d.partner = perm_inverse(2 * r + (1 - h), W, A_inv, B);
-    d.factor = ndim_m1 * log(d.z);
-    d.logu = log(u53(r1.v[0], r1.v[1]));
-    return d;
-}
 
 // Grid: x covers the E*nh slots of one half-step, (y, z) the 2*n_steps half-steps -- the index
 // arithmetic of a flat 64-bit grid was four 64-bit divisions per slot.  `flat`: one 32-bit index over

@@ -624,11 +624,12 @@ class HipStretchBackend:
         a.coords = st['coords'].data_ptr()
         a.logp = st['logp'].data_ptr()
         off = (k * 2 + h) * st['nh']
-        a.active = st['active'].data_ptr() + 4 * off
-        a.partner = st['partner'].data_ptr() + 4 * off
-        a.zz = st['zz'].data_ptr() + 8 * off
-        a.factor = st['factor'].data_ptr() + 8 * off
-        a.logu = st['logu'].data_ptr() + 8 * off
+        if 'active' in st:                   # (a chunk whose stream is drawn in place has no arrays: run)
+            a.active = st['active'].data_ptr() + 4 * off
+            a.partner = st['partner'].data_ptr() + 4 * off
+            a.zz = st['zz'].data_ptr() + 8 * off
+            a.factor = st['factor'].data_ptr() + 8 * off
+            a.logu = st['logu'].data_ptr() + 8 * off
         a.n_slots = n_slots
         W, ndim = st['coords'].shape
         thin = st.get('thin', 1)
@@ -659,6 +660,11 @@ class HipStretchBackend:
         """All n_steps iterations of a chunk in one C call (2 launches per step, no host
         round trip)."""
         W = st['coords'].shape[0]
+        if 'inline' in st:                   # the Philox stream drawn by the half-step launches themselves
+            a, seed, step0 = st['inline']
+            self.ctx.stretch_run_philox_dev(self._args(st, 0, 0, (W + 1) // 2, base=True), W, n_steps, st.get('thin', 1),
+                                            a, seed, step0, st['perm'].data_ptr(), self.stream())
+            return
         self.ctx.stretch_run_dev(self._args(st, 0, 0, (W + 1) // 2, base=True), W, n_steps,
                                  st.get('thin', 1), self.stream())
 
@@ -772,6 +778,13 @@ class HipStretchBackend:
         with torch.cuda.stream(self._copy_stream):
             dst_host.copy_(src_dev, non_blocking=True)
         src_dev.record_stream(self._copy_stream)
+
+    def draws_in_place(self, W):
+        """Can a chunk of this context's single ensemble of ``W`` walkers run without stream arrays
+        (bisip_stretch_run_philox_dev)?  BISIP_NO_INLINE_DRAW (read per run) keeps the arrays: A/B runs and the test of
+        their equality."""
+        import os
+        return os.environ.get('BISIP_NO_INLINE_DRAW') is None and self.ctx.stretch_philox_inline(W)
 
     def draw(self, st, W, a, seed, step0, n_steps, after=None):
         """Fill a chunk's stream arrays (Philox).  ``after`` = events the draw must wait for (its
@@ -897,6 +910,7 @@ class DeviceEnsembleSampler(_SamplerBase):
         # get_log_prob() ask for it, and param_moments() summarises the chain where it lies
         self.chain_on_device = bool(chain_on_device)
         self.last_path = None
+        self.last_stream = None      # run_mcmc: 'host' (NumPy order), 'arrays' (Philox, drawn per chunk) or 'in place'
         super().__init__(int(nwalkers) * self.n_ensembles, ndim, a, live_dangerously, group, distributed)
         # philox key: explicit seed, else drawn from the (seeded) private RandomState
         # (never in 'numpy' mode: that stream must stay aligned with EnsembleSampler's)
@@ -1014,13 +1028,14 @@ class DeviceEnsembleSampler(_SamplerBase):
         self.timing['guard_s'] = self.timing.get('guard_s', 0.0) + time.perf_counter() - t0
         return not escalated
 
-    def _chunk_steps(self, nsteps):
+    def _chunk_steps(self, nsteps, stream_in_place=False):
         if self.chunk:
             return max(1, int(self.chunk))
-        # bytes resident per iteration: chain row + log-prob + the five stream arrays.  2 GiB
+        # bytes resident per iteration: chain row + log-prob + the five stream arrays (none when the half-step
+        # launches draw the stream themselves).  2 GiB
         # per chunk is <1 % of the 288 GB of HBM and keeps the host work per chunk negligible
         # (the Philox stream is double-buffered: the next chunk's is drawn while this one runs)
-        per_step = self.nwalkers * (8 * self.ndim + 8 + (2 if self.rng == 'philox' else 1) * (3 * 8 + 2 * 4))
+        per_step = self.nwalkers * (8 * self.ndim + 8 + (0 if stream_in_place else 2 if self.rng == 'philox' else 1) * (3 * 8 + 2 * 4))
         n = max(1, min(nsteps, (2 << 30) // per_step))
         if self.rng == 'numpy':
             # the NumPy-order stream is drawn on the host (MT19937 is sequential: ~20-60 ns per
@@ -1093,7 +1108,7 @@ class DeviceEnsembleSampler(_SamplerBase):
         be = self.backend
         W, ndim = self.nwalkers, self.ndim
         single = self._world == 1 and not self.force_sharded_path
-        if single and self.persistent and be.run_persistent(st, self.walkers_per_ensemble, n):
+        if single and self.persistent and 'inline' not in st and be.run_persistent(st, self.walkers_per_ensemble, n):
             # one workgroup per ensemble, or -- a single ensemble beyond that -- several with a barrier of their own
             self.last_path = 'persistent' if self.walkers_per_ensemble * (ndim + 1) * 8 <= 65536 and (self.walkers_per_ensemble + 1) // 2 <= 512 \
                 else 'persistent-multi-workgroup'
@@ -1158,10 +1173,15 @@ class DeviceEnsembleSampler(_SamplerBase):
         self.timing = dict(setup_s=time.perf_counter() - t_start, stream_s=0.0, enqueue_s=0.0, alloc_s=0.0,
                            drain_s=0.0, finish_s=0.0, **setup_detail)
         it_start = self._iterations_run
+        # A single ensemble big enough for the packed-state half-step has its Philox stream drawn by the half-step
+        # launches themselves: no stream arrays (34 MB per iteration at a million walkers), no draw kernel.
+        in_place = (self.rng == 'philox' and self.n_ensembles == 1 and self._world == 1 and not self.force_sharded_path
+                    and not self.simulate_world and hasattr(be, 'draws_in_place') and be.draws_in_place(W))
+        self.last_stream = 'in place' if in_place else ('arrays' if self.rng == 'philox' else 'host')
         # stored samples per chunk, known up front so that the next chunk's stream can be drawn ahead
         sizes, left = [], nsteps
         while left > 0:
-            sizes.append(min(max(1, self._chunk_steps(nsteps * thin_by) // thin_by), left))
+            sizes.append(min(max(1, self._chunk_steps(nsteps * thin_by, in_place) // thin_by), left))
             left -= sizes[-1]
         first_sample = [0]                       # stored samples before chunk k
         for ns in sizes:
@@ -1228,7 +1248,9 @@ class DeviceEnsembleSampler(_SamplerBase):
                 st['chain'] = be.empty((ns, W, ndim), torch.float64)
                 st['logp_chain'] = be.empty((ns, W), torch.float64)
             t_b = time.perf_counter()
-            if self.rng == 'philox':
+            if in_place:
+                st['inline'] = (self.a, self.seed, it0)
+            elif self.rng == 'philox':
                 b = k % 2
                 if stream_bufs[0] is None:       # chunks never grow: later ones reuse these two sets
                     for i, rows in enumerate([sizes[0] * thin_by] + ([sizes[1] * thin_by] if len(sizes) > 1 else [])):
@@ -1258,7 +1280,10 @@ class DeviceEnsembleSampler(_SamplerBase):
 
                 def part(lo, hi):
                     sub = dict(st)
-                    for name in ('active', 'partner', 'zz', 'factor', 'logu'):
+                    if in_place:
+                        sub['perm'] = st['perm'][lo * thin_by:hi * thin_by]
+                        sub['inline'] = (self.a, self.seed, it0 + lo * thin_by)
+                    for name in ('active', 'partner', 'zz', 'factor', 'logu') if not in_place else ():
                         sub[name] = st[name][lo * thin_by:hi * thin_by]
                     sub['chain'], sub['logp_chain'] = st['chain'][lo:hi], st['logp_chain'][lo:hi]
                     return sub
@@ -1270,7 +1295,7 @@ class DeviceEnsembleSampler(_SamplerBase):
                 self._advance(last, tail * thin_by, nh, it0 + head * thin_by)
             else:
                 self._advance(st, n, nh, it0)
-            if self.rng == 'philox' and len(sizes) > 1 and perm_ev is not None:
+            if self.rng == 'philox' and not in_place and len(sizes) > 1 and perm_ev is not None:
                 free_ev[k % 2] = be.mark()
             if guard is not None:
                 if tail:

@@ -41,7 +41,7 @@ extern "C" {
  * ctx_reduced_check, polydecomp_reduced_estimates, read_tables; BISIP_VARIANT_REDUCED_COMP, BISIP_ERCCL.
  * 3: clock_probe_dev, ctx_reduced_guard, polydecomp_reduced_reference, stretch_run_sharded_sim_dev (additions only).
  * 4: chain_shell_rows_dev (+ _workspace), ctx_reduced_guard_rows, ensemble_gram_dev (+ _workspace),
- *    fp64_stream_probe_dev (+ _lanes) (additions only). */
+ *    fp64_stream_probe_dev (+ _lanes), stretch_run_philox_dev (+ stretch_philox_inline) (additions only). */
 #define BISIP_ABI_VERSION 4
 
 /* model_id -- the four reference model classes (src/bisip/models.py:182,232,274,308) */
@@ -250,6 +250,20 @@ int bisip_stretch_draw_dev(bisip_ctx *ctx, int64_t W, double a, uint64_t seed, i
                            int64_t n_steps, const int32_t *d_perm, int32_t *d_active,
                            int32_t *d_partner, double *d_zz, double *d_factor, double *d_logu,
                            void *stream);
+
+/* bisip_stretch_run_dev for the Philox stream WITHOUT its arrays: every half-step launch draws its slots' entries
+ * (walker, partner, z, (ndim-1) ln z, ln u) from their counters in place -- the same numbers bisip_stretch_draw_dev
+ * writes, so the chain is that of draw + run bit for bit -- and nothing of the stream is written, stored or read:
+ * at a million walkers the arrays are 34 MB per iteration, a fifth of the half-step's traffic, and drawing them
+ * took a quarter of its time.  first->active / partner / zz / factor / logu are ignored (may be null); a, seed,
+ * step0, d_perm as for bisip_stretch_draw_dev (d_perm: this chunk's n_steps rows).  Only where
+ * bisip_stretch_philox_inline(ctx, W) returns 1 -- a single ensemble big enough for the packed-state half-step
+ * (ndim <= 7, >= 131,072 walkers) -- otherwise BISIP_EUNSUPPORTED: draw, then run.  (emcee draws its stream on the
+ * host, src/bisip/models.py:111-118 -> EnsembleSampler.run_mcmc.) */
+int bisip_stretch_philox_inline(const bisip_ctx *ctx, int64_t W);
+int bisip_stretch_run_philox_dev(bisip_ctx *ctx, const bisip_stretch_args *first, int64_t W, int64_t n_steps,
+                                 int64_t thin_by, double a, uint64_t seed, int64_t step0, const int32_t *d_perm,
+                                 void *stream);
 
 /* Persistent sampler: one workgroup per ensemble runs n_steps iterations inside ONE launch
  * (ensemble in LDS, workgroup barrier between half-steps, several lanes per walker for the

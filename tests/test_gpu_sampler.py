@@ -323,9 +323,10 @@ def test_philox_draw_kernel_matches_contract():
     g = np.load(_case('case16_'))
     ctx = make_ctx(g, 'PeltonColeCole')
     # 32 / 33: the flat launch shape of small ensembles; 4096 and 65536: 32-bit modular products;
-    # 65537 and 70001: past 2^16 walkers the products need 64 bits
+    # 65537 and 70001: past 2^16 walkers the products need 64 bits (reduced through a quotient estimated in double,
+    # perm_inverse); a million and three million walkers: products up to 2^43
     for W, n, step0, seed in [(32, 9, 0, 1), (33, 5, 1000, 0xdeadbeefcafe), (4096, 3, 7, 42), (65536, 2, 3, 9),
-                              (65537, 2, 11, 5), (70001, 2, 0, 77)]:
+                              (65537, 2, 11, 5), (70001, 2, 0, 77), (1048576, 1, 5, 3), (3000001, 1, 2, 8)]:
         perm = affine_splits(seed, W, step0, n)
         nh = (W + 1) // 2
         dperm = torch.from_numpy(perm).cuda()
@@ -345,7 +346,7 @@ def test_philox_draw_kernel_matches_contract():
         np.testing.assert_allclose(bufs['logu'].cpu().numpy(), want['logu'], rtol=1e-15, atol=1e-15)
         # every step is a balanced partition and partners come from the other half
         act = want['active']
-        for k in range(n):
+        for k in range(n if W < 1000000 else 0):
             halves = [set(act[k, 0, :nh]), set(act[k, 1, :W // 2])]
             assert halves[0] | halves[1] == set(range(W)) and not (halves[0] & halves[1])
             assert set(want['partner'][k, 0, :nh]) <= halves[1]
@@ -475,7 +476,11 @@ def test_big_ensemble_samples_on_a_packed_state_and_keeps_the_chain(model, kw, W
     and the final state equal those of the plain layout (BISIP_NO_PACKED_STATE=1) bit for bit -- rows of 2 ... 7
     doubles, and 10 / 12 (no packed form: the plain kernel both times), even and odd ensembles (a last workgroup
     with dead lanes, halves of different sizes), thinning (iterations with and without a chain row), chunked
-    runs (packed and unpacked again at every chunk)."""
+    runs (packed and unpacked again at every chunk).
+    And the Philox stream of such a chunk is DRAWN IN PLACE by the half-step launches (bisip_stretch_run_philox_dev: no
+    stream arrays, no draw kernel) -- the same entries from the same counters: the same chain as with the arrays
+    (BISIP_NO_INLINE_DRAW=1), over several chunks (the counters carry on where the last chunk stopped) and through a
+    second run_mcmc call."""
     import bisip_amd
     from bisip_amd.sampler import DeviceEnsembleSampler
     from bisip_amd.synthetic import write_spectrum_file
@@ -490,18 +495,25 @@ def test_big_ensemble_samples_on_a_packed_state_and_keeps_the_chain(model, kw, W
     p0 = centre + 1e-3 * (hi - lo) * np.random.RandomState(2).randn(W, ndim)
     p0 = np.clip(p0, lo + 1e-9 * (hi - lo), hi - 1e-9 * (hi - lo))
 
-    def run():
+    packs = ndim <= 7
+
+    def run(stream):
         s = DeviceEnsembleSampler(W, ndim, ctx, rng='philox', seed=9, persistent=False, live_dangerously=True, chunk=4)
         s.run_mcmc(p0, 3, thin_by=2)
-        assert s.last_path == 'launch-per-half-step'
+        assert s.last_path == 'launch-per-half-step' and s.last_stream == stream
+        s.run_mcmc(None, 1, thin_by=3)
+        assert s.last_stream == stream
         return s.get_chain(), s.get_log_prob(), s.acceptance_fraction, s._coords
     monkeypatch.setenv('BISIP_NO_PACKED_STATE', '1')
-    ref = run()
+    ref = run('arrays')
     monkeypatch.delenv('BISIP_NO_PACKED_STATE')
-    got = run()
+    monkeypatch.setenv('BISIP_NO_INLINE_DRAW', '1')
+    packed = run('arrays')
+    monkeypatch.delenv('BISIP_NO_INLINE_DRAW')
+    got = run('in place' if packs else 'arrays')
     assert 0.05 < ref[2].mean() < 0.95
-    for x, y in zip(got, ref):
-        assert np.array_equal(x, y)
+    for x, y, z in zip(got, ref, packed):
+        assert np.array_equal(x, y) and np.array_equal(z, y)
 
 
 @pytest.mark.parametrize('poly_deg', [2, 5, 7, 9, 10])
