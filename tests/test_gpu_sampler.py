@@ -516,6 +516,55 @@ def test_big_ensemble_samples_on_a_packed_state_and_keeps_the_chain(model, kw, W
         assert np.array_equal(x, y) and np.array_equal(z, y)
 
 
+def test_chunk_sent_back_by_the_guard_draws_its_stream_in_place_again(monkeypatch, tmp_path):
+    """A big ensemble draws its Philox stream inside the half-step launches, from counters: a chunk the guard sends
+    back (the tier's own rows failed: the context has moved to the compensated kernel) starts again from its saved
+    state AND from its first counter.  The measurement of the second chunk's rows is made to fail once (the move to
+    the next tier done by hand, as bisip_ctx_reduced_guard_rows does it): chunks 0 stay the plain kernel's, chunks 1
+    and 2 become the compensated kernel's -- the chain of a sampler that is switched by hand after chunk 0."""
+    import bisip_amd
+    from bisip_amd.sampler import DeviceEnsembleSampler
+    from bisip_amd.synthetic import write_spectrum_file
+    path = write_spectrum_file(str(tmp_path / 's.csv'), 32, 3)
+    W, n = 131072, 6
+    m = bisip_amd.PolynomialDecomposition(path, nwalkers=W, nsteps=n, poly_deg=5)
+    lo, hi = m.param_bounds
+    p0 = np.r_[1.0, 0.004, np.zeros(5)] + 1e-3 * (hi - lo) * np.random.RandomState(4).randn(W, 7)
+
+    def fresh():
+        ctx = m._context()
+        ctx.set_bounds(m.param_bounds + 1e-9)
+        ctx.set_bounds(m.param_bounds)
+        ctx.set_variant('auto')
+        assert ctx.kernel_name == 'k_logprob_pd_reduced'
+        return ctx
+    ctx = fresh()
+    s = DeviceEnsembleSampler(W, 7, ctx, rng='philox', seed=21, chunk=2, live_dangerously=True)
+    real = ctx.reduced_guard_rows
+    calls = []
+
+    def failing_once(theta, lp):
+        calls.append(len(theta))
+        if len(calls) == 3:                  # initial rows + chunk 0 pass; chunk 1's rows "fail"
+            ctx.set_variant('reduced_comp')
+            return 1e-9, True
+        return real(theta, lp)
+    monkeypatch.setattr(ctx, 'reduced_guard_rows', failing_once)
+    s.run_mcmc(p0, n)
+    assert s.last_stream == 'in place' and s.guard_['reruns'] == 1 and s.guard_['escalations'] == 1
+    got = s.get_chain(), s.get_log_prob(), s.acceptance_fraction
+    monkeypatch.undo()
+    ctx = fresh()
+    ref = DeviceEnsembleSampler(W, 7, ctx, rng='philox', seed=21, chunk=2, live_dangerously=True)
+    ref.run_mcmc(p0, 2)
+    ctx.set_variant('reduced_comp')
+    ref.backend.logprob(ref._dev['coords'], ref._dev['logp'])       # as the guard does for the state it puts back
+    ref.run_mcmc(None, n - 2)
+    want = ref.get_chain(), ref.get_log_prob(), ref.acceptance_fraction
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize('poly_deg', [2, 5, 7, 9, 10])
 def test_compensated_persistent_kernel_with_and_without_staged_low_words(poly_deg, monkeypatch):
     """The compensated tier in the persistent kernel keeps its triangle in scalar registers and reads its low
