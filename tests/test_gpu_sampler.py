@@ -516,6 +516,33 @@ def test_big_ensemble_samples_on_a_packed_state_and_keeps_the_chain(model, kw, W
         assert np.array_equal(x, y) and np.array_equal(z, y)
 
 
+def test_in_place_stream_of_a_chunk_whose_rows_are_selected_in_two_parts(monkeypatch, tmp_path):
+    """A big chunk of a guarded run is enqueued in two parts (the guard's selection over the first 7/8 of its samples
+    runs beside the last eighth): each part's launches draw from the counters of ITS iterations -- thinned, so that a
+    part starts at a multiple of thin_by -- and the chain is that of the stream arrays."""
+    import bisip_amd
+    from bisip_amd.sampler import DeviceEnsembleSampler
+    from bisip_amd.synthetic import write_spectrum_file
+    path = write_spectrum_file(str(tmp_path / 's.csv'), 32, 2)
+    W = 131072
+    m = bisip_amd.PolynomialDecomposition(path, nwalkers=W, nsteps=16, poly_deg=4)
+    lo, hi = m.param_bounds
+    ctx = m._context()
+    p0 = np.r_[1.0, 0.004, np.zeros(4)] + 1e-3 * (hi - lo) * np.random.RandomState(6).randn(W, 6)
+
+    def run(stream):
+        s = DeviceEnsembleSampler(W, 6, ctx, rng='philox', seed=33, chunk=32, live_dangerously=True)
+        s.run_mcmc(p0, 16, thin_by=2)              # one chunk of 16 stored samples: parts of 14 and 2
+        assert s.last_stream == stream and s.guard_['checks'] >= 2 and s.guard_['reruns'] == 0
+        return s.get_chain(), s.get_log_prob(), s.acceptance_fraction
+    monkeypatch.setenv('BISIP_NO_INLINE_DRAW', '1')
+    ref = run('arrays')
+    monkeypatch.delenv('BISIP_NO_INLINE_DRAW')
+    got = run('in place')
+    for a, b in zip(got, ref):
+        assert np.array_equal(a, b)
+
+
 def test_chunk_sent_back_by_the_guard_draws_its_stream_in_place_again(monkeypatch, tmp_path):
     """A big ensemble draws its Philox stream inside the half-step launches, from counters: a chunk the guard sends
     back (the tier's own rows failed: the context has moved to the compensated kernel) starts again from its saved
