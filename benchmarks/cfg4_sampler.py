@@ -80,6 +80,21 @@ def main():
         s.run_mcmc(p0, args.steps)
         torch.cuda.synchronize(); dist.barrier()
         runs.append((time.perf_counter() - t0, s))
+    # what a half-step costs once a run is long: the difference between 1,000 and 3,000 iterations (stored thinned)
+    marginal = None
+    if args.fused and world == 1:
+        took = {}
+        for n_it in (1000, 3000):
+            best = None
+            for _ in range(2):
+                s_long = make()
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                s_long.run_mcmc(p0, 200, thin_by=n_it // 200)
+                torch.cuda.synchronize(); dt_long = time.perf_counter() - t0
+                best = dt_long if best is None else min(best, dt_long)
+                s_long.close()
+            took[n_it] = best
+        marginal = round((took[3000] - took[1000]) / 4000 * 1e6, 2)
     # every rank keeps the same run: the one that was fastest on rank 0
     pick = torch.tensor([min(range(len(runs)), key=lambda i: runs[i][0])], device='cuda')
     dist.broadcast(pick, 0)
@@ -96,9 +111,12 @@ def main():
                           'it_per_s': round(args.steps / dt, 1),
                           'walker_steps_per_s': float('%.4g' % (args.steps * args.walkers / dt)),
                           'chain': args.chain,
-                          # kernels only when the chain stays on the device; with a host chain the
-                          # drain also covers the device->host copy of the chain
-                          'us_per_half_step': round((s.timing['enqueue_s'] + s.timing['drain_s']) / args.steps / 2 * 1e6, 1),
+                          # the host's view of the device work: enqueueing (the device runs meanwhile), then waiting for
+                          # what is left -- the drain and, with the guard on, its wait for the chunk's rows -- per
+                          # half-step; with a host chain the drain also covers the device->host copy of the chain.
+                          # (Until round 5 the guard's wait was left out: 4.0-4.4 us for what is 6.4-7 us.)
+                          'us_per_half_step': round((s.timing['enqueue_s'] + s.timing['drain_s'] + s.timing.get('guard_s', 0.0)) / args.steps / 2 * 1e6, 1),
+                          'us_per_half_step_long_run': marginal,
                           'timing_s': {k: round(v, 4) for k, v in s.timing.items()},
                           'guard': getattr(s, 'guard_', None),
                           'acceptance': round(float(s.acceptance_fraction.mean()), 3)}))

@@ -67,7 +67,7 @@ def main():
                       'seconds_all_runs': [round(r[0], 4) for r in runs],
                       'summary_s_all_runs': [None if r[1] is None else round(r[1], 5) for r in runs],
                       'it_per_s': round(iters / dt, 1),
-                      'us_per_half_step': round((s.timing['enqueue_s'] + s.timing['drain_s']) / iters / 2 * 1e6, 2),
+                      'us_per_half_step': round((s.timing['enqueue_s'] + s.timing['drain_s'] + s.timing.get('guard_s', 0.0)) / iters / 2 * 1e6, 2),
                       'walker_steps_per_s': float('%.4g' % (iters * E * Wp / dt)),
                       'timing_s': {k: round(v, 4) for k, v in s.timing.items()},
                       'acceptance': round(float(s.acceptance_fraction.mean()), 3)}))
