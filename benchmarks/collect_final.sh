@@ -1,6 +1,6 @@
 #!/bin/bash
 # The one evidence run of a round, at the FINAL kernel sources, in stages that each fit one gpurun call (<= 20 min):
-#   bash benchmarks/collect_final.sh <tag> tests|bench|sweep|sampler|micro|campaign-a|campaign-b
+#   bash benchmarks/collect_final.sh <tag> tests|bench|sweep|sampler|micro|campaign-a|campaign-b|campaign-c
 # Everything lands under gpurun_out/ (scratch); `bash benchmarks/import_profiles.sh <tag>` then copies what is judged
 # into profiles/ and regenerates the tables.  (Replaces the per-round collect_rNN_*.sh scripts.)
 set -o pipefail
@@ -53,5 +53,11 @@ campaign-b)
   fz valley fuzz_parity.py --cases 6000 --seed 312 --valley
   fz sampler fuzz_sampler.py --cases 6000 --seed 27
   fz batch fuzz_batch.py --cases 2000 --seed 28 ;;
+campaign-c)      # a third set of seeds, taken after the last kernel change of the round (the in-place stream)
+  fz parity fuzz_parity.py --cases 12000 --seed 69
+  fz parity fuzz_parity.py --cases 6000 --seed 70 --widen 2
+  fz valley fuzz_parity.py --cases 6000 --seed 313 --valley
+  fz sampler fuzz_sampler.py --cases 6000 --seed 29
+  fz batch fuzz_batch.py --cases 2000 --seed 30 ;;
 *) echo "unknown stage $what" >&2; exit 2 ;;
 esac
