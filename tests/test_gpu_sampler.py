@@ -516,6 +516,48 @@ def test_big_ensemble_samples_on_a_packed_state_and_keeps_the_chain(model, kw, W
         assert np.array_equal(x, y) and np.array_equal(z, y)
 
 
+def test_run_philox_entry_refuses_what_it_does_not_serve(monkeypatch):
+    """bisip_stretch_run_philox_dev draws in place only where the packed-state half-step runs: anything else is
+    refused BEFORE a launch (the caller then draws the arrays and takes bisip_stretch_run_dev), and so are bad
+    arguments; bisip_stretch_philox_inline answers the same question without side effects."""
+    import torch
+    from bisip_amd import _hip
+    from bisip_amd.sampler import affine_splits
+    g = np.load(_case('case16_'))
+    ctx = make_ctx(g, 'PeltonColeCole')
+    ndim = g['bounds'].shape[1]
+    assert ctx.stretch_philox_inline(262144) and not ctx.stretch_philox_inline(65536) and not ctx.stretch_philox_inline(1)
+    monkeypatch.setenv('BISIP_NO_PACKED_STATE', '1')
+    assert not ctx.stretch_philox_inline(262144)
+    monkeypatch.delenv('BISIP_NO_PACKED_STATE')
+
+    def args(W):
+        a = _hip.StretchArgs()
+        st = dict(coords=torch.zeros((W, ndim), dtype=torch.float64, device='cuda'), logp=torch.zeros(W, dtype=torch.float64, device='cuda'),
+                  status=torch.zeros(1, dtype=torch.int32, device='cuda'))
+        a.coords, a.logp, a.status = st['coords'].data_ptr(), st['logp'].data_ptr(), st['status'].data_ptr()
+        a.n_slots = (W + 1) // 2
+        return a, st
+    W = 262144
+    perm = torch.from_numpy(affine_splits(3, W, 0, 2)).cuda()
+    a, keep = args(W)
+    with pytest.raises(ValueError):
+        ctx.stretch_run_philox_dev(a, W, 2, 1, 2.0, 3, 0, 0)                     # no splits
+    with pytest.raises(ValueError):
+        ctx.stretch_run_philox_dev(a, W, 3, 2, 2.0, 3, 0, perm.data_ptr())       # n_steps not a multiple of thin_by
+    with pytest.raises(ValueError):
+        ctx.stretch_run_philox_dev(a, W, 2, 1, 0.0, 3, 0, perm.data_ptr())       # a <= 0
+    with pytest.raises(ValueError):
+        ctx.stretch_run_philox_dev(a, W, 2, 1, 2.0, 3, (1 << 32) - 1, perm.data_ptr())   # the step counter has 32 bits
+    small, keep2 = args(4096)
+    with pytest.raises(RuntimeError, match='packed-state'):
+        ctx.stretch_run_philox_dev(small, 4096, 2, 1, 2.0, 3, 0, perm.data_ptr())       # an ensemble the packed kernel does not take
+    ctx.stretch_run_philox_dev(a, W, 0, 1, 2.0, 3, 0, perm.data_ptr())           # nothing to do: fine
+    torch.cuda.synchronize()
+    assert int(keep['status'].item()) == 0
+    ctx.close()
+
+
 def test_in_place_stream_of_a_chunk_whose_rows_are_selected_in_two_parts(monkeypatch, tmp_path):
     """A big chunk of a guarded run is enqueued in two parts (the guard's selection over the first 7/8 of its samples
     runs beside the last eighth): each part's launches draw from the counters of ITS iterations -- thinned, so that a
