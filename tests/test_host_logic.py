@@ -232,11 +232,13 @@ def test_affine_splits_are_bijections():
 
 def test_c_stream_replays_numpy_randomstate():
     """bisip_numpy_stretch_stream against NumPy itself: same integers, same doubles, same
-    RandomState afterwards -- for even and odd ensembles, from an arbitrary stream position."""
+    RandomState afterwards -- for even and odd ensembles, from an arbitrary stream position; the smallest
+    ensembles, sizes next to powers of two (where the shuffle's and randint's rejection masks change) and enough
+    iterations for every kind of draw to straddle a refill of the 624-word block."""
     from bisip_amd import _hip
     from bisip_amd.sampler import draw_step
-    for W in (14, 15, 32, 33, 64, 257, 1000):
-        n = 60
+    for W in (2, 3, 4, 5, 7, 8, 9, 14, 15, 16, 17, 32, 33, 63, 64, 65, 127, 128, 129, 257, 1000, 1023, 1024, 1025, 2049, 4096):
+        n = 60 if W < 2000 else 12
         r1, r2 = np.random.RandomState(W), np.random.RandomState(W)
         r1.rand(W % 7)
         r2.rand(W % 7)
