@@ -417,8 +417,9 @@ class HipContext:
     def group_walkers(self):
         """Largest single ensemble, beyond one workgroup, for which the multi-workgroup persistent kernel
         (k_stretch_group: a barrier among the ensemble's workgroups per half-step instead of a launch) beats one
-        launch per half-step -- benchmarks/micro/group_sampler.py: 4.0-5.7 us against 4.6-6.5 per half-step at
-        2,048 and 4,096 walkers for the reduced PolynomialDecomposition kernels, Cole-Cole, Dias and Shin (1.15-1.4x);
+        launch per half-step -- benchmarks/micro/group_sampler.py: 2.5-5.2 us against 4.3-6.3 per half-step at
+        2,048 and 4,096 walkers for the reduced PolynomialDecomposition kernels (one lane per slot: one WAVE per
+        workgroup, 1.45-1.75x), Cole-Cole, Dias and Shin (1.15-1.4x);
         at 8,192 the two tie or the launches win (fewer lanes per walker), and the per-frequency
         PolynomialDecomposition form, one lane per walker, loses everywhere.  0: never.  A walker's row must fit 64
         bytes (ndim <= 7)."""

@@ -877,8 +877,12 @@ __device__ __forceinline__ int group_xcc_id()
     return v & 15;
 }
 
-template <class LP, bool STAGED>
-__global__ __launch_bounds__(GROUP_BLK) void k_stretch_group(const PersistArgs a, const LP lp)
+// BLK lanes per workgroup: 256 where a slot has several lanes; 64 (one wave) where it has ONE -- the reduced
+// PolynomialDecomposition kernels: 2,048 slots are then 32 workgroups on 32 compute units instead of 8 on 8, and the
+// gather of their rows, which each compute unit's memory pipeline serialises, takes 0.5 us instead of 1.5 (in-kernel
+// timers, 4,096 walkers: gather 1.48, evaluation 0.52, commit 0.14, barrier 1.41 with 8 workgroups of 256 lanes).
+template <class LP, bool STAGED, int BLK = GROUP_BLK>
+__global__ __launch_bounds__(BLK) void k_stretch_group(const PersistArgs a, const LP lp)
 {
     constexpr int NDIM = LP::NDIM;
     constexpr int L = LP::L;
@@ -896,12 +900,12 @@ __global__ __launch_bounds__(GROUP_BLK) void k_stretch_group(const PersistArgs a
         else {
             const double *__restrict__ src = lp.records(0);
             const int n = lp.n_freq() * LP::REC_DOUBLES;
-            for (int i = tid; i < n; i += GROUP_BLK) lds_records[i] = src[i];
+            for (int i = tid; i < n; i += BLK) lds_records[i] = src[i];
         }
         recs = lds_records;
     }
     // the state into its rows (write-through: any placement may read them), then the first barrier
-    for (long long w = (long long)member * GROUP_BLK + tid; w < a.W; w += (long long)a.G * GROUP_BLK) {
+    for (long long w = (long long)member * BLK + tid; w < a.W; w += (long long)a.G * BLK) {
         dbl2 v[4];
         double r[GROUP_ROW];
 #pragma unroll
@@ -920,7 +924,7 @@ __global__ __launch_bounds__(GROUP_BLK) void k_stretch_group(const PersistArgs a
     const bool one_xcd = __hip_atomic_load(xmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
                          __hip_atomic_load(xmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const long long nh = (a.W + 1) / 2;
-    constexpr int SPW = GROUP_BLK / L;                    // slots per workgroup
+    constexpr int SPW = BLK / L;                    // slots per workgroup
     const long long slot = (long long)member * SPW + tid / L;
     const int g = tid % L;
     const long long t0 = slot < nh ? slot : nh - 1;
@@ -974,7 +978,7 @@ __global__ __launch_bounds__(GROUP_BLK) void k_stretch_group(const PersistArgs a
         if (tid == 0) atomicOr(a.status, 4);
         return;
     }
-    for (long long w = (long long)member * GROUP_BLK + tid; w < a.W; w += (long long)a.G * GROUP_BLK) {
+    for (long long w = (long long)member * BLK + tid; w < a.W; w += (long long)a.G * BLK) {
         dbl2 v[4], dummy[4];
         group_load_rows(a.gstate + w * GROUP_ROW, a.gstate + w * GROUP_ROW, v, dummy);
         double r[GROUP_ROW];

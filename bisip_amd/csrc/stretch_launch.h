@@ -58,22 +58,23 @@ int launch_group(const PersistArgs &p0, const LP &lp, hipStream_t st)
     } else {
         PersistArgs p = p0;
         const long long nh = (p.W + 1) / 2;
-        p.G = (int)((nh * LP::L + GROUP_BLK - 1) / GROUP_BLK);
+        constexpr int BLK = LP::L == 1 ? 64 : GROUP_BLK;      // (see the kernel: one-lane slots spread over more compute units)
+        p.G = (int)((nh * LP::L + BLK - 1) / BLK);
         if (p.G > GROUP_MAX_WORKGROUPS) return fail(BISIP_EUNSUPPORTED, "ensemble of %lld walkers: more than %d workgroups", p.W, GROUP_MAX_WORKGROUPS);
         size_t rec_bytes = 0;
         if constexpr (LP::CAN_STAGE) {
             rec_bytes = (((size_t)lp.n_freq() * LP::REC_DOUBLES + 1) & ~(size_t)1) * sizeof(double);
             if (rec_bytes > 60000 || std::getenv("BISIP_NO_LDS_STAGING") != nullptr) rec_bytes = 0;
         }
-        const dim3 grid((unsigned)(8 * p.G)), block(GROUP_BLK);
+        const dim3 grid((unsigned)(8 * p.G)), block(BLK);
         if constexpr (LP::CAN_STAGE) {
             if (rec_bytes) {
-                hipLaunchKernelGGL((k_stretch_group<LP, true>), grid, block, rec_bytes, st, p, lp);
+                hipLaunchKernelGGL((k_stretch_group<LP, true, BLK>), grid, block, rec_bytes, st, p, lp);
                 HIP_TRY(hipGetLastError());
                 return BISIP_OK;
             }
         }
-        hipLaunchKernelGGL((k_stretch_group<LP, false>), grid, block, 0, st, p, lp);
+        hipLaunchKernelGGL((k_stretch_group<LP, false, BLK>), grid, block, 0, st, p, lp);
         HIP_TRY(hipGetLastError());
         return BISIP_OK;
     }
