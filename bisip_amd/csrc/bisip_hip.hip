@@ -1315,7 +1315,7 @@ int bisip_stretch_persistent_dev(bisip_ctx *c, const bisip_persist_args *u, void
     if (u->n_steps * 2 * 64 > 0x7fffffffLL) return fail(BISIP_EINVAL, "n_steps=%lld: chunk the run", (long long)u->n_steps);
     HIP_TRY(hipSetDevice(c->device));
     PersistArgs p;
-    p.gstate = nullptr; p.gsync = nullptr; p.G = 0; p.spin_limit = 0;
+    p.gstate = nullptr; p.gsync = nullptr; p.G = 0; p.spin_limit = 0; p.spread = 0;
     if (group) {
         const size_t need = 256 + (size_t)Wp * 64;
         if (c->group_bytes < need) {

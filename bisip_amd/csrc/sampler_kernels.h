@@ -687,6 +687,7 @@ struct PersistArgs {
     unsigned *gsync;
     int G;
     unsigned spin_limit;
+    int spread;          // the group is ALL workgroups of the grid (any XCD) instead of its every eighth
 };
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every
@@ -887,10 +888,10 @@ __global__ __launch_bounds__(BLK) void k_stretch_group(const PersistArgs a, cons
     constexpr int NDIM = LP::NDIM;
     constexpr int L = LP::L;
     static_assert(NDIM < GROUP_ROW, "a state row holds theta and the log-probability in 8 doubles");
-    if (blockIdx.x % 8 != 0) return;                      // the group: workgroups 0, 8, 16, ... of the grid
+    if (!a.spread && blockIdx.x % 8 != 0) return;         // the group: workgroups 0, 8, 16, ... of the grid
     extern __shared__ __attribute__((aligned(16))) double lds_records[];
     __shared__ int flag;
-    const int member = blockIdx.x / 8;
+    const int member = a.spread ? blockIdx.x : blockIdx.x / 8;
     const int tid = threadIdx.x;
     // sync words (one 64-byte line each): [0] first barrier, [16] the half-steps' barriers, [32] min XCC id, [33] max
     unsigned *first = a.gsync, *rounds = a.gsync + 16, *xmin = a.gsync + 32, *xmax = a.gsync + 33;

@@ -47,8 +47,8 @@ int launch_persistent(const PersistArgs &p0, const LP &lp, hipStream_t st)
     return BISIP_OK;
 }
 
-// One ensemble over several workgroups (k_stretch_group): G workgroups of 256 lanes hold the larger half's slots,
-// LP::L lanes each; the grid is 8 G (the group is its every eighth workgroup: see the kernel).
+// One ensemble over several workgroups (k_stretch_group): G workgroups of 256 lanes (64 for one-lane functors) hold the
+// larger half's slots, LP::L lanes each; the grid is 8 G (the group is its every eighth workgroup: see the kernel) or G.
 constexpr int GROUP_MAX_WORKGROUPS = 64;
 template <class LP>
 int launch_group(const PersistArgs &p0, const LP &lp, hipStream_t st)
@@ -66,7 +66,12 @@ int launch_group(const PersistArgs &p0, const LP &lp, hipStream_t st)
             rec_bytes = (((size_t)lp.n_freq() * LP::REC_DOUBLES + 1) & ~(size_t)1) * sizeof(double);
             if (rec_bytes > 60000 || std::getenv("BISIP_NO_LDS_STAGING") != nullptr) rec_bytes = 0;
         }
-        const dim3 grid((unsigned)(8 * p.G)), block(BLK);
+        // up to 32 workgroups sit on ONE XCD (every eighth workgroup of the grid); more -- one-lane functors beyond 4,096
+        // walkers -- take every workgroup of the grid, on all XCDs, and the placement-independent protocol: two per
+        // compute unit of one XCD is slower than a launch per half-step (7.8 us at 8,192 walkers), 64 compute units
+        // anywhere are not (3.7 against 4.6); 128 tie and 256 lose (one counter for all: 9.4 against 5.9)
+        p.spread = p.G > 32 ? 1 : 0;
+        const dim3 grid((unsigned)(p.spread ? p.G : 8 * p.G)), block(BLK);
         if constexpr (LP::CAN_STAGE) {
             if (rec_bytes) {
                 hipLaunchKernelGGL((k_stretch_group<LP, true, BLK>), grid, block, rec_bytes, st, p, lp);

@@ -710,11 +710,24 @@ def test_persistent_falls_back_when_ensemble_too_large():
         s.run_mcmc(p0, 3)
         assert s.last_path == want
     ctx.close()
+    assert ctx.group_walkers == 4096
     g = np.load(_case('case17_'))                # three modes: ndim 10, a row does not fit 64 bytes
     ctx = make_ctx(g, 'PeltonColeCole')
     s = DeviceEnsembleSampler(2048, 10, ctx, rng='philox', seed=5, persistent=True)
     s.run_mcmc(_start(g, 2048, 9), 3)
     assert s.last_path == 'launch-per-half-step'
+    ctx.close()
+    # left to itself the sampler takes the multi-workgroup kernel where it wins: the reduced PolynomialDecomposition
+    # kernels (one lane per slot, one wave per workgroup, all XCDs beyond 32 workgroups) up to 8,192 walkers
+    g = np.load(_case('case01_'))
+    ctx = make_ctx(g, 'PolynomialDecomposition')
+    ndim = g['bounds'].shape[1]
+    if ndim <= 7:
+        assert ctx.group_walkers == 8192
+        for W, want in ((8192, 'persistent-multi-workgroup'), (8194, 'launch-per-half-step')):
+            s = DeviceEnsembleSampler(W, ndim, ctx, rng='philox', seed=5)
+            s.run_mcmc(_start(g, W, 9), 3)
+            assert s.last_path == want, (W, s.last_path)
     ctx.close()
 
 
