@@ -731,7 +731,10 @@ def sampler_extra(args, dist, torch, rank, world, local_rank, walkers=32768, ste
 
         def run(n, **kw):
             np.random.seed(7)
-            s = DeviceEnsembleSampler(walkers, 7, ctx, rng='philox', seed=11, persistent=False,
+            # the single-GPU reference run takes what the sampler itself would take (at cfg4's size the multi-workgroup
+            # kernel); with several ranks rehearsing on ONE device its workgroups could not all be resident: launches
+            s = DeviceEnsembleSampler(walkers, 7, ctx, rng='philox', seed=11,
+                                      persistent=(None if not kw and not args.same_device else False),
                                       chain_on_device=True, **kw)
             if kw:
                 s._sharded_comm()

@@ -65,7 +65,7 @@ def main():
     def make():
         np.random.seed(7)
         return DeviceEnsembleSampler(args.walkers, 7, ctx, rng=args.rng, seed=11, distributed=True,
-                                     force_sharded_path=not args.fused, persistent=False,
+                                     force_sharded_path=not args.fused, persistent=(None if args.fused and world == 1 else False),
                                      chain_on_device=(args.chain == 'device'), sharded_loop=args.loop)
     prime = time.perf_counter()           # warm-up + clocks up
     while time.perf_counter() - prime < 0.25:

@@ -174,7 +174,7 @@ def table_samplers():
 
 def table_cfg4():
     rows = []
-    for f, label in ((rn('cfg4_fused_device_chain.json'), 'fused half-step (one launch), single GPU'),
+    for f, label in ((rn('cfg4_fused_device_chain.json'), 'single GPU, no collective (what the sampler picks itself)'),
                      (rn('cfg4_sharded_rccl.json'), "sharded: C loop, eval -> ncclAllGather -> apply, torch's communicator"),
                      (rn('cfg4_sharded_rccl-own.json'), 'sharded: C loop, communicator from bisip_rccl_comm_create'),
                      (rn('cfg4_sharded_python.json'), 'sharded: Python loop over torch.distributed (round 1)')):

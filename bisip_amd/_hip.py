@@ -428,9 +428,9 @@ class HipContext:
         name = self.kernel_name
         if 'PDCollapsed' in name or 'faithful' in name or 'wave' in name:
             return 0
-        # the reduced PolynomialDecomposition kernels (one lane per slot, one wave per workgroup) up to 8,192 walkers:
-        # 64 workgroups on all XCDs, 3.7 us per half-step against 4.6 with a launch each
-        return 8192 if 'k_logprob_pd_reduced' in name else 4096
+        # the reduced PolynomialDecomposition kernels (one lane per slot, one wave per workgroup) up to 32,768 walkers:
+        # up to 256 workgroups on all XCDs, meeting at a two-level barrier
+        return 32768 if 'k_logprob_pd_reduced' in name else 4096
 
     @property
     def persistent_in_big_batches(self):

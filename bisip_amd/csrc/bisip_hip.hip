@@ -1306,18 +1306,20 @@ int bisip_stretch_persistent_dev(bisip_ctx *c, const bisip_persist_args *u, void
     if (u->thin_by < 1 || u->n_steps < 0 || u->n_steps % u->thin_by) return fail(BISIP_EINVAL, "n_steps must be a multiple of thin_by");
     const bool one_workgroup = !((size_t)Wp * (c->ndim + 1) * sizeof(double) > 65536 || (Wp + 1) / 2 > 512);
     // a single ensemble beyond one workgroup: several workgroups and a barrier of their own per half-step
-    // (k_stretch_group), up to 8,192 walkers of at most 7 parameters
-    const bool group = !one_workgroup && c->E == 1 && Wp <= 8192 && c->ndim <= 7;
+    // (k_stretch_group), up to 32,768 walkers (256 workgroups at most: launch_group) of at most 7 parameters
+    const bool group = !one_workgroup && c->E == 1 && Wp <= 32768 && c->ndim <= 7;
     if (!one_workgroup && !group)
         return fail(BISIP_EUNSUPPORTED, "ensemble of %lld walkers does not fit one workgroup%s", (long long)Wp,
-                    c->E == 1 && Wp <= 8192 ? " and its rows do not fit 64 bytes (ndim > 7)" : "");
+                    c->E == 1 && Wp <= 32768 ? " and its rows do not fit 64 bytes (ndim > 7)" : "");
     if (u->n_steps == 0) return BISIP_OK;
     if (u->n_steps * 2 * 64 > 0x7fffffffLL) return fail(BISIP_EINVAL, "n_steps=%lld: chunk the run", (long long)u->n_steps);
     HIP_TRY(hipSetDevice(c->device));
     PersistArgs p;
     p.gstate = nullptr; p.gsync = nullptr; p.G = 0; p.spin_limit = 0; p.spread = 0;
     if (group) {
-        const size_t need = 256 + (size_t)Wp * 64;
+        constexpr size_t SYNC = 4096;        // >= GROUP_SYNC_WORDS unsigned, and the rows stay 64-byte aligned
+        static_assert(SYNC >= GROUP_SYNC_WORDS * sizeof(unsigned) && SYNC % 64 == 0, "the group's sync words");
+        const size_t need = SYNC + (size_t)Wp * 64;
         if (c->group_bytes < need) {
             if (c->d_group) { HIP_TRY(hipDeviceSynchronize()); (void)hipFree(c->d_group); c->d_group = nullptr; c->group_bytes = 0; }
             hipError_t e = hipMalloc((void **)&c->d_group, need);
@@ -1325,10 +1327,10 @@ int bisip_stretch_persistent_dev(bisip_ctx *c, const bisip_persist_args *u, void
             c->group_bytes = need;
         }
         // counters 0, the smallest XCC id seen so far "none" (0xffffffff); ordered before the kernel on its stream
-        HIP_TRY(hipMemsetAsync(c->d_group, 0, 256, (hipStream_t)stream));
+        HIP_TRY(hipMemsetAsync(c->d_group, 0, SYNC, (hipStream_t)stream));
         HIP_TRY(hipMemsetAsync(c->d_group + 32 * sizeof(unsigned), 0xff, sizeof(unsigned), (hipStream_t)stream));
         p.gsync = (unsigned *)c->d_group;
-        p.gstate = (double *)(c->d_group + 256);
+        p.gstate = (double *)(c->d_group + SYNC);
         p.spin_limit = 1u << 22;        // ~0.3 s of polling: only workgroups that never become resident together get there
     }
     p.coords = u->coords; p.logp = u->logp; p.W = Wp; p.E = E; p.n_steps = u->n_steps;

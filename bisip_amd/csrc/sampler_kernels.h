@@ -824,6 +824,7 @@ __global__ __launch_bounds__(512) void k_stretch_persistent(const PersistArgs a,
 // process) each gives up, sets status bit 2 and ends; the host then refuses the chunk.
 // ---------------------------------------------------------------------------------
 constexpr int GROUP_ROW = 8;            // doubles per state row: one 64-byte line
+constexpr int GROUP_SYNC_WORDS = 576;   // the group's synchronisation words (see the kernel), ahead of its state rows
 constexpr int GROUP_BLK = 256;
 
 __device__ __forceinline__ void group_store_row(double *p, const dbl2 (&v)[4], bool through)
@@ -871,6 +872,33 @@ __device__ __forceinline__ bool group_barrier(unsigned *counter, unsigned target
     return *flag != 0;
 }
 
+// The same barrier for a group spread over several XCDs, in two levels: a workgroup arrives at ITS XCD's counter
+// (workgroup scope: the read-modify-write executes in that XCD's L2, which only its own workgroups touch), the last
+// of the XCD's `mine` workgroups to arrive passes the round on to the group's counter (agent scope), and everybody
+// polls that one.  One counter for all serialises every arrival at the memory side: 64 workgroups 1.1 us, 256 (cfg4:
+// 32,768 walkers, one wave per compute unit) 4-5 us; two levels: 8 arrivals there, whatever the group's size.
+// The counters only grow: round r is over when the group's counter reads r * xcds.
+__device__ __forceinline__ bool group_barrier_two_level(unsigned *local, unsigned mine, unsigned *global, unsigned xcds,
+                                                        unsigned round, unsigned limit, int *flag)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's state rows have left (write-through)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned before = __hip_atomic_fetch_add(local, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (before + 1u == round * mine) __hip_atomic_fetch_add(global, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned target = round * xcds;
+        unsigned spins = 0;
+        int ok = 1;
+        while (__hip_atomic_load(global, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > limit) { ok = 0; break; }
+        }
+        *flag = ok;
+    }
+    __syncthreads();
+    return *flag != 0;
+}
+
 __device__ __forceinline__ int group_xcc_id()
 {
     int v;
@@ -891,10 +919,14 @@ __global__ __launch_bounds__(BLK) void k_stretch_group(const PersistArgs a, cons
     if (!a.spread && blockIdx.x % 8 != 0) return;         // the group: workgroups 0, 8, 16, ... of the grid
     extern __shared__ __attribute__((aligned(16))) double lds_records[];
     __shared__ int flag;
+    __shared__ unsigned xcd_mine, xcd_count;
     const int member = a.spread ? blockIdx.x : blockIdx.x / 8;
     const int tid = threadIdx.x;
-    // sync words (one 64-byte line each): [0] first barrier, [16] the half-steps' barriers, [32] min XCC id, [33] max
+    // sync words (one 64-byte line each): [0] first barrier, [16] the half-steps' barriers, [32] min XCC id, [33] max,
+    // [64 + 16 x] workgroups of the group on XCD x, [320 + 16 x] that XCD's arrivals (GROUP_SYNC_WORDS in all)
     unsigned *first = a.gsync, *rounds = a.gsync + 16, *xmin = a.gsync + 32, *xmax = a.gsync + 33;
+    unsigned *members = a.gsync + 64, *arrivals = a.gsync + 320;
+    const unsigned my_xcd = (unsigned)group_xcc_id();
     const double *recs = nullptr;
     if constexpr (STAGED) {
         if constexpr (StagesFromArgs<LP>::value) lp.stage_from_args(lds_records, tid);
@@ -917,13 +949,21 @@ __global__ __launch_bounds__(BLK) void k_stretch_group(const PersistArgs a, cons
         group_store_row(a.gstate + w * GROUP_ROW, v, true);
     }
     if (tid == 0) {
-        const unsigned id = (unsigned)group_xcc_id();
-        __hip_atomic_fetch_min(xmin, id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_max(xmax, id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_min(xmin, my_xcd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_max(xmax, my_xcd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(members + 16 * my_xcd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     bool ok = group_barrier(first, (unsigned)a.G, false, a.spin_limit, &flag);
     const bool one_xcd = __hip_atomic_load(xmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
                          __hip_atomic_load(xmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) {      // who shares my XCD, and how many XCDs hold a part of the group (the two-level barrier)
+        unsigned n = 0;
+        for (int x = 0; x < 16; ++x) n += __hip_atomic_load(members + 16 * x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+        xcd_count = n;
+        xcd_mine = __hip_atomic_load(members + 16 * my_xcd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const unsigned mine = xcd_mine, xcds = xcd_count;
     const long long nh = (a.W + 1) / 2;
     constexpr int SPW = BLK / L;                    // slots per workgroup
     const long long slot = (long long)member * SPW + tid / L;
@@ -970,7 +1010,9 @@ __global__ __launch_bounds__(BLK) void k_stretch_group(const PersistArgs a, cons
                 if (store && a.logp_chain) __builtin_nontemporal_store(lp_row, a.logp_chain + srow * a.W + i);
             }
             cur = nxt;
-            ok = group_barrier(rounds, ++round * (unsigned)a.G, one_xcd, a.spin_limit, &flag);
+            ++round;
+            ok = one_xcd ? group_barrier(rounds, round * (unsigned)a.G, true, a.spin_limit, &flag)
+                         : group_barrier_two_level(arrivals + 16 * my_xcd, mine, rounds, xcds, round, a.spin_limit, &flag);
             if (!ok) break;
         }
         if (store) { ++srow; until_store = a.thin_by; }

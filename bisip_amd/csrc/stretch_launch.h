@@ -49,7 +49,7 @@ int launch_persistent(const PersistArgs &p0, const LP &lp, hipStream_t st)
 
 // One ensemble over several workgroups (k_stretch_group): G workgroups of 256 lanes (64 for one-lane functors) hold the
 // larger half's slots, LP::L lanes each; the grid is 8 G (the group is its every eighth workgroup: see the kernel) or G.
-constexpr int GROUP_MAX_WORKGROUPS = 64;
+constexpr int GROUP_MAX_WORKGROUPS = 256;
 template <class LP>
 int launch_group(const PersistArgs &p0, const LP &lp, hipStream_t st)
 {
@@ -67,9 +67,9 @@ int launch_group(const PersistArgs &p0, const LP &lp, hipStream_t st)
             if (rec_bytes > 60000 || std::getenv("BISIP_NO_LDS_STAGING") != nullptr) rec_bytes = 0;
         }
         // up to 32 workgroups sit on ONE XCD (every eighth workgroup of the grid); more -- one-lane functors beyond 4,096
-        // walkers -- take every workgroup of the grid, on all XCDs, and the placement-independent protocol: two per
-        // compute unit of one XCD is slower than a launch per half-step (7.8 us at 8,192 walkers), 64 compute units
-        // anywhere are not (3.7 against 4.6); 128 tie and 256 lose (one counter for all: 9.4 against 5.9)
+        // walkers -- take every workgroup of the grid, on all XCDs, the placement-independent protocol and the barrier
+        // in two levels: two workgroups per compute unit of one XCD are slower than a launch per half-step (7.8 us at
+        // 8,192 walkers), 64 compute units anywhere are not (3.7 against 4.6)
         p.spread = p.G > 32 ? 1 : 0;
         const dim3 grid((unsigned)(p.spread ? p.G : 8 * p.G)), block(BLK);
         if constexpr (LP::CAN_STAGE) {

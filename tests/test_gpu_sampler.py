@@ -703,7 +703,7 @@ def test_persistent_falls_back_when_ensemble_too_large():
     from bisip_amd.sampler import DeviceEnsembleSampler
     g = np.load(_case('case15_'))
     ctx = make_ctx(g, 'PeltonColeCole')
-    for W, want in ((4096, 'persistent-multi-workgroup'), (8194, 'launch-per-half-step')):
+    for W, want in ((4096, 'persistent-multi-workgroup'), (32770, 'launch-per-half-step')):
         p0 = _start(g, W, 9)
         np.random.seed(2)
         s = DeviceEnsembleSampler(W, 4, ctx, rng='philox', seed=5, persistent=True)
@@ -718,13 +718,13 @@ def test_persistent_falls_back_when_ensemble_too_large():
     assert s.last_path == 'launch-per-half-step'
     ctx.close()
     # left to itself the sampler takes the multi-workgroup kernel where it wins: the reduced PolynomialDecomposition
-    # kernels (one lane per slot, one wave per workgroup, all XCDs beyond 32 workgroups) up to 8,192 walkers
+    # kernels (one lane per slot, one wave per workgroup, all XCDs beyond 32 workgroups) up to 32,768 walkers
     g = np.load(_case('case01_'))
     ctx = make_ctx(g, 'PolynomialDecomposition')
     ndim = g['bounds'].shape[1]
     if ndim <= 7:
-        assert ctx.group_walkers == 8192
-        for W, want in ((8192, 'persistent-multi-workgroup'), (8194, 'launch-per-half-step')):
+        assert ctx.group_walkers == 32768
+        for W, want in ((8192, 'persistent-multi-workgroup'), (32768, 'persistent-multi-workgroup'), (32770, 'launch-per-half-step')):
             s = DeviceEnsembleSampler(W, ndim, ctx, rng='philox', seed=5)
             s.run_mcmc(_start(g, W, 9), 3)
             assert s.last_path == want, (W, s.last_path)
