@@ -1,6 +1,6 @@
 #!/bin/bash
 # The one evidence run of a round, at the FINAL kernel sources, in stages that each fit one gpurun call (<= 20 min):
-#   bash benchmarks/collect_final.sh <tag> tests|bench|sweep|sampler|micro|campaign-a|campaign-b|campaign-c
+#   bash benchmarks/collect_final.sh <tag> tests|bench|sweep|sampler|micro|campaign-a|campaign-b|campaign-c|campaign-group
 # Everything lands under gpurun_out/ (scratch); `bash benchmarks/import_profiles.sh <tag>` then copies what is judged
 # into profiles/ and regenerates the tables.  (Replaces the per-round collect_rNN_*.sh scripts.)
 set -o pipefail
@@ -59,5 +59,8 @@ campaign-c)      # a third set of seeds, taken after the last kernel change of t
   fz valley fuzz_parity.py --cases 6000 --seed 313 --valley
   fz sampler fuzz_sampler.py --cases 6000 --seed 29
   fz batch fuzz_batch.py --cases 2000 --seed 30 ;;
+campaign-group)  # the multi-workgroup sampler against one launch per half-step (every case: hundreds to thousands of barriers)
+  fz group fuzz_group.py --cases 1500 --seed 41
+  fz group fuzz_group.py --cases 1500 --seed 42 ;;
 *) echo "unknown stage $what" >&2; exit 2 ;;
 esac

@@ -40,7 +40,7 @@ cpy $src/micro_group_sampler.jsonl $dst/${tag}_micro_group_sampler.jsonl
 cpy $src/micro_ab_big_ensemble_packed.jsonl $dst/${tag}_micro_ab_big_ensemble_packed.jsonl
 cpy $src/guard_overhead_cfg4.jsonl $dst/${tag}_guard_overhead_cfg4.jsonl
 cpy $src/${tag}_gpu_tests_final.txt $dst/${tag}_gpu_tests_final.txt
-for k in parity valley sampler batch; do cpy $src/fuzz_${k}_summary.jsonl $dst/${tag}_fuzz_${k}_summary.jsonl; done
+for k in parity valley sampler batch group; do cpy $src/fuzz_${k}_summary.jsonl $dst/${tag}_fuzz_${k}_summary.jsonl; done
 # the headline line of the round is the one taken AFTER the counters were summarised on the box (collect_final.sh bench)
 [ -s $src/bench_final.json ] && cp $src/bench_final.json $dst/${tag}_bench.json
 cpy $src/valley_rows.jsonl $dst/${tag}_valley_rows.jsonl

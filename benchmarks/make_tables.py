@@ -380,6 +380,7 @@ FILES = [
     (rn('micro_ab_big_ensemble_rows.jsonl'), 'the same script on a build with `k_stretch_half_rows` (rows moved by four lanes each through LDS; not kept)', 'round 5: PolynomialDecomposition 65 -> 63 us, double Cole-Cole 66 -> 73 us per half-step of 524,288 proposals: requests per instruction were not the bound'),
     (rn('big_ensemble_host_setup.json'), '`BIG_MODEL=pd python benchmarks/micro/ab_big_ensemble.py` after the set-up moved to the device', "round 5: run_mcmc's own timing at 131,072 / 524,288 / 1,048,576 walkers: check_s 0 (the independence test runs on the device), 70.7 -> 33.3 ms end to end at a million walkers"),
     (rn('big_ensemble_kernels.txt'), '`BIG_MODEL=pd rocprofv3 --kernel-trace --stats -- python3 benchmarks/micro/ab_big_ensemble.py`, then two `--pmc` passes (FETCH_SIZE, WRITE_SIZE) of the same command', 'round 5, final sources: the big-ensemble half-step with the stream drawn in place -- 29-31 us per 524,288 proposals, FETCH_SIZE 125 B per proposal for 128 algorithmic (no re-reads), WRITE_SIZE 50; the repacking kernels 21-23 us per million walkers'),
+    (rn('fuzz_group_summary.jsonl'), '`bash benchmarks/collect_final.sh r05 campaign-group` (`benchmarks/fuzz_group.py`)', 'round 5, final sources: the multi-workgroup sampler (one XCD and all XCDs, 4 ... 256 workgroups, the two-level barrier) against one launch per half-step on random models, sizes 1,025 ... 32,768, thinning, chunking, lanes, streams: chains bit-equal, 0 failures'),
     (rn('extreme_shapes.txt'), '`python benchmarks/extreme_shapes.py`', 'round 5, final sources: frequency counts 100 ... 4096 (the reference has 20), every model and PolynomialDecomposition formulation: log-probability and forward against the oracle (worst 8.9e-15), a device sampler run against the host loop (same chain)'),
     (rn('micro_random_lines.txt'), '`benchmarks/micro/random_lines 1048576`, `... 8388608` (hipcc from `random_lines.hip`)', 'round 5: what the chip delivers for the access pattern of a big ensemble\'s half-step -- whole 64-byte rows at random places: two read per proposal 20.4 us per 524,288, and one written 25.8 (3.3-4.1 TB/s; sequential rows 6-7.4): the half-step (29-31 us with its evaluation and its draw) is at 0.85-0.9 of it'),
     (rn('micro_fp64_stream_ceiling.txt'), '`benchmarks/micro/fp64_stream_ceiling 0.5` (hipcc from `fp64_stream_ceiling.hip`)', 'round 5: what a stream of independent fp64 FMAs reaches (0.82-0.89 of the nominal issue peak with full-mantissa operands, the waves at 2.2-2.3 GHz; 0.87-0.94 on small integers): the ceiling `bench.py` measures in every run (`fp64_fma_stream`)'),
