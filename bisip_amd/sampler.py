@@ -1183,6 +1183,14 @@ class DeviceEnsembleSampler(_SamplerBase):
         while left > 0:
             sizes.append(min(max(1, self._chunk_steps(nsteps * thin_by, in_place) // thin_by), left))
             left -= sizes[-1]
+        if not in_place and self.rng == 'philox' and sizes:
+            # a chunk holds whole thinning intervals: with a very long interval its stream arrays (two sets, 32 bytes per
+            # slot and half-step) grow with it -- say so before the allocator does
+            need = 2 * sizes[0] * thin_by * 2 * nh * 32
+            if need > (32 << 30):
+                import warnings
+                warnings.warn(f'thin_by={thin_by} with {W} walkers needs {need / 2**30:.0f} GiB of random-stream arrays per chunk '
+                              '(a chunk holds whole thinning intervals); consider a smaller thin_by', ResourceWarning, stacklevel=2)
         first_sample = [0]                       # stored samples before chunk k
         for ns in sizes:
             first_sample.append(first_sample[-1] + ns)
